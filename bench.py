@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s primal+adjoint DRT on the BASELINE headline workload.
+
+One *step* = one H1 pass (reference: python/batched.py:255-326 with spp_grad = spp)
+over the whole image: primal tracing kernel -> box film -> loss gradient
+(mean((img-0.5)^2), tests/test_integrators.py:119) -> dL -> adjoint tracing kernel
+(consumes the stored primal radiance as state_in) [-> one all-reduce of the
+gradient grids when N > 1].  One *sample* = one camera ray (pixel x spp).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the keys below).  Inputs (the synthetic 256^3
+dust-devil grids) are resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured copy
+
+
+def algorithmic_bytes(cnt, n_samples, primal_io=True, adjoint_io=True):
+    """32 B per sigma_t lookup, 96 B per albedo lookup, 64 B per sigma_t
+    splat, 192 B per albedo splat; ray I/O: primal out 12 B L (+24 B o,d when rays are
+    read); adjoint in 12 B dL + 12 B state_in."""
+    b = 32 * (cnt["n_dt"] + cnt["n_rt"] + cnt["n_drt"]) + 96 * cnt["n_alb"] \
+        + 64 * (cnt["n_tr"] + cnt["n_rt_adj"] + cnt["n_sc"]) + 192 * cnt["n_sc_alb"]
+    io = 0
+    if primal_io:
+        io += 12 + 24
+    if adjoint_io:
+        io += 24
+    return b + io * n_samples
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--res", type=int, default=256, help="grid resolution (headline: 256)")
+    ap.add_argument("--film", type=int, default=512, help="film size (headline: 512)")
+    ap.add_argument("--spp", type=int, default=32, help="samples per pixel (headline: 32)")
+    ap.add_argument("--workload", default="dust-devil", choices=["dust-devil", "smoke", "cube"])
+    ap.add_argument("--integrator", default="volpathsimple-drt")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import uivr_amd as u
+    from uivr_amd import synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the DRT integrator has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # ---- workload (synthetic, seeded; resident in HBM) ---------------------------------
+    if args.workload == "dust-devil":
+        scene = synthetic.dust_devil_scene(res=args.res, film=args.film, device=dev)
+    elif args.workload == "smoke":
+        scene = synthetic.smoke_scene(res=args.res, film=args.film, device=dev)
+    else:
+        scene = synthetic.constant_cube_scene(res=args.res, film=args.film, device=dev)
+    sensor = scene.sensors[0]
+    n_pixels = sensor.width * sensor.height
+    spp = args.spp
+    n_total = n_pixels * spp
+    integ = u.get_int_config(args.integrator).create(max_depth=64)
+    shard = u.ShardSpec(rank, world, u.ShardSpec.default_chunk(n_pixels, world)) if world > 1 else None
+    batch_shard = shard or u.ShardSpec()
+    n_local_pix = batch_shard.n_local_pixels(n_pixels)
+    off, inter = batch_shard.ray_mapping(spp)
+    batch = u.RayBatch(n_rays=n_local_pix * spp, spp=spp, sensor=sensor, ray_offset=off, interleave=inter)
+    grads = u.alloc_grads(scene)
+    loss_scale = 2.0 / (n_pixels * 3)
+    seed_base = 988378   # opt_config.py:24
+
+    def step(i):
+        seed = u.sample_tea_32(2 * i + 1, seed_base)[0]           # seed_grad of iteration i (optimize.py:328)
+        sampler = u.IndependentSampler(seed, spp)
+        grads["_flat"].zero_()
+        L, _, state = integ.sample(u.ADMode.Primal, scene, sampler.clone(), batch)       # batched.py:255-264
+        img = integ.develop(scene, L, spp)                                                # :272-297
+        grad_img = loss_scale * (img - 0.5)                                               # d mean((img-.5)^2)
+        dL = integ.film_backward(scene, grad_img, spp)                                    # :298-306
+        integ.sample(u.ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state, grads=grads)   # :309-318
+        u.allreduce_gradients(grads)                                                      # one RCCL all-reduce
+        return img
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    h = integ.native_handle(scene)
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    h.enable_timing(True)       # HIP event pairs around every tracing launch, on the launch stream
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    t_primal = h.read_timings(False)
+    t_adjoint = h.read_timings(True)
+    h.enable_timing(False)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_total * args.steps / elapsed / 1e6
+
+    # ---- event counts of ONE step (deterministic; outside the timed region) ------------
+    h.enable_counters(True)
+    seed_c = u.sample_tea_32(2 * args.warmup + 1, seed_base)[0]
+    sampler = u.IndependentSampler(seed_c, spp)
+    h.reset_counters()
+    L, _, state = integ.sample(u.ADMode.Primal, scene, sampler.clone(), batch)
+    cnt_p = {k: int(v) for k, v in h.get_counters().items()}
+    img = integ.develop(scene, L, spp)
+    dL = integ.film_backward(scene, loss_scale * (img - 0.5), spp)
+    h.reset_counters()
+    grads["_flat"].zero_()
+    integ.sample(u.ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state, grads=grads)
+    cnt_a = {k: int(v) for k, v in h.get_counters().items()}
+    h.enable_counters(False)
+    n_local = batch.n_rays
+    bytes_p = algorithmic_bytes(cnt_p, n_local, primal_io=True, adjoint_io=False) - 24 * n_local  # rays generated on device
+    bytes_a = algorithmic_bytes(cnt_a, n_local, primal_io=False, adjoint_io=True)
+    avg_p = sum(t_primal) / max(1, len(t_primal))
+    avg_a = sum(t_adjoint) / max(1, len(t_adjoint))
+    ach_a = bytes_a / (avg_a * 1e-3) / 1e9 if avg_a > 0 else 0.0
+    ach_p = bytes_p / (avg_p * 1e-3) / 1e9 if avg_p > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f).get(f"{args.workload}-{args.res}-{args.film}x{spp}")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": "trace_kernel<adjoint> (sample(Backward))",
+        "achieved": round(ach_a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(ach_a / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "algorithmic_bytes_per_launch": bytes_a, "avg_launch_ms": round(avg_a, 4),
+        "bytes_per_sample_h1": round((bytes_p + bytes_a) / n_local, 1),
+        "primal": {"achieved": round(ach_p, 2), "frac": round(ach_p / HBM_PEAK_GBS, 5),
+                   "algorithmic_bytes_per_launch": bytes_p, "avg_launch_ms": round(avg_p, 4)},
+    }
+
+    # ---- CPU baseline: the oracle (a port, NOT the reference's llvm_ad_rgb) ------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as ob
+        cores = os.cpu_count() or 1
+        cpu_scene = u.Scene(medium=u.GridMedium(sigma_t=scene.medium.sigma_t.cpu().numpy(),
+                                                albedo=scene.medium.albedo.cpu().numpy(),
+                                                bbox_min=scene.medium.bbox_min, bbox_max=scene.medium.bbox_max,
+                                                scale=scene.medium.scale),
+                            emitter=scene.emitter, sensors=scene.sensors)
+        osc = ob.OracleScene(cpu_scene)
+        cpu_spp = args.cpu_spp
+        if cpu_spp <= 0:
+            # calibrate on 1/16 of the image rows at spp 1, then size the sample for ~15 s
+            n_cal = max(1, n_pixels // 16)
+            tc = time.perf_counter()
+            ob.h1_step(osc, integ.props(), 1, seed_c, n_rays=n_cal, ray_offset=(n_pixels // 2 - n_cal // 2))
+            rate = n_cal / max(1e-6, time.perf_counter() - tc)
+            cpu_spp = int(max(1, min(spp, round(15.0 * rate / n_pixels))))
+        tc = time.perf_counter()
+        ob.h1_step(osc, integ.props(), cpu_spp, seed_c)
+        dt = time.perf_counter() - tc
+        cpu_baseline = {
+            "value": round(n_pixels * cpu_spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+            "kind": "port",
+            "sample": f"same workload, full {sensor.width}x{sensor.height} image at {cpu_spp} spp "
+                      f"({n_pixels * cpu_spp} samples, {dt:.1f} s); oracle/drt_oracle.c with OpenMP over rays "
+                      f"(the reference's llvm_ad_rgb needs Mitsuba 3 / Dr.Jit, absent here)",
+        }
+
+    if rank == 0:
+        out = {
+            "metric": "Msamples/s primal+adjoint DRT, 256^3 grid 512^2x32spp",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {args.res}^3 sigma_t+albedo, {sensor.width}x{sensor.height}x{spp}spp, "
+                                   f"{args.integrator}, max_depth 64, single sensor, image tiles sharded over {world} GPU(s)",
+                       "n_samples_per_step": n_total, "grid": [args.res] * 3, "film": [sensor.width, sensor.height],
+                       "spp": spp, "integrator": args.integrator},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "t_primal_ms": round(avg_p, 3), "t_adjoint_ms": round(avg_a, 3),
+            "counters_primal": cnt_p, "counters_adjoint": cnt_a,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+/*
+ * drt_hip.h -- C ABI of libdrt_hip.so: the MI355X (gfx950) differential ratio
+ * tracking integrator.  This is the drop-in boundary for the hot path of
+ * rgl-epfl/unbiased-inverse-volume-rendering: what the reference reaches through
+ * `integrator.sample(mode, scene, sampler, ray, dL, state_in, ...)`
+ * (python/integrators/volpathsimple.py:38-49) and the primal -> dL -> adjoint
+ * harness around it (python/batched.py:134-197, 212-326).
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every call returns 0 on success or a negative
+ *    drt_status; `drt_last_error` returns a human-readable message.
+ *  - all tensor arguments are caller-owned DEVICE pointers (HIP, fp32) on the
+ *    handle's device; the library never takes ownership and never allocates
+ *    caller-visible memory.  Grids use Mitsuba's VolumeGrid layout (Z,Y,X,C).
+ *  - all work is enqueued on the handle's stream (drt_set_stream) and is
+ *    asynchronous with respect to the host, like Dr.Jit kernels until dr.eval().
+ *  - one handle is bound to one device; a handle is not thread-safe, distinct
+ *    handles are independent.
+ *  - the library needs a GPU: there is no CPU fallback behind this ABI.
+ */
+#ifndef DRT_HIP_H
+#define DRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct drt_handle_s *drt_handle;
+
+typedef enum drt_status {
+    DRT_OK = 0,
+    DRT_ERR_INVALID_ARGUMENT = -1,
+    DRT_ERR_NOT_CONFIGURED = -2,   /* medium / emitter / sensor missing */
+    DRT_ERR_HIP = -3,              /* a HIP runtime call failed */
+    DRT_ERR_NO_DEVICE = -4,
+    DRT_ERR_UNSUPPORTED = -5
+} drt_status;
+
+/* Integrator properties.  Replaces mi.Properties read in
+ * VolpathSimpleIntegrator.__init__ (volpathsimple.py:19-36) plus max_depth /
+ * rr_depth of the RBIntegrator base (used at :118,200). */
+typedef struct drt_config {
+    int32_t hide_emitters;        /* default 0 */
+    int32_t use_nee;              /* default 1 */
+    int32_t use_drt;              /* default 1 */
+    int32_t use_drt_subsampling;  /* default 1 */
+    int32_t use_drt_mis;          /* default 1 */
+    int32_t max_depth;
+    int32_t rr_depth;             /* IntegratorConfig.create sets max_depth + 1000 (opt_config.py:105-106) */
+} drt_config;
+
+/* Event counters for the algorithmic-bytes roofline. */
+typedef struct drt_counters {
+    uint64_t n_rays;
+    uint64_t n_dt;      /* sigma_t lookups, delta tracking (volpathsimple.py:348,375) */
+    uint64_t n_rt;      /* sigma_t lookups, ratio tracking (:469) */
+    uint64_t n_drt;     /* sigma_t lookups, sample_interaction_drt (:550,554) */
+    uint64_t n_alb;     /* albedo lookups (:141,578) */
+    uint64_t n_tr;      /* transmittance-resampling splats (:594-607) */
+    uint64_t n_rt_adj;  /* ratio-tracking adjoint splats (:487-492) */
+    uint64_t n_sc;      /* sigma_t scattering splats (:170,580) */
+    uint64_t n_sc_alb;  /* albedo scattering splats (:170,580) */
+} drt_counters;
+
+/* mi.load_dict({'type': 'volpathsimple', ...}) / mi.register_integrator factory
+ * (volpathsimple.py:769, opt_config.py:97-108). */
+int drt_create(const drt_config *cfg, int device, drt_handle *out);
+int drt_destroy(drt_handle h);
+/* Python exceptions / asserts of the reference (opt_config.py:98-104, util.py:83-85). */
+const char *drt_last_error(drt_handle h);
+
+/* Stream on which all later calls enqueue work (hipStream_t, NULL = default). */
+int drt_set_stream(drt_handle h, void *hip_stream);
+int drt_synchronize(drt_handle h);
+
+/* Image-tile sharding across GPUs (no counterpart in the single-GPU reference;
+ * SURVEY.md 8e): local ray i of later render calls has the global index
+ * ray_offset + (i / chunk_rays) * stride_rays + (i % chunk_rays).  chunk_rays = 0
+ * restores the contiguous mapping ray_offset + i.  chunk_rays should be a
+ * multiple of spp so that a pixel's samples stay on one rank. */
+int drt_set_ray_interleave(drt_handle h, uint64_t chunk_rays, uint64_t stride_rays);
+
+/* The single medium of the scene: util.get_single_medium (python/util.py:75-86) +
+ * the `heterogeneous` medium / `gridvolume` parameters of the fixture
+ * (tests/test_integrators.py:79-111).  sigma_t: (Z,Y,X,1); albedo: (Z,Y,X,3);
+ * res = {X,Y,Z}.  Pointers are borrowed until the next drt_set_medium.
+ * Also (re)computes the majorant on device. */
+int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, const int32_t res[3],
+                   const float bbox_min[3], const float bbox_max[3], float scale,
+                   int32_t majorant_resolution_factor);
+/* params.update(opt) after an optimizer step (python/optimize.py:354) and
+ * medium.set_majorant_resolution_factor (:195-199): refresh the majorant from
+ * the (same) parameter buffers.  No host synchronisation. */
+int drt_params_changed(drt_handle h);
+
+/* `constant` emitter (tests/test_integrators.py:73-77); the integrator only
+ * supports infinite emitters (volpathsimple.py:16). */
+int drt_set_emitter_constant(drt_handle h, const float radiance[3]);
+
+/* `perspective` sensor + box-filter hdrfilm used by mi.render
+ * (tests/test_integrators.py:46-67; python/optimize.py:44,129,345). */
+int drt_set_sensor_perspective(drt_handle h, const float origin[3], const float left[3],
+                               const float up[3], const float dir[3], float tan_x, float tan_y,
+                               int32_t width, int32_t height);
+
+/* sample(mode=Primal) over a ray batch: volpathsimple.py:38-290 as called from
+ * render_batch_primal (batched.py:163-173) / render_batch_backward step (1)
+ * (batched.py:255-264).  Ray i has global index ray_offset + i, pixel
+ * (ray_offset + i) / spp and the PCG32 stream tea32(seed, ray_offset + i).
+ *   rays_o/rays_d != NULL : batched flow, [n][3] each (batched.py:426-467)
+ *   rays_o/rays_d == NULL : mi.render flow, rays generated from the sensor with
+ *                           the film position drawn from the ray's own stream.
+ * L_out: [n][3]. */
+int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
+                      uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_out);
+
+/* sample(mode=Backward, dL, state_in=L_in): render_batch_backward step (2)
+ * (batched.py:309-326).  Same rays / seed as the primal call that produced L_in.
+ * ACCUMULATES (+=) into grad_sigma_t (Z,Y,X,1) and grad_albedo (Z,Y,X,3) - the
+ * reference's dr.grad(params[k]) after scatter_reduce(Add) (volpathsimple.py:170,489,580,607). */
+int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
+                        uint64_t ray_offset, uint32_t spp, uint32_t seed, const float *dL,
+                        const float *L_in, float *grad_sigma_t, float *grad_albedo);
+
+/* Box-filter film: image[p] = mean over the pixel's spp samples
+ * (block.put + film.develop, batched.py:176-197).  L: [n_pixels*spp][3]. */
+int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t spp, float *image);
+/* Its adjoint: dL[i] = grad_image[i / spp] / spp (batched.py:298-306). */
+int drt_film_backward(drt_handle h, const float *grad_image, uint64_t n_pixels, uint32_t spp,
+                      float *dL);
+
+/* Event counting (off by default; enabling selects a counting build of the kernels). */
+int drt_enable_counters(drt_handle h, int enable);
+int drt_reset_counters(drt_handle h);
+int drt_get_counters(drt_handle h, drt_counters *out);   /* synchronises the stream */
+
+/* Kernel timing for the roofline leg of bench.py: while enabled, every tracing
+ * launch is bracketed by a HIP event pair recorded on the handle's stream.
+ * drt_enable_timing (either value) synchronises and discards recorded pairs.
+ * drt_read_timings synchronises, writes up to `capacity` durations (ms, launch
+ * order) of the primal (backward = 0) or adjoint (backward = 1) launches and
+ * returns the number recorded (>= 0) or a negative drt_status. */
+int drt_enable_timing(drt_handle h, int enable);
+int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity);
+
+const char *drt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,951 @@
+/*
+ * drt_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).
+ * See drt_oracle.h for scope, the list of reference files restated here and
+ * the "parity unpinned" statement.  Build: oracle/Makefile (gcc, -ffp-contract=off).
+ *
+ * Every float operation is written out in a fixed order (explicit fmaf where a
+ * fused op is meant) so that an independent implementation following the same
+ * specification (DESIGN.md "Arithmetic specification") reproduces the primal
+ * radiance bit for bit.
+ */
+#include "drt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* small helpers                                                              */
+/* ------------------------------------------------------------------------- */
+typedef struct { float x, y, z; } v3;
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline v3 v3_make(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+/* Ray3f::operator()(t) = fmadd(d, t, o) [M3-ext] */
+static inline v3 ray_at(v3 o, v3 d, float t)
+{
+    return v3_make(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
+}
+static inline float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
+
+#define DRT_INV_FOURPI 0.07957747154594767f   /* 1/(4 pi) */
+#define DRT_FOURPI     12.566370614359172f
+#define DRT_HALF_PI    1.5707963267948966f
+#define DRT_LARGEST    3.4028234663852886e38f /* dr.largest(Float) */
+#define DRT_RAY_EPS    (1500.0f * 5.9604644775390625e-8f) /* math::RayEpsilon<float> [M3-ext] */
+
+/* ------------------------------------------------------------------------- */
+/* E7: sample_tea_32 + PCG32 `independent` sampler [M3-ext]                   */
+/* call sites volpathsimple.py:71,99,105-107,120,222,348,359,383,418,470,536,595,632 */
+/* ------------------------------------------------------------------------- */
+static inline void tea32(uint32_t v0, uint32_t v1, uint32_t *o0, uint32_t *o1)
+{
+    uint32_t sum = 0;
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    *o0 = v0; *o1 = v1;
+}
+
+typedef struct { uint64_t state, inc; } pcg32;
+
+static inline uint32_t pcg32_next_u32(pcg32 *r)
+{
+    uint64_t old = r->state;
+    r->state = old * 0x5851f42d4c957f2dull + r->inc;
+    uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+    uint32_t rot = (uint32_t)(old >> 59);
+    return (xs >> rot) | (xs << ((0u - rot) & 31u));
+}
+/* PCG32::seed(initstate, initseq) */
+static inline void pcg32_seed(pcg32 *r, uint64_t initstate, uint64_t initseq)
+{
+    r->state = 0;
+    r->inc = (initseq << 1) | 1ull;
+    pcg32_next_u32(r);
+    r->state += initstate;
+    pcg32_next_u32(r);
+}
+/* Sampler::seed(seed, wavefront): lane `index` gets PCG32(tea32(seed, index)) */
+static inline void sampler_seed(pcg32 *r, uint32_t seed, uint32_t index)
+{
+    uint32_t v0, v1;
+    tea32(seed, index, &v0, &v1);
+    pcg32_seed(r, (uint64_t) v0, (uint64_t) v1);
+}
+/* next_float32: 23 random mantissa bits in [0,1) */
+static inline float next_1d(pcg32 *r)
+{
+    return u2f((pcg32_next_u32(r) >> 9) | 0x3f800000u) - 1.0f;
+}
+
+/* ------------------------------------------------------------------------- */
+/* deterministic elementary functions (specified op by op)         */
+/* ------------------------------------------------------------------------- */
+/* natural log for normal positive x (Cephes logf polynomial, Horner in fmaf). */
+static inline float drt_logf(float x)
+{
+    uint32_t ix = f2u(x);
+    int e = (int)(ix >> 23) - 126;                 /* x = m * 2^e, m in [0.5,1) */
+    float m = u2f((ix & 0x007fffffu) | 0x3f000000u);
+    float f;
+    if (m < 0.70710678118654752440f) { e -= 1; f = (m + m) - 1.0f; }
+    else { f = m - 1.0f; }
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (f * z) * p;
+    float fe = (float) e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = fmaf(0.693359375f, fe, r);
+    return r;
+}
+
+/* sin/cos of 2*pi*u for u in [0,1): exact quadrant split, Cephes minimax on [0,pi/4]. */
+static inline void drt_sincos_2pi(float u, float *s_out, float *c_out)
+{
+    float a = u * 4.0f;
+    int q = (int) a;                 /* 0..3 */
+    float f = a - (float) q;         /* exact, [0,1) */
+    int swap = f > 0.5f;
+    float g = swap ? (1.0f - f) : f; /* [0,0.5] */
+    float x = g * DRT_HALF_PI;       /* [0,pi/4] */
+    float x2 = x * x;
+    float ps = -1.9515295891e-4f;
+    ps = fmaf(ps, x2, 8.3321608736e-3f);
+    ps = fmaf(ps, x2, -1.6666654611e-1f);
+    float s = fmaf(x * x2, ps, x);
+    float pc = 2.443315711809948e-5f;
+    pc = fmaf(pc, x2, -1.388731625493765e-3f);
+    pc = fmaf(pc, x2, 4.166664568298827e-2f);
+    float c = fmaf(x2 * x2, pc, fmaf(-0.5f, x2, 1.0f));
+    if (swap) { float t = s; s = c; c = t; }
+    float sq, cq;
+    switch (q & 3) {
+        case 0: sq = s;  cq = c;  break;
+        case 1: sq = c;  cq = -s; break;
+        case 2: sq = -s; cq = -c; break;
+        default: sq = -c; cq = s; break;
+    }
+    *s_out = sq; *c_out = cq;
+}
+
+/* warp::square_to_uniform_sphere [M3-ext]; used by the isotropic phase (E6,
+ * volpathsimple.py:221,630) and the constant emitter (E5, :419). */
+static inline v3 square_to_uniform_sphere(float ux, float uy)
+{
+    float z = fmaf(-2.0f, uy, 1.0f);
+    float r = sqrtf(fmaxf(0.0f, fmaf(-z, z, 1.0f)));
+    float s, c;
+    drt_sincos_2pi(ux, &s, &c);
+    return v3_make(r * c, r * s, z);
+}
+
+/* mi.ad.common.mis_weight (E8): power heuristic, non-finite -> 0 */
+static inline float mis_weight(float a, float b)
+{
+    float a2 = a * a, b2 = b * b;
+    float w = a2 / (a2 + b2);
+    return isfinite(w) ? w : 0.0f;
+}
+
+/* ------------------------------------------------------------------------- */
+/* scene                                                                      */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    drto_config cfg;
+    const float *sigma_t, *albedo;
+    int rx, ry, rz;
+    v3 bmin, bmax, inv_ext;
+    float scale, majorant, inv_majorant;
+    float Le[3];
+} scene_t;
+
+typedef struct {
+    const scene_t *sc;
+    double *g_sigma, *g_albedo;   /* NULL in primal */
+    drto_counters cnt;
+    uint32_t alt_seed;
+    uint32_t ray_index;
+} ctx_t;
+
+/* E3: GridVolume::eval, trilinear, clamp, cell-centred (q = p*res - 0.5) */
+typedef struct { int idx[8]; float wx0, wx1, wy0, wy1, wz0, wz1; } stencil_t;
+
+static inline void axis_setup(float p, float bmin, float inv_ext, int res,
+                              int *i0, int *i1, float *w0, float *w1)
+{
+    float l = (p - bmin) * inv_ext;
+    float q = fmaf(l, (float) res, -0.5f);
+    float fl = floorf(q);
+    float fw = q - fl;
+    fl = fminf(fmaxf(fl, -1.0f), (float) res);
+    int i = (int) fl;
+    int a = i < 0 ? 0 : (i > res - 1 ? res - 1 : i);
+    int b = i + 1 < 0 ? 0 : (i + 1 > res - 1 ? res - 1 : i + 1);
+    *i0 = a; *i1 = b; *w1 = fw; *w0 = 1.0f - fw;
+}
+
+static inline void make_stencil(const scene_t *sc, v3 p, stencil_t *s)
+{
+    int x0, x1, y0, y1, z0, z1;
+    axis_setup(p.x, sc->bmin.x, sc->inv_ext.x, sc->rx, &x0, &x1, &s->wx0, &s->wx1);
+    axis_setup(p.y, sc->bmin.y, sc->inv_ext.y, sc->ry, &y0, &y1, &s->wy0, &s->wy1);
+    axis_setup(p.z, sc->bmin.z, sc->inv_ext.z, sc->rz, &z0, &z1, &s->wz0, &s->wz1);
+    int sy = sc->rx, sz = sc->rx * sc->ry;
+    s->idx[0] = z0 * sz + y0 * sy + x0; s->idx[1] = z0 * sz + y0 * sy + x1;
+    s->idx[2] = z0 * sz + y1 * sy + x0; s->idx[3] = z0 * sz + y1 * sy + x1;
+    s->idx[4] = z1 * sz + y0 * sy + x0; s->idx[5] = z1 * sz + y0 * sy + x1;
+    s->idx[6] = z1 * sz + y1 * sy + x0; s->idx[7] = z1 * sz + y1 * sy + x1;
+}
+
+static inline float trilerp(const stencil_t *s, const float *data, int stride, int ch)
+{
+    float d[8];
+    for (int k = 0; k < 8; ++k) d[k] = data[(size_t) s->idx[k] * stride + ch];
+    float v00 = fmaf(s->wx0, d[0], s->wx1 * d[1]);
+    float v01 = fmaf(s->wx0, d[2], s->wx1 * d[3]);
+    float v10 = fmaf(s->wx0, d[4], s->wx1 * d[5]);
+    float v11 = fmaf(s->wx0, d[6], s->wx1 * d[7]);
+    float v0 = fmaf(s->wy0, v00, s->wy1 * v01);
+    float v1 = fmaf(s->wy0, v10, s->wy1 * v11);
+    return fmaf(s->wz0, v0, s->wz1 * v1);
+}
+
+/* get_scattering_coefficients: sigma_t = scale * trilerp(sigma_t.data) */
+static inline float eval_sigma_t(const scene_t *sc, v3 p)
+{
+    stencil_t s;
+    make_stencil(sc, p, &s);
+    return trilerp(&s, sc->sigma_t, 1, 0) * sc->scale;
+}
+/* get_albedo */
+static inline void eval_albedo(const scene_t *sc, v3 p, float out[3])
+{
+    stencil_t s;
+    make_stencil(sc, p, &s);
+    for (int c = 0; c < 3; ++c) out[c] = trilerp(&s, sc->albedo, 3, c);
+}
+
+static inline void stencil_weights(const stencil_t *s, float w[8])
+{
+    float zy00 = s->wz0 * s->wy0, zy01 = s->wz0 * s->wy1;
+    float zy10 = s->wz1 * s->wy0, zy11 = s->wz1 * s->wy1;
+    w[0] = zy00 * s->wx0; w[1] = zy00 * s->wx1; w[2] = zy01 * s->wx0; w[3] = zy01 * s->wx1;
+    w[4] = zy10 * s->wx0; w[5] = zy10 * s->wx1; w[6] = zy11 * s->wx0; w[7] = zy11 * s->wx1;
+}
+
+/* reverse-mode of the trilinear gather = 8-corner scatter_reduce(Add) (E3/E9) */
+static inline void splat_sigma_t(ctx_t *c, v3 p, float g)
+{
+    stencil_t s; float w[8];
+    make_stencil(c->sc, p, &s);
+    stencil_weights(&s, w);
+    float gs = g * c->sc->scale;
+    for (int k = 0; k < 8; ++k) {
+        double v = (double)(w[k] * gs);
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        c->g_sigma[s.idx[k]] += v;
+    }
+}
+static inline void splat_albedo(ctx_t *c, v3 p, const float g[3])
+{
+    stencil_t s; float w[8];
+    make_stencil(c->sc, p, &s);
+    stencil_weights(&s, w);
+    for (int k = 0; k < 8; ++k)
+        for (int ch = 0; ch < 3; ++ch) {
+            double v = (double)(w[k] * g[ch]);
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+            c->g_albedo[(size_t) s.idx[k] * 3 + ch] += v;
+        }
+}
+
+/* E4: scene.ray_intersect with use_bbox_fast_path: nearest hit with the box
+ * surface at t > 0 (entry face from outside, exit face from inside). */
+typedef struct { int valid; float t; v3 p; v3 n; } si_t;
+
+static inline si_t box_hit(const scene_t *sc, v3 o, v3 d)
+{
+    si_t si; si.valid = 0; si.t = INFINITY; si.p = v3_make(0, 0, 0); si.n = v3_make(0, 0, 0);
+    float tn = -INFINITY, tf = INFINITY;
+    int an = 0, af = 0;
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    const float lo[3] = { sc->bmin.x, sc->bmin.y, sc->bmin.z };
+    const float hi[3] = { sc->bmax.x, sc->bmax.y, sc->bmax.z };
+    for (int a = 0; a < 3; ++a) {
+        if (dd[a] != 0.0f) {
+            float t0 = (lo[a] - oo[a]) / dd[a];
+            float t1 = (hi[a] - oo[a]) / dd[a];
+            if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
+            if (t0 > tn) { tn = t0; an = a; }
+            if (t1 < tf) { tf = t1; af = a; }
+        } else if (oo[a] < lo[a] || oo[a] > hi[a]) {
+            return si;
+        }
+    }
+    if (!(tn <= tf)) return si;
+    float t; int ax; float sgn;
+    if (tn > 0.0f) { t = tn; ax = an; sgn = dd[ax] > 0.0f ? -1.0f : 1.0f; }
+    else if (tf > 0.0f) { t = tf; ax = af; sgn = dd[ax] > 0.0f ? 1.0f : -1.0f; }
+    else return si;
+    if (!isfinite(t)) return si;
+    si.valid = 1; si.t = t; si.p = ray_at(o, d, t);
+    float n[3] = { 0, 0, 0 }; n[ax] = sgn;
+    si.n = v3_make(n[0], n[1], n[2]);
+    return si;
+}
+
+/* SurfaceInteraction::spawn_ray -> offset_p(d) [M3-ext] */
+static inline v3 offset_p(const si_t *si, v3 d)
+{
+    float mag = (1.0f + max3f(fabsf(si->p.x), fabsf(si->p.y), fabsf(si->p.z))) * DRT_RAY_EPS;
+    float dn = si->n.x * d.x + si->n.y * d.y + si->n.z * d.z;
+    if (dn < 0.0f) mag = -mag;
+    return v3_make(fmaf(mag, si->n.x, si->p.x), fmaf(mag, si->n.y, si->p.y), fmaf(mag, si->n.z, si->p.z));
+}
+
+/* E1: free-flight distance of Medium::sample_interaction with a global
+ * majorant: t = -log(1-u)/majorant (multiplication by the reciprocal). */
+static inline float sample_distance(const scene_t *sc, float u)
+{
+    if (sc->majorant == 0.0f) return INFINITY;
+    return -drt_logf(1.0f - u) * sc->inv_majorant;
+}
+
+typedef struct { v3 o, d; float maxt; } ray_t;
+
+/* ------------------------------------------------------------------------- */
+/* A8: estimate_transmittance -- ratio tracking  (volpathsimple.py:436-504)   */
+/* adj == NULL: primal.  adj != NULL: also back-propagate (lines 483-492).    */
+/* ------------------------------------------------------------------------- */
+static float estimate_transmittance(ctx_t *c, v3 o, v3 d, float tmax, pcg32 *S, const float *adj)
+{
+    const scene_t *sc = c->sc;
+    float T = 1.0f;
+    for (;;) {
+        float dt = sample_distance(sc, next_1d(S));
+        if (!(dt <= tmax)) break;                       /* :480-481 */
+        v3 p = ray_at(o, d, dt);
+        float sig = eval_sigma_t(sc, p);
+        float tr = (sc->majorant - sig) * sc->inv_majorant;   /* sigma_n / majorant :473-476 */
+        c->cnt.n_rt++;
+        if (adj && tr > 0.0f) {                          /* :487-492 */
+            float a = (adj[0] + adj[1]) + adj[2];
+            c->cnt.n_rt_adj++;
+            splat_sigma_t(c, p, -(a * sc->inv_majorant) / tr);
+        }
+        T *= tr;                                         /* :495 */
+        o = p; tmax -= dt;                               /* :497-499 */
+        if (T == 0.0f) break;                            /* :502 */
+    }
+    return T;
+}
+
+/* A7: sample_emitter (volpathsimple.py:406-433), constant emitter. Returns
+ * emitter_val * transmittance (RGB) in out[]. */
+static void sample_emitter(ctx_t *c, v3 p, pcg32 *S, const float *adj, float out[3])
+{
+    const scene_t *sc = c->sc;
+    float ux = next_1d(S), uy = next_1d(S);              /* :418 */
+    v3 wd = square_to_uniform_sphere(ux, uy);            /* constant::sample_direction */
+    si_t si = box_hit(sc, p, wd);                        /* mei.spawn_ray: no offset (n=0) :427-428 */
+    float T = 0.0f;
+    if (si.valid) T = estimate_transmittance(c, p, wd, si.t, S, adj);
+    for (int k = 0; k < 3; ++k) out[k] = (sc->Le[k] * DRT_FOURPI) * T;  /* radiance / pdf */
+}
+
+/* A7: sample_emitter_for_nee (volpathsimple.py:380-403) */
+static void sample_emitter_for_nee(ctx_t *c, v3 p, pcg32 *S, const float beta[3], const float *dL,
+                                   float contrib[3])
+{
+    pcg32 clone = *S;                                    /* :383 */
+    float emitted[3];
+    sample_emitter(c, p, S, NULL, emitted);              /* :385 */
+    float w = mis_weight(DRT_INV_FOURPI, DRT_INV_FOURPI);/* ds.pdf vs phase_pdf :391 */
+    for (int k = 0; k < 3; ++k)
+        contrib[k] = ((beta[k] * DRT_INV_FOURPI) * w) * emitted[k];
+    if (dL) {                                            /* :393-401 */
+        float adj[3] = { dL[0] * contrib[0], dL[1] * contrib[1], dL[2] * contrib[2] };
+        float unused[3];
+        sample_emitter(c, p, &clone, adj, unused);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A4: sample_real_interaction -- delta tracking  (volpathsimple.py:323-377)  */
+/* ------------------------------------------------------------------------- */
+typedef struct { int valid; float t; v3 p; float sigma_t; } mei_t;
+
+static mei_t sample_real_interaction(ctx_t *c, const ray_t *ray, pcg32 *S, int attached)
+{
+    const scene_t *sc = c->sc;
+    mei_t mei; mei.valid = 0; mei.t = INFINITY; mei.p = v3_make(0, 0, 0); mei.sigma_t = 0.0f;
+    v3 ro = ray->o; float rmaxt = ray->maxt; float running_t = 0.0f;
+    for (;;) {
+        float dt = sample_distance(sc, next_1d(S));      /* :348 */
+        if (!(dt <= rmaxt)) break;                       /* :358 escaped */
+        v3 p = ray_at(ro, ray->d, dt);
+        float sig = eval_sigma_t(sc, p);
+        c->cnt.n_dt++;
+        float r = sig * sc->inv_majorant;                /* :354 */
+        float u = next_1d(S);                            /* :359 */
+        if (!(u >= r)) {                                 /* real collision */
+            mei.valid = 1; mei.t = running_t + dt;       /* :351 */
+            break;
+        }
+        ro = p; rmaxt -= dt; running_t += dt;            /* :364-367 */
+    }
+    if (mei.valid) {
+        mei.p = ray_at(ray->o, ray->d, mei.t);           /* :371 */
+        if (attached) {                                  /* :373-375 */
+            mei.sigma_t = eval_sigma_t(sc, mei.p);
+            c->cnt.n_dt++;
+        }
+    }
+    return mei;
+}
+
+/* ------------------------------------------------------------------------- */
+/* E2: Medium::sample_interaction_drt [M3-ext]: ratio tracking along          */
+/* [0, maxt]; every tentative collision x_i carries weight T_i / majorant;    */
+/* one kept by weighted reservoir sampling; returns W = sum_i T_i / majorant  */
+/* so that E[W f(x')] = int_0^maxt T(t) f(t) dt  (call site :549-551).         */
+/* ------------------------------------------------------------------------- */
+static int sample_interaction_drt(ctx_t *c, const ray_t *ray, pcg32 *A, float *t_out, float *W_out)
+{
+    const scene_t *sc = c->sc;
+    float t = 0.0f, T = 1.0f, wsum = 0.0f, tsel = INFINITY;
+    int valid = 0;
+    for (;;) {
+        t += sample_distance(sc, next_1d(A));
+        if (!(t <= ray->maxt)) break;
+        float sig = eval_sigma_t(sc, ray_at(ray->o, ray->d, t));
+        c->cnt.n_drt++;
+        float w = T * sc->inv_majorant;
+        wsum += w;
+        float u = next_1d(A);
+        if (w > 0.0f && u * wsum <= w) { tsel = t; valid = 1; }
+        T *= (sc->majorant - sig) * sc->inv_majorant;
+        if (T == 0.0f) break;
+    }
+    *t_out = tsel; *W_out = wsum;
+    return valid;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A11/A12: PathState / DRTPathState / DRTReservoir (volpathsimple.py:660-765) */
+/* ------------------------------------------------------------------------- */
+typedef struct { int depth; si_t si; float last_pdf; int escaped; int active; } pstate_t;
+typedef struct {
+    int depth; si_t si; ray_t ray; int active;
+    float wsum[3], cw[3];
+} reservoir_t;
+
+static void drt_sample(ctx_t *c, pcg32 *S, int adjoint, ray_t ray, const float *dL,
+                       const float *state_in, const pstate_t *ps, float out[3]);
+
+/* A10: sample_recursive (volpathsimple.py:610-655) */
+static void sample_recursive(ctx_t *c, pcg32 *A, v3 p, int depth, float Li[3])
+{
+    const scene_t *sc = c->sc;
+    Li[0] = Li[1] = Li[2] = 0.0f;
+    if (sc->cfg.use_nee) {                               /* :621-624 */
+        const float one[3] = { 1.0f, 1.0f, 1.0f };
+        float nee[3];
+        sample_emitter_for_nee(c, p, A, one, NULL, nee);
+        for (int k = 0; k < 3; ++k) Li[k] += nee[k];
+    }
+    (void) next_1d(A);                                   /* phase.sample sample1 :632 */
+    float ux = next_1d(A), uy = next_1d(A);
+    v3 wo = square_to_uniform_sphere(ux, uy);
+    ray_t rr; rr.o = p; rr.d = wo;
+    si_t sn = box_hit(sc, p, wo);                        /* :637 */
+    rr.maxt = sn.valid ? sn.t : DRT_LARGEST;             /* :639-640 */
+    pstate_t ps;
+    ps.depth = depth + 1; ps.si = sn; ps.last_pdf = DRT_INV_FOURPI; ps.escaped = 0;
+    /* DEVIATION: an invalid si_next (fp corner case) deactivates the
+     * recursive path instead of tracking forever with maxt = largest. */
+    ps.active = (ps.depth < sc->cfg.max_depth) && sn.valid;  /* :647 */
+    float Lr[3];
+    drt_sample(c, A, 0, rr, NULL, NULL, &ps, Lr);        /* :651 */
+    for (int k = 0; k < 3; ++k) Li[k] += Lr[k];
+}
+
+/* A9: backpropagate_scattering_drt, final/quadratic branch (volpathsimple.py:543-581) */
+static void drt_backprop(ctx_t *c, pcg32 *A, const ray_t *ray, const si_t *si, int depth,
+                         const float adj[3])
+{
+    const scene_t *sc = c->sc;
+    ray_t sub = *ray;
+    sub.maxt = isfinite(si->t) ? si->t : DRT_LARGEST;    /* :544-545 */
+    float tp, W;
+    if (!sample_interaction_drt(c, &sub, A, &tp, &W)) return;   /* :550,558 */
+    v3 p = ray_at(sub.o, sub.d, tp);
+    float sig = eval_sigma_t(sc, p);                     /* :553-554 attached */
+    c->cnt.n_drt++;
+    float Li[3];
+    sample_recursive(c, A, p, depth, Li);                /* :565-568 */
+    float w = sc->cfg.use_drt_mis ? 1.0f / (1.0f + sig * sig) : 1.0f;   /* :571-575 */
+    float alb[3];
+    eval_albedo(sc, p, alb);                             /* :578 */
+    c->cnt.n_alb++;
+    float ww = w * W;
+    float gs = 0.0f, ga[3];
+    for (int k = 0; k < 3; ++k) {
+        float a = (ww * adj[k]) * Li[k];
+        gs += a * alb[k];
+        ga[k] = a * sig;
+    }
+    splat_sigma_t(c, p, gs); c->cnt.n_sc++;              /* :577-581 */
+    splat_albedo(c, p, ga);  c->cnt.n_sc_alb++;
+}
+
+/* A6: backpropagate_transmittance (volpathsimple.py:584-607) */
+static void backprop_transmittance(ctx_t *c, pcg32 *A, const ray_t *ray, float interval,
+                                   const float dL[3], const float result[3])
+{
+    float adjw = (dL[0] * result[0] + dL[1] * result[1]) + dL[2] * result[2];
+    float g = -(adjw * (interval / 4.0f));               /* contribs -= sigma_t; inv_pdf = interval/n */
+    for (int j = 0; j < 4; ++j) {
+        float t = next_1d(A) * interval;                 /* :595 */
+        splat_sigma_t(c, ray_at(ray->o, ray->d, t), g);
+        c->cnt.n_tr++;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A2: VolpathSimpleIntegrator.sample (volpathsimple.py:38-290)               */
+/* ------------------------------------------------------------------------- */
+static void drt_sample(ctx_t *c, pcg32 *S, int adjoint, ray_t ray, const float *dL,
+                       const float *state_in, const pstate_t *ps, float out[3])
+{
+    const scene_t *sc = c->sc;
+    const drto_config *cfg = &sc->cfg;
+    float result[3] = { 0, 0, 0 };
+    float beta[3] = { 1.0f, 1.0f, 1.0f };
+    if (adjoint) { result[0] = state_in[0]; result[1] = state_in[1]; result[2] = state_in[2]; }
+
+    int active, depth, escaped;
+    si_t si;
+    if (ps) {                                            /* :61-67 */
+        active = ps->active; depth = ps->depth; si = ps->si; escaped = ps->escaped;
+    } else {
+        active = 1; depth = 0; escaped = 0;
+        (void) next_1d(S);                               /* :71 colour-channel draw */
+        /* A3: reach_medium (:292-319) */
+        si = box_hit(sc, ray.o, ray.d);
+        if (!si.valid) { escaped = 1; active = 0; }
+        else {
+            ray.o = offset_p(&si, ray.d);                /* :306 */
+            si_t sn = box_hit(sc, ray.o, ray.d);         /* :307 */
+            if (!sn.valid) active = 0;                   /* :310 */
+            else { ray.maxt = sn.t; si = sn; }           /* :316-317 */
+        }
+    }
+    int has_scattered = ps ? (active && !escaped) : 0;   /* :84-89 */
+    float last_pdf = ps ? ps->last_pdf : 1.0f;
+
+    reservoir_t R;                                       /* :94-96 */
+    memset(&R, 0, sizeof R);
+    R.depth = -1; R.active = active;
+
+    pcg32 A; A.state = 0; A.inc = 1;
+    if (active) (void) next_1d(S);                       /* :99 alt_seed_rnd */
+    if (adjoint) sampler_seed(&A, c->alt_seed, c->ray_index);   /* :100-107 */
+
+    while (active) {                                     /* :114 */
+        /* Russian roulette (:117-121); the draw is consumed every iteration */
+        float q = fminf(max3f(beta[0], beta[1], beta[2]), 0.99f);
+        int perform_rr = depth > cfg->rr_depth;
+        float u_rr = next_1d(S);
+        active = (beta[0] != 0.0f || beta[1] != 0.0f || beta[2] != 0.0f)
+                 && (!perform_rr || (u_rr < q));
+        if (perform_rr) { float iq = 1.0f / q; beta[0] *= iq; beta[1] *= iq; beta[2] *= iq; }
+        if (!active) break;      /* everything below is masked by `active` */
+
+        mei_t mei = sample_real_interaction(c, &ray, S, adjoint);   /* :126 */
+        int did_escape = !mei.valid, did_scatter = mei.valid;       /* :130-134 */
+        has_scattered |= did_scatter;
+
+        float albedo[3] = { 1.0f, 1.0f, 1.0f };          /* :141 */
+        if (did_scatter) { eval_albedo(sc, mei.p, albedo); c->cnt.n_alb++; }
+
+        if (adjoint) {
+            if (cfg->use_drt) {                          /* :143-150 */
+                float adj[3] = { dL[0] * beta[0], dL[1] * beta[1], dL[2] * beta[2] };
+                if (cfg->use_drt_subsampling) {          /* :521-539, DRTReservoir.update :745-753 */
+                    float u = next_1d(&A);
+                    float m = 0.0f;
+                    for (int k = 0; k < 3; ++k) { R.wsum[k] += beta[k]; m += beta[k] / R.wsum[k]; }
+                    m = m / 3.0f;
+                    if (u <= m) {
+                        R.cw[0] = beta[0]; R.cw[1] = beta[1]; R.cw[2] = beta[2];
+                        R.depth = depth; R.si = si; R.ray = ray; R.active = 1;
+                    }
+                } else {
+                    drt_backprop(c, &A, &ray, &si, depth, adj);
+                }
+            }
+            if ((!cfg->use_drt || cfg->use_drt_mis) && did_scatter) {   /* :152-172 */
+                float w = 1.0f;
+                if (cfg->use_drt && cfg->use_drt_mis) {
+                    float s2 = mei.sigma_t * mei.sigma_t;
+                    w = s2 / (1.0f + s2);
+                }
+                float inv_pdf = 1.0f / mei.sigma_t;
+                float gs = 0.0f, ga[3];
+                for (int k = 0; k < 3; ++k) {
+                    float Li = result[k] / fmaxf(1e-8f, albedo[k]);     /* :167 */
+                    float a = ((w * dL[k]) * Li) * inv_pdf;
+                    gs += a * albedo[k];
+                    ga[k] = a * mei.sigma_t;
+                }
+                splat_sigma_t(c, mei.p, gs); c->cnt.n_sc++;
+                splat_albedo(c, mei.p, ga);  c->cnt.n_sc_alb++;
+            }
+            /* :181-189 */
+            backprop_transmittance(c, &A, &ray, did_escape ? si.t : mei.t, dL, result);
+        }
+
+        beta[0] *= albedo[0]; beta[1] *= albedo[1]; beta[2] *= albedo[2];   /* :193 */
+        if (did_scatter) depth += 1;                     /* :199 */
+        active = did_scatter && (depth < cfg->max_depth);/* :200 */
+
+        if (cfg->use_nee && did_scatter && active) {     /* :206-215 */
+            float nee[3];
+            sample_emitter_for_nee(c, mei.p, S, beta, adjoint ? dL : NULL, nee);
+            for (int k = 0; k < 3; ++k) result[k] = adjoint ? result[k] - nee[k] : result[k] + nee[k];
+        }
+
+        if (did_scatter) {                               /* :221-230 */
+            (void) next_1d(S);
+            float ux = next_1d(S), uy = next_1d(S);
+            ray.o = mei.p; ray.d = square_to_uniform_sphere(ux, uy); ray.maxt = DRT_LARGEST;
+            last_pdf = DRT_INV_FOURPI;
+        }
+        si = box_hit(sc, ray.o, ray.d);                  /* :233-235 (did_scatter | did_escape) */
+        ray.maxt = isfinite(si.t) ? si.t : DRT_LARGEST;
+        if (did_scatter && !si.valid) active = 0;        /* :240-241 accidental escape */
+        if (did_escape) {                                /* :244-245 */
+            if (si.valid) ray.o = offset_p(&si, ray.d);
+            escaped = 1;
+        }
+    }
+
+    if (adjoint && cfg->use_drt && cfg->use_drt_subsampling && R.active && R.depth >= 0) {  /* :249-259 */
+        float d = ((R.cw[0] + R.cw[1]) + R.cw[2]) / 3.0f;      /* DRTReservoir.get :756-760 */
+        float ws = ((R.wsum[0] + R.wsum[1]) + R.wsum[2]) / 3.0f;
+        float adj[3];
+        for (int k = 0; k < 3; ++k) adj[k] = (d != 0.0f ? (ws * R.cw[k]) / d : 0.0f) * dL[k];
+        drt_backprop(c, &A, &R.ray, &R.si, R.depth, adj);
+    }
+
+    if (!adjoint) {                                      /* :263-287 envmap, primal only */
+        if (escaped && !(depth <= 0 && cfg->hide_emitters)) {
+            float w = 1.0f;
+            if (cfg->use_nee) {
+                float epdf = has_scattered ? DRT_INV_FOURPI : 0.0f;    /* :273-277 */
+                w = mis_weight(last_pdf, epdf);
+            }
+            for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * sc->Le[k];
+        }
+    }
+    out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
+}
+
+/* ------------------------------------------------------------------------- */
+/* harness: scene setup, ray generation, job loops                            */
+/* ------------------------------------------------------------------------- */
+static int scene_init(scene_t *sc, const drto_job *job)
+{
+    const drto_medium *m = job->medium;
+    if (!job->cfg || !m || !job->emitter || !m->sigma_t) return -1;
+    sc->cfg = *job->cfg;
+    sc->sigma_t = m->sigma_t; sc->albedo = m->albedo;
+    sc->rx = m->res[0]; sc->ry = m->res[1]; sc->rz = m->res[2];
+    sc->bmin = v3_make(m->bbox_min[0], m->bbox_min[1], m->bbox_min[2]);
+    sc->bmax = v3_make(m->bbox_max[0], m->bbox_max[1], m->bbox_max[2]);
+    sc->inv_ext = v3_make(1.0f / (sc->bmax.x - sc->bmin.x), 1.0f / (sc->bmax.y - sc->bmin.y),
+                          1.0f / (sc->bmax.z - sc->bmin.z));
+    sc->scale = m->scale;
+    float mx = 0.0f;
+    size_t n = (size_t) sc->rx * sc->ry * sc->rz;
+    for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, m->sigma_t[i]);
+    sc->majorant = mx * m->scale;                         /* global majorant = scale * max(grid) */
+    sc->inv_majorant = sc->majorant != 0.0f ? 1.0f / sc->majorant : 0.0f;
+    for (int k = 0; k < 3; ++k) sc->Le[k] = job->emitter->radiance[k];
+    return 0;
+}
+
+/* perspective sensor (tests/test_integrators.py:46-67): sample position in
+ * [0,1]^2, (0,0) = top-left; camera x axis = `left`. */
+static inline void sensor_ray(const drto_sensor *s, uint32_t pixel, float ux, float uy, v3 *o, v3 *d)
+{
+    uint32_t py = pixel / (uint32_t) s->width, px = pixel - py * (uint32_t) s->width;
+    float sx = ((float) px + ux) * (1.0f / (float) s->width);
+    float sy = ((float) py + uy) * (1.0f / (float) s->height);
+    float cx = fmaf(-2.0f, sx, 1.0f) * s->tan_x;
+    float cy = fmaf(-2.0f, sy, 1.0f) * s->tan_y;
+    float inv = 1.0f / sqrtf(fmaf(cx, cx, fmaf(cy, cy, 1.0f)));
+    cx *= inv; cy *= inv; float cz = inv;
+    *o = v3_make(s->origin[0], s->origin[1], s->origin[2]);
+    *d = v3_make(fmaf(s->left[0], cx, fmaf(s->up[0], cy, s->dir[0] * cz)),
+                 fmaf(s->left[1], cx, fmaf(s->up[1], cy, s->dir[1] * cz)),
+                 fmaf(s->left[2], cx, fmaf(s->up[2], cy, s->dir[2] * cz)));
+}
+
+static inline void job_ray(const drto_job *job, uint64_t i, pcg32 *S, ray_t *ray)
+{
+    uint32_t gi = (uint32_t)(job->ray_offset + i);
+    sampler_seed(S, job->seed, gi);
+    if (job->sensor) {
+        float ux = next_1d(S), uy = next_1d(S);
+        sensor_ray(job->sensor, gi / job->spp, ux, uy, &ray->o, &ray->d);
+    } else {
+        ray->o = v3_make(job->rays_o[3 * i], job->rays_o[3 * i + 1], job->rays_o[3 * i + 2]);
+        ray->d = v3_make(job->rays_d[3 * i], job->rays_d[3 * i + 1], job->rays_d[3 * i + 2]);
+    }
+    ray->maxt = DRT_LARGEST;
+}
+
+/* volpathsimple.py:99-107: alt_seed = tea32(bits(lane-0 draw), 1)[0].  Lane 0's
+ * draw index is fixed (2nd draw of its stream; 4th in the sensor flow). */
+uint32_t drto_alt_seed(uint32_t seed, int sensor_flow)
+{
+    pcg32 S;
+    sampler_seed(&S, seed, 0);
+    int skip = sensor_flow ? 3 : 1;
+    for (int k = 0; k < skip; ++k) (void) next_1d(&S);
+    float u = next_1d(&S);
+    uint32_t v0, v1;
+    tea32(f2u(u), 1u, &v0, &v1);
+    return v0;
+}
+
+static void cnt_add(drto_counters *a, const drto_counters *b)
+{
+    a->n_rays += b->n_rays; a->n_dt += b->n_dt; a->n_rt += b->n_rt; a->n_drt += b->n_drt;
+    a->n_alb += b->n_alb; a->n_tr += b->n_tr; a->n_rt_adj += b->n_rt_adj;
+    a->n_sc += b->n_sc; a->n_sc_alb += b->n_sc_alb;
+}
+
+static int run_job(const drto_job *job, int adjoint, const float *dL, const float *L_in,
+                   float *L_out, double *g_sigma, double *g_albedo, drto_counters *cnt)
+{
+    scene_t sc;
+    if (scene_init(&sc, job)) return -1;
+    if (!sc.albedo) return -2;
+    uint32_t alt_seed = drto_alt_seed(job->seed, job->sensor != NULL);
+    drto_counters total; memset(&total, 0, sizeof total);
+#ifdef _OPENMP
+    int nt = job->n_threads > 0 ? job->n_threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nt)
+#endif
+    {
+        ctx_t c; memset(&c, 0, sizeof c);
+        c.sc = &sc; c.g_sigma = g_sigma; c.g_albedo = g_albedo; c.alt_seed = alt_seed;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 256)
+#endif
+        for (int64_t i = 0; i < (int64_t) job->n_rays; ++i) {
+            pcg32 S; ray_t ray;
+            job_ray(job, (uint64_t) i, &S, &ray);
+            c.ray_index = (uint32_t)(job->ray_offset + (uint64_t) i);
+            c.cnt.n_rays++;
+            float L[3];
+            if (adjoint) drt_sample(&c, &S, 1, ray, dL + 3 * i, L_in + 3 * i, NULL, L);
+            else {
+                drt_sample(&c, &S, 0, ray, NULL, NULL, NULL, L);
+                L_out[3 * i] = L[0]; L_out[3 * i + 1] = L[1]; L_out[3 * i + 2] = L[2];
+            }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        cnt_add(&total, &c.cnt);
+    }
+    if (cnt) cnt_add(cnt, &total);
+    return 0;
+}
+
+int drto_render_primal(const drto_job *job, float *L_out, drto_counters *cnt)
+{
+    return run_job(job, 0, NULL, NULL, L_out, NULL, NULL, cnt);
+}
+
+int drto_render_backward(const drto_job *job, const float *dL, const float *L_in,
+                         double *grad_sigma_t, double *grad_albedo, drto_counters *cnt)
+{
+    return run_job(job, 1, dL, L_in, NULL, grad_sigma_t, grad_albedo, cnt);
+}
+
+int drto_h1_step(const drto_job *job, float *L, float *image, double *loss_out,
+                 double *grad_sigma_t, double *grad_albedo, drto_counters *cnt)
+{
+    int rc = drto_render_primal(job, L, cnt);             /* batched.py:255-264 */
+    if (rc) return rc;
+    uint64_t npix = job->n_rays / job->spp;
+    double loss = 0.0;
+    float inv_spp = 1.0f / (float) job->spp;
+    /* box film: image[p] = mean_spp L (batched.py:272-297); loss = mean((img-0.5)^2) */
+    for (uint64_t p = 0; p < npix; ++p)
+        for (int k = 0; k < 3; ++k) {
+            float s = 0.0f;
+            for (uint32_t j = 0; j < job->spp; ++j) s += L[3 * (p * job->spp + j) + k];
+            float v = s * inv_spp;
+            image[3 * p + k] = v;
+            loss += ((double) v - 0.5) * ((double) v - 0.5);
+        }
+    loss /= (double)(npix * 3);
+    if (loss_out) *loss_out = loss;
+    /* dL_i = dloss/dimage[p(i)] / spp  (batched.py:298-306) */
+    float *dL = (float *) malloc(sizeof(float) * 3 * job->n_rays);
+    if (!dL) return -3;
+    float gscale = 2.0f / (float)(npix * 3);
+    for (uint64_t i = 0; i < job->n_rays; ++i)
+        for (int k = 0; k < 3; ++k)
+            dL[3 * i + k] = (gscale * (image[3 * (i / job->spp) + k] - 0.5f)) * inv_spp;
+    rc = drto_render_backward(job, dL, L, grad_sigma_t, grad_albedo, cnt);  /* batched.py:309-318 */
+    free(dL);
+    return rc;
+}
+
+/* Textbook analog delta-tracking path tracer: escape -> Le, collide -> albedo,
+ * uniform phase.  No NEE/MIS; its own RNG consumption order. */
+int drto_render_textbook(const drto_job *job, float *L_out)
+{
+    scene_t sc;
+    if (scene_init(&sc, job)) return -1;
+#ifdef _OPENMP
+    int nt = job->n_threads > 0 ? job->n_threads : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nt)
+#endif
+    for (int64_t i = 0; i < (int64_t) job->n_rays; ++i) {
+        pcg32 S; ray_t ray;
+        job_ray(job, (uint64_t) i, &S, &ray);
+        float beta[3] = { 1, 1, 1 }, L[3] = { 0, 0, 0 };
+        si_t si = box_hit(&sc, ray.o, ray.d);
+        int inside = 0;
+        if (si.valid) {
+            ray.o = offset_p(&si, ray.d);
+            si_t sn = box_hit(&sc, ray.o, ray.d);
+            if (sn.valid) { inside = 1; ray.maxt = sn.t; }
+        }
+        int depth = 0, alive = 1;
+        while (inside && alive) {
+            float t = 0.0f; int real = 0;
+            for (;;) {
+                t += sample_distance(&sc, next_1d(&S));
+                if (!(t <= ray.maxt)) break;
+                float sig = eval_sigma_t(&sc, ray_at(ray.o, ray.d, t));
+                if (next_1d(&S) * sc.majorant < sig) { real = 1; break; }
+            }
+            if (!real) break;                             /* escaped: add Le below */
+            v3 p = ray_at(ray.o, ray.d, t);
+            float a[3]; eval_albedo(&sc, p, a);
+            beta[0] *= a[0]; beta[1] *= a[1]; beta[2] *= a[2];
+            if (++depth >= sc.cfg.max_depth) { alive = 0; break; }
+            float ux = next_1d(&S), uy = next_1d(&S);
+            ray.o = p; ray.d = square_to_uniform_sphere(ux, uy);
+            si_t sn = box_hit(&sc, ray.o, ray.d);
+            if (!sn.valid) { alive = 0; break; }
+            ray.maxt = sn.t;
+        }
+        if (alive) for (int k = 0; k < 3; ++k) L[k] = beta[k] * sc.Le[k];
+        L_out[3 * i] = L[0]; L_out[3 * i + 1] = L[1]; L_out[3 * i + 2] = L[2];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* test hooks                                                                 */
+/* ------------------------------------------------------------------------- */
+static void scene_from_medium(scene_t *sc, const drto_medium *m)
+{
+    drto_config cfg; memset(&cfg, 0, sizeof cfg);
+    drto_emitter em = { { 0, 0, 0 } };
+    drto_job job; memset(&job, 0, sizeof job);
+    job.cfg = &cfg; job.medium = m; job.emitter = &em;
+    scene_init(sc, &job);
+}
+uint32_t drto_tea32(uint32_t v0, uint32_t v1, uint32_t *out_v1)
+{
+    uint32_t a, b; tea32(v0, v1, &a, &b); if (out_v1) *out_v1 = b; return a;
+}
+void drto_pcg32_floats(uint32_t seed, uint32_t index, int n, float *out)
+{
+    pcg32 S; sampler_seed(&S, seed, index);
+    for (int i = 0; i < n; ++i) out[i] = next_1d(&S);
+}
+void drto_pcg32_raw(uint64_t initstate, uint64_t initseq, int n, uint32_t *out)
+{
+    pcg32 S; pcg32_seed(&S, initstate, initseq);
+    for (int i = 0; i < n; ++i) out[i] = pcg32_next_u32(&S);
+}
+void drto_uniform_sphere(float ux, float uy, float out[3])
+{
+    v3 d = square_to_uniform_sphere(ux, uy);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+float drto_logf(float x) { return drt_logf(x); }
+void drto_sincos_2pi(float u, float *s, float *c) { drt_sincos_2pi(u, s, c); }
+float drto_eval_sigma_t(const drto_medium *m, const float p[3])
+{
+    scene_t sc; scene_from_medium(&sc, m);
+    return eval_sigma_t(&sc, v3_make(p[0], p[1], p[2]));
+}
+void drto_eval_albedo(const drto_medium *m, const float p[3], float out[3])
+{
+    scene_t sc; scene_from_medium(&sc, m);
+    eval_albedo(&sc, v3_make(p[0], p[1], p[2]), out);
+}
+float drto_majorant(const drto_medium *m)
+{
+    scene_t sc; scene_from_medium(&sc, m);
+    return sc.majorant;
+}
+double drto_ratio_tracking_mean(const drto_medium *m, const float o[3], const float d[3],
+                                float tmax, uint32_t seed, int n)
+{
+    scene_t sc; scene_from_medium(&sc, m);
+    ctx_t c; memset(&c, 0, sizeof c); c.sc = &sc;
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+        pcg32 S; sampler_seed(&S, seed, (uint32_t) i);
+        acc += (double) estimate_transmittance(&c, v3_make(o[0], o[1], o[2]),
+                                               v3_make(d[0], d[1], d[2]), tmax, &S, NULL);
+    }
+    return acc / (double) n;
+}
+int drto_box_hit(const drto_medium *m, const float o[3], const float d[3], float *t, float n[3])
+{
+    scene_t sc; scene_from_medium(&sc, m);
+    si_t si = box_hit(&sc, v3_make(o[0], o[1], o[2]), v3_make(d[0], d[1], d[2]));
+    *t = si.t; n[0] = si.n.x; n[1] = si.n.y; n[2] = si.n.z;
+    return si.valid;
+}
+void drto_sensor_ray(const drto_sensor *s, uint32_t pixel, float ux, float uy, float o[3], float d[3])
+{
+    v3 oo, dd; sensor_ray(s, pixel, ux, uy, &oo, &dd);
+    o[0] = oo.x; o[1] = oo.y; o[2] = oo.z; d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
+}

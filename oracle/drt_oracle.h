@@ -1,0 +1,150 @@
+/*
+ * drt_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Scalar, per-ray restatement in plain C of the reference's differential
+ * ratio tracking integrator:
+ *     /root/reference/python/integrators/volpathsimple.py   (whole file)
+ *     /root/reference/python/batched.py:212-326             (primal -> dL -> adjoint sequence)
+ * plus the slice of the Mitsuba 3 branch `unbiased-inverse-volume-rendering`
+ * that those files call (Medium::sample_interaction[_drt], GridVolume::eval,
+ * PCG32 `independent` sampler, sample_tea_32, constant emitter, isotropic
+ * phase, AABB fast-path intersection).
+ *
+ * PARITY UNPINNED: Mitsuba 3 / Dr.Jit are third-party dependencies that are
+ * absent from /root/reference and cannot be imported in the authoring
+ * container (no wheel, no network, branch pinned by name only in
+ * README.md:97-104); the reference tests store no golden vectors
+ * (tests/test_integrators.py:222-347 compare two live Mitsuba runs).
+ * The Mitsuba-side semantics are therefore restated from the call sites
+ * and public upstream behaviour; the oracle is pinned by analytic
+ * known-answer tests and finite differences (tests/test_oracle_*.py), not
+ * by reference outputs.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (unbiased-inverse-volume-rendering_amd/)
+ * never links, imports or calls it.
+ */
+#ifndef DRT_ORACLE_H
+#define DRT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Integrator properties: volpathsimple.py:19-36 (+ max_depth / rr_depth of the
+ * RBIntegrator base, used at :118,200). */
+typedef struct drto_config {
+    int32_t hide_emitters;
+    int32_t use_nee;
+    int32_t use_drt;
+    int32_t use_drt_subsampling;
+    int32_t use_drt_mis;
+    int32_t max_depth;
+    int32_t rr_depth;
+} drto_config;
+
+/* Heterogeneous medium inside an axis-aligned box (tests/test_integrators.py:79-111).
+ * Grids are Mitsuba VolumeGrid tensors, shape (Z,Y,X,C), x fastest. */
+typedef struct drto_medium {
+    const float *sigma_t;   /* (Z,Y,X,1) */
+    const float *albedo;    /* (Z,Y,X,3) */
+    int32_t res[3];         /* X, Y, Z */
+    float bbox_min[3];
+    float bbox_max[3];
+    float scale;            /* medium `scale` (density_scale) */
+} drto_medium;
+
+/* `constant` emitter (tests/test_integrators.py:73-77). */
+typedef struct drto_emitter {
+    float radiance[3];
+} drto_emitter;
+
+/* Perspective sensor after look_at: world-space orthonormal frame.
+ * left = normalize(cross(up, dir)), up' = cross(dir, left). */
+typedef struct drto_sensor {
+    float origin[3];
+    float left[3];
+    float up[3];
+    float dir[3];
+    float tan_x;            /* tan(fov_x / 2) */
+    float tan_y;            /* tan_x * height / width */
+    int32_t width, height;
+} drto_sensor;
+
+/* Event counters: one unit = one trilinear lookup or splat. */
+typedef struct drto_counters {
+    uint64_t n_rays;
+    uint64_t n_dt;       /* sigma_t lookups in delta tracking (A4) incl. attached re-eval */
+    uint64_t n_rt;       /* sigma_t lookups in ratio tracking (A8), all runs */
+    uint64_t n_drt;      /* sigma_t lookups in sample_interaction_drt (E2) incl. re-eval */
+    uint64_t n_alb;      /* albedo lookups (A5, A9) */
+    uint64_t n_tr;       /* transmittance-resampling splats (A6) */
+    uint64_t n_rt_adj;   /* ratio-tracking adjoint splats (A8 second run) */
+    uint64_t n_sc;       /* sigma_t scattering-gradient splats (A5 + A9) */
+    uint64_t n_sc_alb;   /* albedo scattering-gradient splats (A5 + A9) */
+} drto_counters;
+
+/* A render job.  Ray i (global index = ray_offset + i) uses the primary PCG32
+ * stream seeded with tea32(seed, ray_offset + i).
+ *   sensor != NULL : mi.render flow - pixel = index / spp, film position drawn
+ *                    from the ray's own stream (2 draws) before sample().
+ *   sensor == NULL : batched flow (batched.py:426-467) - rays_o/rays_d given. */
+typedef struct drto_job {
+    const drto_config  *cfg;
+    const drto_medium  *medium;
+    const drto_emitter *emitter;
+    const drto_sensor  *sensor;
+    const float *rays_o;    /* [n][3] or NULL */
+    const float *rays_d;    /* [n][3] or NULL */
+    uint64_t n_rays;        /* rays in this job (shard) */
+    uint64_t ray_offset;    /* global index of the first ray */
+    uint32_t spp;
+    uint32_t seed;
+    int32_t  n_threads;     /* OpenMP threads (0 = default) */
+} drto_job;
+
+/* sample(Primal): L_out[n][3].  volpathsimple.py:38-290 */
+int drto_render_primal(const drto_job *job, float *L_out, drto_counters *cnt);
+
+/* sample(Backward) given dL[n][3] and state_in = L_in[n][3] (batched.py:309-318).
+ * Accumulates (+=) into grad_sigma_t (Z,Y,X,1) and grad_albedo (Z,Y,X,3). */
+int drto_render_backward(const drto_job *job, const float *dL, const float *L_in,
+                         double *grad_sigma_t, double *grad_albedo, drto_counters *cnt);
+
+/* Whole H1 step (batched.py:255-326) with the test loss mean((img-0.5)^2)
+ * (tests/test_integrators.py:119): primal -> image -> dL -> adjoint.
+ * image_out[n/spp][3] and L_scratch[n][3] are caller-allocated. */
+int drto_h1_step(const drto_job *job, float *L_scratch, float *image_out, double *loss_out,
+                 double *grad_sigma_t, double *grad_albedo, drto_counters *cnt);
+
+/* Independent textbook delta-tracking path tracer (no NEE, no MIS, own RNG use):
+ * plays the role of Mitsuba's builtin `volpath` in tests/test_integrators.py:222-257. */
+int drto_render_textbook(const drto_job *job, float *L_out);
+
+/* --- test hooks on the primitives ---------------------------------------- */
+uint32_t drto_tea32(uint32_t v0, uint32_t v1, uint32_t *out_v1);
+void     drto_pcg32_floats(uint32_t seed, uint32_t index, int n, float *out);
+void     drto_pcg32_raw(uint64_t initstate, uint64_t initseq, int n, uint32_t *out);
+void     drto_uniform_sphere(float ux, float uy, float out[3]);
+float    drto_logf(float x);
+void     drto_sincos_2pi(float u, float *s, float *c);
+float    drto_eval_sigma_t(const drto_medium *m, const float p[3]);
+void     drto_eval_albedo(const drto_medium *m, const float p[3], float out[3]);
+float    drto_majorant(const drto_medium *m);
+/* mean ratio-tracking transmittance estimate over n independent walks (A8). */
+double   drto_ratio_tracking_mean(const drto_medium *m, const float o[3], const float d[3],
+                                  float tmax, uint32_t seed, int n);
+/* returns 1 and fills t / normal if the ray hits the medium box surface (E4). */
+int      drto_box_hit(const drto_medium *m, const float o[3], const float d[3],
+                      float *t, float n[3]);
+void     drto_sensor_ray(const drto_sensor *s, uint32_t pixel, float ux, float uy,
+                         float o[3], float d[3]);
+/* alt-sampler seed derived from lane 0's draw (volpathsimple.py:99-107). */
+uint32_t drto_alt_seed(uint32_t seed, int sensor_flow);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

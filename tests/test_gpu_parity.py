@@ -1,0 +1,267 @@
+"""GPU parity tests: the HIP path (through the pybind11 shim over the C ABI) against
+the CPU oracle on the same seeded inputs, plus size-independent properties at the
+BASELINE sizes.  Tolerances:
+  * primal radiance per ray: BIT-EXACT (same arithmetic specification)
+  * event counters: exactly equal (integers)
+  * gradients: |hip - oracle| <= 2e-4 * max|oracle| + 1e-9 (fp32 atomics in
+    arbitrary order vs fp64 accumulation of identical per-ray contributions)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import VARIANTS, props_for
+
+pytestmark = pytest.mark.gpu
+
+GRAD_RTOL = 2e-4
+
+
+def _integrator(uivr, props):
+    d = {"type": "volpathsimple"}
+    d.update(props)
+    return uivr.load_dict(d)
+
+
+def _h1_gpu(uivr, scene_gpu, integ, spp, seed, shard=None):
+    """primal -> dL (loss mean((img-0.5)^2) over the FULL image) -> adjoint on the GPU."""
+    s = scene_gpu.sensors[0]
+    n_total = s.width * s.height
+    img = uivr.render_primal(scene_gpu, integ, 0, spp, seed, shard)
+    grad_img = (2.0 / (n_total * 3)) * (img - 0.5)
+    grads = uivr.render_backward(scene_gpu, integ, grad_img.contiguous(), 0, spp, seed, shard)
+    return img, grads
+
+
+def _assert_grads_close(g_hip, g_ref, what):
+    g_hip = g_hip.detach().cpu().numpy().astype(np.float64)
+    tol = GRAD_RTOL * np.abs(g_ref).max() + 1e-9
+    err = np.abs(g_hip - g_ref).max()
+    assert err <= tol, f"{what}: max abs err {err:.3e} > tol {tol:.3e}"
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_cube_primal_bit_exact_and_gradients(uivr, oracle, gpu, variant):
+    """3^3 fixture of the reference (tests/test_integrators.py:19-116), every estimator."""
+    props = props_for(variant)
+    scene = uivr.cube_test_scene(32, 32, density_scale=2.0)
+    spp, seed = 16, 12345
+    osc = oracle.OracleScene(scene)
+    ref = oracle.h1_step(osc, props, spp, seed)
+
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props)
+    batch = uivr.RayBatch(n_rays=32 * 32 * spp, spp=spp, sensor=sg.sensors[0])
+    L, valid, state = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(seed, spp), batch)
+    L = L.cpu().numpy()
+    assert L.dtype == np.float32
+    np.testing.assert_array_equal(L.view(np.uint32), ref["L"].view(np.uint32))
+
+    img, grads = _h1_gpu(uivr, sg, integ, spp, seed)
+    np.testing.assert_allclose(img.cpu().numpy(), ref["image"], rtol=0, atol=1e-6)
+    _assert_grads_close(grads[uivr.SIGMA_T_KEY], ref["grad_sigma_t"], f"{variant} grad sigma_t")
+    _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], f"{variant} grad albedo")
+
+
+def test_counters_equal_oracle(uivr, oracle, gpu):
+    props = props_for("drt")
+    scene = uivr.cube_test_scene(16, 16, density_scale=2.0)
+    spp, seed = 8, 99
+    ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props)
+    h = integ.native_handle(sg)
+    h.enable_counters(True)
+    h.reset_counters()
+    _h1_gpu(uivr, sg, integ, spp, seed)
+    cnt = h.get_counters()
+    h.enable_counters(False)
+    # render_backward re-runs the primal (H1 step 1): the oracle's h1_step counts
+    # primal + adjoint once each, the GPU sequence primal (image) + primal + adjoint.
+    primal_only, _ = None, None
+    L, c_primal = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)
+    expect = {k: ref["counters"][k] + c_primal[k] for k in ref["counters"]}
+    assert {k: int(v) for k, v in cnt.items()} == expect
+
+
+def test_heterogeneous_grid_explicit_rays(uivr, oracle, gpu):
+    """Batched flow (explicit rays, batched.py:426-467) on a 16^3 random grid."""
+    rng = np.random.default_rng(7)
+    res = 16
+    sigma_t = (rng.random((res, res, res, 1), dtype=np.float32) ** 3 * 6.0).astype(np.float32)
+    albedo = rng.random((res, res, res, 3), dtype=np.float32) * 0.9 + 0.05
+    medium = uivr.GridMedium(sigma_t=sigma_t, albedo=albedo.astype(np.float32),
+                             bbox_min=(-1, -0.5, 0), bbox_max=(1, 1.5, 3), scale=1.5)
+    scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter((0.7, 1.1, 0.4)), sensors=[])
+    n, spp, seed = 4096, 4, 4242
+    o = rng.normal(size=(n, 3)).astype(np.float32) * 0.3 + np.array([0, 0.5, -4], dtype=np.float32)
+    tgt = rng.random((n, 3), dtype=np.float32) * np.array([2, 2, 3], dtype=np.float32) + np.array([-1, -0.5, 0], dtype=np.float32)
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    props = props_for("drt")
+    osc = oracle.OracleScene(scene, sensor_index=None)
+    Lr, _ = oracle.render_primal(osc, props, spp, seed, rays_o=o, rays_d=d)
+    dL = (rng.random((n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    gs, ga, _ = oracle.render_backward(osc, props, spp, seed, dL, Lr, rays_o=o, rays_d=d)
+
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props)
+    batch = uivr.RayBatch(n_rays=n, spp=spp, o=torch.from_numpy(o).to(gpu), d=torch.from_numpy(d).to(gpu))
+    samp = uivr.IndependentSampler(seed, spp)
+    L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+    grads = uivr.alloc_grads(sg)
+    integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=st, grads=grads)
+    _assert_grads_close(grads[uivr.SIGMA_T_KEY], gs, "grad sigma_t")
+    _assert_grads_close(grads[uivr.ALBEDO_KEY], ga, "grad albedo")
+
+
+def test_edge_cases(uivr, oracle, gpu):
+    """Empty batch, all rays missing the box, zero density, zero albedo, max_depth 0/1."""
+    scene = uivr.cube_test_scene(8, 8, density_scale=2.0)
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props_for("drt"))
+    # empty batch
+    batch = uivr.RayBatch(n_rays=0, spp=1, o=torch.zeros((0, 3), device=gpu), d=torch.zeros((0, 3), device=gpu))
+    L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(1, 1), batch)
+    assert L.shape == (0, 3)
+    # all rays miss: L == Le exactly (MIS weight 1 for directly visible emitter)
+    n = 256
+    o = torch.tensor([[10.0, 10.0, 10.0]], device=gpu).repeat(n, 1)
+    d = torch.tensor([[0.0, 1.0, 0.0]], device=gpu).repeat(n, 1)
+    L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(1, 1), uivr.RayBatch(n_rays=n, spp=1, o=o, d=d))
+    np.testing.assert_array_equal(L.cpu().numpy(), np.tile(np.array([1.0, 0.8, 0.2], np.float32), (n, 1)))
+    # zero density / zero albedo / shallow depth: bit-exact against the oracle
+    for mod, over in [("zero_density", {}), ("zero_albedo", {}), ("depth0", dict(max_depth=0)), ("depth1", dict(max_depth=1))]:
+        sc = uivr.cube_test_scene(8, 8, density_scale=2.0)
+        if mod == "zero_density":
+            sc.medium.sigma_t[...] = 0.0
+        if mod == "zero_albedo":
+            sc.medium.albedo[...] = 0.0
+        props = props_for("drt", **over)
+        ref = oracle.h1_step(oracle.OracleScene(sc), props, 4, 5)
+        sgi = uivr.scene_to(sc, gpu)
+        it = _integrator(uivr, props)
+        img, grads = _h1_gpu(uivr, sgi, it, 4, 5)
+        np.testing.assert_allclose(img.cpu().numpy(), ref["image"], rtol=0, atol=1e-6, err_msg=mod)
+        _assert_grads_close(grads[uivr.SIGMA_T_KEY], ref["grad_sigma_t"], mod)
+        _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], mod)
+        assert torch.isfinite(grads["_flat"]).all(), mod
+
+
+def test_error_behaviour(uivr, gpu):
+    scene = uivr.cube_test_scene(8, 8)
+    integ = _integrator(uivr, props_for("drt"))
+    with pytest.raises((TypeError, RuntimeError)):
+        # numpy grids: no CPU path
+        integ.sample(uivr.ADMode.Primal, scene, uivr.IndependentSampler(1, 1),
+                     uivr.RayBatch(n_rays=64, spp=1, sensor=scene.sensors[0]))
+    sg = uivr.scene_to(scene, gpu)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(1, 1),
+                     uivr.RayBatch(n_rays=8 * 8 * 2, spp=1, sensor=sg.sensors[0]))
+    with pytest.raises(ValueError):
+        integ.sample(uivr.ADMode.Backward, sg, uivr.IndependentSampler(1, 1),
+                     uivr.RayBatch(n_rays=64, spp=1, sensor=sg.sensors[0]))
+    with pytest.raises(Exception, match="seed"):
+        uivr.render(sg, integrator=integ, spp=1, seed=5, seed_grad=5)
+
+
+def test_sharded_equals_unsharded(uivr, gpu):
+    """Logical shards on one device: image tiles dealt to `world` ranks,
+    global-index random streams => identical pixels, gradients equal up to fp order."""
+    scene = uivr.cube_test_scene(32, 32, density_scale=2.0)
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props_for("drt"))
+    spp, seed = 8, 321
+    img, grads = _h1_gpu(uivr, sg, integ, spp, seed)
+    for world in (2, 4):
+        acc_img = torch.zeros_like(img)
+        acc = None
+        for rank in range(world):
+            shard = uivr.ShardSpec(rank, world, chunk_pixels=64)
+            li, lg = _h1_gpu(uivr, sg, integ, spp, seed, shard)
+            acc_img[shard.pixel_indices(32 * 32, gpu)] = li
+            acc = lg["_flat"].clone() if acc is None else acc + lg["_flat"]
+        assert torch.equal(acc_img, img)
+        tol = GRAD_RTOL * grads["_flat"].abs().max().item()
+        assert (acc - grads["_flat"]).abs().max().item() <= tol
+
+
+def test_autograd_render_op(uivr, gpu):
+    """`render` + torch autograd == explicit H1 sequence (mi.render / dr.backward)."""
+    scene = uivr.cube_test_scene(16, 16, density_scale=2.0)
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props_for("drt"))
+    params = {uivr.SIGMA_T_KEY: sg.medium.sigma_t.clone().requires_grad_(True),
+              uivr.ALBEDO_KEY: sg.medium.albedo.clone().requires_grad_(True)}
+    img = uivr.render(sg, params=params, integrator=integ, spp=8, spp_grad=4, seed=10, seed_grad=11)
+    loss = ((img - 0.5) ** 2).mean()
+    loss.backward()
+    grad_img = (2.0 / img.numel()) * (img.detach() - 0.5)
+    ref = uivr.render_backward(sg, integ, grad_img.contiguous(), 0, 4, 11)
+    tol = GRAD_RTOL * ref["_flat"].abs().max().item()
+    assert (params[uivr.SIGMA_T_KEY].grad - ref[uivr.SIGMA_T_KEY]).abs().max().item() <= tol
+    assert (params[uivr.ALBEDO_KEY].grad - ref[uivr.ALBEDO_KEY]).abs().max().item() <= tol
+
+
+def test_full_size_properties(uivr, gpu):
+    """BASELINE headline size (256^3 grid, 512^2 x 32 spp): properties that need no oracle.
+    (a) white furnace: albedo 1, constant emitter => every pixel == Le up to the energy
+        lost to max_depth (none here: the volume is thin enough) and MC noise;
+    (b) determinism: the primal is bitwise reproducible;
+    (c) linearity of the adjoint in dL."""
+    from uivr_amd import synthetic
+    scene = synthetic.dust_devil_scene(res=256, film=512, device=gpu)
+    integ = _integrator(uivr, props_for("drt"))
+    spp = 32
+    sc_white = uivr.Scene(medium=uivr.GridMedium(sigma_t=scene.medium.sigma_t,
+                                                albedo=torch.ones_like(scene.medium.albedo),
+                                                bbox_min=scene.medium.bbox_min, bbox_max=scene.medium.bbox_max),
+                          emitter=uivr.ConstantEmitter((1.0, 0.8, 0.2)), sensors=scene.sensors)
+    img = uivr.render_primal(sc_white, integ, 0, spp, 7)
+    mean = img.mean(dim=0).cpu().numpy()
+    np.testing.assert_allclose(mean, [1.0, 0.8, 0.2], rtol=2e-3)
+    assert float(img.max()) < 4.0 and float(img.min()) >= 0.0
+
+    a = uivr.render_primal(scene, integ, 0, spp, 7)
+    b = uivr.render_primal(scene, integ, 0, spp, 7)
+    assert torch.equal(a, b)
+
+    s = scene.sensors[0]
+    gi = torch.randn((s.width * s.height, 3), device=gpu) * 1e-6
+    g1 = uivr.render_backward(scene, integ, gi, 0, 4, 9)["_flat"]
+    g2 = uivr.render_backward(scene, integ, 2.0 * gi, 0, 4, 9)["_flat"]
+    scale = g1.abs().max().item()
+    assert scale > 0
+    assert (g2 - 2.0 * g1).abs().max().item() <= 1e-3 * scale
+
+
+def test_constant_cube_transmittance_kat(uivr, gpu):
+    """BASELINE config 1 (64^3 constant sigma_t, 128^2 x 4 spp... here 64 spp for noise):
+    albedo 0 => L = Le * exp(-sigma_t * chord) in expectation (analytic known answer)."""
+    from uivr_amd import synthetic
+    scene = synthetic.constant_cube_scene(res=64, sigma_t=1.0, albedo=0.0, film=128, device=gpu)
+    integ = _integrator(uivr, props_for("drt"))
+    spp = 64
+    img = uivr.render_primal(scene, integ, 0, spp, 1234).cpu().numpy().reshape(128, 128, 3)
+    # analytic chord through [-0.5,1.5]^3 along each pixel-centre ray
+    f = scene.sensors[0].frame()
+    ys, xs = np.meshgrid(np.arange(128) + 0.5, np.arange(128) + 0.5, indexing="ij")
+    cx = (1 - 2 * xs / 128) * f["tan_x"]
+    cy = (1 - 2 * ys / 128) * f["tan_y"]
+    d = cx[..., None] * f["left"] + cy[..., None] * f["up"] + f["dir"]
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    o = f["origin"]
+    with np.errstate(divide="ignore"):
+        t0 = (-0.5 - o) / d
+        t1 = (1.5 - o) / d
+    tn = np.minimum(t0, t1).max(-1)
+    tf = np.maximum(t0, t1).min(-1)
+    chord = np.clip(tf - np.maximum(tn, 0), 0, None)
+    expect = np.exp(-chord)[..., None] * np.array([1.0, 0.8, 0.2])
+    inner = chord > 0.5   # away from silhouette pixels (sub-pixel chord variation)
+    err = np.abs(img - expect)[inner]
+    sigma = np.sqrt(np.maximum(expect * (1 - np.exp(-chord)[..., None]), 1e-6) / spp)[inner]
+    assert (err < 5 * sigma + 0.02).all()
+    assert abs(img[inner].mean() - expect[inner].mean()) < 5e-3

@@ -1,0 +1,371 @@
+// drt_capi.cpp -- the C ABI of libdrt_hip.so (include/drt_hip.h).
+//
+// Host-side state of one integrator instance bound to one GPU: the borrowed
+// parameter pointers, the device-resident majorant, the emitter / sensor, and the
+// stream all work is enqueued on.  No C++ exceptions cross the ABI.
+#include "../../include/drt_hip.h"
+#include "drt_launch.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct drt_handle_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    drt_config cfg{};
+    drt::Params base{};            // scene part of the kernel parameter block
+    bool have_medium = false, have_emitter = false, have_sensor = false;
+    float *d_majorant = nullptr;   // [2]
+    uint32_t *d_scratch = nullptr; // [1]
+    unsigned long long *d_counters = nullptr;   // [C_COUNT]
+    bool counting = false;
+    uint64_t chunk = 0, stride = 0;   // ray interleave (drt_set_ray_interleave)
+    bool timing = false;
+    // HIP event pairs around every tracing launch while timing is on: [0] primal, [1] backward
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[2];
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(drt_handle h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->error = buf;
+    g_error = buf;
+    return code;
+}
+
+#define DRT_HIP_CHECK(h, expr)                                                              \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(h, DRT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+
+int check_job(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
+              uint64_t ray_offset, uint32_t spp)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->have_medium) return fail(h, DRT_ERR_NOT_CONFIGURED, "no medium: call drt_set_medium first");
+    if (!h->have_emitter) return fail(h, DRT_ERR_NOT_CONFIGURED, "no emitter: call drt_set_emitter_constant first");
+    if ((rays_o == nullptr) != (rays_d == nullptr))
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "rays_o and rays_d must both be given or both be NULL");
+    if (!rays_o && !h->have_sensor)
+        return fail(h, DRT_ERR_NOT_CONFIGURED, "no rays and no sensor: call drt_set_sensor_perspective");
+    if (spp == 0) return fail(h, DRT_ERR_INVALID_ARGUMENT, "spp must be > 0");
+    // wavefront size limit of the reference (batched.py:378-388): ray indices are 32-bit
+    uint64_t last = ray_offset + n_rays;   // one past the largest global index
+    if (h->chunk && n_rays)
+        last = ray_offset + ((n_rays - 1) / h->chunk) * h->stride + ((n_rays - 1) % h->chunk) + 1;
+    if (last > 0xffffffffull)
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "global ray index exceeds 2^32 - 1 (render in several passes)");
+    if (!rays_o) {
+        uint64_t total = (uint64_t) h->base.width * (uint64_t) h->base.height * spp;
+        if (last > total)
+            return fail(h, DRT_ERR_INVALID_ARGUMENT, "ray range exceeds width*height*spp");
+    }
+    return DRT_OK;
+}
+
+void fill_job(drt_handle h, drt::Params &P, const float *rays_o, const float *rays_d, uint64_t n_rays,
+              uint64_t ray_offset, uint32_t spp, uint32_t seed)
+{
+    P = h->base;
+    P.majorant = h->d_majorant;
+    P.hide_emitters = h->cfg.hide_emitters; P.use_nee = h->cfg.use_nee; P.use_drt = h->cfg.use_drt;
+    P.use_drt_subsampling = h->cfg.use_drt_subsampling; P.use_drt_mis = h->cfg.use_drt_mis;
+    P.max_depth = h->cfg.max_depth; P.rr_depth = h->cfg.rr_depth;
+    P.sensor_flow = rays_o ? 0 : 1;
+    P.rays_o = rays_o; P.rays_d = rays_d;
+    P.n_rays = n_rays; P.ray_offset = ray_offset; P.spp = spp; P.seed = seed;
+    P.chunk = h->chunk; P.stride = h->stride;
+    P.alt_seed = drt::host_alt_seed(seed, rays_o == nullptr);
+    P.counters = h->counting ? h->d_counters : nullptr;
+}
+
+void clear_timings(drt_handle h)
+{
+    for (auto &v : h->timed) {
+        for (auto &p : v) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
+        v.clear();
+    }
+}
+
+// launch bracketed by an event pair on the handle's stream when timing is enabled
+int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventCreate(&a));
+        DRT_HIP_CHECK(h, hipEventCreate(&b));
+        DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
+    }
+    DRT_HIP_CHECK(h, drt::launch_trace(P, adjoint, h->counting, h->stream));
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
+        h->timed[which].emplace_back(a, b);
+    }
+    return DRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *drt_version(void) { return "drt-hip 0.1 (gfx950)"; }
+
+const char *drt_last_error(drt_handle h)
+{
+    if (h) return h->error.c_str();
+    return g_error.c_str();
+}
+
+int drt_create(const drt_config *cfg, int device, drt_handle *out)
+{
+    if (!cfg || !out) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "drt_create: null argument");
+    *out = nullptr;
+    if (cfg->max_depth < 0) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "max_depth must be >= 0");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(nullptr, DRT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n_dev)
+        return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, n_dev);
+    drt_handle h = new (std::nothrow) drt_handle_s();
+    if (!h) return fail(nullptr, DRT_ERR_HIP, "out of host memory");
+    h->device = device;
+    h->cfg = *cfg;
+    DeviceGuard g(device);
+    if (!g.ok) { delete h; return fail(nullptr, DRT_ERR_HIP, "hipSetDevice(%d) failed", device); }
+    hipError_t e = hipMalloc(&h->d_majorant, 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&h->d_scratch, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&h->d_counters, drt::C_COUNT * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_counters, 0, drt::C_COUNT * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, DRT_ERR_HIP, "device allocation failed: %s", hipGetErrorString(e));
+        drt_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return DRT_OK;
+}
+
+int drt_destroy(drt_handle h)
+{
+    if (!h) return DRT_OK;
+    DeviceGuard g(h->device);
+    if (h->d_majorant) (void) hipFree(h->d_majorant);
+    if (h->d_scratch) (void) hipFree(h->d_scratch);
+    if (h->d_counters) (void) hipFree(h->d_counters);
+    clear_timings(h);
+    delete h;
+    return DRT_OK;
+}
+
+int drt_set_stream(drt_handle h, void *hip_stream)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    h->stream = (hipStream_t) hip_stream;
+    return DRT_OK;
+}
+
+int drt_set_ray_interleave(drt_handle h, uint64_t chunk_rays, uint64_t stride_rays)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (chunk_rays && stride_rays < chunk_rays)
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "stride_rays must be >= chunk_rays");
+    h->chunk = chunk_rays; h->stride = chunk_rays ? stride_rays : 0;
+    return DRT_OK;
+}
+
+int drt_synchronize(drt_handle h)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return DRT_OK;
+}
+
+int drt_params_changed(drt_handle h)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->have_medium) return fail(h, DRT_ERR_NOT_CONFIGURED, "no medium set");
+    DeviceGuard g(h->device);
+    size_t n = (size_t) h->base.rx * h->base.ry * h->base.rz;
+    DRT_HIP_CHECK(h, drt::launch_majorant(h->base.sigma_t, n, h->base.scale, h->d_scratch, h->d_majorant, h->stream));
+    return DRT_OK;
+}
+
+int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, const int32_t res[3],
+                   const float bbox_min[3], const float bbox_max[3], float scale,
+                   int32_t majorant_resolution_factor)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!sigma_t || !albedo || !res || !bbox_min || !bbox_max)
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_set_medium: null argument");
+    for (int a = 0; a < 3; ++a) {
+        if (res[a] < 1) return fail(h, DRT_ERR_INVALID_ARGUMENT, "grid resolution must be >= 1");
+        if (!(bbox_max[a] > bbox_min[a])) return fail(h, DRT_ERR_INVALID_ARGUMENT, "empty bounding box");
+    }
+    if ((uint64_t) res[0] * res[1] * res[2] > 0x7fffffffull / 3)
+        return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for 32-bit voxel indexing");
+    if (majorant_resolution_factor != 0)
+        return fail(h, DRT_ERR_UNSUPPORTED, "majorant supergrid (factor %d) not implemented yet; use 0", majorant_resolution_factor);
+    drt::Params &B = h->base;
+    B.sigma_t = sigma_t; B.albedo = albedo;
+    B.rx = res[0]; B.ry = res[1]; B.rz = res[2];
+    for (int a = 0; a < 3; ++a) {
+        B.bmin[a] = bbox_min[a]; B.bmax[a] = bbox_max[a];
+        B.inv_ext[a] = 1.0f / (bbox_max[a] - bbox_min[a]);
+    }
+    B.scale = scale;
+    h->have_medium = true;
+    return drt_params_changed(h);
+}
+
+int drt_set_emitter_constant(drt_handle h, const float radiance[3])
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!radiance) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null radiance");
+    for (int k = 0; k < 3; ++k) h->base.Le[k] = radiance[k];
+    h->have_emitter = true;
+    return DRT_OK;
+}
+
+int drt_set_sensor_perspective(drt_handle h, const float origin[3], const float left[3],
+                               const float up[3], const float dir[3], float tan_x, float tan_y,
+                               int32_t width, int32_t height)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!origin || !left || !up || !dir) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null sensor frame");
+    if (width < 1 || height < 1) return fail(h, DRT_ERR_INVALID_ARGUMENT, "film size must be >= 1");
+    drt::Params &B = h->base;
+    for (int k = 0; k < 3; ++k) {
+        B.cam_o[k] = origin[k]; B.cam_left[k] = left[k]; B.cam_up[k] = up[k]; B.cam_dir[k] = dir[k];
+    }
+    B.tan_x = tan_x; B.tan_y = tan_y; B.width = width; B.height = height;
+    h->have_sensor = true;
+    return DRT_OK;
+}
+
+int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
+                      uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_out)
+{
+    int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp);
+    if (rc) return rc;
+    if (!L_out && n_rays) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null L_out");
+    DeviceGuard g(h->device);
+    drt::Params P;
+    fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
+    P.L_out = L_out;
+    return timed_launch(h, 0, P, false);
+}
+
+int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
+                        uint64_t ray_offset, uint32_t spp, uint32_t seed, const float *dL,
+                        const float *L_in, float *grad_sigma_t, float *grad_albedo)
+{
+    int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp);
+    if (rc) return rc;
+    if (n_rays && (!dL || !L_in || !grad_sigma_t || !grad_albedo))
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_render_backward: null dL / L_in / gradient buffer");
+    DeviceGuard g(h->device);
+    drt::Params P;
+    fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
+    P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
+    return timed_launch(h, 1, P, true);
+}
+
+int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t spp, float *image)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (spp == 0 || (n_pixels && (!L || !image))) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_film_develop: bad argument");
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, drt::launch_film_develop(L, n_pixels, spp, image, h->stream));
+    return DRT_OK;
+}
+
+int drt_film_backward(drt_handle h, const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (spp == 0 || (n_pixels && (!grad_image || !dL))) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_film_backward: bad argument");
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, drt::launch_film_backward(grad_image, n_pixels, spp, dL, h->stream));
+    return DRT_OK;
+}
+
+int drt_enable_counters(drt_handle h, int enable)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    h->counting = enable != 0;
+    return DRT_OK;
+}
+
+int drt_reset_counters(drt_handle h)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, hipMemsetAsync(h->d_counters, 0, drt::C_COUNT * sizeof(unsigned long long), h->stream));
+    return DRT_OK;
+}
+
+int drt_get_counters(drt_handle h, drt_counters *out)
+{
+    if (!h || !out) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_get_counters: null argument");
+    DeviceGuard g(h->device);
+    unsigned long long host[drt::C_COUNT];
+    DRT_HIP_CHECK(h, hipMemcpyAsync(host, h->d_counters, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    out->n_rays = host[drt::C_RAYS]; out->n_dt = host[drt::C_DT]; out->n_rt = host[drt::C_RT];
+    out->n_drt = host[drt::C_DRT]; out->n_alb = host[drt::C_ALB]; out->n_tr = host[drt::C_TR];
+    out->n_rt_adj = host[drt::C_RT_ADJ]; out->n_sc = host[drt::C_SC]; out->n_sc_alb = host[drt::C_SC_ALB];
+    return DRT_OK;
+}
+
+int drt_enable_timing(drt_handle h, int enable)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    clear_timings(h);
+    h->timing = enable != 0;
+    return DRT_OK;
+}
+
+int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (capacity > 0 && !out_ms) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null out_ms");
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    auto &v = h->timed[backward ? 1 : 0];
+    int n = (int) v.size();
+    for (int i = 0; i < n && i < capacity; ++i)
+        DRT_HIP_CHECK(h, hipEventElapsedTime(out_ms + i, v[i].first, v[i].second));
+    return n;
+}
+
+}  // extern "C"

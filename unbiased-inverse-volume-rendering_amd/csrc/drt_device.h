@@ -1,0 +1,364 @@
+// drt_device.h -- device-side primitives of the gfx950 DRT integrator.
+//
+// Everything here follows the arithmetic specification in DESIGN.md: each fp32
+// operation is individually rounded (the library is compiled with
+// -ffp-contract=off), fused multiply-adds appear only as explicit fmaf(), and the
+// elementary functions (log, sincos) are fixed polynomials.  This is what makes a
+// ray's primal radiance independent of how rays are scheduled onto wavefronts.
+//
+// Reference semantics being implemented (python/integrators/volpathsimple.py and
+// the Mitsuba 3 calls it makes) are cited per function.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace drt {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{ x, y, z }; }
+// Ray3f::operator()(t) = fmadd(d, t, o)
+__device__ __forceinline__ V3 ray_at(V3 o, V3 d, float t)
+{
+    return V3{ fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z) };
+}
+
+constexpr float kInvFourPi = 0.07957747154594767f;
+constexpr float kFourPi    = 12.566370614359172f;
+constexpr float kHalfPi    = 1.5707963267948966f;
+constexpr float kLargest   = 3.4028234663852886e38f;                 // dr.largest(Float)
+constexpr float kRayEps    = 1500.0f * 5.9604644775390625e-8f;       // math::RayEpsilon<float>
+constexpr float kInf       = __builtin_huge_valf();
+
+// ---------------------------------------------------------------------------
+// sample_tea_32 + PCG32 (`independent` sampler); call sites
+// volpathsimple.py:71,99,105-107,120,222,348,359,383,418,470,536,595,632
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ void tea32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1)
+{
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    o0 = v0; o1 = v1;
+}
+
+struct Pcg32 {
+    uint64_t state, inc;
+
+    __host__ __device__ __forceinline__ uint32_t next_u32()
+    {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dull + inc;
+        uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+        uint32_t rot = (uint32_t)(old >> 59);
+        return (xs >> rot) | (xs << ((0u - rot) & 31u));
+    }
+    // Sampler::seed(seed, wavefront): lane `index` -> PCG32(initstate, initseq) = tea32(seed, index)
+    __host__ __device__ __forceinline__ void seed(uint32_t seed_value, uint32_t index)
+    {
+        uint32_t v0, v1;
+        tea32(seed_value, index, v0, v1);
+        state = 0;
+        inc = ((uint64_t) v1 << 1) | 1ull;
+        next_u32();
+        state += (uint64_t) v0;
+        next_u32();
+    }
+    // next_float32: 23 mantissa bits, [0,1)
+    __host__ __device__ __forceinline__ float next_1d()
+    {
+        uint32_t bits = (next_u32() >> 9) | 0x3f800000u;
+        float f;
+        __builtin_memcpy(&f, &bits, 4);
+        return f - 1.0f;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// fixed elementary functions
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float drt_logf(float x)
+{
+    uint32_t ix = __float_as_uint(x);
+    int e = (int)(ix >> 23) - 126;
+    float m = __uint_as_float((ix & 0x007fffffu) | 0x3f000000u);
+    float f;
+    if (m < 0.70710678118654752440f) { e -= 1; f = (m + m) - 1.0f; }
+    else { f = m - 1.0f; }
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (f * z) * p;
+    float fe = (float) e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = fmaf(0.693359375f, fe, r);
+    return r;
+}
+
+__device__ __forceinline__ void drt_sincos_2pi(float u, float &s_out, float &c_out)
+{
+    float a = u * 4.0f;
+    int q = (int) a;
+    float f = a - (float) q;
+    bool swap = f > 0.5f;
+    float g = swap ? (1.0f - f) : f;
+    float x = g * kHalfPi;
+    float x2 = x * x;
+    float ps = -1.9515295891e-4f;
+    ps = fmaf(ps, x2, 8.3321608736e-3f);
+    ps = fmaf(ps, x2, -1.6666654611e-1f);
+    float s = fmaf(x * x2, ps, x);
+    float pc = 2.443315711809948e-5f;
+    pc = fmaf(pc, x2, -1.388731625493765e-3f);
+    pc = fmaf(pc, x2, 4.166664568298827e-2f);
+    float c = fmaf(x2 * x2, pc, fmaf(-0.5f, x2, 1.0f));
+    if (swap) { float t = s; s = c; c = t; }
+    q &= 3;
+    float sq = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    float cq = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+    s_out = sq; c_out = cq;
+}
+
+// warp::square_to_uniform_sphere: isotropic phase (volpathsimple.py:221,630) and
+// constant emitter direction sampling (:419)
+__device__ __forceinline__ V3 square_to_uniform_sphere(float ux, float uy)
+{
+    float z = fmaf(-2.0f, uy, 1.0f);
+    float r = sqrtf(fmaxf(0.0f, fmaf(-z, z, 1.0f)));
+    float s, c;
+    drt_sincos_2pi(ux, s, c);
+    return V3{ r * c, r * s, z };
+}
+
+// mi.ad.common.mis_weight: power heuristic, non-finite -> 0 (volpathsimple.py:278,391)
+__device__ __forceinline__ float mis_weight(float a, float b)
+{
+    float a2 = a * a, b2 = b * b;
+    float w = a2 / (a2 + b2);
+    return isfinite(w) ? w : 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// kernel parameter block (passed by value in the kernarg segment)
+// ---------------------------------------------------------------------------
+struct Params {
+    // medium
+    const float *sigma_t;      // (Z,Y,X,1)
+    const float *albedo;       // (Z,Y,X,3)
+    const float *majorant;     // device: [0] = scale*max(sigma_t), [1] = 1/[0] (0 if [0]==0)
+    int rx, ry, rz;
+    float bmin[3], bmax[3], inv_ext[3];
+    float scale;
+    float Le[3];
+    // integrator flags
+    int hide_emitters, use_nee, use_drt, use_drt_subsampling, use_drt_mis, max_depth, rr_depth;
+    // sensor (mi.render flow)
+    int sensor_flow;
+    float cam_o[3], cam_left[3], cam_up[3], cam_dir[3];
+    float tan_x, tan_y;
+    int width, height;
+    // job
+    const float *rays_o, *rays_d;
+    uint64_t n_rays, ray_offset;
+    uint64_t chunk, stride;    // global index of local ray i = ray_offset + (i/chunk)*stride + i%chunk (chunk 0: + i)
+    uint32_t spp, seed, alt_seed;
+    // outputs / adjoint inputs
+    float *L_out;
+    const float *dL, *L_in;
+    float *g_sigma, *g_albedo;
+    unsigned long long *counters;   // 9 x u64 or nullptr
+};
+
+enum CounterSlot { C_RAYS = 0, C_DT, C_RT, C_DRT, C_ALB, C_TR, C_RT_ADJ, C_SC, C_SC_ALB, C_COUNT };
+
+// ---------------------------------------------------------------------------
+// GridVolume::eval: trilinear, clamp, cell-centred (q = p_local*res - 0.5);
+// get_scattering_coefficients / get_albedo (volpathsimple.py:141,375,554,578,598)
+// ---------------------------------------------------------------------------
+struct Stencil {
+    int x0, x1, y0, y1, z0, z1;      // y*/z* premultiplied by their strides
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+};
+
+__device__ __forceinline__ void axis_setup(float p, float bmin, float inv_ext, int res,
+                                           int &i0, int &i1, float &w0, float &w1)
+{
+    float l = (p - bmin) * inv_ext;
+    float q = fmaf(l, (float) res, -0.5f);
+    float fl = floorf(q);
+    float fw = q - fl;
+    fl = fminf(fmaxf(fl, -1.0f), (float) res);
+    int i = (int) fl;
+    i0 = min(max(i, 0), res - 1);
+    i1 = min(max(i + 1, 0), res - 1);
+    w1 = fw; w0 = 1.0f - fw;
+}
+
+__device__ __forceinline__ Stencil make_stencil(const Params &P, V3 p)
+{
+    Stencil s;
+    axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, s.x0, s.x1, s.wx0, s.wx1);
+    axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, s.y0, s.y1, s.wy0, s.wy1);
+    axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, s.z0, s.z1, s.wz0, s.wz1);
+    s.y0 *= P.rx; s.y1 *= P.rx;
+    int sz = P.rx * P.ry;
+    s.z0 *= sz; s.z1 *= sz;
+    return s;
+}
+
+__device__ __forceinline__ float trilerp8(const Stencil &s, float d0, float d1, float d2, float d3,
+                                          float d4, float d5, float d6, float d7)
+{
+    float v00 = fmaf(s.wx0, d0, s.wx1 * d1);
+    float v01 = fmaf(s.wx0, d2, s.wx1 * d3);
+    float v10 = fmaf(s.wx0, d4, s.wx1 * d5);
+    float v11 = fmaf(s.wx0, d6, s.wx1 * d7);
+    float v0 = fmaf(s.wy0, v00, s.wy1 * v01);
+    float v1 = fmaf(s.wy0, v10, s.wy1 * v11);
+    return fmaf(s.wz0, v0, s.wz1 * v1);
+}
+
+__device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p)
+{
+    Stencil s = make_stencil(P, p);
+    const float *g = P.sigma_t;
+    int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
+    float d0 = g[a + s.x0], d1 = g[a + s.x1], d2 = g[b + s.x0], d3 = g[b + s.x1];
+    float d4 = g[c + s.x0], d5 = g[c + s.x1], d6 = g[d + s.x0], d7 = g[d + s.x1];
+    return trilerp8(s, d0, d1, d2, d3, d4, d5, d6, d7) * P.scale;
+}
+
+__device__ __forceinline__ void eval_albedo(const Params &P, V3 p, float out[3])
+{
+    Stencil s = make_stencil(P, p);
+    const float *g = P.albedo;
+    int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
+    int i0 = 3 * (a + s.x0), i1 = 3 * (a + s.x1), i2 = 3 * (b + s.x0), i3 = 3 * (b + s.x1);
+    int i4 = 3 * (c + s.x0), i5 = 3 * (c + s.x1), i6 = 3 * (d + s.x0), i7 = 3 * (d + s.x1);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+        out[ch] = trilerp8(s, g[i0 + ch], g[i1 + ch], g[i2 + ch], g[i3 + ch],
+                           g[i4 + ch], g[i5 + ch], g[i6 + ch], g[i7 + ch]);
+}
+
+// Reverse mode of the trilinear gather = 8-corner scatter-add.  gfx950 has a
+// hardware fp32 global atomic add (global_atomic_add_f32, device scope); the
+// library is built with -munsafe-fp-atomics so atomicAdd lowers to it.
+__device__ __forceinline__ void stencil_weights(const Stencil &s, float w[8])
+{
+    float zy00 = s.wz0 * s.wy0, zy01 = s.wz0 * s.wy1;
+    float zy10 = s.wz1 * s.wy0, zy11 = s.wz1 * s.wy1;
+    w[0] = zy00 * s.wx0; w[1] = zy00 * s.wx1; w[2] = zy01 * s.wx0; w[3] = zy01 * s.wx1;
+    w[4] = zy10 * s.wx0; w[5] = zy10 * s.wx1; w[6] = zy11 * s.wx0; w[7] = zy11 * s.wx1;
+}
+
+__device__ __forceinline__ void stencil_indices(const Stencil &s, int idx[8])
+{
+    int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
+    idx[0] = a + s.x0; idx[1] = a + s.x1; idx[2] = b + s.x0; idx[3] = b + s.x1;
+    idx[4] = c + s.x0; idx[5] = c + s.x1; idx[6] = d + s.x0; idx[7] = d + s.x1;
+}
+
+__device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g)
+{
+    Stencil s = make_stencil(P, p);
+    float w[8]; int idx[8];
+    stencil_weights(s, w);
+    stencil_indices(s, idx);
+    float gs = g * P.scale;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(P.g_sigma + idx[k], w[k] * gs);
+}
+
+__device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float g[3])
+{
+    Stencil s = make_stencil(P, p);
+    float w[8]; int idx[8];
+    stencil_weights(s, w);
+    stencil_indices(s, idx);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float *dst = P.g_albedo + 3 * (size_t) idx[k];
+        atomicAdd(dst + 0, w[k] * g[0]);
+        atomicAdd(dst + 1, w[k] * g[1]);
+        atomicAdd(dst + 2, w[k] * g[2]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scene.ray_intersect with use_bbox_fast_path: nearest hit with the medium box
+// surface at t > 0 (volpathsimple.py:234,265,298,307,428,637)
+// ---------------------------------------------------------------------------
+struct Hit { bool valid; float t; V3 p; V3 n; };
+
+__device__ __forceinline__ Hit box_hit(const Params &P, V3 o, V3 d)
+{
+    Hit h; h.valid = false; h.t = kInf; h.p = v3(0, 0, 0); h.n = v3(0, 0, 0);
+    float tn = -kInf, tf = kInf;
+    int an = 0, af = 0;
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (dd[a] != 0.0f) {
+            float t0 = (P.bmin[a] - oo[a]) / dd[a];
+            float t1 = (P.bmax[a] - oo[a]) / dd[a];
+            if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
+            if (t0 > tn) { tn = t0; an = a; }
+            if (t1 < tf) { tf = t1; af = a; }
+        } else if (oo[a] < P.bmin[a] || oo[a] > P.bmax[a]) {
+            miss = true;
+        }
+    }
+    if (miss || !(tn <= tf)) return h;
+    float t, sgn; int ax;
+    if (tn > 0.0f) { t = tn; ax = an; sgn = (dd[ax] > 0.0f) ? -1.0f : 1.0f; }
+    else if (tf > 0.0f) { t = tf; ax = af; sgn = (dd[ax] > 0.0f) ? 1.0f : -1.0f; }
+    else return h;
+    if (!isfinite(t)) return h;
+    h.valid = true; h.t = t; h.p = ray_at(o, d, t);
+    h.n = v3(ax == 0 ? sgn : 0.0f, ax == 1 ? sgn : 0.0f, ax == 2 ? sgn : 0.0f);
+    return h;
+}
+
+// SurfaceInteraction::spawn_ray -> offset_p(d)
+__device__ __forceinline__ V3 offset_p(const Hit &h, V3 d)
+{
+    float mag = (1.0f + fmaxf(fabsf(h.p.x), fmaxf(fabsf(h.p.y), fabsf(h.p.z)))) * kRayEps;
+    float dn = h.n.x * d.x + h.n.y * d.y + h.n.z * d.z;
+    if (dn < 0.0f) mag = -mag;
+    return V3{ fmaf(mag, h.n.x, h.p.x), fmaf(mag, h.n.y, h.p.y), fmaf(mag, h.n.z, h.p.z) };
+}
+
+// perspective sensor ray (tests/test_integrators.py:46-67 fixture; Mitsuba look_at frame)
+__device__ __forceinline__ void sensor_ray(const Params &P, uint32_t pixel, float ux, float uy,
+                                           V3 &o, V3 &d)
+{
+    uint32_t py = pixel / (uint32_t) P.width, px = pixel - py * (uint32_t) P.width;
+    float sx = ((float) px + ux) * (1.0f / (float) P.width);
+    float sy = ((float) py + uy) * (1.0f / (float) P.height);
+    float cx = fmaf(-2.0f, sx, 1.0f) * P.tan_x;
+    float cy = fmaf(-2.0f, sy, 1.0f) * P.tan_y;
+    float inv = 1.0f / sqrtf(fmaf(cx, cx, fmaf(cy, cy, 1.0f)));
+    cx *= inv; cy *= inv; float cz = inv;
+    o = v3(P.cam_o[0], P.cam_o[1], P.cam_o[2]);
+    d = v3(fmaf(P.cam_left[0], cx, fmaf(P.cam_up[0], cy, P.cam_dir[0] * cz)),
+           fmaf(P.cam_left[1], cx, fmaf(P.cam_up[1], cy, P.cam_dir[1] * cz)),
+           fmaf(P.cam_left[2], cx, fmaf(P.cam_up[2], cy, P.cam_dir[2] * cz)));
+}
+
+}  // namespace drt

@@ -1,0 +1,490 @@
+// drt_kernels.hip -- gfx950 kernels of the DRT integrator (v1: one ray per lane).
+//
+// Implements VolpathSimpleIntegrator.sample (python/integrators/volpathsimple.py:38-290)
+// in both AD modes for a batch of rays, plus the box film and the majorant
+// reduction.  Gradients are scattered with hardware fp32 atomics into the dense
+// (Z,Y,X,C) buffers the caller owns.
+#include "drt_device.h"
+#include "drt_launch.h"
+
+namespace drt {
+
+struct Ray { V3 o, d; float maxt; };
+struct Mei { bool valid; float t; V3 p; float sigma_t; };
+struct PathState { int depth; Hit si; float last_pdf; bool escaped; bool active; };
+
+template <bool COUNT>
+struct Tracer {
+    const Params &P;
+    float maj, inv_maj;
+    uint32_t ray_index;
+    uint32_t cnt[C_COUNT];
+
+    __device__ __forceinline__ Tracer(const Params &p) : P(p)
+    {
+        maj = p.majorant[0]; inv_maj = p.majorant[1];
+        ray_index = 0;
+#pragma unroll
+        for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
+    }
+    __device__ __forceinline__ void count(int slot) { if (COUNT) cnt[slot]++; }
+
+    // Medium::sample_interaction free-flight distance with a global majorant
+    // (call sites volpathsimple.py:348,469)
+    __device__ __forceinline__ float sample_distance(float u) const
+    {
+        if (maj == 0.0f) return kInf;
+        return -drt_logf(1.0f - u) * inv_maj;
+    }
+
+    // estimate_transmittance: ratio tracking (volpathsimple.py:436-504)
+    template <bool ADJ>
+    __device__ float estimate_transmittance(V3 o, V3 d, float tmax, Pcg32 &S, const float *adj)
+    {
+        float T = 1.0f;
+        for (;;) {
+            float dt = sample_distance(S.next_1d());
+            if (!(dt <= tmax)) break;                                   // :480-481
+            V3 p = ray_at(o, d, dt);
+            float sig = eval_sigma_t(P, p);
+            float tr = (maj - sig) * inv_maj;                           // :473-476
+            count(C_RT);
+            if constexpr (ADJ) if (tr > 0.0f) {                         // :487-492
+                float a = (adj[0] + adj[1]) + adj[2];
+                splat_sigma_t(P, p, -(a * inv_maj) / tr);
+                count(C_RT_ADJ);
+            }
+            T *= tr;                                                    // :495
+            o = p; tmax -= dt;                                          // :497-499
+            if (T == 0.0f) break;                                       // :502
+        }
+        return T;
+    }
+
+    // sample_emitter (volpathsimple.py:406-433), `constant` emitter
+    template <bool ADJ>
+    __device__ void sample_emitter(V3 p, Pcg32 &S, const float *adj, float out[3])
+    {
+        float ux = S.next_1d(), uy = S.next_1d();                       // :418
+        V3 wd = square_to_uniform_sphere(ux, uy);
+        Hit si = box_hit(P, p, wd);                                     // :427-428
+        float T = 0.0f;
+        if (si.valid) T = estimate_transmittance<ADJ>(p, wd, si.t, S, adj);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] = (P.Le[k] * kFourPi) * T;
+    }
+
+    // sample_emitter_for_nee (volpathsimple.py:380-403)
+    template <bool ADJ>
+    __device__ void sample_emitter_for_nee(V3 p, Pcg32 &S, const float beta[3], const float *dL,
+                                           float contrib[3])
+    {
+        Pcg32 clone = S;                                                // :383
+        float emitted[3];
+        sample_emitter<false>(p, S, nullptr, emitted);                  // :385
+        float w = mis_weight(kInvFourPi, kInvFourPi);                   // :391
+#pragma unroll
+        for (int k = 0; k < 3; ++k) contrib[k] = ((beta[k] * kInvFourPi) * w) * emitted[k];
+        if constexpr (ADJ) {                                            // :393-401
+            float adj[3] = { dL[0] * contrib[0], dL[1] * contrib[1], dL[2] * contrib[2] };
+            float unused[3];
+            sample_emitter<true>(p, clone, adj, unused);
+        }
+    }
+
+    // sample_real_interaction: delta tracking (volpathsimple.py:323-377)
+    template <bool ATTACHED>
+    __device__ Mei sample_real_interaction(const Ray &ray, Pcg32 &S)
+    {
+        Mei mei; mei.valid = false; mei.t = kInf; mei.p = v3(0, 0, 0); mei.sigma_t = 0.0f;
+        V3 ro = ray.o; float rmaxt = ray.maxt, running_t = 0.0f;
+        for (;;) {
+            float dt = sample_distance(S.next_1d());                    // :348
+            if (!(dt <= rmaxt)) break;                                  // :358
+            V3 p = ray_at(ro, ray.d, dt);
+            float sig = eval_sigma_t(P, p);
+            count(C_DT);
+            float r = sig * inv_maj;                                    // :354
+            float u = S.next_1d();                                      // :359
+            if (!(u >= r)) { mei.valid = true; mei.t = running_t + dt; break; }   // :351
+            ro = p; rmaxt -= dt; running_t += dt;                       // :364-367
+        }
+        if (mei.valid) {
+            mei.p = ray_at(ray.o, ray.d, mei.t);                        // :371
+            if (ATTACHED) { mei.sigma_t = eval_sigma_t(P, mei.p); count(C_DT); }   // :373-375
+        }
+        return mei;
+    }
+
+    // Medium::sample_interaction_drt (call site volpathsimple.py:549-551): ratio
+    // tracking over [0,maxt]; tentative collision i has weight T_i/majorant; one
+    // is kept by weighted reservoir sampling; W = sum of weights.
+    __device__ bool sample_interaction_drt(const Ray &ray, Pcg32 &A, float &t_out, float &W_out)
+    {
+        float t = 0.0f, T = 1.0f, wsum = 0.0f, tsel = kInf;
+        bool valid = false;
+        for (;;) {
+            t += sample_distance(A.next_1d());
+            if (!(t <= ray.maxt)) break;
+            float sig = eval_sigma_t(P, ray_at(ray.o, ray.d, t));
+            count(C_DRT);
+            float w = T * inv_maj;
+            wsum += w;
+            float u = A.next_1d();
+            if (w > 0.0f && u * wsum <= w) { tsel = t; valid = true; }
+            T *= (maj - sig) * inv_maj;
+            if (T == 0.0f) break;
+        }
+        t_out = tsel; W_out = wsum;
+        return valid;
+    }
+
+    // sample_recursive (volpathsimple.py:610-655)
+    __device__ void sample_recursive(Pcg32 &A, V3 p, int depth, float Li[3])
+    {
+        Li[0] = Li[1] = Li[2] = 0.0f;
+        if (P.use_nee) {                                                // :621-624
+            const float one[3] = { 1.0f, 1.0f, 1.0f };
+            float nee[3];
+            sample_emitter_for_nee<false>(p, A, one, nullptr, nee);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Li[k] += nee[k];
+        }
+        (void) A.next_1d();                                             // :632
+        float ux = A.next_1d(), uy = A.next_1d();
+        Ray rr; rr.o = p; rr.d = square_to_uniform_sphere(ux, uy);
+        Hit sn = box_hit(P, p, rr.d);                                   // :637
+        rr.maxt = sn.valid ? sn.t : kLargest;                           // :639-640
+        PathState ps;
+        ps.depth = depth + 1; ps.si = sn; ps.last_pdf = kInvFourPi; ps.escaped = false;
+        ps.active = (ps.depth < P.max_depth) && sn.valid;               // :647 (+ DESIGN.md deviation)
+        float Lr[3];
+        sample<false, true>(A, rr, nullptr, nullptr, &ps, Lr);          // :651
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Li[k] += Lr[k];
+    }
+
+    // backpropagate_scattering_drt, final / quadratic branch (volpathsimple.py:543-581)
+    __device__ void drt_backprop(Pcg32 &A, const Ray &ray, float si_t, int depth, const float adj[3])
+    {
+        Ray sub = ray;
+        sub.maxt = isfinite(si_t) ? si_t : kLargest;                    // :544-545
+        float tp, W;
+        if (!sample_interaction_drt(sub, A, tp, W)) return;             // :550,558
+        V3 p = ray_at(sub.o, sub.d, tp);
+        float sig = eval_sigma_t(P, p);                                 // :553-554
+        count(C_DRT);
+        float Li[3];
+        sample_recursive(A, p, depth, Li);                              // :565-568
+        float w = P.use_drt_mis ? 1.0f / (1.0f + sig * sig) : 1.0f;     // :571-575
+        float alb[3];
+        eval_albedo(P, p, alb);                                         // :578
+        count(C_ALB);
+        float ww = w * W;
+        float gs = 0.0f, ga[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float a = (ww * adj[k]) * Li[k];
+            gs += a * alb[k];
+            ga[k] = a * sig;
+        }
+        splat_sigma_t(P, p, gs); count(C_SC);                           // :577-581
+        splat_albedo(P, p, ga);  count(C_SC_ALB);
+    }
+
+    // backpropagate_transmittance (volpathsimple.py:584-607)
+    __device__ void backprop_transmittance(Pcg32 &A, const Ray &ray, float interval,
+                                           const float dL[3], const float result[3])
+    {
+        float adjw = (dL[0] * result[0] + dL[1] * result[1]) + dL[2] * result[2];
+        float g = -(adjw * (interval / 4.0f));
+        for (int j = 0; j < 4; ++j) {
+            float t = A.next_1d() * interval;                           // :595
+            splat_sigma_t(P, ray_at(ray.o, ray.d, t), g);
+            count(C_TR);
+        }
+    }
+
+    // VolpathSimpleIntegrator.sample (volpathsimple.py:38-290)
+    template <bool ADJ, bool RECURSIVE>
+    __device__ void sample(Pcg32 &S, Ray ray, const float *dL, const float *state_in,
+                           const PathState *ps, float out[3])
+    {
+        float result[3] = { 0.0f, 0.0f, 0.0f };
+        float beta[3] = { 1.0f, 1.0f, 1.0f };
+        if (ADJ) { result[0] = state_in[0]; result[1] = state_in[1]; result[2] = state_in[2]; }
+
+        bool active, escaped; int depth; Hit si;
+        if (RECURSIVE) {                                                // :61-67
+            active = ps->active; depth = ps->depth; si = ps->si; escaped = ps->escaped;
+        } else {
+            active = true; depth = 0; escaped = false;
+            (void) S.next_1d();                                         // :71
+            si = box_hit(P, ray.o, ray.d);                              // reach_medium :292-319
+            if (!si.valid) { escaped = true; active = false; }
+            else {
+                ray.o = offset_p(si, ray.d);
+                Hit sn = box_hit(P, ray.o, ray.d);
+                if (!sn.valid) active = false;
+                else { ray.maxt = sn.t; si = sn; }
+            }
+        }
+        bool has_scattered = RECURSIVE ? (active && !escaped) : false;  // :84-89
+        float last_pdf = RECURSIVE ? ps->last_pdf : 1.0f;
+
+        // DRTReservoir(n=1) + DRTPathState (:94-96, :710-765)
+        int r_depth = -1; float r_si_t = kInf; Ray r_ray = ray;
+        float r_wsum[3] = { 0, 0, 0 }, r_cw[3] = { 0, 0, 0 };
+
+        Pcg32 A; A.state = 0; A.inc = 1;
+        if (active) (void) S.next_1d();                                 // :99
+        if constexpr (ADJ) A.seed(P.alt_seed, ray_index);               // :100-107
+
+        while (active) {                                                // :114
+            float q = fminf(fmaxf(beta[0], fmaxf(beta[1], beta[2])), 0.99f);   // :117-121
+            bool perform_rr = depth > P.rr_depth;
+            float u_rr = S.next_1d();
+            active = (beta[0] != 0.0f || beta[1] != 0.0f || beta[2] != 0.0f)
+                     && (!perform_rr || (u_rr < q));
+            if (perform_rr) { float iq = 1.0f / q; beta[0] *= iq; beta[1] *= iq; beta[2] *= iq; }
+            if (!active) break;
+
+            Mei mei = sample_real_interaction<ADJ>(ray, S);             // :126
+            bool did_escape = !mei.valid, did_scatter = mei.valid;      // :130-134
+            has_scattered |= did_scatter;
+
+            float albedo[3] = { 1.0f, 1.0f, 1.0f };                     // :141
+            if (did_scatter) { eval_albedo(P, mei.p, albedo); count(C_ALB); }
+
+            if constexpr (ADJ) {
+                if (P.use_drt) {                                        // :143-150
+                    if (P.use_drt_subsampling) {                        // :521-539, :745-753
+                        float u = A.next_1d();
+                        float m = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { r_wsum[k] += beta[k]; m += beta[k] / r_wsum[k]; }
+                        m = m / 3.0f;
+                        if (u <= m) {
+                            r_cw[0] = beta[0]; r_cw[1] = beta[1]; r_cw[2] = beta[2];
+                            r_depth = depth; r_si_t = si.t; r_ray = ray;
+                        }
+                    } else {
+                        float adj[3] = { dL[0] * beta[0], dL[1] * beta[1], dL[2] * beta[2] };
+                        drt_backprop(A, ray, si.t, depth, adj);
+                    }
+                }
+                if ((!P.use_drt || P.use_drt_mis) && did_scatter) {     // :152-172
+                    float w = 1.0f;
+                    if (P.use_drt && P.use_drt_mis) {
+                        float s2 = mei.sigma_t * mei.sigma_t;
+                        w = s2 / (1.0f + s2);
+                    }
+                    float inv_pdf = 1.0f / mei.sigma_t;
+                    float gs = 0.0f, ga[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float Li = result[k] / fmaxf(1e-8f, albedo[k]); // :167
+                        float a = ((w * dL[k]) * Li) * inv_pdf;
+                        gs += a * albedo[k];
+                        ga[k] = a * mei.sigma_t;
+                    }
+                    splat_sigma_t(P, mei.p, gs); count(C_SC);
+                    splat_albedo(P, mei.p, ga);  count(C_SC_ALB);
+                }
+                backprop_transmittance(A, ray, did_escape ? si.t : mei.t, dL, result);   // :181-189
+            }
+
+            beta[0] *= albedo[0]; beta[1] *= albedo[1]; beta[2] *= albedo[2];           // :193
+            if (did_scatter) depth += 1;                                // :199
+            active = did_scatter && (depth < P.max_depth);              // :200
+
+            if (P.use_nee && did_scatter && active) {                   // :206-215
+                float nee[3];
+                sample_emitter_for_nee<ADJ>(mei.p, S, beta, dL, nee);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) result[k] = ADJ ? result[k] - nee[k] : result[k] + nee[k];
+            }
+
+            if (did_scatter) {                                          // :221-230
+                (void) S.next_1d();
+                float ux = S.next_1d(), uy = S.next_1d();
+                ray.o = mei.p; ray.d = square_to_uniform_sphere(ux, uy); ray.maxt = kLargest;
+                last_pdf = kInvFourPi;
+            }
+            si = box_hit(P, ray.o, ray.d);                              // :233-235
+            ray.maxt = isfinite(si.t) ? si.t : kLargest;
+            if (did_scatter && !si.valid) active = false;               // :240-241
+            if (did_escape) {                                           // :244-245
+                if (si.valid) ray.o = offset_p(si, ray.d);
+                escaped = true;
+            }
+        }
+
+        if constexpr (ADJ) {
+            if (P.use_drt && P.use_drt_subsampling && r_depth >= 0) {   // :249-259, :756-760
+                float d = ((r_cw[0] + r_cw[1]) + r_cw[2]) / 3.0f;
+                float ws = ((r_wsum[0] + r_wsum[1]) + r_wsum[2]) / 3.0f;
+                float adj[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) adj[k] = (d != 0.0f ? (ws * r_cw[k]) / d : 0.0f) * dL[k];
+                drt_backprop(A, r_ray, r_si_t, r_depth, adj);
+            }
+        } else {                                                        // :263-287
+            if (escaped && !(depth <= 0 && P.hide_emitters)) {
+                float w = 1.0f;
+                if (P.use_nee) {
+                    float epdf = has_scattered ? kInvFourPi : 0.0f;     // :273-277
+                    w = mis_weight(last_pdf, epdf);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * P.Le[k];
+            }
+        }
+        out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
+    }
+};
+
+template <bool ADJ, bool COUNT>
+__global__ void __launch_bounds__(256) trace_kernel(const Params P)
+{
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    Tracer<COUNT> tr(P);
+    if (i < P.n_rays) {
+        uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
+        uint32_t gi = (uint32_t) g64;
+        tr.ray_index = gi;
+        Pcg32 S; S.seed(P.seed, gi);
+        Ray ray;
+        if (P.sensor_flow) {
+            float ux = S.next_1d(), uy = S.next_1d();
+            sensor_ray(P, gi / P.spp, ux, uy, ray.o, ray.d);
+        } else {
+            ray.o = v3(P.rays_o[3 * i], P.rays_o[3 * i + 1], P.rays_o[3 * i + 2]);
+            ray.d = v3(P.rays_d[3 * i], P.rays_d[3 * i + 1], P.rays_d[3 * i + 2]);
+        }
+        ray.maxt = kLargest;
+        tr.count(C_RAYS);
+        float L[3];
+        if (ADJ) {
+            float dL[3] = { P.dL[3 * i], P.dL[3 * i + 1], P.dL[3 * i + 2] };
+            float Lin[3] = { P.L_in[3 * i], P.L_in[3 * i + 1], P.L_in[3 * i + 2] };
+            tr.template sample<true, false>(S, ray, dL, Lin, nullptr, L);
+        } else {
+            tr.template sample<false, false>(S, ray, nullptr, nullptr, nullptr, L);
+            P.L_out[3 * i] = L[0]; P.L_out[3 * i + 1] = L[1]; P.L_out[3 * i + 2] = L[2];
+        }
+    }
+    if (COUNT) {
+        // wave reduction, then one device atomic per wave and slot
+#pragma unroll
+        for (int s = 0; s < C_COUNT; ++s) {
+            uint32_t v = tr.cnt[s];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(P.counters + s, (unsigned long long) v);
+        }
+    }
+}
+
+// majorant = scale * max(sigma_t grid) (Medium::get_majorant with a global
+// majorant; carries no gradient, refreshed on parameter update - optimize.py:195-199)
+__global__ void __launch_bounds__(256) majorant_reduce_kernel(const float *sigma_t, size_t n, uint32_t *max_bits)
+{
+    float m = 0.0f;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+        m = fmaxf(m, sigma_t[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(m));
+}
+
+__global__ void majorant_finalize_kernel(const uint32_t *max_bits, float scale, float *majorant)
+{
+    float m = __uint_as_float(*max_bits) * scale;
+    majorant[0] = m;
+    majorant[1] = (m != 0.0f) ? 1.0f / m : 0.0f;
+}
+
+// box film: image[p] = mean_spp L (batched.py:176-197)
+__global__ void __launch_bounds__(256) film_develop_kernel(const float *L, uint64_t n_pixels, uint32_t spp, float *image)
+{
+    uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (pixel, channel)
+    if (t >= n_pixels * 3) return;
+    uint64_t p = t / 3; uint32_t c = (uint32_t)(t - p * 3);
+    const float *src = L + 3 * p * spp + c;
+    float s = 0.0f;
+    for (uint32_t j = 0; j < spp; ++j) s += src[3 * (uint64_t) j];
+    image[t] = s * (1.0f / (float) spp);
+}
+
+// dL[i] = grad_image[i / spp] / spp (batched.py:298-306)
+__global__ void __launch_bounds__(256) film_backward_kernel(const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL)
+{
+    uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (sample, channel)
+    if (t >= n_pixels * spp * 3) return;
+    uint64_t i = t / 3; uint32_t c = (uint32_t)(t - i * 3);
+    dL[t] = grad_image[3 * (i / spp) + c] * (1.0f / (float) spp);
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers (host)
+// ---------------------------------------------------------------------------
+hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t stream)
+{
+    if (P.n_rays == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((P.n_rays + 255) / 256));
+    if (adjoint) {
+        if (count) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, stream, P);
+        else       hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, stream, P);
+    } else {
+        if (count) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, P);
+        else       hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, P);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t *scratch_bits,
+                           float *majorant, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(scratch_bits, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    unsigned blocks = (unsigned) ((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(majorant_reduce_kernel, dim3(blocks), dim3(256), 0, stream, sigma_t, n, scratch_bits);
+    hipLaunchKernelGGL(majorant_finalize_kernel, dim3(1), dim3(1), 0, stream, scratch_bits, scale, majorant);
+    return hipGetLastError();
+}
+
+hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, float *image, hipStream_t stream)
+{
+    uint64_t n = n_pixels * 3;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(film_develop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, L, n_pixels, spp, image);
+    return hipGetLastError();
+}
+
+hipError_t launch_film_backward(const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL, hipStream_t stream)
+{
+    uint64_t n = n_pixels * spp * 3;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(film_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, grad_image, n_pixels, spp, dL);
+    return hipGetLastError();
+}
+
+uint32_t host_alt_seed(uint32_t seed, bool sensor_flow)
+{
+    // volpathsimple.py:99-107: alt_seed = tea32(bits(lane-0 draw), 1)[0]; lane 0's
+    // draw is the 2nd of its stream (4th in the sensor flow) whatever the geometry.
+    Pcg32 S; S.seed(seed, 0);
+    int skip = sensor_flow ? 3 : 1;
+    for (int k = 0; k < skip; ++k) (void) S.next_1d();
+    float u = S.next_1d();
+    uint32_t bits; __builtin_memcpy(&bits, &u, 4);
+    uint32_t v0, v1;
+    tea32(bits, 1u, v0, v1);
+    return v0;
+}
+
+}  // namespace drt

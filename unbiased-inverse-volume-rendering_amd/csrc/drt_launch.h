@@ -1,0 +1,19 @@
+// drt_launch.h -- host-side launch interface between the C ABI (drt_capi.cpp)
+// and the kernels (drt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "drt_device.h"
+
+namespace drt {
+
+hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t stream);
+hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t *scratch_bits,
+                           float *majorant, hipStream_t stream);
+hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, float *image,
+                               hipStream_t stream);
+hipError_t launch_film_backward(const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL,
+                                hipStream_t stream);
+uint32_t host_alt_seed(uint32_t seed, bool sensor_flow);
+
+}  // namespace drt

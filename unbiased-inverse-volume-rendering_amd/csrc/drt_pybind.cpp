@@ -1,0 +1,184 @@
+// drt_pybind.cpp -- thin pybind11 shim over the C ABI (include/drt_hip.h).
+//
+// Pointers cross as integers (torch.Tensor.data_ptr()); the GIL is released around
+// every call that enqueues or waits for device work; a non-zero status becomes
+// RuntimeError(drt_last_error()).  No torch headers, no logic.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/drt_hip.h"
+
+namespace py = pybind11;
+
+namespace {
+
+template <typename T>
+T *ptr(uintptr_t p) { return reinterpret_cast<T *>(p); }
+
+class Integrator {
+public:
+    Integrator(const py::dict &props, int device)
+    {
+        drt_config c{};
+        auto geti = [&](const char *k, int dflt) {
+            return props.contains(k) ? py::cast<int>(py::int_(py::cast<py::object>(props[k]))) : dflt;
+        };
+        auto getb = [&](const char *k, bool dflt) {
+            return props.contains(k) ? (py::cast<bool>(props[k]) ? 1 : 0) : (dflt ? 1 : 0);
+        };
+        if (!props.contains("max_depth")) throw std::invalid_argument("props must contain max_depth");
+        c.hide_emitters = getb("hide_emitters", false);
+        c.use_nee = getb("use_nee", true);
+        c.use_drt = getb("use_drt", true);
+        c.use_drt_subsampling = getb("use_drt_subsampling", true);
+        c.use_drt_mis = getb("use_drt_mis", true);
+        c.max_depth = geti("max_depth", 0);
+        c.rr_depth = geti("rr_depth", c.max_depth + 1000);
+        int rc = drt_create(&c, device, &h_);
+        if (rc) throw std::runtime_error(std::string("drt_create: ") + drt_last_error(nullptr));
+    }
+    ~Integrator() { drt_destroy(h_); }
+    Integrator(const Integrator &) = delete;
+    Integrator &operator=(const Integrator &) = delete;
+
+    void check(int rc, const char *what) const
+    {
+        if (rc) throw std::runtime_error(std::string(what) + ": " + drt_last_error(h_));
+    }
+
+    void set_stream(uintptr_t s) { check(drt_set_stream(h_, ptr<void>(s)), "drt_set_stream"); }
+    void synchronize()
+    {
+        py::gil_scoped_release nogil;
+        int rc = drt_synchronize(h_);
+        py::gil_scoped_acquire gil;
+        check(rc, "drt_synchronize");
+    }
+    void set_ray_interleave(uint64_t chunk, uint64_t stride)
+    {
+        check(drt_set_ray_interleave(h_, chunk, stride), "drt_set_ray_interleave");
+    }
+    void set_medium(uintptr_t sigma_t, uintptr_t albedo, std::array<int32_t, 3> res,
+                    std::array<float, 3> bmin, std::array<float, 3> bmax, float scale, int factor)
+    {
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = drt_set_medium(h_, ptr<const float>(sigma_t), ptr<const float>(albedo), res.data(),
+                                bmin.data(), bmax.data(), scale, factor);
+        }
+        check(rc, "drt_set_medium");
+    }
+    void params_changed()
+    {
+        int rc;
+        { py::gil_scoped_release nogil; rc = drt_params_changed(h_); }
+        check(rc, "drt_params_changed");
+    }
+    void set_emitter_constant(std::array<float, 3> rgb)
+    {
+        check(drt_set_emitter_constant(h_, rgb.data()), "drt_set_emitter_constant");
+    }
+    void set_sensor_perspective(std::array<float, 3> o, std::array<float, 3> left, std::array<float, 3> up,
+                                std::array<float, 3> dir, float tan_x, float tan_y, int w, int hgt)
+    {
+        check(drt_set_sensor_perspective(h_, o.data(), left.data(), up.data(), dir.data(), tan_x, tan_y, w, hgt),
+              "drt_set_sensor_perspective");
+    }
+    void render_primal(uintptr_t rays_o, uintptr_t rays_d, uint64_t n, uint64_t off, uint32_t spp,
+                       uint32_t seed, uintptr_t L_out)
+    {
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = drt_render_primal(h_, ptr<const float>(rays_o), ptr<const float>(rays_d), n, off, spp, seed,
+                                   ptr<float>(L_out));
+        }
+        check(rc, "drt_render_primal");
+    }
+    void render_backward(uintptr_t rays_o, uintptr_t rays_d, uint64_t n, uint64_t off, uint32_t spp,
+                         uint32_t seed, uintptr_t dL, uintptr_t L_in, uintptr_t g_sigma, uintptr_t g_albedo)
+    {
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = drt_render_backward(h_, ptr<const float>(rays_o), ptr<const float>(rays_d), n, off, spp, seed,
+                                     ptr<const float>(dL), ptr<const float>(L_in), ptr<float>(g_sigma),
+                                     ptr<float>(g_albedo));
+        }
+        check(rc, "drt_render_backward");
+    }
+    void film_develop(uintptr_t L, uint64_t n_pixels, uint32_t spp, uintptr_t image)
+    {
+        int rc;
+        { py::gil_scoped_release nogil; rc = drt_film_develop(h_, ptr<const float>(L), n_pixels, spp, ptr<float>(image)); }
+        check(rc, "drt_film_develop");
+    }
+    void film_backward(uintptr_t grad_image, uint64_t n_pixels, uint32_t spp, uintptr_t dL)
+    {
+        int rc;
+        { py::gil_scoped_release nogil; rc = drt_film_backward(h_, ptr<const float>(grad_image), n_pixels, spp, ptr<float>(dL)); }
+        check(rc, "drt_film_backward");
+    }
+    void enable_counters(bool on) { check(drt_enable_counters(h_, on ? 1 : 0), "drt_enable_counters"); }
+    void reset_counters() { check(drt_reset_counters(h_), "drt_reset_counters"); }
+    py::dict get_counters()
+    {
+        drt_counters c{};
+        int rc;
+        { py::gil_scoped_release nogil; rc = drt_get_counters(h_, &c); }
+        check(rc, "drt_get_counters");
+        py::dict d;
+        d["n_rays"] = c.n_rays; d["n_dt"] = c.n_dt; d["n_rt"] = c.n_rt; d["n_drt"] = c.n_drt;
+        d["n_alb"] = c.n_alb; d["n_tr"] = c.n_tr; d["n_rt_adj"] = c.n_rt_adj; d["n_sc"] = c.n_sc;
+        d["n_sc_alb"] = c.n_sc_alb;
+        return d;
+    }
+    void enable_timing(bool on) { check(drt_enable_timing(h_, on ? 1 : 0), "drt_enable_timing"); }
+    std::vector<float> read_timings(bool backward)
+    {
+        int n = drt_read_timings(h_, backward ? 1 : 0, nullptr, 0);
+        if (n < 0) check(n, "drt_read_timings");
+        std::vector<float> out((size_t) n);
+        if (n > 0) {
+            int rc = drt_read_timings(h_, backward ? 1 : 0, out.data(), n);
+            if (rc < 0) check(rc, "drt_read_timings");
+        }
+        return out;
+    }
+
+private:
+    drt_handle h_ = nullptr;
+};
+
+}  // namespace
+
+PYBIND11_MODULE(_drt_pybind, m)
+{
+    m.doc() = "pybind11 shim over libdrt_hip.so (C ABI in include/drt_hip.h)";
+    m.def("version", []() { return std::string(drt_version()); });
+    py::class_<Integrator>(m, "Integrator")
+        .def(py::init<const py::dict &, int>(), py::arg("props"), py::arg("device") = 0)
+        .def("set_stream", &Integrator::set_stream)
+        .def("synchronize", &Integrator::synchronize)
+        .def("set_ray_interleave", &Integrator::set_ray_interleave)
+        .def("set_medium", &Integrator::set_medium)
+        .def("params_changed", &Integrator::params_changed)
+        .def("set_emitter_constant", &Integrator::set_emitter_constant)
+        .def("set_sensor_perspective", &Integrator::set_sensor_perspective)
+        .def("render_primal", &Integrator::render_primal)
+        .def("render_backward", &Integrator::render_backward)
+        .def("film_develop", &Integrator::film_develop)
+        .def("film_backward", &Integrator::film_backward)
+        .def("enable_counters", &Integrator::enable_counters)
+        .def("reset_counters", &Integrator::reset_counters)
+        .def("get_counters", &Integrator::get_counters)
+        .def("enable_timing", &Integrator::enable_timing)
+        .def("read_timings", &Integrator::read_timings);
+}

@@ -1,0 +1,260 @@
+"""Integrator plugins behind the reference's plugin surface.
+
+Mirrors (names, argument meaning, error behaviour):
+  * `mi.register_integrator("volpathsimple", lambda props: ...)`
+    - python/integrators/volpathsimple.py:769
+  * `mi.load_dict({'type': 'volpathsimple', ...})` - python/opt_config.py:108
+  * `VolpathSimpleIntegrator.sample(mode, scene, sampler, ray, dL, state_in, active, **kwargs)
+     -> (L, valid, state_out)` - python/integrators/volpathsimple.py:38-49
+  * `integrator.aovs() -> []`, no `reparam` attribute - python/batched.py:152,223,235
+
+The arithmetic runs in the HIP library (csrc/, C ABI in include/drt_hip.h) on the
+device of the parameter tensors; nothing here computes radiance on the host.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from enum import IntEnum
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from ._native import native
+from .scene import ALBEDO_KEY, SIGMA_T_KEY, PerspectiveSensor, Scene
+
+
+class ADMode(IntEnum):
+    """dr.ADMode values used by the reference (volpathsimple.py:51, batched.py:164,256,310)."""
+    Primal = 0
+    Forward = 1
+    Backward = 2
+
+
+# --- plugin registry (mi.register_integrator / mi.load_dict) ------------------------------
+_INTEGRATORS: Dict[str, Callable[[dict], object]] = {}
+
+
+def register_integrator(name: str, factory: Callable[[dict], object]) -> None:
+    _INTEGRATORS[name] = factory
+
+
+def load_dict(d: dict):
+    """`mi.load_dict` for integrator dictionaries: {'type': <plugin>, **props}."""
+    if "type" not in d:
+        raise ValueError("load_dict: missing 'type'")
+    t = d["type"]
+    if t not in _INTEGRATORS:
+        raise ValueError(f"load_dict: unknown integrator plugin '{t}' (registered: {sorted(_INTEGRATORS)})")
+    props = {k: v for k, v in d.items() if k != "type"}
+    return _INTEGRATORS[t](props)
+
+
+# --- sampler / ray descriptors ---------------------------------------------------------------
+class IndependentSampler:
+    """`independent` sampler: one PCG32 per wavefront lane seeded with
+    tea32(seed, lane) - only the seed lives on the host (batched.py:366-391)."""
+
+    def __init__(self, seed: int = 0, sample_count: int = 1):
+        self._seed = int(seed) & 0xffffffff
+        self._sample_count = int(sample_count)
+
+    def seed(self, seed: int, wavefront_size: Optional[int] = None) -> None:
+        self._seed = int(seed) & 0xffffffff
+
+    def clone(self) -> "IndependentSampler":
+        return IndependentSampler(self._seed, self._sample_count)
+
+    def set_sample_count(self, spp: int) -> None:
+        self._sample_count = int(spp)
+
+    def sample_count(self) -> int:
+        return self._sample_count
+
+    @property
+    def seed_value(self) -> int:
+        return self._seed
+
+
+@dataclass
+class RayBatch:
+    """The `ray` argument of `sample()`.
+
+    Either explicit rays (`o`, `d`: [n,3] float32 device tensors - the batched flow,
+    batched.py:426-467) or rays generated on device from `sensor` (the `mi.render`
+    flow: pixel = global_index // spp, film position drawn from the ray's stream).
+    `ray_offset` / `interleave` place the local rays in the global wavefront so that
+    a sharded render uses the same random streams as an unsharded one.
+    """
+    n_rays: int
+    spp: int
+    o: Optional[torch.Tensor] = None
+    d: Optional[torch.Tensor] = None
+    sensor: Optional[PerspectiveSensor] = None
+    ray_offset: int = 0
+    interleave: Optional[Tuple[int, int]] = None   # (chunk_rays, stride_rays)
+
+
+def sample_tea_32(v0: int, v1: int, rounds: int = 4) -> Tuple[int, int]:
+    """mi.sample_tea_32 (used for seeds: optimize.py:327-328, batched.py:119,411)."""
+    v0 &= 0xffffffff
+    v1 &= 0xffffffff
+    s = 0
+    for _ in range(rounds):
+        s = (s + 0x9e3779b9) & 0xffffffff
+        v0 = (v0 + ((((v1 << 4) & 0xffffffff) + 0xa341316c) ^ ((v1 + s) & 0xffffffff)
+                    ^ ((v1 >> 5) + 0xc8013ea4))) & 0xffffffff
+        v1 = (v1 + ((((v0 << 4) & 0xffffffff) + 0xad90777d) ^ ((v0 + s) & 0xffffffff)
+                    ^ ((v0 >> 5) + 0x7e95761e))) & 0xffffffff
+    return v0, v1
+
+
+# --- the integrator ------------------------------------------------------------------------
+class VolpathSimpleIntegrator:
+    """Differential-ratio-tracking volumetric path tracer (volpathsimple.py:10-36).
+
+    Assumptions inherited from the reference: no surfaces, a single medium inside a
+    convex (here: axis-aligned box) boundary with a null BSDF, one infinite emitter.
+    """
+
+    def __init__(self, props: Optional[dict] = None):
+        props = dict(props or {})
+        self.hide_emitters = bool(props.get("hide_emitters", False))
+        self.use_nee = bool(props.get("use_nee", True))
+        self.use_drt = bool(props.get("use_drt", True))
+        self.use_drt_subsampling = bool(props.get("use_drt_subsampling", True))
+        self.use_drt_mis = bool(props.get("use_drt_mis", True))
+        # RBIntegrator base properties (defaults of mi.ad.integrators.common)
+        self.max_depth = int(props.get("max_depth", 6))
+        self.rr_depth = int(props.get("rr_depth", 5))
+        if self.max_depth < 0:
+            raise ValueError("max_depth must be >= 0 (unbounded depth is not supported)")
+        self._handles: Dict[int, object] = {}
+        self._bound: Dict[int, tuple] = {}
+
+    # -- reference surface ---------------------------------------------------
+    def aovs(self):
+        return []
+
+    def props(self) -> dict:
+        return dict(hide_emitters=self.hide_emitters, use_nee=self.use_nee, use_drt=self.use_drt,
+                    use_drt_subsampling=self.use_drt_subsampling, use_drt_mis=self.use_drt_mis,
+                    max_depth=self.max_depth, rr_depth=self.rr_depth)
+
+    def sample(self, mode, scene: Scene, sampler: IndependentSampler, ray: RayBatch,
+               δL: Optional[torch.Tensor] = None, state_in: Optional[torch.Tensor] = None,
+               active=None, grads: Optional[Dict[str, torch.Tensor]] = None, **kwargs):
+        """-> (L, valid, state_out).  Primal: L = state_out = radiance [n,3].
+        Backward: gradients are ACCUMULATED into `grads[key]` (tensors shaped like the
+        parameters); returns (None, True, None).  Extra kwargs (`depth`, `reparam`)
+        are absorbed like the reference does (volpathsimple.py:47)."""
+        mode = ADMode(int(mode))
+        h, dev = self._bind(scene)
+        self._set_rays(h, ray)
+        n = int(ray.n_rays)
+        ro = ray.o.data_ptr() if ray.o is not None else 0
+        rd = ray.d.data_ptr() if ray.d is not None else 0
+        if ray.o is not None:
+            _check(ray.o, (n, 3), dev, "ray.o")
+            _check(ray.d, (n, 3), dev, "ray.d")
+        if mode == ADMode.Primal:
+            L = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            h.render_primal(ro, rd, n, int(ray.ray_offset), int(ray.spp), sampler.seed_value, L.data_ptr())
+            return L, True, L
+        if mode == ADMode.Backward:
+            if δL is None or state_in is None:
+                raise ValueError("sample(Backward) needs δL and state_in")
+            if grads is None:
+                raise ValueError("sample(Backward) needs `grads` (dict of accumulation tensors)")
+            _check(δL, (n, 3), dev, "δL")
+            _check(state_in, (n, 3), dev, "state_in")
+            gs, ga = grads[SIGMA_T_KEY], grads[ALBEDO_KEY]
+            _check(gs, tuple(scene.medium.sigma_t.shape), dev, "grads[sigma_t]")
+            _check(ga, tuple(scene.medium.albedo.shape), dev, "grads[albedo]")
+            h.render_backward(ro, rd, n, int(ray.ray_offset), int(ray.spp), sampler.seed_value,
+                              δL.data_ptr(), state_in.data_ptr(), gs.data_ptr(), ga.data_ptr())
+            return None, True, None
+        raise NotImplementedError("forward-mode differentiation is not supported "
+                                  "(render_batch_forward raises in the reference too, batched.py:200-209)")
+
+    # -- film helpers (hdrfilm + box filter, batched.py:176-197 / 298-306) -----
+    def develop(self, scene: Scene, L: torch.Tensor, spp: int) -> torch.Tensor:
+        h, dev = self._bind(scene)
+        n_pix = L.shape[0] // spp
+        img = torch.empty((n_pix, 3), dtype=torch.float32, device=dev)
+        h.film_develop(L.data_ptr(), n_pix, int(spp), img.data_ptr())
+        return img
+
+    def film_backward(self, scene: Scene, grad_image: torch.Tensor, spp: int) -> torch.Tensor:
+        h, dev = self._bind(scene)
+        grad_image = grad_image.contiguous().view(-1, 3)
+        n_pix = grad_image.shape[0]
+        dL = torch.empty((n_pix * spp, 3), dtype=torch.float32, device=dev)
+        h.film_backward(grad_image.data_ptr(), n_pix, int(spp), dL.data_ptr())
+        return dL
+
+    # -- instrumentation ---------------------------------------------------------
+    def native_handle(self, scene: Scene):
+        return self._bind(scene)[0]
+
+    # -- internals ---------------------------------------------------------------
+    def _bind(self, scene: Scene):
+        m = scene.medium
+        st, al = m.sigma_t, m.albedo
+        if not (isinstance(st, torch.Tensor) and isinstance(al, torch.Tensor)):
+            raise TypeError("the HIP integrator needs torch device tensors for sigma_t / albedo "
+                            "(use Scene.to(device))")
+        if not st.is_cuda:
+            raise RuntimeError("sigma_t is not on a GPU: the DRT integrator has no CPU path")
+        dev = st.device
+        _check(st, None, dev, "sigma_t")
+        _check(al, tuple(st.shape[:3]) + (3,), dev, "albedo")
+        if st.dim() != 4 or st.shape[-1] != 1:
+            raise ValueError(f"sigma_t must have shape (Z,Y,X,1), got {tuple(st.shape)}")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        h = self._handles.get(idx)
+        if h is None:
+            h = native().Integrator(self.props(), idx)
+            self._handles[idx] = h
+        h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        key = (st.data_ptr(), st._version, al.data_ptr(), al._version, tuple(st.shape),
+               tuple(m.bbox_min), tuple(m.bbox_max), float(m.scale), int(m.majorant_resolution_factor),
+               tuple(scene.emitter.radiance))
+        if self._bound.get(idx) != key:
+            z, y, x = st.shape[:3]
+            h.set_medium(st.data_ptr(), al.data_ptr(), [int(x), int(y), int(z)],
+                         [float(v) for v in m.bbox_min], [float(v) for v in m.bbox_max],
+                         float(m.scale), int(m.majorant_resolution_factor))
+            h.set_emitter_constant([float(v) for v in scene.emitter.radiance])
+            self._bound[idx] = key
+        return h, dev
+
+    @staticmethod
+    def _set_rays(h, ray: RayBatch):
+        if ray.interleave:
+            h.set_ray_interleave(int(ray.interleave[0]), int(ray.interleave[1]))
+        else:
+            h.set_ray_interleave(0, 0)
+        if ray.o is None:
+            if ray.sensor is None:
+                raise ValueError("RayBatch needs explicit rays or a sensor")
+            f = ray.sensor.frame()
+            h.set_sensor_perspective([float(v) for v in f["origin"]], [float(v) for v in f["left"]],
+                                     [float(v) for v in f["up"]], [float(v) for v in f["dir"]],
+                                     float(f["tan_x"]), float(f["tan_y"]),
+                                     int(ray.sensor.width), int(ray.sensor.height))
+
+
+def _check(t: torch.Tensor, shape, dev, name: str):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if t.device != dev:
+        raise ValueError(f"{name} is on {t.device}, expected {dev}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+
+
+register_integrator("volpathsimple", lambda props: VolpathSimpleIntegrator(props))

@@ -1,0 +1,68 @@
+"""`IntegratorConfig` registry - the configuration surface of the reference kept
+as is (python/opt_config.py:83-169): same names, same `create(max_depth=...)`
+contract (deep copy of `params`, `rr_depth` forbidden as a kwarg and forced to
+`max_depth + 1000`, i.e. Russian roulette disabled).
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from dataclasses import dataclass
+from typing import Dict
+
+from .integrators import load_dict
+
+
+@dataclass
+class IntegratorConfig:
+    name: str
+    pretty_name: str
+    params: Dict
+
+    uses_fd: bool = False
+    fd_epsilon: float = None
+    fd_spp_multiplier: int = 16
+
+    def __post_init__(self):
+        if self.uses_fd:
+            assert self.fd_epsilon is not None
+
+    def create(self, **kwargs):
+        assert 'max_depth' in kwargs
+        d = deepcopy(self.params)
+        d.update(kwargs)
+
+        assert d['max_depth'] >= 0
+        assert 'rr_depth' not in kwargs
+        if 'rr_depth' not in self.params:
+            d['rr_depth'] = d['max_depth'] + 1000
+
+        return load_dict(d)
+
+
+_INTEGRATOR_CONFIGS: Dict[str, IntegratorConfig] = {}
+
+
+def add_int_config(name, **kwargs):
+    assert name not in _INTEGRATOR_CONFIGS, f'Duplicate integrator config name: {name}'
+    _INTEGRATOR_CONFIGS[name] = IntegratorConfig(name, **kwargs)
+
+
+def get_int_config(name):
+    if isinstance(name, IntegratorConfig):
+        return deepcopy(name)
+    return deepcopy(_INTEGRATOR_CONFIGS[name])
+
+
+# The five registered names of the reference (opt_config.py:123-169).
+add_int_config('fd-forward', pretty_name='Finite differences',
+               params={'type': 'volpathsimple', 'use_drt': False},
+               uses_fd=True, fd_epsilon=5e-3)
+add_int_config('volpathsimple-drt', pretty_name='Differential Ratio Tracking',
+               params={'type': 'volpathsimple', 'use_drt': True,
+                       'use_drt_subsampling': True, 'use_drt_mis': True})
+add_int_config('volpathsimple-drt-quadratic', pretty_name='Differential Ratio Tracking (quadratic)',
+               params={'type': 'volpathsimple', 'use_drt': True,
+                       'use_drt_subsampling': False, 'use_drt_mis': True})
+add_int_config('volpathsimple-basic', pretty_name='Free-flight based',
+               params={'type': 'volpathsimple', 'use_drt': False})
+# 'nerf' (python/integrators/nerf.py) is registered once its plugin exists; see DESIGN.md.

@@ -1,0 +1,115 @@
+"""Differentiable render ops: the callers of the hot path.
+
+`render(...)` mirrors `mi.render(scene, params, integrator, sensor, spp, spp_grad,
+seed, seed_grad)` as the reference uses it (python/optimize.py:44,129,345,
+python/fd.py:12,45): forward = primal pass at (seed, spp); backward = the
+radiative-backprop sequence of `render_batch_backward` (python/batched.py:212-326)
+at (seed_grad, spp_grad):
+    (1) sample(Primal) with a clone of the sampler          -> L
+    (2) film: image = mean_spp L ; dL = grad_image[pixel]/spp (box filter)
+    (3) sample(Backward, same sampler, dL, state_in = L)    -> gradients
+exposed to PyTorch through a `torch.autograd.Function` so that
+`loss.backward()` / an optimizer work like `dr.backward(loss)` / `opt.step()`.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .distributed import ShardSpec, allreduce_gradients
+from .integrators import ADMode, IndependentSampler, RayBatch, sample_tea_32
+from .scene import ALBEDO_KEY, SIGMA_T_KEY, GridMedium, Scene
+
+
+def alloc_grads(scene: Scene) -> Dict[str, torch.Tensor]:
+    """Zeroed gradient grids shaped like the parameters, carved out of ONE flat
+    buffer (`_flat`) so that the multi-GPU all-reduce is a single collective."""
+    st, al = scene.medium.sigma_t, scene.medium.albedo
+    flat = torch.zeros(st.numel() + al.numel(), dtype=torch.float32, device=st.device)
+    return {SIGMA_T_KEY: flat[:st.numel()].view(st.shape),
+            ALBEDO_KEY: flat[st.numel():].view(al.shape),
+            "_flat": flat}
+
+
+def _with_params(scene: Scene, sigma_t: torch.Tensor, albedo: torch.Tensor) -> Scene:
+    m = scene.medium
+    medium = GridMedium(sigma_t=sigma_t, albedo=albedo, bbox_min=m.bbox_min, bbox_max=m.bbox_max,
+                        scale=m.scale, majorant_resolution_factor=m.majorant_resolution_factor)
+    return Scene(medium=medium, emitter=scene.emitter, sensors=scene.sensors)
+
+
+def _sensor_batch(scene: Scene, sensor_index: int, spp: int, shard: Optional[ShardSpec]) -> RayBatch:
+    sensor = scene.sensors[sensor_index]
+    n_pixels = sensor.width * sensor.height
+    shard = shard or ShardSpec()
+    n_local = shard.n_local_pixels(n_pixels)
+    off, inter = shard.ray_mapping(spp)
+    return RayBatch(n_rays=n_local * spp, spp=spp, sensor=sensor, ray_offset=off, interleave=inter)
+
+
+def render_primal(scene: Scene, integrator, sensor: int = 0, spp: int = 1, seed: int = 0,
+                  shard: Optional[ShardSpec] = None) -> torch.Tensor:
+    """Detached primal image of the local pixels, [n_local_pixels, 3]
+    (render_batch_primal, batched.py:134-197)."""
+    batch = _sensor_batch(scene, sensor, spp, shard)
+    L, _, _ = integrator.sample(ADMode.Primal, scene, IndependentSampler(seed, spp), batch)
+    return integrator.develop(scene, L, spp)
+
+
+def render_backward(scene: Scene, integrator, grad_image: torch.Tensor, sensor: int = 0,
+                    spp: int = 1, seed: int = 0, shard: Optional[ShardSpec] = None,
+                    grads: Optional[Dict[str, torch.Tensor]] = None,
+                    allreduce: bool = True) -> Dict[str, torch.Tensor]:
+    """The H1 sequence (batched.py:212-326) for the local pixels; returns the
+    gradient grids (summed over all ranks when a process group is active)."""
+    batch = _sensor_batch(scene, sensor, spp, shard)
+    sampler = IndependentSampler(seed, spp)
+    L, _, state_out = integrator.sample(ADMode.Primal, scene, sampler.clone(), batch)     # :255-264
+    dL = integrator.film_backward(scene, grad_image, spp)                                  # :272-306
+    if grads is None:
+        grads = alloc_grads(scene)
+    integrator.sample(ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state_out,  # :309-318
+                      grads=grads)
+    if allreduce:
+        allreduce_gradients(grads)
+    return grads
+
+
+class _RenderOp(torch.autograd.Function):
+    """Counterpart of `mi._RenderOp` / `_BatchedRenderOp` (batched.py:13-85)."""
+
+    @staticmethod
+    def forward(ctx, sigma_t, albedo, scene, integrator, sensor, spp, spp_grad, seed, seed_grad, shard):
+        sc = _with_params(scene, sigma_t.detach(), albedo.detach())
+        ctx.scene, ctx.integrator, ctx.sensor = sc, integrator, sensor
+        ctx.spp_grad, ctx.seed_grad, ctx.shard = spp_grad, seed_grad, shard
+        return render_primal(sc, integrator, sensor, spp, seed, shard)
+
+    @staticmethod
+    def backward(ctx, grad_image):
+        g = render_backward(ctx.scene, ctx.integrator, grad_image.contiguous(), ctx.sensor,
+                            ctx.spp_grad, ctx.seed_grad, ctx.shard)
+        return g[SIGMA_T_KEY], g[ALBEDO_KEY], None, None, None, None, None, None, None, None
+
+
+def render(scene: Scene, params: Optional[Dict[str, torch.Tensor]] = None, integrator=None,
+           sensor: int = 0, spp: int = 1, spp_grad: int = 0, seed: int = 0, seed_grad: int = 0,
+           shard: Optional[ShardSpec] = None) -> torch.Tensor:
+    """`mi.render`: image of the local pixels, [n_local_pixels, 3] (the whole image,
+    row-major, when unsharded - reshape to (H, W, 3)).  Differentiable with respect to
+    `params[SIGMA_T_KEY]` / `params[ALBEDO_KEY]`."""
+    if integrator is None:
+        raise ValueError("render: an integrator is required")
+    if spp_grad == 0:
+        spp_grad = spp
+    if seed_grad == 0:
+        # de-correlate the primal and differential phases (batched.py:117-122)
+        seed_grad = sample_tea_32(seed, 1)[0]
+    elif seed_grad == seed:
+        raise Exception('The primal and differential seed should be different '
+                        'to ensure unbiased gradient computation!')
+    if params is None:
+        params = {SIGMA_T_KEY: scene.medium.sigma_t, ALBEDO_KEY: scene.medium.albedo}
+    return _RenderOp.apply(params[SIGMA_T_KEY], params[ALBEDO_KEY], scene, integrator, sensor,
+                           int(spp), int(spp_grad), int(seed), int(seed_grad), shard)
