@@ -145,6 +145,13 @@ int drt_get_counters(drt_handle h, drt_counters *out);   /* synchronises the str
 int drt_enable_timing(drt_handle h, int enable);
 int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity);
 
+/* Test hook: evaluate one device primitive per item (6 floats in, 6 floats out) so
+ * that the parity tests can compare the [M3-ext] building blocks bit for bit with
+ * the oracle.  op: 0 log, 1 sincos(2 pi u), 2 square_to_uniform_sphere, 3 sigma_t(p),
+ * 4 albedo(p), 5 box hit (o,d) -> valid,t,n, 6 PCG32 floats of (seed,index) bit
+ * patterns, 7 sensor ray (pixel bits, ux, uy), 8 mis_weight / div / sqrt / fma. */
+int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out);
+
 const char *drt_version(void);
 
 #ifdef __cplusplus

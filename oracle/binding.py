@@ -128,7 +128,7 @@ def make_config(props: dict) -> Config:
         use_drt_subsampling=int(props.get("use_drt_subsampling", True)),
         use_drt_mis=int(props.get("use_drt_mis", True)),
         max_depth=max_depth,
-        rr_depth=int(props.get("rr_depth", max_depth + 1000)))
+        rr_depth=int(props.get("rr_depth", 5)))   # Mitsuba RBIntegrator default
 
 
 class OracleScene:

@@ -34,7 +34,8 @@ def gpu():
     return torch.device("cuda:0")
 
 
-DEFAULT_PROPS = dict(max_depth=64, use_nee=True, use_drt=True, use_drt_subsampling=True, use_drt_mis=True)
+DEFAULT_PROPS = dict(max_depth=64, rr_depth=1064, use_nee=True, use_drt=True, use_drt_subsampling=True,
+                     use_drt_mis=True)
 
 VARIANTS = {
     "drt": dict(use_drt=True, use_drt_subsampling=True, use_drt_mis=True),
@@ -46,7 +47,11 @@ VARIANTS = {
 
 
 def props_for(variant: str, **over):
+    """Integrator properties of a registered estimator; Russian roulette disabled the way
+    IntegratorConfig.create does it (rr_depth = max_depth + 1000, opt_config.py:105-106)
+    unless `rr_depth` is given."""
     p = dict(max_depth=64, use_nee=True)
     p.update(VARIANTS[variant])
     p.update(over)
+    p.setdefault("rr_depth", p["max_depth"] + 1000)
     return p

@@ -131,8 +131,10 @@ def test_edge_cases(uivr, oracle, gpu):
     d = torch.tensor([[0.0, 1.0, 0.0]], device=gpu).repeat(n, 1)
     L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(1, 1), uivr.RayBatch(n_rays=n, spp=1, o=o, d=d))
     np.testing.assert_array_equal(L.cpu().numpy(), np.tile(np.array([1.0, 0.8, 0.2], np.float32), (n, 1)))
-    # zero density / zero albedo / shallow depth: bit-exact against the oracle
-    for mod, over in [("zero_density", {}), ("zero_albedo", {}), ("depth0", dict(max_depth=0)), ("depth1", dict(max_depth=1))]:
+    # zero density / zero albedo / shallow depth / Russian roulette on: against the oracle
+    for mod, over in [("zero_density", {}), ("zero_albedo", {}), ("depth0", dict(max_depth=0)),
+                      ("depth1", dict(max_depth=1)), ("russian_roulette", dict(rr_depth=2)),
+                      ("no_nee", dict(use_nee=False)), ("hide_emitters", dict(hide_emitters=True))]:
         sc = uivr.cube_test_scene(8, 8, density_scale=2.0)
         if mod == "zero_density":
             sc.medium.sigma_t[...] = 0.0

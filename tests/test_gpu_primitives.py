@@ -1,0 +1,134 @@
+"""Device primitives vs the oracle, bit for bit (drt_debug_eval hook of the C ABI).
+These are the [M3-ext] building blocks restated in DESIGN.md: PCG32/TEA, the fixed
+log / sincos polynomials, sphere warping, trilinear grid lookup, box intersection,
+sensor rays, and IEEE division / sqrt."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import props_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _eval(uivr, gpu, scene, op, inp):
+    sg = uivr.scene_to(scene, gpu)
+    integ = uivr.load_dict(dict(type="volpathsimple", **props_for("drt")))
+    h = integ.native_handle(sg)
+    if scene.sensors:
+        integ._set_rays(h, uivr.RayBatch(n_rays=1, spp=1, sensor=scene.sensors[0]))
+    n = inp.shape[0]
+    buf = np.zeros((n, 6), dtype=np.float32)
+    buf[:, :inp.shape[1]] = inp
+    tin = torch.from_numpy(buf).to(gpu)
+    tout = torch.empty_like(tin)
+    h.debug_eval(op, tin.data_ptr(), n, tout.data_ptr())
+    torch.cuda.synchronize()
+    return tout.cpu().numpy()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_log_sincos_sphere(uivr, oracle, gpu):
+    L = oracle.lib()
+    scene = uivr.cube_test_scene(8, 8)
+    k = np.arange(1, 1 << 23, 997, dtype=np.int64)
+    x = (k.astype(np.float64) / float(1 << 23)).astype(np.float32)       # the values 1-u can take
+    x = np.concatenate([x, np.float32([1.0, 2.0 ** -23, 0.5, 0.70710677, 0.7071068])])
+    got = _eval(uivr, gpu, scene, 0, x[:, None])[:, 0]
+    ref = np.array([L.drto_logf(float(v)) for v in x], dtype=np.float32)
+    np.testing.assert_array_equal(_bits(got), _bits(ref))
+
+    u = np.concatenate([np.random.default_rng(1).random(20000, dtype=np.float32),
+                        np.float32([0, 0.25, 0.5, 0.75, 0.125, 0.375, 1 - 2.0 ** -23])])
+    got = _eval(uivr, gpu, scene, 1, u[:, None])[:, :2]
+    s, c = C.c_float(), C.c_float()
+    ref = np.zeros_like(got)
+    for i, v in enumerate(u):
+        L.drto_sincos_2pi(float(v), C.byref(s), C.byref(c))
+        ref[i] = (s.value, c.value)
+    np.testing.assert_array_equal(_bits(got), _bits(ref))
+
+    uv = np.random.default_rng(2).random((20000, 2), dtype=np.float32)
+    got = _eval(uivr, gpu, scene, 2, uv)[:, :3]
+    out = (C.c_float * 3)()
+    ref = np.zeros_like(got)
+    for i, (a, b) in enumerate(uv):
+        L.drto_uniform_sphere(float(a), float(b), out)
+        ref[i] = out[:]
+    np.testing.assert_array_equal(_bits(got), _bits(ref))
+
+
+def test_pcg32_and_sensor(uivr, oracle, gpu):
+    L = oracle.lib()
+    scene = uivr.cube_test_scene(128, 128)
+    rng = np.random.default_rng(3)
+    seeds = rng.integers(0, 2 ** 32, size=(2000, 2), dtype=np.uint64).astype(np.uint32)
+    got = _eval(uivr, gpu, scene, 6, seeds.view(np.float32))
+    ref = np.zeros((2000, 6), dtype=np.float32)
+    for i, (s, idx) in enumerate(seeds):
+        L.drto_pcg32_floats(int(s), int(idx), 6, ref[i].ctypes.data_as(C.POINTER(C.c_float)))
+    np.testing.assert_array_equal(_bits(got), _bits(ref))
+
+    osc = oracle.OracleScene(scene)
+    pix = rng.integers(0, 128 * 128, size=5000, dtype=np.uint64).astype(np.uint32)
+    uv = rng.random((5000, 2), dtype=np.float32)
+    inp = np.concatenate([pix.view(np.float32)[:, None], uv], axis=1)
+    got = _eval(uivr, gpu, scene, 7, inp)
+    ref = np.zeros((5000, 6), dtype=np.float32)
+    o, d = (C.c_float * 3)(), (C.c_float * 3)()
+    for i in range(5000):
+        L.drto_sensor_ray(C.byref(osc.sensor), int(pix[i]), float(uv[i, 0]), float(uv[i, 1]), o, d)
+        ref[i, :3] = o[:]
+        ref[i, 3:] = d[:]
+    np.testing.assert_array_equal(_bits(got), _bits(ref))
+
+
+def test_grid_lookup_and_box(uivr, oracle, gpu):
+    L = oracle.lib()
+    rng = np.random.default_rng(4)
+    res = (5, 7, 6)   # X, Y, Z - ragged on purpose
+    sigma_t = rng.random((res[2], res[1], res[0], 1), dtype=np.float32) * 3
+    albedo = rng.random((res[2], res[1], res[0], 3), dtype=np.float32)
+    medium = uivr.GridMedium(sigma_t=sigma_t, albedo=albedo, bbox_min=(-1, 0, 2), bbox_max=(1.5, 3, 2.5), scale=1.7)
+    scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter(), sensors=[])
+    osc = oracle.OracleScene(scene, sensor_index=None)
+    lo, hi = np.float32(medium.bbox_min), np.float32(medium.bbox_max)
+    p = (lo + (hi - lo) * (rng.random((20000, 3), dtype=np.float32) * 1.1 - 0.05)).astype(np.float32)  # incl. slightly outside
+    got = _eval(uivr, gpu, scene, 3, p)[:, 0]
+    ref = np.array([L.drto_eval_sigma_t(C.byref(osc.medium), (C.c_float * 3)(*q)) for q in p], dtype=np.float32)
+    np.testing.assert_array_equal(_bits(got), _bits(ref))
+    got = _eval(uivr, gpu, scene, 4, p)[:, :3]
+    out = (C.c_float * 3)()
+    ref = np.zeros_like(got)
+    for i, q in enumerate(p):
+        L.drto_eval_albedo(C.byref(osc.medium), (C.c_float * 3)(*q), out)
+        ref[i] = out[:]
+    np.testing.assert_array_equal(_bits(got), _bits(ref))
+
+    o = (rng.normal(size=(20000, 3)) * 2 + (lo + hi) / 2).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:50, 0] = 0.0   # axis-parallel rays
+    got = _eval(uivr, gpu, scene, 5, np.concatenate([o, d], axis=1))
+    ref = np.zeros((20000, 5), dtype=np.float32)
+    t, nrm = C.c_float(), (C.c_float * 3)()
+    for i in range(20000):
+        v = L.drto_box_hit(C.byref(osc.medium), (C.c_float * 3)(*o[i]), (C.c_float * 3)(*d[i]), C.byref(t), nrm)
+        ref[i] = (float(v), t.value, nrm[0], nrm[1], nrm[2])
+    np.testing.assert_array_equal(_bits(got[:, :5]), _bits(ref))
+
+
+def test_ieee_div_sqrt(uivr, gpu):
+    scene = uivr.cube_test_scene(8, 8)
+    rng = np.random.default_rng(5)
+    a = (rng.random((50000, 3), dtype=np.float32) * 10 + 1e-3).astype(np.float32)
+    got = _eval(uivr, gpu, scene, 8, a)
+    np.testing.assert_array_equal(_bits(got[:, 1]), _bits(a[:, 0] / a[:, 1]))
+    np.testing.assert_array_equal(_bits(got[:, 2]), _bits(np.sqrt(a[:, 0])))
+    a2, b2 = a[:, 0] * a[:, 0], a[:, 1] * a[:, 1]
+    np.testing.assert_array_equal(_bits(got[:, 0]), _bits(a2 / (a2 + b2)))

@@ -274,6 +274,7 @@ int drt_set_sensor_perspective(drt_handle h, const float origin[3], const float 
 int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
                       uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_out)
 {
+    if (h && n_rays == 0) return DRT_OK;    /* empty batch: nothing to enqueue */
     int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp);
     if (rc) return rc;
     if (!L_out && n_rays) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null L_out");
@@ -288,6 +289,7 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
                         uint64_t ray_offset, uint32_t spp, uint32_t seed, const float *dL,
                         const float *L_in, float *grad_sigma_t, float *grad_albedo)
 {
+    if (h && n_rays == 0) return DRT_OK;
     int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp);
     if (rc) return rc;
     if (n_rays && (!dL || !L_in || !grad_sigma_t || !grad_albedo))
@@ -314,6 +316,19 @@ int drt_film_backward(drt_handle h, const float *grad_image, uint64_t n_pixels, 
     if (spp == 0 || (n_pixels && (!grad_image || !dL))) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_film_backward: bad argument");
     DeviceGuard g(h->device);
     DRT_HIP_CHECK(h, drt::launch_film_backward(grad_image, n_pixels, spp, dL, h->stream));
+    return DRT_OK;
+}
+
+int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (n && (!in || !out)) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_debug_eval: null buffer");
+    if ((op == 3 || op == 4 || op == 5) && !h->have_medium) return fail(h, DRT_ERR_NOT_CONFIGURED, "no medium set");
+    if (op == 7 && !h->have_sensor) return fail(h, DRT_ERR_NOT_CONFIGURED, "no sensor set");
+    DeviceGuard g(h->device);
+    drt::Params P = h->base;
+    P.majorant = h->d_majorant;
+    DRT_HIP_CHECK(h, drt::launch_debug_eval(P, op, in, n, out, h->stream));
     return DRT_OK;
 }
 

@@ -427,6 +427,45 @@ __global__ void __launch_bounds__(256) film_backward_kernel(const float *grad_im
     dL[t] = grad_image[3 * (i / spp) + c] * (1.0f / (float) spp);
 }
 
+// Primitive evaluation for the parity tests (tests/test_gpu_primitives.py): one
+// thread per item, 6 floats in, 6 floats out.
+__global__ void __launch_bounds__(256) debug_eval_kernel(const Params P, int op, const float *in, uint64_t n, float *out)
+{
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *a = in + 6 * i;
+    float *o = out + 6 * i;
+    for (int k = 0; k < 6; ++k) o[k] = 0.0f;
+    switch (op) {
+        case 0: o[0] = drt_logf(a[0]); break;
+        case 1: drt_sincos_2pi(a[0], o[0], o[1]); break;
+        case 2: { V3 d = square_to_uniform_sphere(a[0], a[1]); o[0] = d.x; o[1] = d.y; o[2] = d.z; } break;
+        case 3: o[0] = eval_sigma_t(P, v3(a[0], a[1], a[2])); break;
+        case 4: eval_albedo(P, v3(a[0], a[1], a[2]), o); break;
+        case 5: {
+            Hit h = box_hit(P, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]));
+            o[0] = h.valid ? 1.0f : 0.0f; o[1] = h.t; o[2] = h.n.x; o[3] = h.n.y; o[4] = h.n.z;
+        } break;
+        case 6: {
+            Pcg32 S; S.seed(__float_as_uint(a[0]), __float_as_uint(a[1]));
+            for (int k = 0; k < 6; ++k) o[k] = S.next_1d();
+        } break;
+        case 7: {
+            V3 ro, rd; sensor_ray(P, __float_as_uint(a[0]), a[1], a[2], ro, rd);
+            o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
+        } break;
+        case 8: o[0] = mis_weight(a[0], a[1]); o[1] = a[0] / a[1]; o[2] = sqrtf(a[0]); o[3] = fmaf(a[0], a[1], a[2]); break;
+        default: break;
+    }
+}
+
+hipError_t launch_debug_eval(const Params &P, int op, const float *in, uint64_t n, float *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P, op, in, n, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // launch wrappers (host)
 // ---------------------------------------------------------------------------

@@ -15,5 +15,6 @@ hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, 
 hipError_t launch_film_backward(const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL,
                                 hipStream_t stream);
 uint32_t host_alt_seed(uint32_t seed, bool sensor_flow);
+hipError_t launch_debug_eval(const Params &P, int op, const float *in, uint64_t n, float *out, hipStream_t stream);
 
 }  // namespace drt

@@ -126,6 +126,12 @@ public:
         { py::gil_scoped_release nogil; rc = drt_film_backward(h_, ptr<const float>(grad_image), n_pixels, spp, ptr<float>(dL)); }
         check(rc, "drt_film_backward");
     }
+    void debug_eval(int op, uintptr_t in, uint64_t n, uintptr_t out)
+    {
+        int rc;
+        { py::gil_scoped_release nogil; rc = drt_debug_eval(h_, op, ptr<const float>(in), n, ptr<float>(out)); }
+        check(rc, "drt_debug_eval");
+    }
     void enable_counters(bool on) { check(drt_enable_counters(h_, on ? 1 : 0), "drt_enable_counters"); }
     void reset_counters() { check(drt_reset_counters(h_), "drt_reset_counters"); }
     py::dict get_counters()
@@ -176,6 +182,7 @@ PYBIND11_MODULE(_drt_pybind, m)
         .def("render_backward", &Integrator::render_backward)
         .def("film_develop", &Integrator::film_develop)
         .def("film_backward", &Integrator::film_backward)
+        .def("debug_eval", &Integrator::debug_eval)
         .def("enable_counters", &Integrator::enable_counters)
         .def("reset_counters", &Integrator::reset_counters)
         .def("get_counters", &Integrator::get_counters)
