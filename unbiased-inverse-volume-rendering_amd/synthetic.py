@@ -33,6 +33,19 @@ def _fbm(res: int, seed: int, octaves: int = 5, base: int = 4, device="cpu") -> 
     return (out / total)[0, 0]
 
 
+def _shape_density(d: torch.Tensor, majorant: float, floor: float = 0.06, q: float = 0.97) -> torch.Tensor:
+    """Normalise a raw density field: the q-quantile of the occupied voxels maps to the
+    majorant (values above are clipped, so the maximum is not a lone outlier), values
+    below `floor` of it become exactly empty space."""
+    flat = d.reshape(-1)
+    occ = flat[flat > 1e-4 * flat.max()]
+    sub = occ[:: max(1, occ.numel() // 1_000_000)]
+    ref = torch.quantile(sub, q).clamp_min(1e-12)
+    d = torch.clamp(d / ref, max=1.0)
+    d = torch.where(d < floor, torch.zeros_like(d), d)
+    return d * majorant
+
+
 def _coords(res: int, device):
     c = (torch.arange(res, dtype=torch.float32, device=device) + 0.5) / res
     z, y, x = torch.meshgrid(c, c, c, indexing="ij")   # grids are (Z, Y, X)
@@ -76,7 +89,7 @@ def smoke_scene(res: int = 128, film: int = 512, seed: int = 1234, device="cpu",
     plume = torch.exp(-r2 / (2.0 * width ** 2)) * torch.clamp(1.2 - y, 0.0, 1.0) * torch.clamp(y * 8.0, 0.0, 1.0)
     d = torch.clamp(n - 0.45, min=0.0) * plume
     side = 2.0
-    d = d * (optical_side / side / d.max().clamp_min(1e-12))
+    d = _shape_density(d, optical_side / side)
     st = d.unsqueeze(-1).contiguous()
     al = torch.full((res, res, res, 3), 0.6, dtype=torch.float32, device=device)
     medium = GridMedium(sigma_t=st, albedo=al, bbox_min=(-1.0, -1.0, -1.0), bbox_max=(1.0, 1.0, 1.0))
@@ -102,7 +115,7 @@ def dust_devil_scene(res: int = 256, film: int = 512, seed: int = 4321, device="
     base_cloud = torch.exp(-((y - 0.04) / 0.05) ** 2) * torch.exp(-(r / 0.35) ** 2)
     d = (wall * swirl * torch.clamp(1.1 - y, 0.0, 1.0) + 0.8 * base_cloud) * torch.clamp(n * 1.8 - 0.5, min=0.0)
     side = 2.0
-    d = d * (optical_side / side / d.max().clamp_min(1e-12))
+    d = _shape_density(d, optical_side / side)
     st = d.unsqueeze(-1).contiguous()
     sand = torch.tensor([0.8, 0.65, 0.45], dtype=torch.float32, device=device)
     al = (sand * (0.9 + 0.1 * _fbm(res, seed + 1, octaves=3, device=device)).unsqueeze(-1)).contiguous()
