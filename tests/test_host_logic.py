@@ -1,0 +1,219 @@
+"""Host-side logic that needs no GPU: the reference's configuration surface
+(opt_config.py:83-169), plugin registry, seed handling, shard mapping, the C-ABI
+library's exported symbols, and the multi-process gradient all-reduce (gloo)."""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --- IntegratorConfig / registry (reference: python/opt_config.py:83-169) ----------------
+def test_integrator_config_registry(uivr):
+    for name in ("fd-forward", "volpathsimple-drt", "volpathsimple-drt-quadratic", "volpathsimple-basic"):
+        assert uivr.get_int_config(name).name == name
+    c = uivr.get_int_config("volpathsimple-drt")
+    c.params["use_drt"] = False                      # get_int_config returns deep copies
+    assert uivr.get_int_config("volpathsimple-drt").params["use_drt"] is True
+    assert uivr.get_int_config(c) is not c
+    fd = uivr.get_int_config("fd-forward")
+    assert fd.uses_fd and fd.fd_epsilon == 5e-3 and fd.fd_spp_multiplier == 16
+    with pytest.raises(AssertionError):
+        uivr.add_int_config("volpathsimple-drt", pretty_name="dup", params={})
+    with pytest.raises(AssertionError):
+        uivr.IntegratorConfig("x", "x", {}, uses_fd=True)          # fd_epsilon required
+
+
+def test_integrator_config_create(uivr):
+    integ = uivr.get_int_config("volpathsimple-drt-quadratic").create(max_depth=64)
+    assert isinstance(integ, uivr.VolpathSimpleIntegrator)
+    p = integ.props()
+    assert p["max_depth"] == 64 and p["rr_depth"] == 1064          # RR disabled: max_depth + 1000
+    assert p["use_drt"] and not p["use_drt_subsampling"] and p["use_drt_mis"]
+    assert uivr.get_int_config("volpathsimple-basic").create(max_depth=3).props()["use_drt"] is False
+    with pytest.raises(AssertionError):
+        uivr.get_int_config("volpathsimple-drt").create()           # max_depth is mandatory
+    with pytest.raises(AssertionError):
+        uivr.get_int_config("volpathsimple-drt").create(max_depth=4, rr_depth=2)
+    with pytest.raises(AssertionError):
+        uivr.get_int_config("volpathsimple-drt").create(max_depth=-1)
+    assert integ.aovs() == [] and not hasattr(integ, "reparam")    # batched.py:152,223,235
+
+
+def test_plugin_registry_and_defaults(uivr):
+    integ = uivr.load_dict({"type": "volpathsimple", "max_depth": 8})
+    assert (integ.hide_emitters, integ.use_nee, integ.use_drt, integ.use_drt_subsampling,
+            integ.use_drt_mis) == (False, True, True, True, True)  # volpathsimple.py:22-34
+    with pytest.raises(ValueError):
+        uivr.load_dict({"type": "no-such-plugin"})
+    with pytest.raises(ValueError):
+        uivr.load_dict({"max_depth": 3})
+    made = []
+    uivr.register_integrator("unit-test-plugin", lambda props: made.append(props) or "ok")
+    assert uivr.load_dict({"type": "unit-test-plugin", "a": 1}) == "ok" and made == [{"a": 1}]
+
+
+def test_render_seed_rules(uivr):
+    scene = uivr.cube_test_scene(4, 4)
+    integ = uivr.load_dict({"type": "volpathsimple", "max_depth": 2})
+    with pytest.raises(Exception, match="seed should be different"):
+        uivr.render(scene, integrator=integ, seed=3, seed_grad=3)   # batched.py:120-122
+    with pytest.raises(ValueError):
+        uivr.render(scene, integrator=None)
+    with pytest.raises((TypeError, RuntimeError)):                   # numpy grids: no CPU path
+        uivr.render(scene, integrator=integ, seed=3)
+
+
+def test_cube_fixture_values(uivr):
+    """tests/test_integrators.py:23-37."""
+    sc = uivr.cube_test_scene()
+    st, al = sc.medium.sigma_t, sc.medium.albedo
+    assert st.shape == (3, 3, 3, 1) and al.shape == (3, 3, 3, 3)
+    assert (st[0, 0, 0, 0], st[0, 2, 0, 0], st[0, 0, 2, 0], st[1, 1, 1, 0]) == (np.float32(0.1), 2.0, np.float32(0.2), 0.5)
+    np.testing.assert_allclose(al[0, 0, 0], [0.3 / 9, 0.5 * (2 / 3) / 9, 0.9], rtol=1e-6)
+    np.testing.assert_allclose(al[2, 1, 2], [0.3, 0.0, 0.9], atol=1e-7)
+    assert tuple(sc.medium.bbox_min) == (-0.5,) * 3 and tuple(sc.medium.bbox_max) == (1.5,) * 3
+    f = sc.sensors[0].frame()
+    assert abs(np.dot(f["left"], f["up"])) < 1e-6 and abs(np.dot(f["left"], f["dir"])) < 1e-6
+    np.testing.assert_allclose(np.cross(f["dir"], f["left"]), f["up"], atol=1e-6)
+
+
+# --- sharding ---------------------------------------------------------------------------
+def test_shard_spec_partitions_pixels(uivr):
+    n = 64 * 64
+    for world in (1, 2, 4, 8):
+        chunk = uivr.ShardSpec.default_chunk(n, world, target=128)
+        seen = torch.cat([uivr.ShardSpec(r, world, chunk).pixel_indices(n) for r in range(world)])
+        assert torch.equal(torch.sort(seen).values, torch.arange(n))
+        for r in range(world):
+            s = uivr.ShardSpec(r, world, chunk)
+            off, inter = s.ray_mapping(spp=4)
+            if world == 1:
+                assert (off, inter) == (0, None)
+                continue
+            c, stride = inter
+            i = torch.arange(s.n_local_pixels(n) * 4)
+            gi = off + (i // c) * stride + (i % c)                   # drt_set_ray_interleave mapping
+            assert torch.equal(gi // 4, s.pixel_indices(n).repeat_interleave(4))
+    with pytest.raises(ValueError):
+        uivr.ShardSpec(2, 2)
+    with pytest.raises(ValueError):
+        uivr.ShardSpec(0, 3, 1000).check(4096)
+
+
+# --- the C ABI ----------------------------------------------------------------------------
+def _header_functions():
+    with open(os.path.join(ROOT, "include", "drt_hip.h")) as f:
+        src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(drt_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_c_abi_library_exports_every_declared_symbol(uivr):
+    from uivr_amd._native import library_path, native
+    names = _header_functions()
+    assert {"drt_create", "drt_destroy", "drt_last_error", "drt_set_medium", "drt_render_primal",
+            "drt_render_backward", "drt_film_develop", "drt_film_backward", "drt_get_counters",
+            "drt_set_ray_interleave", "drt_params_changed"} <= set(names)
+    lib = ctypes.CDLL(library_path())
+    for n in names:
+        assert hasattr(lib, n), f"libdrt_hip.so does not export {n}"
+    lib.drt_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.drt_version()
+    assert "gfx950" in native().version()            # the pybind11 shim loads too
+
+
+def test_c_abi_argument_errors_without_gpu(uivr):
+    """Error convention: negative status + message, no exceptions, no crash (no compute)."""
+    from uivr_amd._native import library_path
+    lib = ctypes.CDLL(library_path())
+    lib.drt_last_error.restype = ctypes.c_char_p
+    h = ctypes.c_void_p()
+    assert lib.drt_create(None, 0, ctypes.byref(h)) == -1
+    assert b"null" in lib.drt_last_error(None)
+    assert lib.drt_set_stream(None, None) == -1
+    assert lib.drt_render_primal(None, None, None, ctypes.c_uint64(0), ctypes.c_uint64(0), 1, 0, None) == -1
+    assert lib.drt_destroy(None) == 0
+    if not torch.cuda.is_available():
+        cfg = (ctypes.c_int32 * 7)(0, 1, 1, 1, 1, 8, 1008)
+        assert lib.drt_create(cfg, 0, ctypes.byref(h)) == -4          # DRT_ERR_NO_DEVICE: no CPU fallback
+        assert b"no HIP device" in lib.drt_last_error(None)
+
+
+# --- multi-process all-reduce (gloo, world size 2) ------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import uivr_amd as u
+    from conftest import props_for
+    from oracle import binding as ob
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scene = u.cube_test_scene(16, 16, density_scale=2.0)
+        n_pix, spp, seed = 256, 4, 77
+        shard = u.from_environment(n_pix)
+        shard = u.ShardSpec(shard.rank, shard.world, 32)
+        props = props_for("drt")
+        osc = ob.OracleScene(scene)
+        # the oracle stands in for the device integrator: render this rank's pixel chunks
+        pix = shard.pixel_indices(n_pix)
+        L = np.zeros((pix.numel() * spp, 3), np.float32)
+        for c in range(pix.numel() // shard.chunk_pixels):
+            p0 = int(pix[c * shard.chunk_pixels])
+            Lc, _ = ob.render_primal(osc, props, spp, seed, n_rays=shard.chunk_pixels * spp, ray_offset=p0 * spp)
+            L[c * shard.chunk_pixels * spp:(c + 1) * shard.chunk_pixels * spp] = Lc
+        img = ob.develop(L, spp)
+        dL = np.repeat((2.0 / (n_pix * 3)) * (img - 0.5) / spp, spp, axis=0).astype(np.float32)
+        grads = {u.SIGMA_T_KEY: torch.zeros(3, 3, 3, 1, dtype=torch.float64),
+                 u.ALBEDO_KEY: torch.zeros(3, 3, 3, 3, dtype=torch.float64)}
+        for c in range(pix.numel() // shard.chunk_pixels):
+            p0 = int(pix[c * shard.chunk_pixels])
+            sl = slice(c * shard.chunk_pixels * spp, (c + 1) * shard.chunk_pixels * spp)
+            gs, ga, _ = ob.render_backward(osc, props, spp, seed, dL[sl], L[sl],
+                                           n_rays=shard.chunk_pixels * spp, ray_offset=p0 * spp)
+            grads[u.SIGMA_T_KEY] += torch.from_numpy(gs)
+            grads[u.ALBEDO_KEY] += torch.from_numpy(ga)
+        loss_part = torch.tensor(float(((img.astype(np.float64) - 0.5) ** 2).sum() / (n_pix * 3)))
+        u.allreduce_gradients(grads)                                  # the collective under test
+        loss = u.allreduce_scalar(loss_part)
+        # flat-buffer variant (render.alloc_grads layout)
+        flat = torch.full((8,), float(rank + 1))
+        g2 = {"a": flat[:3], "b": flat[3:], "_flat": flat}
+        u.allreduce_gradients(g2)
+        if rank == 0:
+            q.put((grads[u.SIGMA_T_KEY].numpy(), grads[u.ALBEDO_KEY].numpy(), float(loss), flat.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_allreduce_equals_unsharded_gloo(oracle, uivr):
+    import torch.multiprocessing as mp
+    from conftest import props_for
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gs, ga, loss, flat = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = oracle.h1_step(oracle.OracleScene(uivr.cube_test_scene(16, 16, density_scale=2.0)), props_for("drt"), 4, 77)
+    np.testing.assert_allclose(gs, ref["grad_sigma_t"], rtol=2e-5, atol=1e-12)   # dL rounded differently on the host
+    np.testing.assert_allclose(ga, ref["grad_albedo"], rtol=2e-5, atol=1e-12)
+    assert loss == pytest.approx(ref["loss"], rel=1e-6)
+    np.testing.assert_array_equal(flat, np.full(8, 3.0))

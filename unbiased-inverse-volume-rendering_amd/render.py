@@ -111,5 +111,9 @@ def render(scene: Scene, params: Optional[Dict[str, torch.Tensor]] = None, integ
                         'to ensure unbiased gradient computation!')
     if params is None:
         params = {SIGMA_T_KEY: scene.medium.sigma_t, ALBEDO_KEY: scene.medium.albedo}
+    for k in (SIGMA_T_KEY, ALBEDO_KEY):
+        if not isinstance(params[k], torch.Tensor):
+            raise TypeError(f"render: params['{k}'] must be a torch device tensor "
+                            "(the DRT integrator has no CPU path; use scene_to(scene, device))")
     return _RenderOp.apply(params[SIGMA_T_KEY], params[ALBEDO_KEY], scene, integrator, sensor,
                            int(spp), int(spp_grad), int(seed), int(seed_grad), shard)
