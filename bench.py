@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--integrator", default="volpathsimple-drt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU sample (0 = auto)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="profiling ablations (drt_set_debug_flags); invalidates the result")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +113,8 @@ def main():
         torch.cuda.synchronize()
 
     h = integ.native_handle(scene)
+    if args.debug_flags:
+        h.set_debug_flags(args.debug_flags)
     for i in range(args.warmup):
         step(i)
     sync()
@@ -216,6 +219,8 @@ def main():
             "t_primal_ms": round(avg_p, 3), "t_adjoint_ms": round(avg_a, 3),
             "counters_primal": cnt_p, "counters_adjoint": cnt_a,
         }
+        if args.debug_flags:
+            out["INVALID_ablation_debug_flags"] = args.debug_flags
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

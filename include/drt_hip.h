@@ -152,6 +152,9 @@ int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity);
  * patterns, 7 sensor ray (pixel bits, ux, uy), 8 mis_weight / div / sqrt / fma. */
 int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out);
 
+/* Profiling ablations (bit 0: skip the gradient atomics).  0 in production. */
+int drt_set_debug_flags(drt_handle h, uint32_t flags);
+
 const char *drt_version(void);
 
 #ifdef __cplusplus

@@ -45,7 +45,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(_CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(_CSRC, h) for h in HIP_HEADERS]
     if force or _newer(LIB_PATH, deps):
-        cmd = [_hipcc()] + HIP_FLAGS + srcs + ["-o", LIB_PATH]
+        extra = [f"-D{k}={v}" for k, v in os.environ.items() if k.startswith("DRT_") and v.lstrip("-").isdigit()]
+        cmd = [_hipcc()] + HIP_FLAGS + extra + srcs + ["-o", LIB_PATH]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=_CSRC)

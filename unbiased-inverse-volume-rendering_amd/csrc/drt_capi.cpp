@@ -27,6 +27,7 @@ struct drt_handle_s {
     unsigned long long *d_counters = nullptr;   // [C_COUNT]
     bool counting = false;
     uint64_t chunk = 0, stride = 0;   // ray interleave (drt_set_ray_interleave)
+    uint32_t debug_flags = 0;
     bool timing = false;
     // HIP event pairs around every tracing launch while timing is on: [0] primal, [1] backward
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[2];
@@ -105,6 +106,7 @@ void fill_job(drt_handle h, drt::Params &P, const float *rays_o, const float *ra
     P.chunk = h->chunk; P.stride = h->stride;
     P.alt_seed = drt::host_alt_seed(seed, rays_o == nullptr);
     P.counters = h->counting ? h->d_counters : nullptr;
+    P.debug_flags = h->debug_flags;
 }
 
 void clear_timings(drt_handle h)
@@ -329,6 +331,13 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
     drt::Params P = h->base;
     P.majorant = h->d_majorant;
     DRT_HIP_CHECK(h, drt::launch_debug_eval(P, op, in, n, out, h->stream));
+    return DRT_OK;
+}
+
+int drt_set_debug_flags(drt_handle h, uint32_t flags)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    h->debug_flags = flags;
     return DRT_OK;
 }
 

@@ -181,6 +181,7 @@ struct Params {
     const float *dL, *L_in;
     float *g_sigma, *g_albedo;
     unsigned long long *counters;   // 9 x u64 or nullptr
+    uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
 };
 
 enum CounterSlot { C_RAYS = 0, C_DT, C_RT, C_DRT, C_ALB, C_TR, C_RT_ADJ, C_SC, C_SC_ALB, C_COUNT };
@@ -273,30 +274,93 @@ __device__ __forceinline__ void stencil_indices(const Stencil &s, int idx[8])
     idx[4] = c + s.x0; idx[5] = c + s.x1; idx[6] = d + s.x0; idx[7] = d + s.x1;
 }
 
-__device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g)
+// Cooperative scatter.  Measured on MI355X (tools/ubench/atomic_*.hip): the fp32
+// atomic path retires ~21 G requests/s chip-wide, where one request = one 64-byte
+// line touched by one wave instruction, whatever the number of lanes that hit it
+// (16 lanes on 16 consecutive floats cost the same as 1).  A lane that issues its
+// 8 corners as 8 instructions therefore pays 8 requests; if the lanes that are
+// active at the splat site share the work so that the two x-neighbours of a corner
+// pair leave in the SAME instruction, the pair costs one request.  The active
+// lanes stage (index, value) records in a wave-private LDS area and then, in groups
+// of up to 8 lanes, walk the group's records: lane j of the group adds corner j.
+constexpr int kCoopDwords = 32;   // per lane: 8 indices + 3 x 8 values
+
+__device__ __forceinline__ void coop_stage_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NCH>
+__device__ __forceinline__ void coop_scatter(float *dst, int stride, const int idx[8],
+                                             const float (&val)[NCH][8], uint32_t *rec)
+{
+    const uint64_t mask = __ballot(1);
+    const uint32_t lane = __lane_id();
+    const uint32_t rank = (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+    const uint32_t k = (uint32_t) __popcll(mask);
+    uint32_t *mine = rec + rank * kCoopDwords;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        mine[c] = (uint32_t) idx[c];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) mine[8 + 8 * ch + c] = __float_as_uint(val[ch][c]);
+    }
+    coop_stage_sync();
+    const uint32_t g0 = rank & ~7u, j = rank & 7u;
+    const uint32_t m = min(8u, k - g0);
+    for (uint32_t t = 0; t < m; ++t) {
+        const uint32_t *src = rec + (g0 + t) * kCoopDwords;
+        for (uint32_t c = j; c < 8; c += m) {
+            float *p = dst + (size_t) stride * src[c];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) atomicAdd(p + ch, __uint_as_float(src[8 + 8 * ch + c]));
+        }
+    }
+    coop_stage_sync();
+}
+
+__device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, uint32_t *rec)
 {
     Stencil s = make_stencil(P, p);
     float w[8]; int idx[8];
     stencil_weights(s, w);
     stencil_indices(s, idx);
     float gs = g * P.scale;
+    if (P.debug_flags & 1u) return;   // ablation: no gradient atomics
+    if (P.debug_flags & 2u) {         // ablation: one lane, eight instructions (round-1 v1 behaviour)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) atomicAdd(P.g_sigma + idx[k], w[k] * gs);
+        for (int k = 0; k < 8; ++k) atomicAdd(P.g_sigma + idx[k], w[k] * gs);
+        return;
+    }
+    float val[1][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) val[0][k] = w[k] * gs;
+    coop_scatter<1>(P.g_sigma, 1, idx, val, rec);
 }
 
-__device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float g[3])
+__device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float g[3], uint32_t *rec)
 {
     Stencil s = make_stencil(P, p);
     float w[8]; int idx[8];
     stencil_weights(s, w);
     stencil_indices(s, idx);
+    if (P.debug_flags & 1u) return;
+    if (P.debug_flags & 2u) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float *dst = P.g_albedo + 3 * (size_t) idx[k];
-        atomicAdd(dst + 0, w[k] * g[0]);
-        atomicAdd(dst + 1, w[k] * g[1]);
-        atomicAdd(dst + 2, w[k] * g[2]);
+        for (int k = 0; k < 8; ++k) {
+            float *dst = P.g_albedo + 3 * (size_t) idx[k];
+            atomicAdd(dst + 0, w[k] * g[0]);
+            atomicAdd(dst + 1, w[k] * g[1]);
+            atomicAdd(dst + 2, w[k] * g[2]);
+        }
+        return;
     }
+    float val[3][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { val[0][k] = w[k] * g[0]; val[1][k] = w[k] * g[1]; val[2][k] = w[k] * g[2]; }
+    coop_scatter<3>(P.g_albedo, 3, idx, val, rec);
 }
 
 // ---------------------------------------------------------------------------

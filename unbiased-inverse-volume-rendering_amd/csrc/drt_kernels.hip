@@ -7,6 +7,9 @@
 #include "drt_device.h"
 #include "drt_launch.h"
 
+#ifndef DRT_TRACE_WAVES
+#define DRT_TRACE_WAVES 1
+#endif
 namespace drt {
 
 struct Ray { V3 o, d; float maxt; };
@@ -18,12 +21,13 @@ struct Tracer {
     const Params &P;
     float maj, inv_maj;
     uint32_t ray_index;
+    uint32_t *rec;          // wave-private LDS staging area of the cooperative scatter
     uint32_t cnt[C_COUNT];
 
     __device__ __forceinline__ Tracer(const Params &p) : P(p)
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
-        ray_index = 0;
+        ray_index = 0; rec = nullptr;
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
@@ -51,7 +55,7 @@ struct Tracer {
             count(C_RT);
             if constexpr (ADJ) if (tr > 0.0f) {                         // :487-492
                 float a = (adj[0] + adj[1]) + adj[2];
-                splat_sigma_t(P, p, -(a * inv_maj) / tr);
+                splat_sigma_t(P, p, -(a * inv_maj) / tr, rec);
                 count(C_RT_ADJ);
             }
             T *= tr;                                                    // :495
@@ -188,8 +192,8 @@ struct Tracer {
             gs += a * alb[k];
             ga[k] = a * sig;
         }
-        splat_sigma_t(P, p, gs); count(C_SC);                           // :577-581
-        splat_albedo(P, p, ga);  count(C_SC_ALB);
+        splat_sigma_t(P, p, gs, rec); count(C_SC);                           // :577-581
+        splat_albedo(P, p, ga, rec);  count(C_SC_ALB);
     }
 
     // backpropagate_transmittance (volpathsimple.py:584-607)
@@ -200,7 +204,7 @@ struct Tracer {
         float g = -(adjw * (interval / 4.0f));
         for (int j = 0; j < 4; ++j) {
             float t = A.next_1d() * interval;                           // :595
-            splat_sigma_t(P, ray_at(ray.o, ray.d, t), g);
+            splat_sigma_t(P, ray_at(ray.o, ray.d, t), g, rec);
             count(C_TR);
         }
     }
@@ -288,8 +292,8 @@ struct Tracer {
                         gs += a * albedo[k];
                         ga[k] = a * mei.sigma_t;
                     }
-                    splat_sigma_t(P, mei.p, gs); count(C_SC);
-                    splat_albedo(P, mei.p, ga);  count(C_SC_ALB);
+                    splat_sigma_t(P, mei.p, gs, rec); count(C_SC);
+                    splat_albedo(P, mei.p, ga, rec);  count(C_SC_ALB);
                 }
                 backprop_transmittance(A, ray, did_escape ? si.t : mei.t, dL, result);   // :181-189
             }
@@ -345,10 +349,14 @@ struct Tracer {
 };
 
 template <bool ADJ, bool COUNT>
-__global__ void __launch_bounds__(256) trace_kernel(const Params P)
+__global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Params P)
 {
     uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     Tracer<COUNT> tr(P);
+    if constexpr (ADJ) {
+        __shared__ uint32_t coop_rec[4 * 64 * kCoopDwords];
+        tr.rec = coop_rec + (threadIdx.x >> 6) * (64 * kCoopDwords);
+    }
     if (i < P.n_rays) {
         uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
         uint32_t gi = (uint32_t) g64;

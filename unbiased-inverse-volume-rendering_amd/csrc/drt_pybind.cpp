@@ -132,6 +132,7 @@ public:
         { py::gil_scoped_release nogil; rc = drt_debug_eval(h_, op, ptr<const float>(in), n, ptr<float>(out)); }
         check(rc, "drt_debug_eval");
     }
+    void set_debug_flags(uint32_t f) { check(drt_set_debug_flags(h_, f), "drt_set_debug_flags"); }
     void enable_counters(bool on) { check(drt_enable_counters(h_, on ? 1 : 0), "drt_enable_counters"); }
     void reset_counters() { check(drt_reset_counters(h_), "drt_reset_counters"); }
     py::dict get_counters()
@@ -183,6 +184,7 @@ PYBIND11_MODULE(_drt_pybind, m)
         .def("film_develop", &Integrator::film_develop)
         .def("film_backward", &Integrator::film_backward)
         .def("debug_eval", &Integrator::debug_eval)
+        .def("set_debug_flags", &Integrator::set_debug_flags)
         .def("enable_counters", &Integrator::enable_counters)
         .def("reset_counters", &Integrator::reset_counters)
         .def("get_counters", &Integrator::get_counters)
