@@ -25,6 +25,8 @@ struct drt_handle_s {
     float *d_majorant = nullptr;   // [2]
     uint32_t *d_scratch = nullptr; // [1]
     unsigned long long *d_counters = nullptr;   // [C_COUNT]
+    float *d_gt = nullptr;         // tiled gradient scratch, 4 planes (always zero between launches)
+    size_t gt_floats = 0;
     bool counting = false;
     uint64_t chunk = 0, stride = 0;   // ray interleave (drt_set_ray_interleave)
     uint32_t debug_flags = 0;
@@ -182,6 +184,7 @@ int drt_destroy(drt_handle h)
     if (h->d_majorant) (void) hipFree(h->d_majorant);
     if (h->d_scratch) (void) hipFree(h->d_scratch);
     if (h->d_counters) (void) hipFree(h->d_counters);
+    if (h->d_gt) (void) hipFree(h->d_gt);
     clear_timings(h);
     delete h;
     return DRT_OK;
@@ -244,6 +247,21 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         B.inv_ext[a] = 1.0f / (bbox_max[a] - bbox_min[a]);
     }
     B.scale = scale;
+    // gradient scratch: 4 planes tiled 4x2x2 (see drt_device.h: Params::gt)
+    {
+        size_t tx = ((size_t) res[0] + 3) / 4, ty = ((size_t) res[1] + 1) / 2, tz = ((size_t) res[2] + 1) / 2;
+        size_t plane = tx * ty * tz * 16;
+        if (plane > 0x7fffffffull) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the gradient scratch");
+        if (plane * 4 != h->gt_floats) {
+            DeviceGuard g(h->device);
+            if (h->d_gt) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_gt); h->d_gt = nullptr; h->gt_floats = 0; }
+            DRT_HIP_CHECK(h, hipMalloc(&h->d_gt, plane * 4 * sizeof(float)));
+            DRT_HIP_CHECK(h, hipMemsetAsync(h->d_gt, 0, plane * 4 * sizeof(float), h->stream));
+            h->gt_floats = plane * 4;
+        }
+        B.gt = h->d_gt; B.gt_plane = (uint32_t) plane;
+        B.gt_ystride = (int) (tx * 16); B.gt_zstride = (int) (ty * tx * 16);
+    }
     h->have_medium = true;
     return drt_params_changed(h);
 }
@@ -300,7 +318,10 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     drt::Params P;
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
-    return timed_launch(h, 1, P, true);
+    rc = timed_launch(h, 1, P, true);
+    if (rc) return rc;
+    DRT_HIP_CHECK(h, drt::launch_untile(P, h->stream));
+    return DRT_OK;
 }
 
 int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t spp, float *image)

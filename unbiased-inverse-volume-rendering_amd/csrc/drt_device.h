@@ -180,6 +180,11 @@ struct Params {
     float *L_out;
     const float *dL, *L_in;
     float *g_sigma, *g_albedo;
+    // library-owned gradient scratch: 4 planes [sigma_t, r, g, b], each tiled 4x2x2 voxels per
+    // 64-byte line so that a 2x2x2 splat footprint touches ~2.8 lines instead of 4.25
+    float *gt;                 // plane c at gt + c * gt_plane
+    uint32_t gt_plane;         // floats per plane = tiles * 16
+    int gt_ystride, gt_zstride; // floats between tile rows (tx*16) / tile slabs (ty*tx*16)
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
 };
@@ -218,6 +223,24 @@ __device__ __forceinline__ Stencil make_stencil(const Params &P, V3 p)
     s.y0 *= P.rx; s.y1 *= P.rx;
     int sz = P.rx * P.ry;
     s.z0 *= sz; s.z1 *= sz;
+    return s;
+}
+
+// Stencil whose index parts address the tiled gradient scratch (see Params::gt): for voxel
+// (ix,iy,iz) the float offset is  tile(ix>>2, iy>>1, iz>>1) * 16 + (iz&1)*8 + (iy&1)*4 + (ix&3),
+// which is again a sum of one part per axis.
+__device__ __forceinline__ Stencil make_grad_stencil(const Params &P, V3 p)
+{
+    Stencil s;
+    axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, s.x0, s.x1, s.wx0, s.wx1);
+    axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, s.y0, s.y1, s.wy0, s.wy1);
+    axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, s.z0, s.z1, s.wz0, s.wz1);
+    s.x0 = ((s.x0 >> 2) << 4) | (s.x0 & 3);
+    s.x1 = ((s.x1 >> 2) << 4) | (s.x1 & 3);
+    s.y0 = (s.y0 >> 1) * P.gt_ystride + ((s.y0 & 1) << 2);
+    s.y1 = (s.y1 >> 1) * P.gt_ystride + ((s.y1 & 1) << 2);
+    s.z0 = (s.z0 >> 1) * P.gt_zstride + ((s.z0 & 1) << 3);
+    s.z1 = (s.z1 >> 1) * P.gt_zstride + ((s.z1 & 1) << 3);
     return s;
 }
 
@@ -293,7 +316,7 @@ __device__ __forceinline__ void coop_stage_sync()
 }
 
 template <int NCH>
-__device__ __forceinline__ void coop_scatter(float *dst, int stride, const int idx[8],
+__device__ __forceinline__ void coop_scatter(float *dst, uint32_t chan_stride, const int idx[8],
                                              const float (&val)[NCH][8], uint32_t *rec)
 {
     const uint64_t mask = __ballot(1);
@@ -313,9 +336,9 @@ __device__ __forceinline__ void coop_scatter(float *dst, int stride, const int i
     for (uint32_t t = 0; t < m; ++t) {
         const uint32_t *src = rec + (g0 + t) * kCoopDwords;
         for (uint32_t c = j; c < 8; c += m) {
-            float *p = dst + (size_t) stride * src[c];
+            float *p = dst + src[c];
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) atomicAdd(p + ch, __uint_as_float(src[8 + 8 * ch + c]));
+            for (int ch = 0; ch < NCH; ++ch) atomicAdd(p + (size_t) ch * chan_stride, __uint_as_float(src[8 + 8 * ch + c]));
         }
     }
     coop_stage_sync();
@@ -323,7 +346,7 @@ __device__ __forceinline__ void coop_scatter(float *dst, int stride, const int i
 
 __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, uint32_t *rec)
 {
-    Stencil s = make_stencil(P, p);
+    Stencil s = make_grad_stencil(P, p);
     float w[8]; int idx[8];
     stencil_weights(s, w);
     stencil_indices(s, idx);
@@ -331,18 +354,18 @@ __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, ui
     if (P.debug_flags & 1u) return;   // ablation: no gradient atomics
     if (P.debug_flags & 2u) {         // ablation: one lane, eight instructions (round-1 v1 behaviour)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(P.g_sigma + idx[k], w[k] * gs);
+        for (int k = 0; k < 8; ++k) atomicAdd(P.gt + idx[k], w[k] * gs);
         return;
     }
     float val[1][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) val[0][k] = w[k] * gs;
-    coop_scatter<1>(P.g_sigma, 1, idx, val, rec);
+    coop_scatter<1>(P.gt, 0, idx, val, rec);
 }
 
 __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float g[3], uint32_t *rec)
 {
-    Stencil s = make_stencil(P, p);
+    Stencil s = make_grad_stencil(P, p);
     float w[8]; int idx[8];
     stencil_weights(s, w);
     stencil_indices(s, idx);
@@ -350,17 +373,17 @@ __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float 
     if (P.debug_flags & 2u) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float *dst = P.g_albedo + 3 * (size_t) idx[k];
-            atomicAdd(dst + 0, w[k] * g[0]);
-            atomicAdd(dst + 1, w[k] * g[1]);
-            atomicAdd(dst + 2, w[k] * g[2]);
+            float *dst = P.gt + P.gt_plane + idx[k];
+            atomicAdd(dst, w[k] * g[0]);
+            atomicAdd(dst + P.gt_plane, w[k] * g[1]);
+            atomicAdd(dst + 2 * (size_t) P.gt_plane, w[k] * g[2]);
         }
         return;
     }
     float val[3][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { val[0][k] = w[k] * g[0]; val[1][k] = w[k] * g[1]; val[2][k] = w[k] * g[2]; }
-    coop_scatter<3>(P.g_albedo, 3, idx, val, rec);
+    coop_scatter<3>(P.gt + P.gt_plane, P.gt_plane, idx, val, rec);
 }
 
 // ---------------------------------------------------------------------------

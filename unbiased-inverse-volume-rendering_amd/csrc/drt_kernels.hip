@@ -8,7 +8,10 @@
 #include "drt_launch.h"
 
 #ifndef DRT_TRACE_WAVES
-#define DRT_TRACE_WAVES 1
+#define DRT_TRACE_WAVES 4      // waves per SIMD the tracing kernels are compiled for (VGPR <= 128)
+#endif
+#ifndef DRT_XCD_RUN
+#define DRT_XCD_RUN 256        // workgroups per XCD-contiguous run (0 = identity block map); swept 16..4096 on MI355X
 #endif
 namespace drt {
 
@@ -351,7 +354,22 @@ struct Tracer {
 template <bool ADJ, bool COUNT>
 __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Params P)
 {
-    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware block -> ray-chunk map.  Workgroup b runs on XCD b % 8 (observed dispatch
+    // order, used for speed only); consecutive ray chunks are spatially coherent, so XCD k is
+    // given the k-th contiguous run of DRT_XCD_RUN workgroups of every group of 8 runs: its
+    // private 4 MiB L2 then serves one image region instead of every 8th 8-pixel strip.
+    uint32_t b = blockIdx.x;
+#if DRT_XCD_RUN > 0
+    {
+        const uint32_t span = 8u * DRT_XCD_RUN;
+        const uint32_t full = (gridDim.x / span) * span;     // tail blocks keep the identity map
+        if (b < full) {
+            uint32_t grp = b / span, r = b % span;
+            b = grp * span + (r % 8u) * DRT_XCD_RUN + r / 8u;
+        }
+    }
+#endif
+    uint64_t i = (uint64_t) b * blockDim.x + threadIdx.x;
     Tracer<COUNT> tr(P);
     if constexpr (ADJ) {
         __shared__ uint32_t coop_rec[4 * 64 * kCoopDwords];
@@ -412,6 +430,27 @@ __global__ void majorant_finalize_kernel(const uint32_t *max_bits, float scale, 
     float m = __uint_as_float(*max_bits) * scale;
     majorant[0] = m;
     majorant[1] = (m != 0.0f) ? 1.0f / m : 0.0f;
+}
+
+// Gradient scratch -> caller's (Z,Y,X,1) / (Z,Y,X,3) buffers: += (the ABI accumulates) and
+// reset of the scratch for the next launch.  One thread per voxel.
+__global__ void __launch_bounds__(256) untile_gradients_kernel(const Params P, uint32_t n_voxels)
+{
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_voxels) return;
+    uint32_t ix = v % (uint32_t) P.rx, t = v / (uint32_t) P.rx;
+    uint32_t iy = t % (uint32_t) P.ry, iz = t / (uint32_t) P.ry;
+    uint32_t ti = ((ix >> 2) << 4 | (ix & 3)) + (iy >> 1) * (uint32_t) P.gt_ystride + ((iy & 1) << 2)
+                + (iz >> 1) * (uint32_t) P.gt_zstride + ((iz & 1) << 3);
+    float *src = P.gt + ti;
+    float gs = src[0];
+    if (gs != 0.0f) { P.g_sigma[v] += gs; src[0] = 0.0f; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float *sc = src + (size_t)(c + 1) * P.gt_plane;
+        float ga = *sc;
+        if (ga != 0.0f) { P.g_albedo[3 * (size_t) v + c] += ga; *sc = 0.0f; }
+    }
 }
 
 // box film: image[p] = mean_spp L (batched.py:176-197)
@@ -488,6 +527,13 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
         if (count) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, P);
         else       hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, P);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_untile(const Params &P, hipStream_t stream)
+{
+    uint32_t n = (uint32_t) P.rx * P.ry * P.rz;
+    hipLaunchKernelGGL(untile_gradients_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, P, n);
     return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 namespace drt {
 
 hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t stream);
+hipError_t launch_untile(const Params &P, hipStream_t stream);
 hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t *scratch_bits,
                            float *majorant, hipStream_t stream);
 hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, float *image,
