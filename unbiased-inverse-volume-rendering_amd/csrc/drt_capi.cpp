@@ -26,6 +26,8 @@ struct drt_handle_s {
     uint32_t *d_scratch = nullptr; // [1]
     unsigned long long *d_counters = nullptr;   // [C_COUNT]
     float *d_gt = nullptr;         // tiled gradient scratch, 4 planes (always zero between launches)
+    float *d_sigma_b = nullptr;    // bricked copy of sigma_t (refreshed by drt_params_changed)
+    size_t sigma_b_floats = 0;
     size_t gt_floats = 0;
     bool counting = false;
     uint64_t chunk = 0, stride = 0;   // ray interleave (drt_set_ray_interleave)
@@ -185,6 +187,7 @@ int drt_destroy(drt_handle h)
     if (h->d_scratch) (void) hipFree(h->d_scratch);
     if (h->d_counters) (void) hipFree(h->d_counters);
     if (h->d_gt) (void) hipFree(h->d_gt);
+    if (h->d_sigma_b) (void) hipFree(h->d_sigma_b);
     clear_timings(h);
     delete h;
     return DRT_OK;
@@ -221,6 +224,8 @@ int drt_params_changed(drt_handle h)
     DeviceGuard g(h->device);
     size_t n = (size_t) h->base.rx * h->base.ry * h->base.rz;
     DRT_HIP_CHECK(h, drt::launch_majorant(h->base.sigma_t, n, h->base.scale, h->d_scratch, h->d_majorant, h->stream));
+    DRT_HIP_CHECK(h, drt::launch_brick_sigma(h->base.sigma_t, h->d_sigma_b, h->base.rx, h->base.ry, h->base.rz,
+                                             h->base.sb_ystride, h->base.sb_zstride, h->stream));
     return DRT_OK;
 }
 
@@ -261,6 +266,21 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         }
         B.gt = h->d_gt; B.gt_plane = (uint32_t) plane;
         B.gt_ystride = (int) (tx * 16); B.gt_zstride = (int) (ty * tx * 16);
+    }
+    // bricked sigma_t copy: 4x4x2 voxels per 128-byte line
+    {
+        size_t bx = ((size_t) res[0] + 3) / 4, by = ((size_t) res[1] + 3) / 4, bz = ((size_t) res[2] + 1) / 2;
+        size_t floats = bx * by * bz * 32;
+        if (floats > 0x7fffffffull) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the bricked copy");
+        if (floats != h->sigma_b_floats) {
+            DeviceGuard g(h->device);
+            if (h->d_sigma_b) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_sigma_b); h->d_sigma_b = nullptr; h->sigma_b_floats = 0; }
+            DRT_HIP_CHECK(h, hipMalloc(&h->d_sigma_b, floats * sizeof(float)));
+            DRT_HIP_CHECK(h, hipMemsetAsync(h->d_sigma_b, 0, floats * sizeof(float), h->stream));
+            h->sigma_b_floats = floats;
+        }
+        B.sigma_b = h->d_sigma_b;
+        B.sb_ystride = (int) (bx * 32); B.sb_zstride = (int) (by * bx * 32);
     }
     h->have_medium = true;
     return drt_params_changed(h);

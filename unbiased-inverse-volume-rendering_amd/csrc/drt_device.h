@@ -157,7 +157,10 @@ __device__ __forceinline__ float mis_weight(float a, float b)
 // ---------------------------------------------------------------------------
 struct Params {
     // medium
-    const float *sigma_t;      // (Z,Y,X,1)
+    const float *sigma_t;      // (Z,Y,X,1), caller's layout (majorant reduction, re-bricking)
+    const float *sigma_b;      // library-owned bricked copy read by the tracking loops: one 128-byte
+                               // line = 4x4x2 voxels, so a trilinear footprint spans ~2.3 lines, not ~4.1
+    int sb_ystride, sb_zstride; // floats between brick rows (bx*32) / brick slabs (by*bx*32)
     const float *albedo;       // (Z,Y,X,3)
     const float *majorant;     // device: [0] = scale*max(sigma_t), [1] = 1/[0] (0 if [0]==0)
     int rx, ry, rz;
@@ -256,10 +259,27 @@ __device__ __forceinline__ float trilerp8(const Stencil &s, float d0, float d1, 
     return fmaf(s.wz0, v0, s.wz1 * v1);
 }
 
+// Stencil into the bricked sigma_t copy: voxel (ix,iy,iz) lives at
+// brick(ix>>2, iy>>2, iz>>1) * 32 + (iz&1)*16 + (iy&3)*4 + (ix&3) - again one part per axis.
+__device__ __forceinline__ Stencil make_brick_stencil(const Params &P, V3 p)
+{
+    Stencil s;
+    axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, s.x0, s.x1, s.wx0, s.wx1);
+    axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, s.y0, s.y1, s.wy0, s.wy1);
+    axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, s.z0, s.z1, s.wz0, s.wz1);
+    s.x0 = ((s.x0 >> 2) << 5) | (s.x0 & 3);
+    s.x1 = ((s.x1 >> 2) << 5) | (s.x1 & 3);
+    s.y0 = (s.y0 >> 2) * P.sb_ystride + ((s.y0 & 3) << 2);
+    s.y1 = (s.y1 >> 2) * P.sb_ystride + ((s.y1 & 3) << 2);
+    s.z0 = (s.z0 >> 1) * P.sb_zstride + ((s.z0 & 1) << 4);
+    s.z1 = (s.z1 >> 1) * P.sb_zstride + ((s.z1 & 1) << 4);
+    return s;
+}
+
 __device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p)
 {
-    Stencil s = make_stencil(P, p);
-    const float *g = P.sigma_t;
+    Stencil s = make_brick_stencil(P, p);
+    const float *g = P.sigma_b;
     int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
     float d0 = g[a + s.x0], d1 = g[a + s.x1], d2 = g[b + s.x0], d3 = g[b + s.x1];
     float d4 = g[c + s.x0], d5 = g[c + s.x1], d6 = g[d + s.x0], d7 = g[d + s.x1];

@@ -432,6 +432,19 @@ __global__ void majorant_finalize_kernel(const uint32_t *max_bits, float scale, 
     majorant[1] = (m != 0.0f) ? 1.0f / m : 0.0f;
 }
 
+// Caller's (Z,Y,X,1) sigma_t -> bricked copy (Params::sigma_b); one thread per voxel.
+__global__ void __launch_bounds__(256) brick_sigma_kernel(const float *src, float *dst, int rx, int ry, int rz,
+                                                          int ystride, int zstride)
+{
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= (uint32_t) rx * ry * rz) return;
+    uint32_t ix = v % (uint32_t) rx, t = v / (uint32_t) rx;
+    uint32_t iy = t % (uint32_t) ry, iz = t / (uint32_t) ry;
+    uint32_t bi = (((ix >> 2) << 5) | (ix & 3)) + (iy >> 2) * (uint32_t) ystride + ((iy & 3) << 2)
+                + (iz >> 1) * (uint32_t) zstride + ((iz & 1) << 4);
+    dst[bi] = src[v];
+}
+
 // Gradient scratch -> caller's (Z,Y,X,1) / (Z,Y,X,3) buffers: += (the ABI accumulates) and
 // reset of the scratch for the next launch.  One thread per voxel.
 __global__ void __launch_bounds__(256) untile_gradients_kernel(const Params P, uint32_t n_voxels)
@@ -527,6 +540,14 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
         if (count) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, P);
         else       hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, P);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int ystride, int zstride,
+                              hipStream_t stream)
+{
+    uint32_t n = (uint32_t) rx * ry * rz;
+    hipLaunchKernelGGL(brick_sigma_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, rx, ry, rz, ystride, zstride);
     return hipGetLastError();
 }
 
