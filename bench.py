@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--spp", type=int, default=32, help="samples per pixel (headline: 32)")
     ap.add_argument("--workload", default="dust-devil", choices=["dust-devil", "smoke", "cube"])
     ap.add_argument("--integrator", default="volpathsimple-drt")
+    ap.add_argument("--majorant-factor", type=int, default=0,
+                    help="majorant_resolution_factor of the medium (reference scenes: 8, scene_config.py:36; 0 = global majorant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU sample (0 = auto)")
     ap.add_argument("--debug-flags", type=int, default=0, help="profiling ablations (drt_set_debug_flags); invalidates the result")
@@ -81,6 +83,7 @@ def main():
         scene = synthetic.smoke_scene(res=args.res, film=args.film, device=dev)
     else:
         scene = synthetic.constant_cube_scene(res=args.res, film=args.film, device=dev)
+    scene.medium.majorant_resolution_factor = args.majorant_factor
     sensor = scene.sensors[0]
     n_pixels = sensor.width * sensor.height
     spp = args.spp
@@ -181,7 +184,8 @@ def main():
         cpu_scene = u.Scene(medium=u.GridMedium(sigma_t=scene.medium.sigma_t.cpu().numpy(),
                                                 albedo=scene.medium.albedo.cpu().numpy(),
                                                 bbox_min=scene.medium.bbox_min, bbox_max=scene.medium.bbox_max,
-                                                scale=scene.medium.scale),
+                                                scale=scene.medium.scale,
+                                                majorant_resolution_factor=args.majorant_factor),
                             emitter=scene.emitter, sensors=scene.sensors)
         osc = ob.OracleScene(cpu_scene)
         cpu_spp = args.cpu_spp
@@ -211,7 +215,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} {args.res}^3 sigma_t+albedo, {sensor.width}x{sensor.height}x{spp}spp, "
-                                   f"{args.integrator}, max_depth 64, single sensor, image tiles sharded over {world} GPU(s)",
+                                   f"{args.integrator}, max_depth 64, majorant_resolution_factor {args.majorant_factor}, single sensor, "
+                                   f"image tiles sharded over {world} GPU(s)",
                        "n_samples_per_step": n_total, "grid": [args.res] * 3, "film": [sensor.width, sensor.height],
                        "spp": spp, "integrator": args.integrator},
             "roofline": roofline,

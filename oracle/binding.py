@@ -27,7 +27,7 @@ class Config(C.Structure):
 class Medium(C.Structure):
     _fields_ = [("sigma_t", C.POINTER(C.c_float)), ("albedo", C.POINTER(C.c_float)),
                 ("res", C.c_int32 * 3), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("majorant_factor", C.c_int32)]
 
 
 class Emitter(C.Structure):
@@ -92,6 +92,8 @@ def lib():
         L.drto_eval_albedo.restype = None
         L.drto_majorant.argtypes = [C.POINTER(Medium)]
         L.drto_majorant.restype = C.c_float
+        L.drto_majorant_grid.argtypes = [C.POINTER(Medium), C.POINTER(C.c_int32), fp]
+        L.drto_majorant_grid.restype = C.c_int
         L.drto_ratio_tracking_mean.argtypes = [C.POINTER(Medium), fp, fp, C.c_float, C.c_uint32, C.c_int]
         L.drto_ratio_tracking_mean.restype = C.c_double
         L.drto_box_hit.argtypes = [C.POINTER(Medium), fp, fp, fp, fp]
@@ -142,8 +144,7 @@ class OracleScene:
         assert self.albedo.shape[:3] == (z, y, x) and self.albedo.shape[-1] == 3
         self.medium = Medium(_fp(self.sigma_t), _fp(self.albedo), (C.c_int32 * 3)(x, y, z),
                              (C.c_float * 3)(*m.bbox_min), (C.c_float * 3)(*m.bbox_max),
-                             float(m.scale))
-        assert getattr(m, "majorant_resolution_factor", 0) == 0, "oracle: global majorant only"
+                             float(m.scale), int(getattr(m, "majorant_resolution_factor", 0)))
         self.emitter = Emitter((C.c_float * 3)(*scene.emitter.radiance))
         self.sensor = None
         self.film = None

@@ -173,6 +173,10 @@ typedef struct {
     int rx, ry, rz;
     v3 bmin, bmax, inv_ext;
     float scale, majorant, inv_majorant;
+    /* majorant supergrid (majorant_resolution_factor > 0): gx*gy*gz cells, [2*cell] = majorant,
+     * [2*cell+1] = 1/majorant (0 if empty) */
+    int gx, gy, gz;
+    float *mgrid;
     float Le[3];
 } scene_t;
 
@@ -332,6 +336,58 @@ static inline float sample_distance(const scene_t *sc, float u)
     return -drt_logf(1.0f - u) * sc->inv_majorant;
 }
 
+/* E1 with a majorant supergrid [M3-ext] (scene_config.py:36, optimize.py:182-199): the free-flight
+ * distance is sampled against piecewise-constant local majorants by a 3-D DDA through the
+ * supergrid: walk the cells the ray crosses, accumulating majorant * length until the target
+ * optical depth tau = -log(1-u) is reached.  Returns the distance (INFINITY if the ray leaves
+ * [0,tmax] first) and the local majorant / its reciprocal at the collision. */
+static float sample_collision(const scene_t *sc, v3 o, v3 d, float tmax, float u, float *m_out, float *im_out)
+{
+    if (!sc->mgrid) {
+        *m_out = sc->majorant; *im_out = sc->inv_majorant;
+        return sample_distance(sc, u);
+    }
+    const float tau = -drt_logf(1.0f - u);
+    const int G[3] = { sc->gx, sc->gy, sc->gz };
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    const float lo[3] = { sc->bmin.x, sc->bmin.y, sc->bmin.z };
+    const float ie[3] = { sc->inv_ext.x, sc->inv_ext.y, sc->inv_ext.z };
+    int cell[3], step[3]; float tnext[3], tdelta[3];
+    for (int a = 0; a < 3; ++a) {
+        float g = ((oo[a] - lo[a]) * ie[a]) * (float) G[a];
+        float dg = (dd[a] * ie[a]) * (float) G[a];
+        float fl = fminf(fmaxf(floorf(g), 0.0f), (float)(G[a] - 1));
+        cell[a] = (int) fl;
+        if (dg > 0.0f) { tnext[a] = ((fl + 1.0f) - g) / dg; tdelta[a] = 1.0f / dg; step[a] = 1; }
+        else if (dg < 0.0f) { tnext[a] = (fl - g) / dg; tdelta[a] = -1.0f / dg; step[a] = -1; }
+        else { tnext[a] = INFINITY; tdelta[a] = INFINITY; step[a] = 0; }
+    }
+    float t = 0.0f, acc = 0.0f;
+    for (;;) {
+        int a = 0;
+        if (tnext[1] < tnext[a]) a = 1;
+        if (tnext[2] < tnext[a]) a = 2;
+        float texit = fminf(tnext[a], tmax);
+        const float *mc = sc->mgrid + 2 * (size_t)((cell[2] * G[1] + cell[1]) * G[0] + cell[0]);
+        float m = mc[0];
+        if (m > 0.0f) {
+            float dtau = m * (texit - t);
+            if (acc + dtau >= tau) {
+                *m_out = m; *im_out = mc[1];
+                return fmaf(tau - acc, mc[1], t);
+            }
+            acc += dtau;
+        }
+        t = texit;
+        if (!(texit < tmax)) break;
+        cell[a] += step[a];
+        if (cell[a] < 0 || cell[a] >= G[a]) break;
+        tnext[a] += tdelta[a];
+    }
+    *m_out = 0.0f; *im_out = 0.0f;
+    return INFINITY;
+}
+
 typedef struct { v3 o, d; float maxt; } ray_t;
 
 /* ------------------------------------------------------------------------- */
@@ -343,16 +399,17 @@ static float estimate_transmittance(ctx_t *c, v3 o, v3 d, float tmax, pcg32 *S, 
     const scene_t *sc = c->sc;
     float T = 1.0f;
     for (;;) {
-        float dt = sample_distance(sc, next_1d(S));
+        float maj, imaj;
+        float dt = sample_collision(sc, o, d, tmax, next_1d(S), &maj, &imaj);
         if (!(dt <= tmax)) break;                       /* :480-481 */
         v3 p = ray_at(o, d, dt);
         float sig = eval_sigma_t(sc, p);
-        float tr = (sc->majorant - sig) * sc->inv_majorant;   /* sigma_n / majorant :473-476 */
+        float tr = (maj - sig) * imaj;                  /* sigma_n / majorant :473-476 */
         c->cnt.n_rt++;
         if (adj && tr > 0.0f) {                          /* :487-492 */
             float a = (adj[0] + adj[1]) + adj[2];
             c->cnt.n_rt_adj++;
-            splat_sigma_t(c, p, -(a * sc->inv_majorant) / tr);
+            splat_sigma_t(c, p, -(a * imaj) / tr);
         }
         T *= tr;                                         /* :495 */
         o = p; tmax -= dt;                               /* :497-499 */
@@ -402,12 +459,13 @@ static mei_t sample_real_interaction(ctx_t *c, const ray_t *ray, pcg32 *S, int a
     mei_t mei; mei.valid = 0; mei.t = INFINITY; mei.p = v3_make(0, 0, 0); mei.sigma_t = 0.0f;
     v3 ro = ray->o; float rmaxt = ray->maxt; float running_t = 0.0f;
     for (;;) {
-        float dt = sample_distance(sc, next_1d(S));      /* :348 */
+        float maj, imaj;
+        float dt = sample_collision(sc, ro, ray->d, rmaxt, next_1d(S), &maj, &imaj);   /* :348 */
         if (!(dt <= rmaxt)) break;                       /* :358 escaped */
         v3 p = ray_at(ro, ray->d, dt);
         float sig = eval_sigma_t(sc, p);
         c->cnt.n_dt++;
-        float r = sig * sc->inv_majorant;                /* :354 */
+        float r = sig * imaj;                            /* :354 */
         float u = next_1d(S);                            /* :359 */
         if (!(u >= r)) {                                 /* real collision */
             mei.valid = 1; mei.t = running_t + dt;       /* :351 */
@@ -437,15 +495,17 @@ static int sample_interaction_drt(ctx_t *c, const ray_t *ray, pcg32 *A, float *t
     float t = 0.0f, T = 1.0f, wsum = 0.0f, tsel = INFINITY;
     int valid = 0;
     for (;;) {
-        t += sample_distance(sc, next_1d(A));
+        float maj, imaj;
+        if (sc->mgrid) t += sample_collision(sc, ray_at(ray->o, ray->d, t), ray->d, ray->maxt - t, next_1d(A), &maj, &imaj);
+        else { t += sample_distance(sc, next_1d(A)); maj = sc->majorant; imaj = sc->inv_majorant; }
         if (!(t <= ray->maxt)) break;
         float sig = eval_sigma_t(sc, ray_at(ray->o, ray->d, t));
         c->cnt.n_drt++;
-        float w = T * sc->inv_majorant;
+        float w = T * imaj;
         wsum += w;
         float u = next_1d(A);
         if (w > 0.0f && u * wsum <= w) { tsel = t; valid = 1; }
-        T *= (sc->majorant - sig) * sc->inv_majorant;
+        T *= (maj - sig) * imaj;
         if (T == 0.0f) break;
     }
     *t_out = tsel; *W_out = wsum;
@@ -694,8 +754,37 @@ static int scene_init(scene_t *sc, const drto_job *job)
     sc->majorant = mx * m->scale;                         /* global majorant = scale * max(grid) */
     sc->inv_majorant = sc->majorant != 0.0f ? 1.0f / sc->majorant : 0.0f;
     for (int k = 0; k < 3; ++k) sc->Le[k] = job->emitter->radiance[k];
+    sc->mgrid = NULL; sc->gx = sc->gy = sc->gz = 0;
+    if (m->majorant_factor > 0) {
+        /* cell (I,J,K) covers 1/G of the box per axis; its majorant is scale * max over every
+         * voxel a trilinear lookup inside the cell can touch, padded by one voxel:
+         * [floor(I*res/G) - 1, ceil((I+1)*res/G)] per axis, clamped. */
+        int f = m->majorant_factor;
+        int R[3] = { sc->rx, sc->ry, sc->rz }, G[3];
+        for (int a = 0; a < 3; ++a) { G[a] = R[a] / f; if (G[a] < 1) G[a] = 1; }
+        sc->gx = G[0]; sc->gy = G[1]; sc->gz = G[2];
+        sc->mgrid = (float *) malloc(sizeof(float) * 2 * (size_t) G[0] * G[1] * G[2]);
+        if (!sc->mgrid) return -4;
+        for (int K = 0; K < G[2]; ++K) for (int J = 0; J < G[1]; ++J) for (int I = 0; I < G[0]; ++I) {
+            int c[3] = { I, J, K }, lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = (int)(((long long) c[a] * R[a]) / G[a]) - 1;
+                hi[a] = (int)((((long long)(c[a] + 1)) * R[a] + G[a] - 1) / G[a]);
+                if (lo[a] < 0) lo[a] = 0;
+                if (hi[a] > R[a] - 1) hi[a] = R[a] - 1;
+            }
+            float mxc = 0.0f;
+            for (int z = lo[2]; z <= hi[2]; ++z) for (int y = lo[1]; y <= hi[1]; ++y) for (int x = lo[0]; x <= hi[0]; ++x)
+                mxc = fmaxf(mxc, m->sigma_t[((size_t) z * R[1] + y) * R[0] + x]);
+            float mm = mxc * m->scale;
+            float *dst = sc->mgrid + 2 * (size_t)((K * G[1] + J) * G[0] + I);
+            dst[0] = mm; dst[1] = mm != 0.0f ? 1.0f / mm : 0.0f;
+        }
+    }
     return 0;
 }
+
+static void scene_free(scene_t *sc) { free(sc->mgrid); sc->mgrid = NULL; }
 
 /* perspective sensor (tests/test_integrators.py:46-67): sample position in
  * [0,1]^2, (0,0) = top-left; camera x axis = `left`. */
@@ -754,7 +843,7 @@ static int run_job(const drto_job *job, int adjoint, const float *dL, const floa
 {
     scene_t sc;
     if (scene_init(&sc, job)) return -1;
-    if (!sc.albedo) return -2;
+    if (!sc.albedo) { scene_free(&sc); return -2; }
     uint32_t alt_seed = drto_alt_seed(job->seed, job->sensor != NULL);
     drto_counters total; memset(&total, 0, sizeof total);
 #ifdef _OPENMP
@@ -785,6 +874,7 @@ static int run_job(const drto_job *job, int adjoint, const float *dL, const floa
         cnt_add(&total, &c.cnt);
     }
     if (cnt) cnt_add(cnt, &total);
+    scene_free(&sc);
     return 0;
 }
 
@@ -874,6 +964,7 @@ int drto_render_textbook(const drto_job *job, float *L_out)
         if (alive) for (int k = 0; k < 3; ++k) L[k] = beta[k] * sc.Le[k];
         L_out[3 * i] = L[0]; L_out[3 * i + 1] = L[1]; L_out[3 * i + 2] = L[2];
     }
+    scene_free(&sc);
     return 0;
 }
 
@@ -912,17 +1003,30 @@ void drto_sincos_2pi(float u, float *s, float *c) { drt_sincos_2pi(u, s, c); }
 float drto_eval_sigma_t(const drto_medium *m, const float p[3])
 {
     scene_t sc; scene_from_medium(&sc, m);
-    return eval_sigma_t(&sc, v3_make(p[0], p[1], p[2]));
+    float r = eval_sigma_t(&sc, v3_make(p[0], p[1], p[2]));
+    scene_free(&sc);
+    return r;
 }
 void drto_eval_albedo(const drto_medium *m, const float p[3], float out[3])
 {
     scene_t sc; scene_from_medium(&sc, m);
     eval_albedo(&sc, v3_make(p[0], p[1], p[2]), out);
+    scene_free(&sc);
 }
 float drto_majorant(const drto_medium *m)
 {
     scene_t sc; scene_from_medium(&sc, m);
+    scene_free(&sc);
     return sc.majorant;
+}
+int drto_majorant_grid(const drto_medium *m, int32_t dims[3], float *out)
+{
+    scene_t sc; scene_from_medium(&sc, m);
+    int n = sc.mgrid ? sc.gx * sc.gy * sc.gz : 0;
+    dims[0] = sc.gx; dims[1] = sc.gy; dims[2] = sc.gz;
+    if (out) for (int i = 0; i < n; ++i) out[i] = sc.mgrid[2 * i];
+    scene_free(&sc);
+    return n;
 }
 double drto_ratio_tracking_mean(const drto_medium *m, const float o[3], const float d[3],
                                 float tmax, uint32_t seed, int n)
@@ -935,6 +1039,7 @@ double drto_ratio_tracking_mean(const drto_medium *m, const float o[3], const fl
         acc += (double) estimate_transmittance(&c, v3_make(o[0], o[1], o[2]),
                                                v3_make(d[0], d[1], d[2]), tmax, &S, NULL);
     }
+    scene_free(&sc);
     return acc / (double) n;
 }
 int drto_box_hit(const drto_medium *m, const float o[3], const float d[3], float *t, float n[3])
@@ -942,6 +1047,7 @@ int drto_box_hit(const drto_medium *m, const float o[3], const float d[3], float
     scene_t sc; scene_from_medium(&sc, m);
     si_t si = box_hit(&sc, v3_make(o[0], o[1], o[2]), v3_make(d[0], d[1], d[2]));
     *t = si.t; n[0] = si.n.x; n[1] = si.n.y; n[2] = si.n.z;
+    scene_free(&sc);
     return si.valid;
 }
 void drto_sensor_ray(const drto_sensor *s, uint32_t pixel, float ux, float uy, float o[3], float d[3])

@@ -54,6 +54,7 @@ typedef struct drto_medium {
     float bbox_min[3];
     float bbox_max[3];
     float scale;            /* medium `scale` (density_scale) */
+    int32_t majorant_factor; /* majorant_resolution_factor (scene_config.py:36); 0 = global majorant */
 } drto_medium;
 
 /* `constant` emitter (tests/test_integrators.py:73-77). */
@@ -133,6 +134,9 @@ void     drto_sincos_2pi(float u, float *s, float *c);
 float    drto_eval_sigma_t(const drto_medium *m, const float p[3]);
 void     drto_eval_albedo(const drto_medium *m, const float p[3], float out[3]);
 float    drto_majorant(const drto_medium *m);
+/* supergrid: writes gx*gy*gz cell majorants (x fastest) into out (may be NULL) and returns the
+ * cell count; dims[3] receives (gx,gy,gz).  0 cells when majorant_factor == 0. */
+int      drto_majorant_grid(const drto_medium *m, int32_t dims[3], float *out);
 /* mean ratio-tracking transmittance estimate over n independent walks (A8). */
 double   drto_ratio_tracking_mean(const drto_medium *m, const float o[3], const float d[3],
                                   float tmax, uint32_t seed, int n);

@@ -116,6 +116,56 @@ def test_heterogeneous_grid_explicit_rays(uivr, oracle, gpu):
     _assert_grads_close(grads[uivr.ALBEDO_KEY], ga, "grad albedo")
 
 
+@pytest.mark.parametrize("factor", [2, 4, 5])
+def test_majorant_supergrid(uivr, oracle, gpu, factor):
+    """majorant_resolution_factor > 0 (scene_config.py:36): supergrid values, primal bit-exact,
+    counters equal, gradients close - on a sparse 20x16x24 grid (ragged: 5 does not divide it)."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    res = (20, 16, 24)                                   # X, Y, Z
+    st = rng.random((res[2], res[1], res[0], 1), dtype=np.float32) * 8.0
+    st[rng.random(st.shape) < 0.6] = 0.0
+    st[:, :, :8] = 0.0                                   # a fully empty slab (empty supercells)
+    al = (rng.random((res[2], res[1], res[0], 3), dtype=np.float32) * 0.8 + 0.1).astype(np.float32)
+    medium = uivr.GridMedium(sigma_t=st, albedo=al, bbox_min=(-1, -1, -1), bbox_max=(1, 0.8, 1.4), scale=1.3,
+                             majorant_resolution_factor=factor)
+    sensor = uivr.PerspectiveSensor(origin=(3.0, 2.0, 4.0), target=(0, 0, 0.2), fov=35.0, width=24, height=24)
+    scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter((0.9, 1.0, 1.1)), sensors=[sensor])
+    props, spp, seed = props_for("drt"), 8, 31
+    osc = oracle.OracleScene(scene)
+    ref = oracle.h1_step(osc, props, spp, seed)
+    _, c_primal = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)
+
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props)
+    h = integ.native_handle(sg)
+    # the supergrid itself
+    dims = (C.c_int32 * 3)()
+    n = oracle.lib().drto_majorant_grid(C.byref(osc.medium), dims, None)
+    assert n == (res[0] // factor) * (res[1] // factor) * (res[2] // factor)
+    cells = np.zeros(n, dtype=np.float32)
+    oracle.lib().drto_majorant_grid(C.byref(osc.medium), dims, cells.ctypes.data_as(C.POINTER(C.c_float)))
+    inp = np.zeros((n, 6), dtype=np.float32)
+    inp[:, 0] = np.arange(n, dtype=np.uint32).view(np.float32)
+    tin = torch.from_numpy(inp).to(gpu)
+    tout = torch.empty_like(tin)
+    h.debug_eval(9, tin.data_ptr(), n, tout.data_ptr())
+    np.testing.assert_array_equal(tout.cpu().numpy()[:, 0], cells)
+    assert (cells == 0).any() and (cells > 0).any()
+
+    h.enable_counters(True)
+    h.reset_counters()
+    batch = uivr.RayBatch(n_rays=24 * 24 * spp, spp=spp, sensor=sg.sensors[0])
+    L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(seed, spp), batch)
+    np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), ref["L"].view(np.uint32))
+    img, grads = _h1_gpu(uivr, sg, integ, spp, seed)
+    cnt = {k: int(v) for k, v in h.get_counters().items()}
+    h.enable_counters(False)
+    assert cnt == {k: ref["counters"][k] + 2 * c_primal[k] for k in ref["counters"]}
+    _assert_grads_close(grads[uivr.SIGMA_T_KEY], ref["grad_sigma_t"], "grad sigma_t")
+    _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], "grad albedo")
+
+
 def test_edge_cases(uivr, oracle, gpu):
     """Empty batch, all rays missing the box, zero density, zero albedo, max_depth 0/1."""
     scene = uivr.cube_test_scene(8, 8, density_scale=2.0)

@@ -27,6 +27,8 @@ struct drt_handle_s {
     unsigned long long *d_counters = nullptr;   // [C_COUNT]
     float *d_gt = nullptr;         // tiled gradient scratch, 4 planes (always zero between launches)
     float *d_sigma_b = nullptr;    // bricked copy of sigma_t (refreshed by drt_params_changed)
+    float *d_mgrid = nullptr;      // majorant supergrid (refreshed by drt_params_changed)
+    size_t mgrid_cells = 0;
     size_t sigma_b_floats = 0;
     size_t gt_floats = 0;
     bool counting = false;
@@ -188,6 +190,7 @@ int drt_destroy(drt_handle h)
     if (h->d_counters) (void) hipFree(h->d_counters);
     if (h->d_gt) (void) hipFree(h->d_gt);
     if (h->d_sigma_b) (void) hipFree(h->d_sigma_b);
+    if (h->d_mgrid) (void) hipFree(h->d_mgrid);
     clear_timings(h);
     delete h;
     return DRT_OK;
@@ -224,6 +227,9 @@ int drt_params_changed(drt_handle h)
     DeviceGuard g(h->device);
     size_t n = (size_t) h->base.rx * h->base.ry * h->base.rz;
     DRT_HIP_CHECK(h, drt::launch_majorant(h->base.sigma_t, n, h->base.scale, h->d_scratch, h->d_majorant, h->stream));
+    if (h->base.mgrid)
+        DRT_HIP_CHECK(h, drt::launch_majorant_grid(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.gx, h->base.gy,
+                                                   h->base.gz, h->base.scale, h->d_mgrid, h->stream));
     DRT_HIP_CHECK(h, drt::launch_brick_sigma(h->base.sigma_t, h->d_sigma_b, h->base.rx, h->base.ry, h->base.rz,
                                              h->base.sb_ystride, h->base.sb_zstride, h->stream));
     return DRT_OK;
@@ -242,8 +248,8 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
     }
     if ((uint64_t) res[0] * res[1] * res[2] > 0x7fffffffull / 3)
         return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for 32-bit voxel indexing");
-    if (majorant_resolution_factor != 0)
-        return fail(h, DRT_ERR_UNSUPPORTED, "majorant supergrid (factor %d) not implemented yet; use 0", majorant_resolution_factor);
+    if (majorant_resolution_factor < 0)
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "majorant_resolution_factor must be >= 0");
     drt::Params &B = h->base;
     B.sigma_t = sigma_t; B.albedo = albedo;
     B.rx = res[0]; B.ry = res[1]; B.rz = res[2];
@@ -266,6 +272,21 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         }
         B.gt = h->d_gt; B.gt_plane = (uint32_t) plane;
         B.gt_ystride = (int) (tx * 16); B.gt_zstride = (int) (ty * tx * 16);
+    }
+    // majorant supergrid (0 = global majorant only)
+    if (majorant_resolution_factor > 0) {
+        int G[3];
+        for (int a = 0; a < 3; ++a) { G[a] = res[a] / majorant_resolution_factor; if (G[a] < 1) G[a] = 1; }
+        size_t cells = (size_t) G[0] * G[1] * G[2];
+        if (cells != h->mgrid_cells) {
+            DeviceGuard g(h->device);
+            if (h->d_mgrid) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_mgrid); h->d_mgrid = nullptr; h->mgrid_cells = 0; }
+            DRT_HIP_CHECK(h, hipMalloc(&h->d_mgrid, cells * sizeof(float)));
+            h->mgrid_cells = cells;
+        }
+        B.mgrid = h->d_mgrid; B.gx = G[0]; B.gy = G[1]; B.gz = G[2];
+    } else {
+        B.mgrid = nullptr; B.gx = B.gy = B.gz = 0;
     }
     // bricked sigma_t copy: 4x4x2 voxels per 128-byte line
     {

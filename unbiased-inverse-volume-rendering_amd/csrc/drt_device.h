@@ -163,6 +163,8 @@ struct Params {
     int sb_ystride, sb_zstride; // floats between brick rows (bx*32) / brick slabs (by*bx*32)
     const float *albedo;       // (Z,Y,X,3)
     const float *majorant;     // device: [0] = scale*max(sigma_t), [1] = 1/[0] (0 if [0]==0)
+    const float *mgrid;        // majorant supergrid, one majorant per cell (x fastest), or nullptr
+    int gx, gy, gz;
     int rx, ry, rz;
     float bmin[3], bmax[3], inv_ext[3];
     float scale;

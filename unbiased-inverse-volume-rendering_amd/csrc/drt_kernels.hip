@@ -25,12 +25,14 @@ struct Tracer {
     float maj, inv_maj;
     uint32_t ray_index;
     uint32_t *rec;          // wave-private LDS staging area of the cooperative scatter
+    const float *mg;        // majorant supergrid as the DDA reads it (global memory, L2-resident; an LDS copy
+                            // was measured slower: it costs a wave per SIMD of occupancy)
     uint32_t cnt[C_COUNT];
 
     __device__ __forceinline__ Tracer(const Params &p) : P(p)
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
-        ray_index = 0; rec = nullptr;
+        ray_index = 0; rec = nullptr; mg = p.mgrid;
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
@@ -44,21 +46,70 @@ struct Tracer {
         return -drt_logf(1.0f - u) * inv_maj;
     }
 
+    // Medium::sample_interaction with a majorant supergrid (scene_config.py:36,
+    // optimize.py:182-199): 3-D DDA through the cells the ray crosses, accumulating
+    // majorant * length until tau = -log(1-u) is reached.  Returns the distance (inf if the
+    // ray leaves [0,tmax] first) and the local majorant / reciprocal at the collision.
+    // Without a supergrid: the global majorant (bit-identical to sample_distance).
+    __device__ __forceinline__ float sample_collision(V3 o, V3 d, float tmax, float u, float &m_out, float &im_out) const
+    {
+        if (!P.mgrid) { m_out = maj; im_out = inv_maj; return sample_distance(u); }
+        const float tau = -drt_logf(1.0f - u);
+        float gxf = ((o.x - P.bmin[0]) * P.inv_ext[0]) * (float) P.gx, dgx = (d.x * P.inv_ext[0]) * (float) P.gx;
+        float gyf = ((o.y - P.bmin[1]) * P.inv_ext[1]) * (float) P.gy, dgy = (d.y * P.inv_ext[1]) * (float) P.gy;
+        float gzf = ((o.z - P.bmin[2]) * P.inv_ext[2]) * (float) P.gz, dgz = (d.z * P.inv_ext[2]) * (float) P.gz;
+        float flx = fminf(fmaxf(floorf(gxf), 0.0f), (float)(P.gx - 1));
+        float fly = fminf(fmaxf(floorf(gyf), 0.0f), (float)(P.gy - 1));
+        float flz = fminf(fmaxf(floorf(gzf), 0.0f), (float)(P.gz - 1));
+        int cx = (int) flx, cy = (int) fly, cz = (int) flz;
+        float tnx, tny, tnz, tdx, tdy, tdz; int sx, sy, sz;
+        if (dgx > 0.0f) { tnx = ((flx + 1.0f) - gxf) / dgx; tdx = 1.0f / dgx; sx = 1; }
+        else if (dgx < 0.0f) { tnx = (flx - gxf) / dgx; tdx = -1.0f / dgx; sx = -1; }
+        else { tnx = kInf; tdx = kInf; sx = 0; }
+        if (dgy > 0.0f) { tny = ((fly + 1.0f) - gyf) / dgy; tdy = 1.0f / dgy; sy = 1; }
+        else if (dgy < 0.0f) { tny = (fly - gyf) / dgy; tdy = -1.0f / dgy; sy = -1; }
+        else { tny = kInf; tdy = kInf; sy = 0; }
+        if (dgz > 0.0f) { tnz = ((flz + 1.0f) - gzf) / dgz; tdz = 1.0f / dgz; sz = 1; }
+        else if (dgz < 0.0f) { tnz = (flz - gzf) / dgz; tdz = -1.0f / dgz; sz = -1; }
+        else { tnz = kInf; tdz = kInf; sz = 0; }
+        float t = 0.0f, acc = 0.0f;
+        for (;;) {
+            int a = (tny < tnx) ? 1 : 0;
+            float tmin = (tny < tnx) ? tny : tnx;
+            if (tnz < tmin) { a = 2; tmin = tnz; }
+            float texit = fminf(tmin, tmax);
+            float mc = mg[(cz * P.gy + cy) * P.gx + cx];
+            if (mc > 0.0f) {
+                float dtau = mc * (texit - t);
+                if (acc + dtau >= tau) { float im = 1.0f / mc; m_out = mc; im_out = im; return fmaf(tau - acc, im, t); }
+                acc += dtau;
+            }
+            t = texit;
+            if (!(texit < tmax)) break;
+            if (a == 0) { cx += sx; if (cx < 0 || cx >= P.gx) break; tnx += tdx; }
+            else if (a == 1) { cy += sy; if (cy < 0 || cy >= P.gy) break; tny += tdy; }
+            else { cz += sz; if (cz < 0 || cz >= P.gz) break; tnz += tdz; }
+        }
+        m_out = 0.0f; im_out = 0.0f;
+        return kInf;
+    }
+
     // estimate_transmittance: ratio tracking (volpathsimple.py:436-504)
     template <bool ADJ>
     __device__ float estimate_transmittance(V3 o, V3 d, float tmax, Pcg32 &S, const float *adj)
     {
         float T = 1.0f;
         for (;;) {
-            float dt = sample_distance(S.next_1d());
+            float lm, lim;
+            float dt = sample_collision(o, d, tmax, S.next_1d(), lm, lim);
             if (!(dt <= tmax)) break;                                   // :480-481
             V3 p = ray_at(o, d, dt);
             float sig = eval_sigma_t(P, p);
-            float tr = (maj - sig) * inv_maj;                           // :473-476
+            float tr = (lm - sig) * lim;                                // :473-476
             count(C_RT);
             if constexpr (ADJ) if (tr > 0.0f) {                         // :487-492
                 float a = (adj[0] + adj[1]) + adj[2];
-                splat_sigma_t(P, p, -(a * inv_maj) / tr, rec);
+                splat_sigma_t(P, p, -(a * lim) / tr, rec);
                 count(C_RT_ADJ);
             }
             T *= tr;                                                    // :495
@@ -106,12 +157,13 @@ struct Tracer {
         Mei mei; mei.valid = false; mei.t = kInf; mei.p = v3(0, 0, 0); mei.sigma_t = 0.0f;
         V3 ro = ray.o; float rmaxt = ray.maxt, running_t = 0.0f;
         for (;;) {
-            float dt = sample_distance(S.next_1d());                    // :348
+            float lm, lim;
+            float dt = sample_collision(ro, ray.d, rmaxt, S.next_1d(), lm, lim);   // :348
             if (!(dt <= rmaxt)) break;                                  // :358
             V3 p = ray_at(ro, ray.d, dt);
             float sig = eval_sigma_t(P, p);
             count(C_DT);
-            float r = sig * inv_maj;                                    // :354
+            float r = sig * lim;                                        // :354
             float u = S.next_1d();                                      // :359
             if (!(u >= r)) { mei.valid = true; mei.t = running_t + dt; break; }   // :351
             ro = p; rmaxt -= dt; running_t += dt;                       // :364-367
@@ -131,15 +183,17 @@ struct Tracer {
         float t = 0.0f, T = 1.0f, wsum = 0.0f, tsel = kInf;
         bool valid = false;
         for (;;) {
-            t += sample_distance(A.next_1d());
+            float lm, lim;
+            if (P.mgrid) t += sample_collision(ray_at(ray.o, ray.d, t), ray.d, ray.maxt - t, A.next_1d(), lm, lim);
+            else { t += sample_distance(A.next_1d()); lm = maj; lim = inv_maj; }
             if (!(t <= ray.maxt)) break;
             float sig = eval_sigma_t(P, ray_at(ray.o, ray.d, t));
             count(C_DRT);
-            float w = T * inv_maj;
+            float w = T * lim;
             wsum += w;
             float u = A.next_1d();
             if (w > 0.0f && u * wsum <= w) { tsel = t; valid = true; }
-            T *= (maj - sig) * inv_maj;
+            T *= (lm - sig) * lim;
             if (T == 0.0f) break;
         }
         t_out = tsel; W_out = wsum;
@@ -432,6 +486,29 @@ __global__ void majorant_finalize_kernel(const uint32_t *max_bits, float scale, 
     majorant[1] = (m != 0.0f) ? 1.0f / m : 0.0f;
 }
 
+// Majorant supergrid: cell (I,J,K) = scale * max over the voxels a trilinear lookup inside the
+// cell can touch, padded by one voxel: [floor(I*res/G) - 1, ceil((I+1)*res/G)] per axis, clamped.
+// One wavefront per cell.
+__global__ void __launch_bounds__(256) majorant_grid_kernel(const float *sigma_t, int rx, int ry, int rz,
+                                                            int gx, int gy, int gz, float scale, float *out)
+{
+    uint32_t cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (cell >= (uint32_t) gx * gy * gz) return;
+    int I = cell % gx, J = (cell / gx) % gy, K = cell / (gx * gy);
+    auto lo = [](int c, int R, int G) { int v = (int)(((long long) c * R) / G) - 1; return v < 0 ? 0 : v; };
+    auto hi = [](int c, int R, int G) { int v = (int)((((long long)(c + 1)) * R + G - 1) / G); return v > R - 1 ? R - 1 : v; };
+    int x0 = lo(I, rx, gx), x1 = hi(I, rx, gx), y0 = lo(J, ry, gy), y1 = hi(J, ry, gy), z0 = lo(K, rz, gz), z1 = hi(K, rz, gz);
+    int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    float m = 0.0f;
+    for (int i = lane; i < nx * ny * nz; i += 64) {
+        int x = x0 + i % nx, y = y0 + (i / nx) % ny, z = z0 + i / (nx * ny);
+        m = fmaxf(m, sigma_t[((size_t) z * ry + y) * rx + x]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+    if (lane == 0) out[cell] = m * scale;
+}
+
 // Caller's (Z,Y,X,1) sigma_t -> bricked copy (Params::sigma_b); one thread per voxel.
 __global__ void __launch_bounds__(256) brick_sigma_kernel(const float *src, float *dst, int rx, int ry, int rz,
                                                           int ystride, int zstride)
@@ -514,6 +591,7 @@ __global__ void __launch_bounds__(256) debug_eval_kernel(const Params P, int op,
             V3 ro, rd; sensor_ray(P, __float_as_uint(a[0]), a[1], a[2], ro, rd);
             o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
         } break;
+        case 9: if (P.mgrid) { o[0] = P.mgrid[__float_as_uint(a[0])]; } break;
         case 8: o[0] = mis_weight(a[0], a[1]); o[1] = a[0] / a[1]; o[2] = sqrtf(a[0]); o[3] = fmaf(a[0], a[1], a[2]); break;
         default: break;
     }
@@ -540,6 +618,14 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
         if (count) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, P);
         else       hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, P);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
+                                float *out, hipStream_t stream)
+{
+    uint32_t cells = (uint32_t) gx * gy * gz;
+    hipLaunchKernelGGL(majorant_grid_kernel, dim3((cells * 64 + 255) / 256), dim3(256), 0, stream, sigma_t, rx, ry, rz, gx, gy, gz, scale, out);
     return hipGetLastError();
 }
 
