@@ -27,6 +27,7 @@ struct drt_handle_s {
     unsigned long long *d_counters = nullptr;   // [C_COUNT]
     float *d_gt = nullptr;         // tiled gradient scratch, 4 planes (always zero between launches)
     float *d_sigma_b = nullptr;    // bricked copy of sigma_t (refreshed by drt_params_changed)
+    uint32_t *d_occ = nullptr;     // empty-space bitmask (kOccWords words)
     float *d_mgrid = nullptr;      // majorant supergrid (refreshed by drt_params_changed)
     size_t mgrid_cells = 0;
     size_t sigma_b_floats = 0;
@@ -34,6 +35,7 @@ struct drt_handle_s {
     bool counting = false;
     uint64_t chunk = 0, stride = 0;   // ray interleave (drt_set_ray_interleave)
     uint32_t debug_flags = 0;
+    int occ_z = 0;
     bool timing = false;
     // HIP event pairs around every tracing launch while timing is on: [0] primal, [1] backward
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[2];
@@ -170,6 +172,7 @@ int drt_create(const drt_config *cfg, int device, drt_handle *out)
     if (!g.ok) { delete h; return fail(nullptr, DRT_ERR_HIP, "hipSetDevice(%d) failed", device); }
     hipError_t e = hipMalloc(&h->d_majorant, 2 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->d_scratch, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&h->d_occ, drt::kOccWords * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&h->d_counters, drt::C_COUNT * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->d_counters, 0, drt::C_COUNT * sizeof(unsigned long long));
     if (e != hipSuccess) {
@@ -191,6 +194,7 @@ int drt_destroy(drt_handle h)
     if (h->d_gt) (void) hipFree(h->d_gt);
     if (h->d_sigma_b) (void) hipFree(h->d_sigma_b);
     if (h->d_mgrid) (void) hipFree(h->d_mgrid);
+    if (h->d_occ) (void) hipFree(h->d_occ);
     clear_timings(h);
     delete h;
     return DRT_OK;
@@ -230,6 +234,8 @@ int drt_params_changed(drt_handle h)
     if (h->base.mgrid)
         DRT_HIP_CHECK(h, drt::launch_majorant_grid(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.gx, h->base.gy,
                                                    h->base.gz, h->base.scale, h->d_mgrid, h->stream));
+    DRT_HIP_CHECK(h, drt::launch_occupancy(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.occ_shift, h->base.occ_x,
+                                           h->base.occ_y, h->occ_z, h->d_occ, h->base.occ_words, h->stream));
     DRT_HIP_CHECK(h, drt::launch_brick_sigma(h->base.sigma_t, h->d_sigma_b, h->base.rx, h->base.ry, h->base.rz,
                                              h->base.sb_ystride, h->base.sb_zstride, h->stream));
     return DRT_OK;
@@ -287,6 +293,20 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         B.mgrid = h->d_mgrid; B.gx = G[0]; B.gy = G[1]; B.gz = G[2];
     } else {
         B.mgrid = nullptr; B.gx = B.gy = B.gz = 0;
+    }
+    // empty-space bitmask: cells of 2^shift voxels, at most kOccWords*32 cells
+    {
+        int shift = 3;
+        for (;; ++shift) {
+            size_t ox = ((size_t) res[0] >> shift) + 1, oy = ((size_t) res[1] >> shift) + 1, oz = ((size_t) res[2] >> shift) + 1;
+            if (ox * oy * oz <= (size_t) drt::kOccWords * 32) {
+                B.occ_shift = shift; B.occ_x = (int) ox; B.occ_y = (int) oy;
+                B.occ_words = (int) ((ox * oy * oz + 31) / 32);
+                h->occ_z = (int) oz;
+                break;
+            }
+        }
+        B.occ = h->d_occ;
     }
     // bricked sigma_t copy: 4x4x2 voxels per 128-byte line
     {

@@ -161,6 +161,10 @@ struct Params {
     const float *sigma_b;      // library-owned bricked copy read by the tracking loops: one 128-byte
                                // line = 4x4x2 voxels, so a trilinear footprint spans ~2.3 lines, not ~4.1
     int sb_ystride, sb_zstride; // floats between brick rows (bx*32) / brick slabs (by*bx*32)
+    // empty-space bitmask: bit c of occ is 0 iff every voxel a lookup with base corner inside
+    // cell c (2^occ_shift voxels per axis) can touch is exactly zero -> the lookup is 0 without a fetch
+    const uint32_t *occ;
+    int occ_shift, occ_x, occ_y, occ_words;
     const float *albedo;       // (Z,Y,X,3)
     const float *majorant;     // device: [0] = scale*max(sigma_t), [1] = 1/[0] (0 if [0]==0)
     const float *mgrid;        // majorant supergrid, one majorant per cell (x fastest), or nullptr
@@ -278,9 +282,23 @@ __device__ __forceinline__ Stencil make_brick_stencil(const Params &P, V3 p)
     return s;
 }
 
-__device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p)
+// `occ` = the empty-space bitmask as this wave reads it (LDS copy inside the tracing kernels).
+__device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p, const uint32_t *occ)
 {
-    Stencil s = make_brick_stencil(P, p);
+    Stencil s;
+    axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, s.x0, s.x1, s.wx0, s.wx1);
+    axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, s.y0, s.y1, s.wy0, s.wy1);
+    axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, s.z0, s.z1, s.wz0, s.wz1);
+    if (occ) {
+        const int c = ((s.z0 >> P.occ_shift) * P.occ_y + (s.y0 >> P.occ_shift)) * P.occ_x + (s.x0 >> P.occ_shift);
+        if (!((occ[c >> 5] >> (c & 31)) & 1u)) return 0.0f;      // all 8 corners are exactly 0
+    }
+    s.x0 = ((s.x0 >> 2) << 5) | (s.x0 & 3);
+    s.x1 = ((s.x1 >> 2) << 5) | (s.x1 & 3);
+    s.y0 = (s.y0 >> 2) * P.sb_ystride + ((s.y0 & 3) << 2);
+    s.y1 = (s.y1 >> 2) * P.sb_ystride + ((s.y1 & 3) << 2);
+    s.z0 = (s.z0 >> 1) * P.sb_zstride + ((s.z0 & 1) << 4);
+    s.z1 = (s.z1 >> 1) * P.sb_zstride + ((s.z1 & 1) << 4);
     const float *g = P.sigma_b;
     int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
     float d0 = g[a + s.x0], d1 = g[a + s.x1], d2 = g[b + s.x0], d3 = g[b + s.x1];
@@ -329,6 +347,7 @@ __device__ __forceinline__ void stencil_indices(const Stencil &s, int idx[8])
 // lanes stage (index, value) records in a wave-private LDS area and then, in groups
 // of up to 8 lanes, walk the group's records: lane j of the group adds corner j.
 constexpr int kCoopDwords = 32;   // per lane: 8 indices + 3 x 8 values
+constexpr int kOccWords = 1024;   // empty-space bitmask: at most 32768 cells = 4 KiB of LDS per workgroup
 
 __device__ __forceinline__ void coop_stage_sync()
 {

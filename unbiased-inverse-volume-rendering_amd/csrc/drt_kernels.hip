@@ -25,6 +25,7 @@ struct Tracer {
     float maj, inv_maj;
     uint32_t ray_index;
     uint32_t *rec;          // wave-private LDS staging area of the cooperative scatter
+    const uint32_t *occ;    // empty-space bitmask (LDS copy) or nullptr
     const float *mg;        // majorant supergrid as the DDA reads it (global memory, L2-resident; an LDS copy
                             // was measured slower: it costs a wave per SIMD of occupancy)
     uint32_t cnt[C_COUNT];
@@ -32,7 +33,7 @@ struct Tracer {
     __device__ __forceinline__ Tracer(const Params &p) : P(p)
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
-        ray_index = 0; rec = nullptr; mg = p.mgrid;
+        ray_index = 0; rec = nullptr; mg = p.mgrid; occ = nullptr;
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
@@ -104,7 +105,7 @@ struct Tracer {
             float dt = sample_collision(o, d, tmax, S.next_1d(), lm, lim);
             if (!(dt <= tmax)) break;                                   // :480-481
             V3 p = ray_at(o, d, dt);
-            float sig = eval_sigma_t(P, p);
+            float sig = eval_sigma_t(P, p, occ);
             float tr = (lm - sig) * lim;                                // :473-476
             count(C_RT);
             if constexpr (ADJ) if (tr > 0.0f) {                         // :487-492
@@ -161,7 +162,7 @@ struct Tracer {
             float dt = sample_collision(ro, ray.d, rmaxt, S.next_1d(), lm, lim);   // :348
             if (!(dt <= rmaxt)) break;                                  // :358
             V3 p = ray_at(ro, ray.d, dt);
-            float sig = eval_sigma_t(P, p);
+            float sig = eval_sigma_t(P, p, occ);
             count(C_DT);
             float r = sig * lim;                                        // :354
             float u = S.next_1d();                                      // :359
@@ -170,7 +171,7 @@ struct Tracer {
         }
         if (mei.valid) {
             mei.p = ray_at(ray.o, ray.d, mei.t);                        // :371
-            if (ATTACHED) { mei.sigma_t = eval_sigma_t(P, mei.p); count(C_DT); }   // :373-375
+            if (ATTACHED) { mei.sigma_t = eval_sigma_t(P, mei.p, occ); count(C_DT); }   // :373-375
         }
         return mei;
     }
@@ -187,7 +188,7 @@ struct Tracer {
             if (P.mgrid) t += sample_collision(ray_at(ray.o, ray.d, t), ray.d, ray.maxt - t, A.next_1d(), lm, lim);
             else { t += sample_distance(A.next_1d()); lm = maj; lim = inv_maj; }
             if (!(t <= ray.maxt)) break;
-            float sig = eval_sigma_t(P, ray_at(ray.o, ray.d, t));
+            float sig = eval_sigma_t(P, ray_at(ray.o, ray.d, t), occ);
             count(C_DRT);
             float w = T * lim;
             wsum += w;
@@ -233,7 +234,7 @@ struct Tracer {
         float tp, W;
         if (!sample_interaction_drt(sub, A, tp, W)) return;             // :550,558
         V3 p = ray_at(sub.o, sub.d, tp);
-        float sig = eval_sigma_t(P, p);                                 // :553-554
+        float sig = eval_sigma_t(P, p, occ);                                 // :553-554
         count(C_DRT);
         float Li[3];
         sample_recursive(A, p, depth, Li);                              // :565-568
@@ -429,6 +430,13 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
         __shared__ uint32_t coop_rec[4 * 64 * kCoopDwords];
         tr.rec = coop_rec + (threadIdx.x >> 6) * (64 * kCoopDwords);
     }
+    // empty-space bitmask -> LDS (4 KiB): most lookups of a sparse volume never leave the CU
+    __shared__ uint32_t occ_lds[kOccWords];
+    if (P.occ && !(P.debug_flags & 16u)) {
+        for (int w = threadIdx.x; w < P.occ_words; w += blockDim.x) occ_lds[w] = P.occ[w];
+        __syncthreads();
+        tr.occ = occ_lds;
+    }
     if (i < P.n_rays) {
         uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
         uint32_t gi = (uint32_t) g64;
@@ -509,6 +517,24 @@ __global__ void __launch_bounds__(256) majorant_grid_kernel(const float *sigma_t
     if (lane == 0) out[cell] = m * scale;
 }
 
+// Empty-space bitmask (Params::occ): one thread per cell ORs the voxels [c*S, (c+1)*S] per axis
+// (S = 2^shift; the +1 is the far corner of a lookup whose base corner is the cell's last voxel).
+__global__ void __launch_bounds__(256) occupancy_kernel(const float *sigma_t, int rx, int ry, int rz, int shift,
+                                                        int ox, int oy, int oz, uint32_t *occ)
+{
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (uint32_t) ox * oy * oz) return;
+    int I = c % ox, J = (c / ox) % oy, K = c / (ox * oy);
+    int S = 1 << shift;
+    int x1 = min(rx - 1, (I + 1) * S), y1 = min(ry - 1, (J + 1) * S), z1 = min(rz - 1, (K + 1) * S);
+    bool any = false;
+    for (int z = K * S; z <= z1 && !any; ++z)
+        for (int y = J * S; y <= y1 && !any; ++y)
+            for (int x = I * S; x <= x1; ++x)
+                if (sigma_t[((size_t) z * ry + y) * rx + x] != 0.0f) { any = true; break; }
+    if (any) atomicOr(occ + (c >> 5), 1u << (c & 31));
+}
+
 // Caller's (Z,Y,X,1) sigma_t -> bricked copy (Params::sigma_b); one thread per voxel.
 __global__ void __launch_bounds__(256) brick_sigma_kernel(const float *src, float *dst, int rx, int ry, int rz,
                                                           int ystride, int zstride)
@@ -577,7 +603,7 @@ __global__ void __launch_bounds__(256) debug_eval_kernel(const Params P, int op,
         case 0: o[0] = drt_logf(a[0]); break;
         case 1: drt_sincos_2pi(a[0], o[0], o[1]); break;
         case 2: { V3 d = square_to_uniform_sphere(a[0], a[1]); o[0] = d.x; o[1] = d.y; o[2] = d.z; } break;
-        case 3: o[0] = eval_sigma_t(P, v3(a[0], a[1], a[2])); break;
+        case 3: o[0] = eval_sigma_t(P, v3(a[0], a[1], a[2]), P.occ); break;
         case 4: eval_albedo(P, v3(a[0], a[1], a[2]), o); break;
         case 5: {
             Hit h = box_hit(P, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]));
@@ -626,6 +652,16 @@ hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, in
 {
     uint32_t cells = (uint32_t) gx * gy * gz;
     hipLaunchKernelGGL(majorant_grid_kernel, dim3((cells * 64 + 255) / 256), dim3(256), 0, stream, sigma_t, rx, ry, rz, gx, gy, gz, scale, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int shift, int ox, int oy, int oz,
+                            uint32_t *occ, int words, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(occ, 0, (size_t) words * 4, stream);
+    if (e != hipSuccess) return e;
+    uint32_t cells = (uint32_t) ox * oy * oz;
+    hipLaunchKernelGGL(occupancy_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, sigma_t, rx, ry, rz, shift, ox, oy, oz, occ);
     return hipGetLastError();
 }
 
