@@ -124,6 +124,27 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
                         uint64_t ray_offset, uint32_t spp, uint32_t seed, const float *dL,
                         const float *L_in, float *grad_sigma_t, float *grad_albedo);
 
+/* NeRFIntegrator properties (python/integrators/nerf.py:30-35; density_noise_std is
+ * effectively unsupported in the reference, nerf.py:160-162, and is not exposed). */
+typedef struct drt_nerf_config {
+    int32_t hide_emitters;      /* default 0 */
+    int32_t queries_per_ray;    /* default 128 */
+    int32_t jittering_enabled;  /* default 1 */
+    int32_t activation_relu;    /* 0 identity (default), 1 relu */
+} drt_nerf_config;
+
+/* NeRFIntegrator.sample(mode=Primal / Backward) (python/integrators/nerf.py:47-148): emissive ray
+ * marching through the medium set by drt_set_medium (its albedo may be NULL) with the emission
+ * grid `emission` (Z,Y,X,3) = medium.get_emission (nerf.py:164).  Ray / seed conventions as for
+ * drt_render_*.  The backward call accumulates into grad_sigma_t (Z,Y,X,1) and grad_emission
+ * (Z,Y,X,3) (dr.backward_from, nerf.py:122-129). */
+int drt_nerf_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
+                           const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
+                           float *L_out);
+int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
+                             const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
+                             const float *dL, const float *L_in, float *grad_sigma_t, float *grad_emission);
+
 /* Box-filter film: image[p] = mean over the pixel's spp samples
  * (block.put + film.develop, batched.py:176-197).  L: [n_pixels*spp][3]. */
 int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t spp, float *image);
@@ -149,7 +170,8 @@ int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity);
  * that the parity tests can compare the [M3-ext] building blocks bit for bit with
  * the oracle.  op: 0 log, 1 sincos(2 pi u), 2 square_to_uniform_sphere, 3 sigma_t(p),
  * 4 albedo(p), 5 box hit (o,d) -> valid,t,n, 6 PCG32 floats of (seed,index) bit
- * patterns, 7 sensor ray (pixel bits, ux, uy), 8 mis_weight / div / sqrt / fma. */
+ * patterns, 7 sensor ray (pixel bits, ux, uy), 8 mis_weight / div / sqrt / fma,
+ * 9 majorant supergrid cell (index bits), 10 exp. */
 int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out);
 
 /* Profiling ablations (bit 0: skip the gradient atomics).  0 in production. */

@@ -48,6 +48,10 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class NerfConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("hide_emitters", "queries_per_ray", "jittering_enabled", "activation_relu")]
+
+
 class Job(C.Structure):
     _fields_ = [("cfg", C.POINTER(Config)), ("medium", C.POINTER(Medium)),
                 ("emitter", C.POINTER(Emitter)), ("sensor", C.POINTER(Sensor)),
@@ -74,6 +78,10 @@ def lib():
         L.drto_render_backward.argtypes = [C.POINTER(Job), fp, fp, dp, dp, C.POINTER(Counters)]
         L.drto_h1_step.argtypes = [C.POINTER(Job), fp, fp, dp, dp, dp, C.POINTER(Counters)]
         L.drto_render_textbook.argtypes = [C.POINTER(Job), fp]
+        L.drto_nerf_render.argtypes = [C.POINTER(Job), C.POINTER(NerfConfig), fp, C.c_int, fp, fp, fp, dp, dp,
+                                       C.POINTER(Counters)]
+        L.drto_expf.argtypes = [C.c_float]
+        L.drto_expf.restype = C.c_float
         L.drto_tea32.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.drto_tea32.restype = C.c_uint32
         L.drto_pcg32_floats.argtypes = [C.c_uint32, C.c_uint32, C.c_int, fp]
@@ -139,7 +147,7 @@ class OracleScene:
     def __init__(self, scene, sensor_index: Optional[int] = 0):
         m = scene.medium
         self.sigma_t = _f32(m.sigma_t)
-        self.albedo = _f32(m.albedo)
+        self.albedo = _f32(m.albedo) if m.albedo is not None else np.zeros(self.sigma_t.shape[:3] + (3,), np.float32)
         z, y, x = self.sigma_t.shape[:3]
         assert self.albedo.shape[:3] == (z, y, x) and self.albedo.shape[-1] == 3
         self.medium = Medium(_fp(self.sigma_t), _fp(self.albedo), (C.c_int32 * 3)(x, y, z),
@@ -226,6 +234,42 @@ def h1_step(oscene: OracleScene, props: dict, spp: int, seed: int, **kw):
         raise RuntimeError(f"drto_h1_step failed: {rc}")
     return dict(image=image, loss=loss.value, grad_sigma_t=gs, grad_albedo=ga,
                 counters=cnt.as_dict(), L=L)
+
+
+def make_nerf_config(props: dict) -> NerfConfig:
+    """props: NeRFIntegrator properties (nerf.py:30-35)."""
+    act = str(props.get("activation", "identity")).lower()
+    assert act in ("identity", "relu")
+    assert float(props.get("density_noise_std", 0.0)) == 0.0, "density noise is unsupported (nerf.py:160-162)"
+    return NerfConfig(hide_emitters=int(props.get("hide_emitters", False)),
+                      queries_per_ray=int(props.get("queries_per_ray", 128)),
+                      jittering_enabled=int(props.get("jittering_enabled", True)),
+                      activation_relu=int(act == "relu"))
+
+
+def nerf_render(oscene: OracleScene, emission, props: dict, spp: int, seed: int, dL=None, L_in=None, **kw):
+    """NeRFIntegrator.sample over the sensor's rays.  Primal (dL None): -> (L, counters).
+    Backward: -> (grad_sigma_t, grad_emission, counters)."""
+    cfg = Config(max_depth=0)
+    job = oscene.job(cfg, spp, seed, **kw)
+    ncfg = make_nerf_config(props)
+    em = _f32(emission)
+    cnt = Counters()
+    if dL is None:
+        L = np.zeros((job.n_rays, 3), dtype=np.float32)
+        rc = lib().drto_nerf_render(C.byref(job), C.byref(ncfg), _fp(em), 0, None, None, _fp(L), None, None, C.byref(cnt))
+        if rc:
+            raise RuntimeError(f"drto_nerf_render failed: {rc}")
+        return L, cnt.as_dict()
+    dL, L_in = _f32(dL), _f32(L_in)
+    z, y, x = oscene.grid_shape()
+    gs = np.zeros((z, y, x, 1), dtype=np.float64)
+    ge = np.zeros((z, y, x, 3), dtype=np.float64)
+    rc = lib().drto_nerf_render(C.byref(job), C.byref(ncfg), _fp(em), 1, _fp(dL), _fp(L_in), None, _dp(gs), _dp(ge),
+                                C.byref(cnt))
+    if rc:
+        raise RuntimeError(f"drto_nerf_render failed: {rc}")
+    return gs, ge, cnt.as_dict()
 
 
 def render_textbook(oscene: OracleScene, props: dict, spp: int, seed: int, **kw):

@@ -116,6 +116,25 @@ static inline float drt_logf(float x)
     return r;
 }
 
+/* exp for x <= 0 (Cephes expf: range reduction by ln2 split, degree-5 polynomial, exact 2^n scale). */
+static inline float drt_expf(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    float z = floorf(fmaf(1.44269504088896341f, x, 0.5f));
+    x = fmaf(-0.693359375f, z, x);
+    x = fmaf(2.12194440e-4f, z, x);
+    int n = (int) z;
+    float x2 = x * x;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, x, 1.3981999507e-3f);
+    p = fmaf(p, x, 8.3334519073e-3f);
+    p = fmaf(p, x, 4.1665795894e-2f);
+    p = fmaf(p, x, 1.6666665459e-1f);
+    p = fmaf(p, x, 5.0000001201e-1f);
+    float r = fmaf(p, x2, x) + 1.0f;
+    return r * u2f((uint32_t)(n + 127) << 23);     /* n in [-126, 1] here */
+}
+
 /* sin/cos of 2*pi*u for u in [0,1): exact quadrant split, Cephes minimax on [0,pi/4]. */
 static inline void drt_sincos_2pi(float u, float *s_out, float *c_out)
 {
@@ -734,6 +753,136 @@ static void drt_sample(ctx_t *c, pcg32 *S, int adjoint, ray_t ray, const float *
 }
 
 /* ------------------------------------------------------------------------- */
+/* A17: NeRFIntegrator.sample (python/integrators/nerf.py:47-148)             */
+/* emission-absorption ray marching, queries_per_ray jittered queries,        */
+/* PRB-style backward.  `emission` grid (Z,Y,X,3) = medium.get_emission.       */
+/* ------------------------------------------------------------------------- */
+static int scene_init(scene_t *sc, const drto_job *job);
+static void scene_free(scene_t *sc);
+static inline void job_ray(const drto_job *job, uint64_t i, pcg32 *S, ray_t *ray);
+static void cnt_add(drto_counters *a, const drto_counters *b);
+
+typedef struct {
+    int hide_emitters, queries, jitter, relu;
+    const float *emission;
+    double *g_emission;
+} nerf_t;
+
+static void nerf_sample(ctx_t *c, const nerf_t *nf, pcg32 *S, int adjoint, ray_t ray, const float *dL,
+                        const float *state_in, float out[3])
+{
+    const scene_t *sc = c->sc;
+    float result[3] = { 0, 0, 0 };
+    if (adjoint) { result[0] = state_in[0]; result[1] = state_in[1]; result[2] = state_in[2]; }
+    float throughput = 1.0f, weights_sum = 0.0f;
+    si_t si = box_hit(sc, ray.o, ray.d);                       /* nerf.py:67-79 */
+    int active = si.valid, escaped = !active;
+    if (active) {
+        ray.o = offset_p(&si, ray.d);
+        si = box_hit(sc, ray.o, ray.d);
+        active = si.valid;
+    }
+    if (active) {
+        const int N = nf->queries;
+        float step = nf->jitter ? (si.t - 0.0f) / (float) N : (si.t - 0.0f) / (float)(N - 1);   /* nerf.py:6-10,82 */
+        float t_a = 0.0f;
+        float jit = next_1d(S);                               /* :88 one jitter per ray */
+        for (int j = 0; j < N; ++j) {                         /* :94-129 */
+            float t_b = nf->jitter ? step * ((float)(j + 1) + jit) : step * (float)(j + 1);   /* :12-17 */
+            float dt = t_b - t_a;
+            v3 p = ray_at(ray.o, ray.d, t_b);                 /* query_medium :151-165 */
+            float raw = eval_sigma_t(sc, p);
+            c->cnt.n_dt++;
+            float sigma = nf->relu ? fmaxf(0.0f, raw) : raw;
+            float em[3];
+            { stencil_t s; make_stencil(sc, p, &s); for (int k = 0; k < 3; ++k) em[k] = trilerp(&s, nf->emission, 3, k); }
+            c->cnt.n_alb++;
+            int last = !(j + 1 < N);
+            float a = last ? 1.0f : drt_expf(-sigma * dt);    /* :104-106 */
+            float weight = (1.0f - a) * throughput;
+            float safe_a = a + 1e-10f;
+            for (int k = 0; k < 3; ++k)
+                result[k] = adjoint ? result[k] - weight * em[k] : result[k] + weight * em[k];   /* :110-113 */
+            if (adjoint) {                                    /* :122-129 */
+                /* d/d sigma of  dL * (em * weight + (result / det(safe_a)) * safe_a); zero at the last step */
+                float gs = 0.0f, ge[3];
+                float da = last ? 0.0f : -dt * a;             /* d a / d sigma */
+                for (int k = 0; k < 3; ++k) {
+                    gs += dL[k] * (em[k] * (-da * throughput) + (result[k] / safe_a) * da);
+                    ge[k] = dL[k] * weight;
+                }
+                if (nf->relu && !(raw > 0.0f)) gs = 0.0f;
+                splat_sigma_t(c, p, gs); c->cnt.n_sc++;
+                {
+                    stencil_t s; float w[8];
+                    make_stencil(sc, p, &s); stencil_weights(&s, w);
+                    for (int q = 0; q < 8; ++q) for (int k = 0; k < 3; ++k) {
+                        double v = (double)(w[q] * ge[k]);
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                        nf->g_emission[(size_t) s.idx[q] * 3 + k] += v;
+                    }
+                    c->cnt.n_sc_alb++;
+                }
+            }
+            t_a = t_b;
+            if (!last) { throughput *= safe_a; weights_sum += weight; }   /* :117-120 (masked by still_walking) */
+        }
+    }
+    /* composite with the background emitter (:131-146; executes in both modes, :144) */
+    int active_e = escaped || active;
+    if (nf->hide_emitters) active_e = active_e && (weights_sum > 0.0f);
+    if (active_e) for (int k = 0; k < 3; ++k) result[k] += (1.0f - weights_sum) * sc->Le[k];
+    out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
+}
+
+int drto_nerf_render(const drto_job *job, const drto_nerf_config *ncfg, const float *emission, int adjoint,
+                     const float *dL, const float *L_in, float *L_out, double *grad_sigma_t,
+                     double *grad_emission, drto_counters *cnt)
+{
+    scene_t sc;
+    drto_job j2 = *job;
+    drto_config dummy; memset(&dummy, 0, sizeof dummy);
+    if (!j2.cfg) j2.cfg = &dummy;
+    if (scene_init(&sc, &j2)) return -1;
+    if (!emission || !ncfg || ncfg->queries_per_ray < 2) { scene_free(&sc); return -2; }
+    nerf_t nf; nf.hide_emitters = ncfg->hide_emitters; nf.queries = ncfg->queries_per_ray;
+    nf.jitter = ncfg->jittering_enabled; nf.relu = ncfg->activation_relu;
+    nf.emission = emission; nf.g_emission = grad_emission;
+    drto_counters total; memset(&total, 0, sizeof total);
+#ifdef _OPENMP
+    int nt = job->n_threads > 0 ? job->n_threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nt)
+#endif
+    {
+        ctx_t c; memset(&c, 0, sizeof c);
+        c.sc = &sc; c.g_sigma = grad_sigma_t;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 256)
+#endif
+        for (int64_t i = 0; i < (int64_t) job->n_rays; ++i) {
+            pcg32 S; ray_t ray;
+            job_ray(job, (uint64_t) i, &S, &ray);
+            c.cnt.n_rays++;
+            float L[3];
+            if (adjoint) nerf_sample(&c, &nf, &S, 1, ray, dL + 3 * i, L_in + 3 * i, L);
+            else {
+                nerf_sample(&c, &nf, &S, 0, ray, NULL, NULL, L);
+                L_out[3 * i] = L[0]; L_out[3 * i + 1] = L[1]; L_out[3 * i + 2] = L[2];
+            }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        cnt_add(&total, &c.cnt);
+    }
+    if (cnt) cnt_add(cnt, &total);
+    scene_free(&sc);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* harness: scene setup, ray generation, job loops                            */
 /* ------------------------------------------------------------------------- */
 static int scene_init(scene_t *sc, const drto_job *job)
@@ -999,6 +1148,7 @@ void drto_uniform_sphere(float ux, float uy, float out[3])
     out[0] = d.x; out[1] = d.y; out[2] = d.z;
 }
 float drto_logf(float x) { return drt_logf(x); }
+float drto_expf(float x) { return drt_expf(x); }
 void drto_sincos_2pi(float u, float *s, float *c) { drt_sincos_2pi(u, s, c); }
 float drto_eval_sigma_t(const drto_medium *m, const float p[3])
 {

@@ -120,6 +120,21 @@ int drto_render_backward(const drto_job *job, const float *dL, const float *L_in
 int drto_h1_step(const drto_job *job, float *L_scratch, float *image_out, double *loss_out,
                  double *grad_sigma_t, double *grad_albedo, drto_counters *cnt);
 
+/* NeRFIntegrator properties (python/integrators/nerf.py:30-35). */
+typedef struct drto_nerf_config {
+    int32_t hide_emitters;
+    int32_t queries_per_ray;
+    int32_t jittering_enabled;
+    int32_t activation_relu;     /* 0 identity, 1 relu (nerf.py:38-44) */
+} drto_nerf_config;
+
+/* NeRFIntegrator.sample (nerf.py:47-148) over a job: adjoint = 0 writes L_out; adjoint = 1 takes
+ * dL / L_in and accumulates into grad_sigma_t (Z,Y,X,1) and grad_emission (Z,Y,X,3).
+ * `emission` is the (Z,Y,X,3) grid behind medium.get_emission (nerf.py:164). */
+int drto_nerf_render(const drto_job *job, const drto_nerf_config *ncfg, const float *emission, int adjoint,
+                     const float *dL, const float *L_in, float *L_out, double *grad_sigma_t,
+                     double *grad_emission, drto_counters *cnt);
+
 /* Independent textbook delta-tracking path tracer (no NEE, no MIS, own RNG use):
  * plays the role of Mitsuba's builtin `volpath` in tests/test_integrators.py:222-257. */
 int drto_render_textbook(const drto_job *job, float *L_out);
@@ -130,6 +145,7 @@ void     drto_pcg32_floats(uint32_t seed, uint32_t index, int n, float *out);
 void     drto_pcg32_raw(uint64_t initstate, uint64_t initseq, int n, uint32_t *out);
 void     drto_uniform_sphere(float ux, float uy, float out[3]);
 float    drto_logf(float x);
+float    drto_expf(float x);
 void     drto_sincos_2pi(float u, float *s, float *c);
 float    drto_eval_sigma_t(const drto_medium *m, const float p[3]);
 void     drto_eval_albedo(const drto_medium *m, const float p[3], float out[3]);

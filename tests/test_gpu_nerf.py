@@ -1,0 +1,107 @@
+"""GPU parity tests of the `nerf` integrator (python/integrators/nerf.py) - BASELINE config 5's
+emissive RGB + sigma path.  Same bar as the DRT path: primal radiance bit-exact against the
+oracle, gradients within 2e-4 * max|g|; plus the reference's own gradient check
+(tests/test_integrators.py:158-218: radiative-backprop gradients vs forward finite differences,
+eps = 5e-3, at most 3 entries per channel outside rtol = 3e-2, all within rtol = 0.75)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GRAD_RTOL = 2e-4
+
+
+def _close(g_hip, g_ref, what):
+    g_hip = g_hip.detach().cpu().numpy().astype(np.float64)
+    tol = GRAD_RTOL * np.abs(g_ref).max() + 1e-9
+    err = np.abs(g_hip - g_ref).max()
+    assert err <= tol, f"{what}: max abs err {err:.3e} > tol {tol:.3e}"
+
+
+def _h1(uivr, sg, integ, spp, seed):
+    n = sg.sensors[0].width * sg.sensors[0].height
+    img = uivr.render_primal(sg, integ, 0, spp, seed)
+    grads = uivr.render_backward(sg, integ, ((2.0 / (n * 3)) * (img - 0.5)).contiguous(), 0, spp, seed)
+    return img, grads
+
+
+@pytest.mark.parametrize("props", [dict(), dict(queries_per_ray=64, activation="relu"),
+                                   dict(queries_per_ray=17, jittering_enabled=False, hide_emitters=True)])
+def test_nerf_matches_oracle(uivr, oracle, gpu, props):
+    scene = uivr.cube_test_scene(32, 32, density_scale=1.5)
+    if props.get("activation") == "relu":
+        scene.medium.sigma_t[1, 1, 1, 0] = -0.3          # exercise the clamped branch
+    spp, seed = 4, 1234
+    osc = oracle.OracleScene(scene)
+    Lr, cr = oracle.nerf_render(osc, scene.medium.emission, props, spp, seed)
+    img_r = oracle.develop(Lr, spp)
+    dL = np.repeat((2.0 / (32 * 32 * 3)) * (img_r - 0.5) / spp, spp, axis=0).astype(np.float32)
+    gs, ge, _ = oracle.nerf_render(osc, scene.medium.emission, props, spp, seed, dL=dL, L_in=Lr)
+
+    sg = uivr.scene_to(scene, gpu)
+    integ = uivr.load_dict(dict(type="nerf", **props))
+    assert isinstance(integ, uivr.NeRFIntegrator)
+    batch = uivr.RayBatch(n_rays=32 * 32 * spp, spp=spp, sensor=sg.sensors[0])
+    samp = uivr.IndependentSampler(seed, spp)
+    h = integ.native_handle(sg)
+    h.enable_counters(True)
+    h.reset_counters()
+    L, _, state = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+    cnt = {k: int(v) for k, v in h.get_counters().items()}
+    h.enable_counters(False)
+    assert cnt == cr
+    grads = uivr.alloc_grads(sg, integ.param_keys)
+    integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=state, grads=grads)
+    _close(grads[uivr.SIGMA_T_KEY], gs, "grad sigma_t")
+    _close(grads[uivr.EMISSION_KEY], ge, "grad emission")
+
+
+def test_nerf_rb_gradients_vs_finite_differences(uivr, gpu):
+    """tests/test_integrators.py:158-218 on the HIP path (same seed on both sides, fd.py:12,45)."""
+    scene = uivr.cube_test_scene(32, 32, density_scale=1.0)
+    sg = uivr.scene_to(scene, gpu)
+    integ = uivr.get_int_config("nerf").create(max_depth=64)
+    spp, seed, eps = 4, 1234, 5e-3
+
+    def loss():
+        img = uivr.render_primal(sg, integ, 0, spp, seed)
+        return float(((img.double() - 0.5) ** 2).mean())
+
+    _, grads = _h1(uivr, sg, integ, spp, seed)
+    l0 = loss()
+    for key, grid in ((uivr.SIGMA_T_KEY, sg.medium.sigma_t), (uivr.EMISSION_KEY, sg.medium.emission)):
+        fd = torch.zeros_like(grid, dtype=torch.float64)
+        flat = grid.view(-1)
+        for i in range(flat.numel()):
+            orig = float(flat[i])
+            flat[i] = orig + eps                       # in-place: bumps the tensor version -> params_changed
+            fd.view(-1)[i] = (loss() - l0) / eps
+            flat[i] = orig
+        a = grads[key].double().cpu().numpy()
+        b = fd.cpu().numpy()
+        for c in range(a.shape[-1]):
+            bad = np.sum(np.abs(a[..., c] - b[..., c]) >= 3e-2 * np.abs(b[..., c]))
+            assert bad <= 3, (key, c, bad)
+            # atol: O(eps) curvature of the forward difference of the quadratic loss + fp32 noise floor
+            assert np.allclose(a[..., c], b[..., c], rtol=0.75, atol=1e-5), (key, c)
+
+
+def test_nerf_autograd_and_errors(uivr, gpu):
+    scene = uivr.cube_test_scene(16, 16)
+    sg = uivr.scene_to(scene, gpu)
+    integ = uivr.load_dict({"type": "nerf", "queries_per_ray": 32})
+    params = {uivr.SIGMA_T_KEY: sg.medium.sigma_t.clone().requires_grad_(True),
+              uivr.EMISSION_KEY: sg.medium.emission.clone().requires_grad_(True)}
+    img = uivr.render(sg, params=params, integrator=integ, spp=4, seed=3)
+    ((img - 0.5) ** 2).mean().backward()
+    assert params[uivr.SIGMA_T_KEY].grad.abs().max() > 0 and params[uivr.EMISSION_KEY].grad.abs().max() > 0
+    with pytest.raises(ValueError):
+        uivr.load_dict({"type": "nerf", "activation": "tanh"})                # nerf.py:44
+    with pytest.raises(NotImplementedError):
+        uivr.load_dict({"type": "nerf", "density_noise_std": 0.1})
+    no_em = uivr.Scene(medium=uivr.GridMedium(sigma_t=sg.medium.sigma_t, albedo=None, bbox_min=sg.medium.bbox_min,
+                                              bbox_max=sg.medium.bbox_max), emitter=sg.emitter, sensors=sg.sensors)
+    with pytest.raises(TypeError):
+        uivr.render_primal(no_em, integ, 0, 1, 1)

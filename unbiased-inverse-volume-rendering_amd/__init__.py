@@ -7,7 +7,7 @@ package does not need a GPU; creating an integrator handle does.
 """
 from .scene import (ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, ConstantEmitter, GridMedium,
                     PerspectiveSensor, Scene, cube_test_scene, scene_to)
-from .integrators import (ADMode, IndependentSampler, RayBatch, VolpathSimpleIntegrator, load_dict,
+from .integrators import (ADMode, IndependentSampler, NeRFIntegrator, RayBatch, VolpathSimpleIntegrator, load_dict,
                           register_integrator, sample_tea_32)
 from .opt_config import IntegratorConfig, add_int_config, get_int_config
 from .distributed import ShardSpec, allreduce_gradients, allreduce_scalar, from_environment
@@ -16,7 +16,7 @@ from .render import alloc_grads, render, render_backward, render_primal
 __all__ = [
     "ALBEDO_KEY", "EMISSION_KEY", "SIGMA_T_KEY", "ConstantEmitter", "GridMedium", "PerspectiveSensor",
     "Scene", "cube_test_scene", "scene_to", "ADMode", "IndependentSampler", "RayBatch",
-    "VolpathSimpleIntegrator", "load_dict", "register_integrator", "sample_tea_32", "IntegratorConfig",
+    "VolpathSimpleIntegrator", "NeRFIntegrator", "load_dict", "register_integrator", "sample_tea_32", "IntegratorConfig",
     "add_int_config", "get_int_config", "ShardSpec", "allreduce_gradients", "allreduce_scalar",
     "from_environment", "alloc_grads", "render", "render_backward", "render_primal",
 ]

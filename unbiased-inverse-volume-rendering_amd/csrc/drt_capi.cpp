@@ -76,11 +76,12 @@ struct DeviceGuard {
 };
 
 int check_job(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
-              uint64_t ray_offset, uint32_t spp)
+              uint64_t ray_offset, uint32_t spp, bool need_albedo = true)
 {
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
     if (!h->have_medium) return fail(h, DRT_ERR_NOT_CONFIGURED, "no medium: call drt_set_medium first");
     if (!h->have_emitter) return fail(h, DRT_ERR_NOT_CONFIGURED, "no emitter: call drt_set_emitter_constant first");
+    if (need_albedo && !h->base.albedo) return fail(h, DRT_ERR_NOT_CONFIGURED, "the medium has no albedo grid");
     if ((rays_o == nullptr) != (rays_d == nullptr))
         return fail(h, DRT_ERR_INVALID_ARGUMENT, "rays_o and rays_d must both be given or both be NULL");
     if (!rays_o && !h->have_sensor)
@@ -246,7 +247,7 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
                    int32_t majorant_resolution_factor)
 {
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
-    if (!sigma_t || !albedo || !res || !bbox_min || !bbox_max)
+    if (!sigma_t || !res || !bbox_min || !bbox_max)   /* albedo may be NULL for the nerf integrator */
         return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_set_medium: null argument");
     for (int a = 0; a < 3; ++a) {
         if (res[a] < 1) return fail(h, DRT_ERR_INVALID_ARGUMENT, "grid resolution must be >= 1");
@@ -381,6 +382,53 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
     rc = timed_launch(h, 1, P, true);
     if (rc) return rc;
+    DRT_HIP_CHECK(h, drt::launch_untile(P, h->stream));
+    return DRT_OK;
+}
+
+static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, const float *emission)
+{
+    if (!cfg || !emission) return fail(h, DRT_ERR_INVALID_ARGUMENT, "nerf: null config / emission grid");
+    if (cfg->queries_per_ray < 2) return fail(h, DRT_ERR_INVALID_ARGUMENT, "queries_per_ray must be >= 2");
+    P.emission = emission; P.nerf_queries = cfg->queries_per_ray; P.nerf_jitter = cfg->jittering_enabled ? 1 : 0;
+    P.nerf_relu = cfg->activation_relu ? 1 : 0; P.hide_emitters = cfg->hide_emitters ? 1 : 0;
+    return DRT_OK;
+}
+
+int drt_nerf_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
+                           const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
+                           float *L_out)
+{
+    if (h && n_rays == 0) return DRT_OK;
+    int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp, false);
+    if (rc) return rc;
+    if (!L_out) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null L_out");
+    DeviceGuard g(h->device);
+    drt::Params P;
+    fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
+    rc = nerf_fill(h, P, cfg, emission);
+    if (rc) return rc;
+    P.L_out = L_out;
+    DRT_HIP_CHECK(h, drt::launch_nerf(P, false, h->counting, h->stream));
+    return DRT_OK;
+}
+
+int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
+                             const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
+                             const float *dL, const float *L_in, float *grad_sigma_t, float *grad_emission)
+{
+    if (h && n_rays == 0) return DRT_OK;
+    int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp, false);
+    if (rc) return rc;
+    if (!dL || !L_in || !grad_sigma_t || !grad_emission)
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_nerf_render_backward: null dL / L_in / gradient buffer");
+    DeviceGuard g(h->device);
+    drt::Params P;
+    fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
+    rc = nerf_fill(h, P, cfg, emission);
+    if (rc) return rc;
+    P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_emission;
+    DRT_HIP_CHECK(h, drt::launch_nerf(P, true, h->counting, h->stream));
     DRT_HIP_CHECK(h, drt::launch_untile(P, h->stream));
     return DRT_OK;
 }

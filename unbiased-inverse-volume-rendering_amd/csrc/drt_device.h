@@ -109,6 +109,25 @@ __device__ __forceinline__ float drt_logf(float x)
     return r;
 }
 
+// exp for x <= 0: Cephes expf (ln2 split range reduction, degree-5 polynomial, exact 2^n scale)
+__device__ __forceinline__ float drt_expf(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    float z = floorf(fmaf(1.44269504088896341f, x, 0.5f));
+    x = fmaf(-0.693359375f, z, x);
+    x = fmaf(2.12194440e-4f, z, x);
+    int n = (int) z;
+    float x2 = x * x;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, x, 1.3981999507e-3f);
+    p = fmaf(p, x, 8.3334519073e-3f);
+    p = fmaf(p, x, 4.1665795894e-2f);
+    p = fmaf(p, x, 1.6666665459e-1f);
+    p = fmaf(p, x, 5.0000001201e-1f);
+    float r = fmaf(p, x2, x) + 1.0f;
+    return r * __uint_as_float((uint32_t)(n + 127) << 23);
+}
+
 __device__ __forceinline__ void drt_sincos_2pi(float u, float &s_out, float &c_out)
 {
     float a = u * 4.0f;
@@ -173,6 +192,9 @@ struct Params {
     float bmin[3], bmax[3], inv_ext[3];
     float scale;
     float Le[3];
+    // nerf integrator (python/integrators/nerf.py): emission grid (Z,Y,X,3) and properties
+    const float *emission;
+    int nerf_queries, nerf_jitter, nerf_relu;
     // integrator flags
     int hide_emitters, use_nee, use_drt, use_drt_subsampling, use_drt_mis, max_depth, rr_depth;
     // sensor (mi.render flow)
@@ -306,10 +328,9 @@ __device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p, const uint3
     return trilerp8(s, d0, d1, d2, d3, d4, d5, d6, d7) * P.scale;
 }
 
-__device__ __forceinline__ void eval_albedo(const Params &P, V3 p, float out[3])
+__device__ __forceinline__ void eval_rgb(const Params &P, const float *g, V3 p, float out[3])
 {
     Stencil s = make_stencil(P, p);
-    const float *g = P.albedo;
     int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
     int i0 = 3 * (a + s.x0), i1 = 3 * (a + s.x1), i2 = 3 * (b + s.x0), i3 = 3 * (b + s.x1);
     int i4 = 3 * (c + s.x0), i5 = 3 * (c + s.x1), i6 = 3 * (d + s.x0), i7 = 3 * (d + s.x1);
@@ -318,6 +339,8 @@ __device__ __forceinline__ void eval_albedo(const Params &P, V3 p, float out[3])
         out[ch] = trilerp8(s, g[i0 + ch], g[i1 + ch], g[i2 + ch], g[i3 + ch],
                            g[i4 + ch], g[i5 + ch], g[i6 + ch], g[i7 + ch]);
 }
+
+__device__ __forceinline__ void eval_albedo(const Params &P, V3 p, float out[3]) { eval_rgb(P, P.albedo, p, out); }
 
 // Reverse mode of the trilinear gather = 8-corner scatter-add.  gfx950 has a
 // hardware fp32 global atomic add (global_atomic_add_f32, device scope); the

@@ -474,6 +474,110 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
     }
 }
 
+// ---------------------------------------------------------------------------
+// NeRFIntegrator.sample (python/integrators/nerf.py:47-148): emission-absorption ray marching,
+// queries_per_ray jittered queries per ray, PRB-style backward.  One ray per lane; the loop is
+// regular (no divergence besides rays that miss the box).
+// ---------------------------------------------------------------------------
+template <bool ADJ, bool COUNT>
+__global__ void __launch_bounds__(256) nerf_kernel(const Params P)
+{
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t occ_lds[kOccWords];
+    const uint32_t *occ = nullptr;
+    if (P.occ) {
+        for (int w = threadIdx.x; w < P.occ_words; w += blockDim.x) occ_lds[w] = P.occ[w];
+        __syncthreads();
+        occ = occ_lds;
+    }
+    uint32_t *rec = nullptr;
+    if constexpr (ADJ) {
+        __shared__ uint32_t coop_rec[4 * 64 * kCoopDwords];
+        rec = coop_rec + (threadIdx.x >> 6) * (64 * kCoopDwords);
+    }
+    uint32_t n_q = 0, n_rays = 0;
+    if (i < P.n_rays) {
+        uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
+        uint32_t gi = (uint32_t) g64;
+        Pcg32 S; S.seed(P.seed, gi);
+        V3 o, d;
+        if (P.sensor_flow) {
+            float ux = S.next_1d(), uy = S.next_1d();
+            sensor_ray(P, gi / P.spp, ux, uy, o, d);
+        } else {
+            o = v3(P.rays_o[3 * i], P.rays_o[3 * i + 1], P.rays_o[3 * i + 2]);
+            d = v3(P.rays_d[3 * i], P.rays_d[3 * i + 1], P.rays_d[3 * i + 2]);
+        }
+        n_rays = 1;
+        float result[3] = { 0.0f, 0.0f, 0.0f }, dL[3] = { 0.0f, 0.0f, 0.0f };
+        if constexpr (ADJ) {
+            result[0] = P.L_in[3 * i]; result[1] = P.L_in[3 * i + 1]; result[2] = P.L_in[3 * i + 2];
+            dL[0] = P.dL[3 * i]; dL[1] = P.dL[3 * i + 1]; dL[2] = P.dL[3 * i + 2];
+        }
+        float throughput = 1.0f, weights_sum = 0.0f;
+        Hit si = box_hit(P, o, d);                                           // nerf.py:67-79
+        bool active = si.valid, escaped = !active;
+        if (active) {
+            o = offset_p(si, d);
+            si = box_hit(P, o, d);
+            active = si.valid;
+        }
+        if (active) {
+            const int N = P.nerf_queries;
+            float step = P.nerf_jitter ? (si.t - 0.0f) / (float) N : (si.t - 0.0f) / (float)(N - 1);   // :6-10,82
+            float t_a = 0.0f;
+            float jit = S.next_1d();                                         // :88
+            for (int j = 0; j < N; ++j) {                                    // :94-129
+                float t_b = P.nerf_jitter ? step * ((float)(j + 1) + jit) : step * (float)(j + 1);
+                float dt = t_b - t_a;
+                V3 p = ray_at(o, d, t_b);                                    // query_medium :151-165
+                float raw = eval_sigma_t(P, p, occ);
+                float sigma = P.nerf_relu ? fmaxf(0.0f, raw) : raw;
+                float em[3];
+                eval_rgb(P, P.emission, p, em);
+                n_q++;
+                bool last = !(j + 1 < N);
+                float a = last ? 1.0f : drt_expf(-sigma * dt);               // :104-106
+                float weight = (1.0f - a) * throughput;
+                float safe_a = a + 1e-10f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) result[k] = ADJ ? result[k] - weight * em[k] : result[k] + weight * em[k];
+                if constexpr (ADJ) {                                         // :122-129
+                    float gs = 0.0f, ge[3];
+                    float da = last ? 0.0f : -dt * a;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        gs += dL[k] * (em[k] * (-da * throughput) + (result[k] / safe_a) * da);
+                        ge[k] = dL[k] * weight;
+                    }
+                    if (P.nerf_relu && !(raw > 0.0f)) gs = 0.0f;
+                    splat_sigma_t(P, p, gs, rec);
+                    splat_albedo(P, p, ge, rec);       // planes 1..3 of the scratch = emission gradients here
+                }
+                t_a = t_b;
+                if (!last) { throughput *= safe_a; weights_sum += weight; }  // :117-120
+            }
+        }
+        bool active_e = escaped || active;                                   // :131-146
+        if (P.hide_emitters) active_e = active_e && (weights_sum > 0.0f);
+        if (active_e) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) result[k] += (1.0f - weights_sum) * P.Le[k];
+        }
+        if constexpr (!ADJ) { P.L_out[3 * i] = result[0]; P.L_out[3 * i + 1] = result[1]; P.L_out[3 * i + 2] = result[2]; }
+    }
+    if (COUNT) {
+        uint32_t vals[C_COUNT] = { n_rays, n_q, 0, 0, n_q, 0, 0, ADJ ? n_q : 0u, ADJ ? n_q : 0u };
+#pragma unroll
+        for (int s = 0; s < C_COUNT; ++s) {
+            uint32_t v = vals[s];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(P.counters + s, (unsigned long long) v);
+        }
+    }
+}
+
 // majorant = scale * max(sigma_t grid) (Medium::get_majorant with a global
 // majorant; carries no gradient, refreshed on parameter update - optimize.py:195-199)
 __global__ void __launch_bounds__(256) majorant_reduce_kernel(const float *sigma_t, size_t n, uint32_t *max_bits)
@@ -617,6 +721,7 @@ __global__ void __launch_bounds__(256) debug_eval_kernel(const Params P, int op,
             V3 ro, rd; sensor_ray(P, __float_as_uint(a[0]), a[1], a[2], ro, rd);
             o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
         } break;
+        case 10: o[0] = drt_expf(a[0]); break;
         case 9: if (P.mgrid) { o[0] = P.mgrid[__float_as_uint(a[0])]; } break;
         case 8: o[0] = mis_weight(a[0], a[1]); o[1] = a[0] / a[1]; o[2] = sqrtf(a[0]); o[3] = fmaf(a[0], a[1], a[2]); break;
         default: break;
@@ -670,6 +775,20 @@ hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int 
 {
     uint32_t n = (uint32_t) rx * ry * rz;
     hipLaunchKernelGGL(brick_sigma_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, rx, ry, rz, ystride, zstride);
+    return hipGetLastError();
+}
+
+hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream)
+{
+    if (P.n_rays == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((P.n_rays + 255) / 256));
+    if (adjoint) {
+        if (count) hipLaunchKernelGGL((nerf_kernel<true, true>), grid, block, 0, stream, P);
+        else       hipLaunchKernelGGL((nerf_kernel<true, false>), grid, block, 0, stream, P);
+    } else {
+        if (count) hipLaunchKernelGGL((nerf_kernel<false, true>), grid, block, 0, stream, P);
+        else       hipLaunchKernelGGL((nerf_kernel<false, false>), grid, block, 0, stream, P);
+    }
     return hipGetLastError();
 }
 

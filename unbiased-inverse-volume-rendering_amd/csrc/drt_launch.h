@@ -14,6 +14,7 @@ hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int sh
                             uint32_t *occ, int words, hipStream_t stream);
 hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int ystride, int zstride,
                               hipStream_t stream);
+hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_untile(const Params &P, hipStream_t stream);
 hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t *scratch_bits,
                            float *majorant, hipStream_t stream);

@@ -114,6 +114,41 @@ public:
         }
         check(rc, "drt_render_backward");
     }
+    static drt_nerf_config nerf_cfg(const py::dict &p)
+    {
+        drt_nerf_config c{};
+        c.hide_emitters = p.contains("hide_emitters") && py::cast<bool>(p["hide_emitters"]);
+        c.queries_per_ray = p.contains("queries_per_ray") ? py::cast<int>(p["queries_per_ray"]) : 128;
+        c.jittering_enabled = p.contains("jittering_enabled") ? (py::cast<bool>(p["jittering_enabled"]) ? 1 : 0) : 1;
+        c.activation_relu = p.contains("activation_relu") && py::cast<bool>(p["activation_relu"]);
+        return c;
+    }
+    void nerf_render_primal(const py::dict &props, uintptr_t emission, uintptr_t rays_o, uintptr_t rays_d, uint64_t n,
+                            uint64_t off, uint32_t spp, uint32_t seed, uintptr_t L_out)
+    {
+        drt_nerf_config c = nerf_cfg(props);
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = drt_nerf_render_primal(h_, &c, ptr<const float>(emission), ptr<const float>(rays_o),
+                                        ptr<const float>(rays_d), n, off, spp, seed, ptr<float>(L_out));
+        }
+        check(rc, "drt_nerf_render_primal");
+    }
+    void nerf_render_backward(const py::dict &props, uintptr_t emission, uintptr_t rays_o, uintptr_t rays_d, uint64_t n,
+                              uint64_t off, uint32_t spp, uint32_t seed, uintptr_t dL, uintptr_t L_in,
+                              uintptr_t g_sigma, uintptr_t g_emission)
+    {
+        drt_nerf_config c = nerf_cfg(props);
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = drt_nerf_render_backward(h_, &c, ptr<const float>(emission), ptr<const float>(rays_o),
+                                          ptr<const float>(rays_d), n, off, spp, seed, ptr<const float>(dL),
+                                          ptr<const float>(L_in), ptr<float>(g_sigma), ptr<float>(g_emission));
+        }
+        check(rc, "drt_nerf_render_backward");
+    }
     void film_develop(uintptr_t L, uint64_t n_pixels, uint32_t spp, uintptr_t image)
     {
         int rc;
@@ -181,6 +216,8 @@ PYBIND11_MODULE(_drt_pybind, m)
         .def("set_sensor_perspective", &Integrator::set_sensor_perspective)
         .def("render_primal", &Integrator::render_primal)
         .def("render_backward", &Integrator::render_backward)
+        .def("nerf_render_primal", &Integrator::nerf_render_primal)
+        .def("nerf_render_backward", &Integrator::nerf_render_backward)
         .def("film_develop", &Integrator::film_develop)
         .def("film_backward", &Integrator::film_backward)
         .def("debug_eval", &Integrator::debug_eval)

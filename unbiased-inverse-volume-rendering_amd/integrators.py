@@ -20,7 +20,7 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 from ._native import native
-from .scene import ALBEDO_KEY, SIGMA_T_KEY, PerspectiveSensor, Scene
+from .scene import ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, PerspectiveSensor, Scene
 
 
 class ADMode(IntEnum):
@@ -109,7 +109,95 @@ def sample_tea_32(v0: int, v1: int, rounds: int = 4) -> Tuple[int, int]:
 
 
 # --- the integrator ------------------------------------------------------------------------
-class VolpathSimpleIntegrator:
+class _DeviceIntegrator:
+    """Shared plumbing of the integrator plugins: one native handle per device, medium / emitter /
+    sensor binding, box film helpers."""
+
+    param_keys = (SIGMA_T_KEY, ALBEDO_KEY)       # the differentiable grids this integrator reads
+    needs_albedo = True
+
+    def _native_props(self) -> dict:
+        raise NotImplementedError
+
+    # -- film helpers (hdrfilm + box filter, batched.py:176-197 / 298-306) -----
+    def develop(self, scene: Scene, L: torch.Tensor, spp: int) -> torch.Tensor:
+        h, dev = self._bind(scene)
+        n_pix = L.shape[0] // spp
+        img = torch.empty((n_pix, 3), dtype=torch.float32, device=dev)
+        h.film_develop(L.data_ptr(), n_pix, int(spp), img.data_ptr())
+        return img
+
+    def film_backward(self, scene: Scene, grad_image: torch.Tensor, spp: int) -> torch.Tensor:
+        h, dev = self._bind(scene)
+        grad_image = grad_image.contiguous().view(-1, 3)
+        n_pix = grad_image.shape[0]
+        dL = torch.empty((n_pix * spp, 3), dtype=torch.float32, device=dev)
+        h.film_backward(grad_image.data_ptr(), n_pix, int(spp), dL.data_ptr())
+        return dL
+
+    def native_handle(self, scene: Scene):
+        return self._bind(scene)[0]
+
+    def _bind(self, scene: Scene):
+        m = scene.medium
+        st, al = m.sigma_t, m.albedo
+        if not isinstance(st, torch.Tensor) or (self.needs_albedo and not isinstance(al, torch.Tensor)):
+            raise TypeError("the HIP integrator needs torch device tensors for the medium grids "
+                            "(use scene_to(scene, device))")
+        if not st.is_cuda:
+            raise RuntimeError("sigma_t is not on a GPU: the integrator has no CPU path")
+        dev = st.device
+        _check(st, None, dev, "sigma_t")
+        if st.dim() != 4 or st.shape[-1] != 1:
+            raise ValueError(f"sigma_t must have shape (Z,Y,X,1), got {tuple(st.shape)}")
+        if isinstance(al, torch.Tensor):
+            _check(al, tuple(st.shape[:3]) + (3,), dev, "albedo")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        h = self._handles.get(idx)
+        if h is None:
+            h = native().Integrator(self._native_props(), idx)
+            self._handles[idx] = h
+        h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        al_key = (al.data_ptr(), al._version) if isinstance(al, torch.Tensor) else (0, 0)
+        key = (st.data_ptr(), st._version) + al_key + (tuple(st.shape),
+               tuple(m.bbox_min), tuple(m.bbox_max), float(m.scale), int(m.majorant_resolution_factor),
+               tuple(scene.emitter.radiance))
+        if self._bound.get(idx) != key:
+            z, y, x = st.shape[:3]
+            h.set_medium(st.data_ptr(), al.data_ptr() if isinstance(al, torch.Tensor) else 0,
+                         [int(x), int(y), int(z)],
+                         [float(v) for v in m.bbox_min], [float(v) for v in m.bbox_max],
+                         float(m.scale), int(m.majorant_resolution_factor))
+            h.set_emitter_constant([float(v) for v in scene.emitter.radiance])
+            self._bound[idx] = key
+        return h, dev
+
+    @staticmethod
+    def _set_rays(h, ray: RayBatch):
+        if ray.interleave:
+            h.set_ray_interleave(int(ray.interleave[0]), int(ray.interleave[1]))
+        else:
+            h.set_ray_interleave(0, 0)
+        if ray.o is None:
+            if ray.sensor is None:
+                raise ValueError("RayBatch needs explicit rays or a sensor")
+            f = ray.sensor.frame()
+            h.set_sensor_perspective([float(v) for v in f["origin"]], [float(v) for v in f["left"]],
+                                     [float(v) for v in f["up"]], [float(v) for v in f["dir"]],
+                                     float(f["tan_x"]), float(f["tan_y"]),
+                                     int(ray.sensor.width), int(ray.sensor.height))
+
+    @staticmethod
+    def _ray_ptrs(ray: RayBatch, dev):
+        n = int(ray.n_rays)
+        if ray.o is not None:
+            _check(ray.o, (n, 3), dev, "ray.o")
+            _check(ray.d, (n, 3), dev, "ray.d")
+            return n, ray.o.data_ptr(), ray.d.data_ptr()
+        return n, 0, 0
+
+
+class VolpathSimpleIntegrator(_DeviceIntegrator):
     """Differential-ratio-tracking volumetric path tracer (volpathsimple.py:10-36).
 
     Assumptions inherited from the reference: no surfaces, a single medium inside a
@@ -150,12 +238,7 @@ class VolpathSimpleIntegrator:
         mode = ADMode(int(mode))
         h, dev = self._bind(scene)
         self._set_rays(h, ray)
-        n = int(ray.n_rays)
-        ro = ray.o.data_ptr() if ray.o is not None else 0
-        rd = ray.d.data_ptr() if ray.d is not None else 0
-        if ray.o is not None:
-            _check(ray.o, (n, 3), dev, "ray.o")
-            _check(ray.d, (n, 3), dev, "ray.d")
+        n, ro, rd = self._ray_ptrs(ray, dev)
         if mode == ADMode.Primal:
             L = torch.empty((n, 3), dtype=torch.float32, device=dev)
             h.render_primal(ro, rd, n, int(ray.ray_offset), int(ray.spp), sampler.seed_value, L.data_ptr())
@@ -176,72 +259,8 @@ class VolpathSimpleIntegrator:
         raise NotImplementedError("forward-mode differentiation is not supported "
                                   "(render_batch_forward raises in the reference too, batched.py:200-209)")
 
-    # -- film helpers (hdrfilm + box filter, batched.py:176-197 / 298-306) -----
-    def develop(self, scene: Scene, L: torch.Tensor, spp: int) -> torch.Tensor:
-        h, dev = self._bind(scene)
-        n_pix = L.shape[0] // spp
-        img = torch.empty((n_pix, 3), dtype=torch.float32, device=dev)
-        h.film_develop(L.data_ptr(), n_pix, int(spp), img.data_ptr())
-        return img
-
-    def film_backward(self, scene: Scene, grad_image: torch.Tensor, spp: int) -> torch.Tensor:
-        h, dev = self._bind(scene)
-        grad_image = grad_image.contiguous().view(-1, 3)
-        n_pix = grad_image.shape[0]
-        dL = torch.empty((n_pix * spp, 3), dtype=torch.float32, device=dev)
-        h.film_backward(grad_image.data_ptr(), n_pix, int(spp), dL.data_ptr())
-        return dL
-
-    # -- instrumentation ---------------------------------------------------------
-    def native_handle(self, scene: Scene):
-        return self._bind(scene)[0]
-
-    # -- internals ---------------------------------------------------------------
-    def _bind(self, scene: Scene):
-        m = scene.medium
-        st, al = m.sigma_t, m.albedo
-        if not (isinstance(st, torch.Tensor) and isinstance(al, torch.Tensor)):
-            raise TypeError("the HIP integrator needs torch device tensors for sigma_t / albedo "
-                            "(use Scene.to(device))")
-        if not st.is_cuda:
-            raise RuntimeError("sigma_t is not on a GPU: the DRT integrator has no CPU path")
-        dev = st.device
-        _check(st, None, dev, "sigma_t")
-        _check(al, tuple(st.shape[:3]) + (3,), dev, "albedo")
-        if st.dim() != 4 or st.shape[-1] != 1:
-            raise ValueError(f"sigma_t must have shape (Z,Y,X,1), got {tuple(st.shape)}")
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        h = self._handles.get(idx)
-        if h is None:
-            h = native().Integrator(self.props(), idx)
-            self._handles[idx] = h
-        h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        key = (st.data_ptr(), st._version, al.data_ptr(), al._version, tuple(st.shape),
-               tuple(m.bbox_min), tuple(m.bbox_max), float(m.scale), int(m.majorant_resolution_factor),
-               tuple(scene.emitter.radiance))
-        if self._bound.get(idx) != key:
-            z, y, x = st.shape[:3]
-            h.set_medium(st.data_ptr(), al.data_ptr(), [int(x), int(y), int(z)],
-                         [float(v) for v in m.bbox_min], [float(v) for v in m.bbox_max],
-                         float(m.scale), int(m.majorant_resolution_factor))
-            h.set_emitter_constant([float(v) for v in scene.emitter.radiance])
-            self._bound[idx] = key
-        return h, dev
-
-    @staticmethod
-    def _set_rays(h, ray: RayBatch):
-        if ray.interleave:
-            h.set_ray_interleave(int(ray.interleave[0]), int(ray.interleave[1]))
-        else:
-            h.set_ray_interleave(0, 0)
-        if ray.o is None:
-            if ray.sensor is None:
-                raise ValueError("RayBatch needs explicit rays or a sensor")
-            f = ray.sensor.frame()
-            h.set_sensor_perspective([float(v) for v in f["origin"]], [float(v) for v in f["left"]],
-                                     [float(v) for v in f["up"]], [float(v) for v in f["dir"]],
-                                     float(f["tan_x"]), float(f["tan_y"]),
-                                     int(ray.sensor.width), int(ray.sensor.height))
+    def _native_props(self) -> dict:
+        return self.props()
 
 
 def _check(t: torch.Tensor, shape, dev, name: str):
@@ -257,4 +276,78 @@ def _check(t: torch.Tensor, shape, dev, name: str):
         raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
 
 
+class NeRFIntegrator(_DeviceIntegrator):
+    """Simplified NeRF-style integrator: emission accumulated along the ray, no scattering
+    (python/integrators/nerf.py:20-35).  Reads `medium.sigma_t` and `medium.emission`."""
+
+    param_keys = (SIGMA_T_KEY, EMISSION_KEY)
+    needs_albedo = False
+
+    def __init__(self, props: Optional[dict] = None):
+        props = dict(props or {})
+        self.hide_emitters = bool(props.get("hide_emitters", False))
+        self.queries_per_ray = int(props.get("queries_per_ray", 128))
+        self.density_noise_std = float(props.get("density_noise_std", 0.0))
+        self.jittering_enabled = bool(props.get("jittering_enabled", True))
+        self.activation_type = str(props.get("activation", "identity")).lower()
+        self.max_depth = int(props.get("max_depth", 6))          # RBIntegrator base; unused (nerf.py)
+        self.rr_depth = int(props.get("rr_depth", 5))
+        if self.activation_type not in ("identity", "relu"):
+            raise ValueError(f"Unsupported activation: {self.activation_type}")         # nerf.py:44
+        if self.density_noise_std > 0:
+            raise NotImplementedError("density_noise_std > 0 is incorrect in the reference's adjoint "
+                                      "(nerf.py:160-162) and is not supported")
+        if self.queries_per_ray < 2:
+            raise ValueError("queries_per_ray must be >= 2")
+        self._handles: Dict[int, object] = {}
+        self._bound: Dict[int, tuple] = {}
+
+    def aovs(self):
+        return []
+
+    def props(self) -> dict:
+        return dict(hide_emitters=self.hide_emitters, queries_per_ray=self.queries_per_ray,
+                    jittering_enabled=self.jittering_enabled, activation=self.activation_type,
+                    density_noise_std=self.density_noise_std)
+
+    def _native_props(self) -> dict:
+        return dict(max_depth=0)
+
+    def _nerf_props(self) -> dict:
+        return dict(hide_emitters=self.hide_emitters, queries_per_ray=self.queries_per_ray,
+                    jittering_enabled=self.jittering_enabled, activation_relu=self.activation_type == "relu")
+
+    def sample(self, mode, scene: Scene, sampler: IndependentSampler, ray: RayBatch,
+               δL: Optional[torch.Tensor] = None, state_in: Optional[torch.Tensor] = None,
+               active=None, grads: Optional[Dict[str, torch.Tensor]] = None, **kwargs):
+        """-> (L, valid, state_out) (nerf.py:47-58); Backward accumulates into `grads`
+        (keys sigma_t / emission)."""
+        mode = ADMode(int(mode))
+        h, dev = self._bind(scene)
+        em = scene.medium.emission
+        if not isinstance(em, torch.Tensor):
+            raise TypeError("the nerf integrator needs medium.emission as a torch device tensor")
+        _check(em, tuple(scene.medium.sigma_t.shape[:3]) + (3,), dev, "emission")
+        self._set_rays(h, ray)
+        n, ro, rd = self._ray_ptrs(ray, dev)
+        if mode == ADMode.Primal:
+            L = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            h.nerf_render_primal(self._nerf_props(), em.data_ptr(), ro, rd, n, int(ray.ray_offset), int(ray.spp),
+                                 sampler.seed_value, L.data_ptr())
+            return L, True, L
+        if mode == ADMode.Backward:
+            if δL is None or state_in is None or grads is None:
+                raise ValueError("sample(Backward) needs δL, state_in and grads")
+            _check(δL, (n, 3), dev, "δL")
+            _check(state_in, (n, 3), dev, "state_in")
+            gs, ge = grads[SIGMA_T_KEY], grads[EMISSION_KEY]
+            _check(gs, tuple(scene.medium.sigma_t.shape), dev, "grads[sigma_t]")
+            _check(ge, tuple(em.shape), dev, "grads[emission]")
+            h.nerf_render_backward(self._nerf_props(), em.data_ptr(), ro, rd, n, int(ray.ray_offset), int(ray.spp),
+                                   sampler.seed_value, δL.data_ptr(), state_in.data_ptr(), gs.data_ptr(), ge.data_ptr())
+            return None, True, None
+        raise NotImplementedError("forward-mode differentiation is not supported")
+
+
 register_integrator("volpathsimple", lambda props: VolpathSimpleIntegrator(props))
+register_integrator("nerf", lambda props: NeRFIntegrator(props))

@@ -65,4 +65,5 @@ add_int_config('volpathsimple-drt-quadratic', pretty_name='Differential Ratio Tr
                        'use_drt_subsampling': False, 'use_drt_mis': True})
 add_int_config('volpathsimple-basic', pretty_name='Free-flight based',
                params={'type': 'volpathsimple', 'use_drt': False})
-# 'nerf' (python/integrators/nerf.py) is registered once its plugin exists; see DESIGN.md.
+add_int_config('nerf', pretty_name='NeRF (grid-backed)',
+               params={'type': 'nerf', 'queries_per_ray': 128})

@@ -19,23 +19,34 @@ import torch
 
 from .distributed import ShardSpec, allreduce_gradients
 from .integrators import ADMode, IndependentSampler, RayBatch, sample_tea_32
-from .scene import ALBEDO_KEY, SIGMA_T_KEY, GridMedium, Scene
+from .scene import ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, GridMedium, Scene
 
 
-def alloc_grads(scene: Scene) -> Dict[str, torch.Tensor]:
-    """Zeroed gradient grids shaped like the parameters, carved out of ONE flat
-    buffer (`_flat`) so that the multi-GPU all-reduce is a single collective."""
-    st, al = scene.medium.sigma_t, scene.medium.albedo
-    flat = torch.zeros(st.numel() + al.numel(), dtype=torch.float32, device=st.device)
-    return {SIGMA_T_KEY: flat[:st.numel()].view(st.shape),
-            ALBEDO_KEY: flat[st.numel():].view(al.shape),
-            "_flat": flat}
+def _grid(scene: Scene, key: str):
+    return {SIGMA_T_KEY: scene.medium.sigma_t, ALBEDO_KEY: scene.medium.albedo,
+            EMISSION_KEY: scene.medium.emission}[key]
 
 
-def _with_params(scene: Scene, sigma_t: torch.Tensor, albedo: torch.Tensor) -> Scene:
+def alloc_grads(scene: Scene, keys=(SIGMA_T_KEY, ALBEDO_KEY)) -> Dict[str, torch.Tensor]:
+    """Zeroed gradient grids shaped like the parameters `keys` (an integrator's `param_keys`),
+    carved out of ONE flat buffer (`_flat`) so that the multi-GPU all-reduce is a single
+    collective."""
+    grids = [_grid(scene, k) for k in keys]
+    flat = torch.zeros(sum(g.numel() for g in grids), dtype=torch.float32, device=grids[0].device)
+    out, off = {"_flat": flat}, 0
+    for k, g in zip(keys, grids):
+        out[k] = flat[off:off + g.numel()].view(g.shape)
+        off += g.numel()
+    return out
+
+
+def _with_params(scene: Scene, keys, tensors) -> Scene:
     m = scene.medium
-    medium = GridMedium(sigma_t=sigma_t, albedo=albedo, bbox_min=m.bbox_min, bbox_max=m.bbox_max,
-                        scale=m.scale, majorant_resolution_factor=m.majorant_resolution_factor)
+    vals = {SIGMA_T_KEY: m.sigma_t, ALBEDO_KEY: m.albedo, EMISSION_KEY: m.emission}
+    vals.update(dict(zip(keys, tensors)))
+    medium = GridMedium(sigma_t=vals[SIGMA_T_KEY], albedo=vals[ALBEDO_KEY], bbox_min=m.bbox_min, bbox_max=m.bbox_max,
+                        scale=m.scale, majorant_resolution_factor=m.majorant_resolution_factor,
+                        emission=vals[EMISSION_KEY])
     return Scene(medium=medium, emitter=scene.emitter, sensors=scene.sensors)
 
 
@@ -68,7 +79,7 @@ def render_backward(scene: Scene, integrator, grad_image: torch.Tensor, sensor: 
     L, _, state_out = integrator.sample(ADMode.Primal, scene, sampler.clone(), batch)     # :255-264
     dL = integrator.film_backward(scene, grad_image, spp)                                  # :272-306
     if grads is None:
-        grads = alloc_grads(scene)
+        grads = alloc_grads(scene, integrator.param_keys)
     integrator.sample(ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state_out,  # :309-318
                       grads=grads)
     if allreduce:
@@ -80,8 +91,8 @@ class _RenderOp(torch.autograd.Function):
     """Counterpart of `mi._RenderOp` / `_BatchedRenderOp` (batched.py:13-85)."""
 
     @staticmethod
-    def forward(ctx, sigma_t, albedo, scene, integrator, sensor, spp, spp_grad, seed, seed_grad, shard):
-        sc = _with_params(scene, sigma_t.detach(), albedo.detach())
+    def forward(ctx, p0, p1, scene, integrator, sensor, spp, spp_grad, seed, seed_grad, shard):
+        sc = _with_params(scene, integrator.param_keys, (p0.detach(), p1.detach()))
         ctx.scene, ctx.integrator, ctx.sensor = sc, integrator, sensor
         ctx.spp_grad, ctx.seed_grad, ctx.shard = spp_grad, seed_grad, shard
         return render_primal(sc, integrator, sensor, spp, seed, shard)
@@ -90,7 +101,8 @@ class _RenderOp(torch.autograd.Function):
     def backward(ctx, grad_image):
         g = render_backward(ctx.scene, ctx.integrator, grad_image.contiguous(), ctx.sensor,
                             ctx.spp_grad, ctx.seed_grad, ctx.shard)
-        return g[SIGMA_T_KEY], g[ALBEDO_KEY], None, None, None, None, None, None, None, None
+        k0, k1 = ctx.integrator.param_keys
+        return g[k0], g[k1], None, None, None, None, None, None, None, None
 
 
 def render(scene: Scene, params: Optional[Dict[str, torch.Tensor]] = None, integrator=None,
@@ -98,7 +110,8 @@ def render(scene: Scene, params: Optional[Dict[str, torch.Tensor]] = None, integ
            shard: Optional[ShardSpec] = None) -> torch.Tensor:
     """`mi.render`: image of the local pixels, [n_local_pixels, 3] (the whole image,
     row-major, when unsharded - reshape to (H, W, 3)).  Differentiable with respect to
-    `params[SIGMA_T_KEY]` / `params[ALBEDO_KEY]`."""
+    the integrator's `param_keys` (sigma_t + albedo for `volpathsimple`, sigma_t + emission
+    for `nerf`)."""
     if integrator is None:
         raise ValueError("render: an integrator is required")
     if spp_grad == 0:
@@ -109,11 +122,12 @@ def render(scene: Scene, params: Optional[Dict[str, torch.Tensor]] = None, integ
     elif seed_grad == seed:
         raise Exception('The primal and differential seed should be different '
                         'to ensure unbiased gradient computation!')
+    keys = integrator.param_keys
     if params is None:
-        params = {SIGMA_T_KEY: scene.medium.sigma_t, ALBEDO_KEY: scene.medium.albedo}
-    for k in (SIGMA_T_KEY, ALBEDO_KEY):
+        params = {k: _grid(scene, k) for k in keys}
+    for k in keys:
         if not isinstance(params[k], torch.Tensor):
             raise TypeError(f"render: params['{k}'] must be a torch device tensor "
                             "(the DRT integrator has no CPU path; use scene_to(scene, device))")
-    return _RenderOp.apply(params[SIGMA_T_KEY], params[ALBEDO_KEY], scene, integrator, sensor,
+    return _RenderOp.apply(params[keys[0]], params[keys[1]], scene, integrator, sensor,
                            int(spp), int(spp_grad), int(seed), int(seed_grad), shard)

@@ -76,6 +76,8 @@ class GridMedium:
     # 0 = global majorant (Mitsuba default); the reference's optimisation scenes
     # use 8 (python/scene_config.py:36).
     majorant_resolution_factor: int = 0
+    # (Z, Y, X, 3) emission grid, only read by the `nerf` integrator (medium.get_emission, nerf.py:164)
+    emission: object = None
 
     @property
     def resolution(self):
@@ -92,7 +94,12 @@ class Scene:
 
     def params(self) -> Dict[str, object]:
         """The differentiable parameters, keyed like `mi.traverse(scene)`."""
-        return {SIGMA_T_KEY: self.medium.sigma_t, ALBEDO_KEY: self.medium.albedo}
+        p = {SIGMA_T_KEY: self.medium.sigma_t}
+        if self.medium.albedo is not None:
+            p[ALBEDO_KEY] = self.medium.albedo
+        if self.medium.emission is not None:
+            p[EMISSION_KEY] = self.medium.emission
+        return p
 
 
 def cube_test_scene(resx: int = 128, resy: int = 128, density_scale: float = 1.0) -> Scene:
@@ -113,9 +120,10 @@ def cube_test_scene(resx: int = 128, resy: int = 128, density_scale: float = 1.0
     base[..., 1] *= (1.0 - ramp)[:, None, None]
     base[..., 1] *= np.square(ramp)[None, :, None]
     albedo = np.clip(base, 0.0, 1.0).astype(np.float32)
+    # the fixture's emission grid is the unclipped base (tests/test_integrators.py:27-37); here <= 1 anyway
     medium = GridMedium(sigma_t=sigma_t, albedo=albedo,
                         bbox_min=(-0.5, -0.5, -0.5), bbox_max=(1.5, 1.5, 1.5),
-                        scale=density_scale)
+                        scale=density_scale, emission=base.astype(np.float32).copy())
     sensor = PerspectiveSensor(origin=(4.0, 4.0, 4.0), target=(0.0, -0.15, 0.0),
                                up=(0.0, 1.0, 0.0), fov=30.0, width=resx, height=resy)
     return Scene(medium=medium, emitter=ConstantEmitter((1.0, 0.8, 0.2)), sensors=[sensor])
@@ -128,11 +136,13 @@ def scene_to(scene: Scene, device) -> Scene:
     m = scene.medium
 
     def conv(a):
+        if a is None:
+            return None
         if isinstance(a, torch.Tensor):
             return a.detach().to(device=device, dtype=torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
 
     medium = GridMedium(sigma_t=conv(m.sigma_t), albedo=conv(m.albedo), bbox_min=tuple(m.bbox_min),
                         bbox_max=tuple(m.bbox_max), scale=m.scale,
-                        majorant_resolution_factor=m.majorant_resolution_factor)
+                        majorant_resolution_factor=m.majorant_resolution_factor, emission=conv(m.emission))
     return Scene(medium=medium, emitter=scene.emitter, sensors=list(scene.sensors))
