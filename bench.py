@@ -190,12 +190,11 @@ def main():
         osc = ob.OracleScene(cpu_scene)
         cpu_spp = args.cpu_spp
         if cpu_spp <= 0:
-            # calibrate on 1/16 of the image rows at spp 1, then size the sample for ~15 s
-            n_cal = max(1, n_pixels // 16)
+            # calibrate on the full image at 1 spp, then size the sample for ~15 s of CPU work
             tc = time.perf_counter()
-            ob.h1_step(osc, integ.props(), 1, seed_c, n_rays=n_cal, ray_offset=(n_pixels // 2 - n_cal // 2))
-            rate = n_cal / max(1e-6, time.perf_counter() - tc)
-            cpu_spp = int(max(1, min(spp, round(15.0 * rate / n_pixels))))
+            ob.h1_step(osc, integ.props(), 1, seed_c)
+            t1 = max(1e-3, time.perf_counter() - tc)
+            cpu_spp = int(max(1, min(spp, round(15.0 / t1))))
         tc = time.perf_counter()
         ob.h1_step(osc, integ.props(), cpu_spp, seed_c)
         dt = time.perf_counter() - tc

@@ -199,3 +199,40 @@ def test_golden_explicit_rays(oracle, uivr):
     osc = oracle.OracleScene(scene, sensor_index=None)
     L, _ = oracle.render_primal(osc, props_for("drt"), 4, 99, rays_o=g["rays/o"], rays_d=g["rays/d"])
     np.testing.assert_array_equal(L.view(np.uint32), g["rays/L"].view(np.uint32))
+
+
+def test_nerf_oracle_gradients_equal_central_fd(oracle, uivr):
+    """nerf.py:122-129 restated: the emission-absorption march is deterministic given the
+    per-ray jitter, so its PRB gradient equals central finite differences of the primal
+    (tests/test_integrators.py:158-218 checks the same thing with forward differences)."""
+    scene = uivr.cube_test_scene(24, 24, density_scale=1.0)
+    props, spp, seed, eps = dict(queries_per_ray=64, activation="relu"), 4, 1234, 5e-3
+    em = scene.medium.emission.copy()
+
+    def loss(st, e):
+        sc = uivr.cube_test_scene(24, 24)
+        sc.medium.sigma_t[...] = st
+        L, _ = oracle.nerf_render(oracle.OracleScene(sc), e, props, spp, seed)
+        return float(np.mean((oracle.develop(L, spp).astype(np.float64) - 0.5) ** 2))
+
+    osc = oracle.OracleScene(scene)
+    L, cnt = oracle.nerf_render(osc, em, props, spp, seed)
+    assert cnt["n_dt"] == cnt["n_alb"] and cnt["n_dt"] % 64 == 0      # 64 queries per ray that hits the box
+    img = oracle.develop(L, spp)
+    dL = np.repeat((2.0 / (24 * 24 * 3)) * (img - 0.5) / spp, spp, axis=0).astype(np.float32)
+    gs, ge, _ = oracle.nerf_render(osc, em, props, spp, seed, dL=dL, L_in=L)
+    st0 = scene.medium.sigma_t.copy()
+    for idx in [(0, 0, 0, 0), (1, 1, 1, 0), (2, 1, 0, 0), (0, 2, 0, 0)]:
+        a, b = st0.copy(), st0.copy()
+        a[idx] += eps
+        b[idx] -= eps
+        assert gs[idx] == pytest.approx((loss(a, em) - loss(b, em)) / (2 * eps), rel=2e-3), idx
+    for idx in [(0, 0, 0, 0), (1, 1, 1, 2), (2, 1, 0, 1)]:
+        a, b = em.copy(), em.copy()
+        a[idx] += eps
+        b[idx] -= eps
+        assert ge[idx] == pytest.approx((loss(st0, a) - loss(st0, b)) / (2 * eps), rel=2e-3), idx
+    # no medium => the background shows through unattenuated (nerf.py:145-146)
+    scene.medium.sigma_t[...] = 0.0
+    L0, _ = oracle.nerf_render(oracle.OracleScene(scene), em, props, spp, seed)
+    np.testing.assert_allclose(L0, np.tile(np.float32([1.0, 0.8, 0.2]), (L0.shape[0], 1)), atol=1e-6)
