@@ -238,7 +238,7 @@ int drt_params_changed(drt_handle h)
     DRT_HIP_CHECK(h, drt::launch_occupancy(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.occ_shift, h->base.occ_x,
                                            h->base.occ_y, h->occ_z, h->d_occ, h->base.occ_words, h->stream));
     DRT_HIP_CHECK(h, drt::launch_brick_sigma(h->base.sigma_t, h->d_sigma_b, h->base.rx, h->base.ry, h->base.rz,
-                                             h->base.sb_ystride, h->base.sb_zstride, h->stream));
+                                             h->base.sb_ystride, h->base.sb_zstride / h->base.sb_ystride, h->stream));
     return DRT_OK;
 }
 
@@ -309,20 +309,20 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         }
         B.occ = h->d_occ;
     }
-    // bricked sigma_t copy: 4x4x2 voxels per 128-byte line
+    // apron-brick sigma_t copy: one 128-byte line per (3x3x1)-voxel base-corner block (eval_sigma_t)
     {
-        size_t bx = ((size_t) res[0] + 3) / 4, by = ((size_t) res[1] + 3) / 4, bz = ((size_t) res[2] + 1) / 2;
-        size_t floats = bx * by * bz * 32;
-        if (floats > 0x7fffffffull) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the bricked copy");
+        size_t nbx = ((size_t) res[0] + 2) / 3, nby = ((size_t) res[1] + 2) / 3;
+        size_t floats = nbx * nby * (size_t) res[2] * 32;
+        if (nbx * nby * (size_t) res[2] > 0x7ffffffull || res[0] > 21000 || res[1] > 21000)
+            return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the apron-brick copy");
         if (floats != h->sigma_b_floats) {
             DeviceGuard g(h->device);
             if (h->d_sigma_b) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_sigma_b); h->d_sigma_b = nullptr; h->sigma_b_floats = 0; }
             DRT_HIP_CHECK(h, hipMalloc(&h->d_sigma_b, floats * sizeof(float)));
-            DRT_HIP_CHECK(h, hipMemsetAsync(h->d_sigma_b, 0, floats * sizeof(float), h->stream));
             h->sigma_b_floats = floats;
         }
         B.sigma_b = h->d_sigma_b;
-        B.sb_ystride = (int) (bx * 32); B.sb_zstride = (int) (by * bx * 32);
+        B.sb_ystride = (int) nbx; B.sb_zstride = (int) (nby * nbx);
     }
     h->have_medium = true;
     return drt_params_changed(h);

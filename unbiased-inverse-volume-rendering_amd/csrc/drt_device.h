@@ -177,9 +177,8 @@ __device__ __forceinline__ float mis_weight(float a, float b)
 struct Params {
     // medium
     const float *sigma_t;      // (Z,Y,X,1), caller's layout (majorant reduction, re-bricking)
-    const float *sigma_b;      // library-owned bricked copy read by the tracking loops: one 128-byte
-                               // line = 4x4x2 voxels, so a trilinear footprint spans ~2.3 lines, not ~4.1
-    int sb_ystride, sb_zstride; // floats between brick rows (bx*32) / brick slabs (by*bx*32)
+    const float *sigma_b;      // library-owned apron-brick copy read by the tracking loops (eval_sigma_t)
+    int sb_ystride, sb_zstride; // bricks per row (nbx) / per z slab (nby*nbx)
     // empty-space bitmask: bit c of occ is 0 iff every voxel a lookup with base corner inside
     // cell c (2^occ_shift voxels per axis) can touch is exactly zero -> the lookup is 0 without a fetch
     const uint32_t *occ;
@@ -287,23 +286,12 @@ __device__ __forceinline__ float trilerp8(const Stencil &s, float d0, float d1, 
     return fmaf(s.wz0, v0, s.wz1 * v1);
 }
 
-// Stencil into the bricked sigma_t copy: voxel (ix,iy,iz) lives at
-// brick(ix>>2, iy>>2, iz>>1) * 32 + (iz&1)*16 + (iy&3)*4 + (ix&3) - again one part per axis.
-__device__ __forceinline__ Stencil make_brick_stencil(const Params &P, V3 p)
-{
-    Stencil s;
-    axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, s.x0, s.x1, s.wx0, s.wx1);
-    axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, s.y0, s.y1, s.wy0, s.wy1);
-    axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, s.z0, s.z1, s.wz0, s.wz1);
-    s.x0 = ((s.x0 >> 2) << 5) | (s.x0 & 3);
-    s.x1 = ((s.x1 >> 2) << 5) | (s.x1 & 3);
-    s.y0 = (s.y0 >> 2) * P.sb_ystride + ((s.y0 & 3) << 2);
-    s.y1 = (s.y1 >> 2) * P.sb_ystride + ((s.y1 & 3) << 2);
-    s.z0 = (s.z0 >> 1) * P.sb_zstride + ((s.z0 & 1) << 4);
-    s.z1 = (s.z1 >> 1) * P.sb_zstride + ((s.z1 & 1) << 4);
-    return s;
-}
-
+// sigma_t lookup from the library-owned APRON-BRICK copy (Params::sigma_b).  One 128-byte line
+// holds the 4x4x2 voxels [3bx, 3bx+3] x [3by, 3by+3] x [z, z+1] (indices clamped): every trilinear
+// footprint whose base corner (x0,y0,z0) has x0 in [3bx,3bx+2], y0 in [3by,3by+2], z0 = z lies in
+// exactly ONE line (an ordinary 4x4x2 brick layout averaged 2.3 lines, the caller's linear layout
+// 4.1), and the two x-neighbours of each corner pair are adjacent floats (4 x 8-byte loads).
+// Storage: 32/9 = 3.6x the grid; the values are copies, so results are unchanged bit for bit.
 // `occ` = the empty-space bitmask as this wave reads it (LDS copy inside the tracing kernels).
 __device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p, const uint32_t *occ)
 {
@@ -315,16 +303,17 @@ __device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p, const uint3
         const int c = ((s.z0 >> P.occ_shift) * P.occ_y + (s.y0 >> P.occ_shift)) * P.occ_x + (s.x0 >> P.occ_shift);
         if (!((occ[c >> 5] >> (c & 31)) & 1u)) return 0.0f;      // all 8 corners are exactly 0
     }
-    s.x0 = ((s.x0 >> 2) << 5) | (s.x0 & 3);
-    s.x1 = ((s.x1 >> 2) << 5) | (s.x1 & 3);
-    s.y0 = (s.y0 >> 2) * P.sb_ystride + ((s.y0 & 3) << 2);
-    s.y1 = (s.y1 >> 2) * P.sb_ystride + ((s.y1 & 3) << 2);
-    s.z0 = (s.z0 >> 1) * P.sb_zstride + ((s.z0 & 1) << 4);
-    s.z1 = (s.z1 >> 1) * P.sb_zstride + ((s.z1 & 1) << 4);
-    const float *g = P.sigma_b;
-    int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
-    float d0 = g[a + s.x0], d1 = g[a + s.x1], d2 = g[b + s.x0], d3 = g[b + s.x1];
-    float d4 = g[c + s.x0], d5 = g[c + s.x1], d6 = g[d + s.x0], d7 = g[d + s.x1];
+    // x0 / 3 and x0 % 3 for x0 < 65536 / 3 (multiply-shift)
+    const uint32_t bx = ((uint32_t) s.x0 * 43691u) >> 17, by = ((uint32_t) s.y0 * 43691u) >> 17;
+    const uint32_t ox = (uint32_t) s.x0 - 3u * bx, oy = (uint32_t) s.y0 - 3u * by;
+    const float *g = P.sigma_b + ((size_t) ((uint32_t) s.z0 * (uint32_t) P.sb_zstride + by * (uint32_t) P.sb_ystride + bx) << 5)
+                   + (oy << 2) + ox;
+    // the line stores clamped neighbours itself, so +1 / +4 / +16 are always the right corners
+    float d0 = g[0], d1 = g[1], d2 = g[4], d3 = g[5], d4 = g[16], d5 = g[17], d6 = g[20], d7 = g[21];
+    // lower clamp (floor(q) = -1): both corners of that axis are voxel 0 (axis_setup), not 0 and 1
+    if (s.x1 == s.x0) { d1 = d0; d3 = d2; d5 = d4; d7 = d6; }
+    if (s.y1 == s.y0) { d2 = d0; d3 = d1; d6 = d4; d7 = d5; }
+    if (s.z1 == s.z0) { d4 = d0; d5 = d1; d6 = d2; d7 = d3; }
     return trilerp8(s, d0, d1, d2, d3, d4, d5, d6, d7) * P.scale;
 }
 

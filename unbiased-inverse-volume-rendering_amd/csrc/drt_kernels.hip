@@ -639,17 +639,20 @@ __global__ void __launch_bounds__(256) occupancy_kernel(const float *sigma_t, in
     if (any) atomicOr(occ + (c >> 5), 1u << (c & 31));
 }
 
-// Caller's (Z,Y,X,1) sigma_t -> bricked copy (Params::sigma_b); one thread per voxel.
+// Caller's (Z,Y,X,1) sigma_t -> apron-brick copy (see eval_sigma_t); one thread per stored float.
 __global__ void __launch_bounds__(256) brick_sigma_kernel(const float *src, float *dst, int rx, int ry, int rz,
-                                                          int ystride, int zstride)
+                                                          int nbx, int nby)
 {
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= (uint32_t) rx * ry * rz) return;
-    uint32_t ix = v % (uint32_t) rx, t = v / (uint32_t) rx;
-    uint32_t iy = t % (uint32_t) ry, iz = t / (uint32_t) ry;
-    uint32_t bi = (((ix >> 2) << 5) | (ix & 3)) + (iy >> 2) * (uint32_t) ystride + ((iy & 3) << 2)
-                + (iz >> 1) * (uint32_t) zstride + ((iz & 1) << 4);
-    dst[bi] = src[v];
+    size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t) nbx * nby * rz * 32;
+    if (t >= total) return;
+    uint32_t o = (uint32_t)(t & 31), brick = (uint32_t)(t >> 5);
+    uint32_t bx = brick % (uint32_t) nbx, r = brick / (uint32_t) nbx;
+    uint32_t by = r % (uint32_t) nby, z = r / (uint32_t) nby;
+    int x = min((int)(3 * bx + (o & 3)), rx - 1);
+    int y = min((int)(3 * by + ((o >> 2) & 3)), ry - 1);
+    int zz = min((int)(z + (o >> 4)), rz - 1);
+    dst[t] = src[((size_t) zz * ry + y) * rx + x];
 }
 
 // Gradient scratch -> caller's (Z,Y,X,1) / (Z,Y,X,3) buffers: += (the ABI accumulates) and
@@ -770,11 +773,11 @@ hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int sh
     return hipGetLastError();
 }
 
-hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int ystride, int zstride,
+hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int nbx, int nby,
                               hipStream_t stream)
 {
-    uint32_t n = (uint32_t) rx * ry * rz;
-    hipLaunchKernelGGL(brick_sigma_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, rx, ry, rz, ystride, zstride);
+    size_t total = (size_t) nbx * nby * rz * 32;
+    hipLaunchKernelGGL(brick_sigma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, rx, ry, rz, nbx, nby);
     return hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, in
                                 float *out, hipStream_t stream);
 hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int shift, int ox, int oy, int oz,
                             uint32_t *occ, int words, hipStream_t stream);
-hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int ystride, int zstride,
+hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int nbx, int nby,
                               hipStream_t stream);
 hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_untile(const Params &P, hipStream_t stream);
