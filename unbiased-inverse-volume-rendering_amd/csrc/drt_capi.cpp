@@ -265,10 +265,10 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         B.inv_ext[a] = 1.0f / (bbox_max[a] - bbox_min[a]);
     }
     B.scale = scale;
-    // gradient scratch: 4 planes tiled 4x2x2 (see drt_device.h: Params::gt)
+    // gradient scratch: 4 planes in the apron layout (drt_device.h: make_grad_indices), 16/3 x the grid each
     {
-        size_t tx = ((size_t) res[0] + 3) / 4, ty = ((size_t) res[1] + 1) / 2, tz = ((size_t) res[2] + 1) / 2;
-        size_t plane = tx * ty * tz * 16;
+        size_t nbx = ((size_t) res[0] + 2) / 3;
+        size_t plane = nbx * (size_t) res[1] * (size_t) res[2] * 16;
         if (plane > 0x7fffffffull) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the gradient scratch");
         if (plane * 4 != h->gt_floats) {
             DeviceGuard g(h->device);
@@ -277,8 +277,7 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
             DRT_HIP_CHECK(h, hipMemsetAsync(h->d_gt, 0, plane * 4 * sizeof(float), h->stream));
             h->gt_floats = plane * 4;
         }
-        B.gt = h->d_gt; B.gt_plane = (uint32_t) plane;
-        B.gt_ystride = (int) (tx * 16); B.gt_zstride = (int) (ty * tx * 16);
+        B.gt = h->d_gt; B.gt_plane = (uint32_t) plane; B.gt_nbx = (int) nbx;
     }
     // majorant supergrid (0 = global majorant only)
     if (majorant_resolution_factor > 0) {

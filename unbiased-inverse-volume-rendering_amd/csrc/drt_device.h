@@ -210,11 +210,13 @@ struct Params {
     float *L_out;
     const float *dL, *L_in;
     float *g_sigma, *g_albedo;
-    // library-owned gradient scratch: 4 planes [sigma_t, r, g, b], each tiled 4x2x2 voxels per
-    // 64-byte line so that a 2x2x2 splat footprint touches ~2.8 lines instead of 4.25
+    // library-owned gradient scratch: 4 planes [sigma_t, r, g, b] in an APRON layout: one 64-byte
+    // line per base corner block (3 voxels along x) holds all 8 corners of a splat -> one atomic
+    // request per splat and plane (see make_grad_indices); reduced into the caller's grids by
+    // untile_gradients_kernel
     float *gt;                 // plane c at gt + c * gt_plane
-    uint32_t gt_plane;         // floats per plane = tiles * 16
-    int gt_ystride, gt_zstride; // floats between tile rows (tx*16) / tile slabs (ty*tx*16)
+    uint32_t gt_plane;         // floats per plane = nbx * ry * rz * 16
+    int gt_nbx;                // lines per grid row = ceil(rx / 3)
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
 };
@@ -256,22 +258,30 @@ __device__ __forceinline__ Stencil make_stencil(const Params &P, V3 p)
     return s;
 }
 
-// Stencil whose index parts address the tiled gradient scratch (see Params::gt): for voxel
-// (ix,iy,iz) the float offset is  tile(ix>>2, iy>>1, iz>>1) * 16 + (iz&1)*8 + (iy&1)*4 + (ix&3),
-// which is again a sum of one part per axis.
-__device__ __forceinline__ Stencil make_grad_stencil(const Params &P, V3 p)
+__device__ __forceinline__ void stencil_weights(const Stencil &s, float w[8]);
+
+// Gradient scratch addressing.  The atomic path retires one request per 64-byte line per wave
+// instruction (tools/ubench), so the scratch is laid out such that a splat's whole 2x2x2 footprint
+// is ONE line: line (bx, y0, z0) with bx = x0 / 3 holds, for the base corners x0 in [3bx, 3bx+2],
+// the 16 floats  [(dz*2 + dy)*4 + (x - 3bx)],  x in [3bx, 3bx+3]  of voxels (x, y0+dy, z0+dz).
+// A voxel therefore has up to 8 slots (2 along x at block seams, 2 along y, 2 along z); they are
+// summed by untile_gradients_kernel.  Storage 16/3 = 5.3x the grid per plane - HBM is plentiful.
+// Clamped corners (x1 == x0 at the grid border) fold onto the x0 slot.
+__device__ __forceinline__ void make_grad_indices(const Params &P, V3 p, int idx[8], float w[8])
 {
     Stencil s;
     axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, s.x0, s.x1, s.wx0, s.wx1);
     axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, s.y0, s.y1, s.wy0, s.wy1);
     axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, s.z0, s.z1, s.wz0, s.wz1);
-    s.x0 = ((s.x0 >> 2) << 4) | (s.x0 & 3);
-    s.x1 = ((s.x1 >> 2) << 4) | (s.x1 & 3);
-    s.y0 = (s.y0 >> 1) * P.gt_ystride + ((s.y0 & 1) << 2);
-    s.y1 = (s.y1 >> 1) * P.gt_ystride + ((s.y1 & 1) << 2);
-    s.z0 = (s.z0 >> 1) * P.gt_zstride + ((s.z0 & 1) << 3);
-    s.z1 = (s.z1 >> 1) * P.gt_zstride + ((s.z1 & 1) << 3);
-    return s;
+    stencil_weights(s, w);
+    const uint32_t bx = ((uint32_t) s.x0 * 43691u) >> 17;            // x0 / 3
+    const int base = (int) ((((uint32_t) s.z0 * (uint32_t) P.ry + (uint32_t) s.y0) * (uint32_t) P.gt_nbx + bx) << 4)
+                   + (s.x0 - 3 * (int) bx);
+    const int dx = s.x1 - s.x0, dy = (s.y1 - s.y0) << 2, dz = (s.z1 - s.z0) << 3;   // 0 when clamped
+    idx[0] = base;           idx[1] = base + dx;
+    idx[2] = base + dy;      idx[3] = base + dy + dx;
+    idx[4] = base + dz;      idx[5] = base + dz + dx;
+    idx[6] = base + dz + dy; idx[7] = base + dz + dy + dx;
 }
 
 __device__ __forceinline__ float trilerp8(const Stencil &s, float d0, float d1, float d2, float d3,
@@ -399,10 +409,8 @@ __device__ __forceinline__ void coop_scatter(float *dst, uint32_t chan_stride, c
 
 __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, uint32_t *rec)
 {
-    Stencil s = make_grad_stencil(P, p);
     float w[8]; int idx[8];
-    stencil_weights(s, w);
-    stencil_indices(s, idx);
+    make_grad_indices(P, p, idx, w);
     float gs = g * P.scale;
     if (P.debug_flags & 1u) return;   // ablation: no gradient atomics
     if (P.debug_flags & 2u) {         // ablation: one lane, eight instructions (round-1 v1 behaviour)
@@ -418,10 +426,8 @@ __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, ui
 
 __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float g[3], uint32_t *rec)
 {
-    Stencil s = make_grad_stencil(P, p);
     float w[8]; int idx[8];
-    stencil_weights(s, w);
-    stencil_indices(s, idx);
+    make_grad_indices(P, p, idx, w);
     if (P.debug_flags & 1u) return;
     if (P.debug_flags & 2u) {
 #pragma unroll

@@ -655,25 +655,44 @@ __global__ void __launch_bounds__(256) brick_sigma_kernel(const float *src, floa
     dst[t] = src[((size_t) zz * ry + y) * rx + x];
 }
 
-// Gradient scratch -> caller's (Z,Y,X,1) / (Z,Y,X,3) buffers: += (the ABI accumulates) and
-// reset of the scratch for the next launch.  One thread per voxel.
+// Gradient scratch (apron layout, make_grad_indices) -> caller's (Z,Y,X,1) / (Z,Y,X,3) buffers:
+// sum the up to 8 slots of every voxel, += into the caller's grids (the ABI accumulates) and reset
+// the scratch for the next launch.  One thread per voxel; each slot belongs to exactly one voxel.
 __global__ void __launch_bounds__(256) untile_gradients_kernel(const Params P, uint32_t n_voxels)
 {
     uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_voxels) return;
-    uint32_t ix = v % (uint32_t) P.rx, t = v / (uint32_t) P.rx;
-    uint32_t iy = t % (uint32_t) P.ry, iz = t / (uint32_t) P.ry;
-    uint32_t ti = ((ix >> 2) << 4 | (ix & 3)) + (iy >> 1) * (uint32_t) P.gt_ystride + ((iy & 1) << 2)
-                + (iz >> 1) * (uint32_t) P.gt_zstride + ((iz & 1) << 3);
-    float *src = P.gt + ti;
-    float gs = src[0];
-    if (gs != 0.0f) { P.g_sigma[v] += gs; src[0] = 0.0f; }
+    const int X = (int)(v % (uint32_t) P.rx); uint32_t t = v / (uint32_t) P.rx;
+    const int Y = (int)(t % (uint32_t) P.ry), Z = (int)(t / (uint32_t) P.ry);
+    const int bx0 = X / 3, ox = X - 3 * bx0;
+    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float *sc = src + (size_t)(c + 1) * P.gt_plane;
-        float ga = *sc;
-        if (ga != 0.0f) { P.g_albedo[3 * (size_t) v + c] += ga; *sc = 0.0f; }
+    for (int dz = 0; dz < 2; ++dz) {
+        const int z = Z - dz;
+        if (z < 0) continue;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int y = Y - dy;
+            if (y < 0) continue;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                // slot ox of line bx0, and slot 3 of line bx0 - 1 when X is the first voxel of a block
+                const int bx = bx0 - sx, slot = sx ? 3 : ox;
+                if (sx && (ox != 0 || bx < 0)) continue;
+                size_t off = ((((size_t) z * P.ry + y) * P.gt_nbx + bx) << 4) + (size_t)((dz * 2 + dy) * 4 + slot);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float *src = P.gt + (size_t) c * P.gt_plane + off;
+                    float g = *src;
+                    if (g != 0.0f) { acc[c] += g; *src = 0.0f; }
+                }
+            }
+        }
     }
+    if (acc[0] != 0.0f) P.g_sigma[v] += acc[0];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (acc[c + 1] != 0.0f) P.g_albedo[3 * (size_t) v + c] += acc[c + 1];
 }
 
 // box film: image[p] = mean_spp L (batched.py:176-197)
