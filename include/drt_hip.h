@@ -174,7 +174,10 @@ int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity);
  * 9 majorant supergrid cell (index bits), 10 exp. */
 int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out);
 
-/* Profiling ablations (bit 0: skip the gradient atomics).  0 in production. */
+/* Profiling ablations / kernel selection for experiments; 0 in production.
+ * bit 0 (1): skip the gradient atomics; bit 1 (2): per-lane (uncoalesced) atomics; bit 3 (8): force the
+ * one-ray-per-lane tracing kernels; bit 4 (16): no empty-space bitmask; bit 5 (32): state-machine
+ * kernel for the adjoint too. */
 int drt_set_debug_flags(drt_handle h, uint32_t flags);
 
 const char *drt_version(void);

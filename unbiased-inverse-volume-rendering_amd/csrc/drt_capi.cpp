@@ -25,7 +25,9 @@ struct drt_handle_s {
     float *d_majorant = nullptr;   // [2]
     uint32_t *d_scratch = nullptr; // [1]
     unsigned long long *d_counters = nullptr;   // [C_COUNT]
-    float *d_gt = nullptr;         // tiled gradient scratch, 4 planes (always zero between launches)
+    float *d_gt = nullptr;         // gradient scratch, 4 planes (always zero between launches)
+    unsigned long long *d_queues = nullptr;   // 8 per-XCD ray queue heads (wavefront kernel)
+    int n_cus = 256;
     float *d_sigma_b = nullptr;    // bricked copy of sigma_t (refreshed by drt_params_changed)
     uint32_t *d_occ = nullptr;     // empty-space bitmask (kOccWords words)
     float *d_mgrid = nullptr;      // majorant supergrid (refreshed by drt_params_changed)
@@ -135,7 +137,22 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         DRT_HIP_CHECK(h, hipEventCreate(&b));
         DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
     }
-    DRT_HIP_CHECK(h, drt::launch_trace(P, adjoint, h->counting, h->stream));
+    // Kernel choice (measured on MI355X, headline workload):
+    //   primal : wave-synchronous state machine (drt_wavefront.hip) - 3.2 ms vs 3.4 ms
+    //   adjoint: one ray per lane (drt_kernels.hip)                 - 22.4 ms vs 24-26 ms; the state
+    //            machine also serves the adjoint (debug bit 32) but its transition blocks run at
+    //            too low a lane occupancy to win; quadratic DRT exists only in the per-lane kernel.
+    // debug bit 8 forces the per-lane kernel everywhere.
+    const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
+    const bool wavefront = !(h->debug_flags & 8u) && (!adjoint || ((h->debug_flags & 32u) && !quadratic));
+    if (!wavefront) {
+        DRT_HIP_CHECK(h, drt::launch_trace(P, adjoint, h->counting, h->stream));
+    } else {
+        drt::Params Q = P;
+        Q.queues = h->d_queues;
+        DRT_HIP_CHECK(h, hipMemsetAsync(h->d_queues, 0, 8 * sizeof(unsigned long long), h->stream));
+        DRT_HIP_CHECK(h, drt::launch_trace_wavefront(Q, adjoint, h->counting, h->n_cus, h->stream));
+    }
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
         h->timed[which].emplace_back(a, b);
@@ -173,6 +190,8 @@ int drt_create(const drt_config *cfg, int device, drt_handle *out)
     if (!g.ok) { delete h; return fail(nullptr, DRT_ERR_HIP, "hipSetDevice(%d) failed", device); }
     hipError_t e = hipMalloc(&h->d_majorant, 2 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&h->d_scratch, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&h->d_queues, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) { hipDeviceProp_t prop; e = hipGetDeviceProperties(&prop, device); if (e == hipSuccess) h->n_cus = prop.multiProcessorCount; }
     if (e == hipSuccess) e = hipMalloc(&h->d_occ, drt::kOccWords * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&h->d_counters, drt::C_COUNT * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->d_counters, 0, drt::C_COUNT * sizeof(unsigned long long));
@@ -193,6 +212,7 @@ int drt_destroy(drt_handle h)
     if (h->d_scratch) (void) hipFree(h->d_scratch);
     if (h->d_counters) (void) hipFree(h->d_counters);
     if (h->d_gt) (void) hipFree(h->d_gt);
+    if (h->d_queues) (void) hipFree(h->d_queues);
     if (h->d_sigma_b) (void) hipFree(h->d_sigma_b);
     if (h->d_mgrid) (void) hipFree(h->d_mgrid);
     if (h->d_occ) (void) hipFree(h->d_occ);

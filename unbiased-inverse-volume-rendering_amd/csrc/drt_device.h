@@ -217,6 +217,7 @@ struct Params {
     float *gt;                 // plane c at gt + c * gt_plane
     uint32_t gt_plane;         // floats per plane = nbx * ry * rz * 16
     int gt_nbx;                // lines per grid row = ceil(rx / 3)
+    unsigned long long *queues;     // 8 per-XCD ray queue heads (wavefront kernel), zeroed per launch
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
 };

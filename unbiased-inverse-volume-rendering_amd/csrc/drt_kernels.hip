@@ -661,38 +661,32 @@ __global__ void __launch_bounds__(256) brick_sigma_kernel(const float *src, floa
 __global__ void __launch_bounds__(256) untile_gradients_kernel(const Params P, uint32_t n_voxels)
 {
     uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;                       // plane: 0 sigma_t, 1..3 albedo / emission rgb
     if (v >= n_voxels) return;
     const int X = (int)(v % (uint32_t) P.rx); uint32_t t = v / (uint32_t) P.rx;
     const int Y = (int)(t % (uint32_t) P.ry), Z = (int)(t / (uint32_t) P.ry);
     const int bx0 = X / 3, ox = X - 3 * bx0;
-    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    float *plane = P.gt + (size_t) c * P.gt_plane;
+    float acc = 0.0f;
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz) {
-        const int z = Z - dz;
-        if (z < 0) continue;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-            const int y = Y - dy;
-            if (y < 0) continue;
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
-                // slot ox of line bx0, and slot 3 of line bx0 - 1 when X is the first voxel of a block
-                const int bx = bx0 - sx, slot = sx ? 3 : ox;
-                if (sx && (ox != 0 || bx < 0)) continue;
-                size_t off = ((((size_t) z * P.ry + y) * P.gt_nbx + bx) << 4) + (size_t)((dz * 2 + dy) * 4 + slot);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float *src = P.gt + (size_t) c * P.gt_plane + off;
-                    float g = *src;
-                    if (g != 0.0f) { acc[c] += g; *src = 0.0f; }
-                }
+            const int z = Z - dz, y = Y - dy;
+            if (z < 0 || y < 0) continue;
+            float *line = plane + ((((size_t) z * P.ry + y) * P.gt_nbx + bx0) << 4) + (dz * 2 + dy) * 4;
+            float g = line[ox];
+            if (g != 0.0f) { acc += g; line[ox] = 0.0f; }
+            if (ox == 0 && bx0 > 0) {               // slot 3 of the previous block is this voxel too
+                float g3 = line[-13];               // (line - 16)[3]
+                if (g3 != 0.0f) { acc += g3; line[-13] = 0.0f; }
             }
         }
     }
-    if (acc[0] != 0.0f) P.g_sigma[v] += acc[0];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        if (acc[c + 1] != 0.0f) P.g_albedo[3 * (size_t) v + c] += acc[c + 1];
+    if (acc != 0.0f) {
+        if (c == 0) P.g_sigma[v] += acc;
+        else P.g_albedo[3 * (size_t) v + (c - 1)] += acc;
+    }
 }
 
 // box film: image[p] = mean_spp L (batched.py:176-197)
@@ -817,7 +811,7 @@ hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t st
 hipError_t launch_untile(const Params &P, hipStream_t stream)
 {
     uint32_t n = (uint32_t) P.rx * P.ry * P.rz;
-    hipLaunchKernelGGL(untile_gradients_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, P, n);
+    hipLaunchKernelGGL(untile_gradients_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, stream, P, n);
     return hipGetLastError();
 }
 

@@ -15,6 +15,7 @@ hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int sh
 hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int nbx, int nby,
                               hipStream_t stream);
 hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream);
+hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
 hipError_t launch_untile(const Params &P, hipStream_t stream);
 hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t *scratch_bits,
                            float *majorant, hipStream_t stream);
