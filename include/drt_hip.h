@@ -145,6 +145,16 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
                              const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
                              const float *dL, const float *L_in, float *grad_sigma_t, float *grad_emission);
 
+/* sample_batch_pixels + sample_batch_rays of the batched (ray-centric) render op
+ * (python/batched.py:397-467).  `sensors`: DEVICE array of n_sensors x 16 floats {origin[3], left[3],
+ * up[3], dir[3], tan_x, tan_y, width, height}.  For every batch entry b a (sensor, pixel) pair is
+ * drawn from lane b of the PCG32 wavefront seeded with sub_seed_pixels; ray r = b*spp + j gets its
+ * sub-pixel offset from lane r of the wavefront seeded with sub_seed_rays.  Outputs: rays_o / rays_d
+ * [batch_size*spp][3], sensor_idx [batch_size] and pixels [batch_size][2] (x, y) (may be NULL). */
+int drt_batch_sample_rays(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_size, uint32_t spp,
+                          uint32_t sub_seed_pixels, uint32_t sub_seed_rays, float *rays_o, float *rays_d,
+                          uint32_t *sensor_idx, uint32_t *pixels);
+
 /* Box-filter film: image[p] = mean over the pixel's spp samples
  * (block.put + film.develop, batched.py:176-197).  L: [n_pixels*spp][3]. */
 int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t spp, float *image);

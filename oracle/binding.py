@@ -82,6 +82,9 @@ def lib():
                                        C.POINTER(Counters)]
         L.drto_expf.argtypes = [C.c_float]
         L.drto_expf.restype = C.c_float
+        L.drto_batch_sample_rays.argtypes = [C.POINTER(Sensor), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             fp, fp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.drto_batch_sample_rays.restype = None
         L.drto_tea32.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.drto_tea32.restype = C.c_uint32
         L.drto_pcg32_floats.argtypes = [C.c_uint32, C.c_uint32, C.c_int, fp]
@@ -270,6 +273,23 @@ def nerf_render(oscene: OracleScene, emission, props: dict, spp: int, seed: int,
     if rc:
         raise RuntimeError(f"drto_nerf_render failed: {rc}")
     return gs, ge, cnt.as_dict()
+
+
+def make_sensor(s) -> Sensor:
+    f = s.frame()
+    return Sensor((C.c_float * 3)(*f["origin"]), (C.c_float * 3)(*f["left"]), (C.c_float * 3)(*f["up"]),
+                  (C.c_float * 3)(*f["dir"]), float(f["tan_x"]), float(f["tan_y"]), s.width, s.height)
+
+
+def batch_sample_rays(sensors, batch_size: int, spp: int, sub_seed_pixels: int, sub_seed_rays: int):
+    """sample_batch_pixels + sample_batch_rays (batched.py:397-467) -> (rays_o, rays_d, sensor_idx, pixels)."""
+    arr = (Sensor * len(sensors))(*[make_sensor(s) for s in sensors])
+    n = batch_size * spp
+    ro = np.zeros((n, 3), np.float32); rd = np.zeros((n, 3), np.float32)
+    si = np.zeros(batch_size, np.uint32); px = np.zeros((batch_size, 2), np.uint32)
+    lib().drto_batch_sample_rays(arr, len(sensors), batch_size, spp, sub_seed_pixels, sub_seed_rays, _fp(ro), _fp(rd),
+                                 si.ctypes.data_as(C.POINTER(C.c_uint32)), px.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return ro, rd, si, px
 
 
 def render_textbook(oscene: OracleScene, props: dict, spp: int, seed: int, **kw):

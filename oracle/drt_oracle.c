@@ -1128,6 +1128,35 @@ static void scene_from_medium(scene_t *sc, const drto_medium *m)
     job.cfg = &cfg; job.medium = m; job.emitter = &em;
     scene_init(sc, &job);
 }
+/* N1: sample_batch_pixels + sample_batch_rays (python/batched.py:397-467).
+ * sampler 0 (wavefront = batch_size, seed sub_seed_pixels): sensor_idx = uint(n_sensors * next_1d()),
+ * pixel = uint(film_size * next_2d()); ray sampler (wavefront = batch_size*spp, seed sub_seed_rays):
+ * sub-pixel offset = next_2d(); pos = (pixel + offset) / film_size; ray = sensor.sample_ray(pos). */
+void drto_batch_sample_rays(const drto_sensor *sensors, int n_sensors, uint32_t batch_size, uint32_t spp,
+                            uint32_t sub_seed_pixels, uint32_t sub_seed_rays, float *rays_o, float *rays_d,
+                            uint32_t *sensor_idx, uint32_t *pixels)
+{
+    for (uint32_t b = 0; b < batch_size; ++b) {
+        pcg32 S0; sampler_seed(&S0, sub_seed_pixels, b);
+        float us = next_1d(&S0), ux = next_1d(&S0), uy = next_1d(&S0);
+        uint32_t si = (uint32_t)((float) n_sensors * us);
+        if (si >= (uint32_t) n_sensors) si = (uint32_t) n_sensors - 1;
+        const drto_sensor *sn = sensors + si;
+        uint32_t px = (uint32_t)((float) sn->width * ux), py = (uint32_t)((float) sn->height * uy);
+        if (sensor_idx) sensor_idx[b] = si;
+        if (pixels) { pixels[2 * b] = px; pixels[2 * b + 1] = py; }
+        for (uint32_t j = 0; j < spp; ++j) {
+            uint32_t r = b * spp + j;
+            pcg32 S1; sampler_seed(&S1, sub_seed_rays, r);
+            float ox = next_1d(&S1), oy = next_1d(&S1);
+            v3 o, d;
+            sensor_ray(sn, py * (uint32_t) sn->width + px, ox, oy, &o, &d);
+            rays_o[3 * r] = o.x; rays_o[3 * r + 1] = o.y; rays_o[3 * r + 2] = o.z;
+            rays_d[3 * r] = d.x; rays_d[3 * r + 1] = d.y; rays_d[3 * r + 2] = d.z;
+        }
+    }
+}
+
 uint32_t drto_tea32(uint32_t v0, uint32_t v1, uint32_t *out_v1)
 {
     uint32_t a, b; tea32(v0, v1, &a, &b); if (out_v1) *out_v1 = b; return a;

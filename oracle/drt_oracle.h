@@ -139,6 +139,11 @@ int drto_nerf_render(const drto_job *job, const drto_nerf_config *ncfg, const fl
  * plays the role of Mitsuba's builtin `volpath` in tests/test_integrators.py:222-257. */
 int drto_render_textbook(const drto_job *job, float *L_out);
 
+/* N1: batched (ray-centric) pixel / ray sampling, python/batched.py:397-467. */
+void drto_batch_sample_rays(const drto_sensor *sensors, int n_sensors, uint32_t batch_size, uint32_t spp,
+                            uint32_t sub_seed_pixels, uint32_t sub_seed_rays, float *rays_o, float *rays_d,
+                            uint32_t *sensor_idx, uint32_t *pixels);
+
 /* --- test hooks on the primitives ---------------------------------------- */
 uint32_t drto_tea32(uint32_t v0, uint32_t v1, uint32_t *out_v1);
 void     drto_pcg32_floats(uint32_t seed, uint32_t index, int n, float *out);

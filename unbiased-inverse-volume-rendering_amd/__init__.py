@@ -12,11 +12,14 @@ from .integrators import (ADMode, IndependentSampler, NeRFIntegrator, RayBatch, 
 from .opt_config import IntegratorConfig, add_int_config, get_int_config
 from .distributed import ShardSpec, allreduce_gradients, allreduce_scalar, from_environment
 from .render import alloc_grads, render, render_backward, render_primal
+from .batched import gather_ref_values, render_batch, sample_batch, sensors_to_device
+from . import losses
 
 __all__ = [
     "ALBEDO_KEY", "EMISSION_KEY", "SIGMA_T_KEY", "ConstantEmitter", "GridMedium", "PerspectiveSensor",
     "Scene", "cube_test_scene", "scene_to", "ADMode", "IndependentSampler", "RayBatch",
     "VolpathSimpleIntegrator", "NeRFIntegrator", "load_dict", "register_integrator", "sample_tea_32", "IntegratorConfig",
     "add_int_config", "get_int_config", "ShardSpec", "allreduce_gradients", "allreduce_scalar",
-    "from_environment", "alloc_grads", "render", "render_backward", "render_primal",
+    "from_environment", "alloc_grads", "render", "render_backward", "render_primal", "render_batch",
+    "gather_ref_values", "sample_batch", "sensors_to_device", "losses",
 ]

@@ -452,6 +452,20 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
     return DRT_OK;
 }
 
+int drt_batch_sample_rays(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_size, uint32_t spp,
+                          uint32_t sub_seed_pixels, uint32_t sub_seed_rays, float *rays_o, float *rays_d,
+                          uint32_t *sensor_idx, uint32_t *pixels)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!sensors || n_sensors < 1 || spp == 0) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_batch_sample_rays: bad sensors / spp");
+    if ((uint64_t) batch_size * spp > 0xffffffffull) return fail(h, DRT_ERR_INVALID_ARGUMENT, "batch_size * spp exceeds 2^32 - 1");
+    if (batch_size && (!rays_o || !rays_d)) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null ray buffers");
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, drt::launch_batch_raygen(sensors, n_sensors, batch_size, spp, sub_seed_pixels, sub_seed_rays, rays_o, rays_d,
+                                              sensor_idx, pixels, h->stream));
+    return DRT_OK;
+}
+
 int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t spp, float *image)
 {
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");

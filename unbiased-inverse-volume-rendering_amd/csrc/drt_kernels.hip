@@ -689,6 +689,40 @@ __global__ void __launch_bounds__(256) untile_gradients_kernel(const Params P, u
     }
 }
 
+// sample_batch_pixels + sample_batch_rays (python/batched.py:397-467): one thread per ray r of the
+// batch; b = r / spp picks (sensor, pixel) from sampler 0's lane b, the sub-pixel offset comes from
+// the ray sampler's lane r.  `sensors`: n_sensors x 16 floats {origin3, left3, up3, dir3, tan_x,
+// tan_y, width, height}.
+__global__ void __launch_bounds__(256) batch_raygen_kernel(const float *sensors, int n_sensors, uint32_t batch_size,
+                                                           uint32_t spp, uint32_t seed_pixels, uint32_t seed_rays,
+                                                           float *rays_o, float *rays_d, uint32_t *sensor_idx,
+                                                           uint32_t *pixels)
+{
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= batch_size * spp) return;
+    uint32_t b = r / spp;
+    Pcg32 S0; S0.seed(seed_pixels, b);
+    float us = S0.next_1d(), ux = S0.next_1d(), uy = S0.next_1d();
+    uint32_t si = (uint32_t)((float) n_sensors * us);
+    if (si >= (uint32_t) n_sensors) si = (uint32_t) n_sensors - 1;
+    const float *sn = sensors + 16 * si;
+    Params P;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { P.cam_o[k] = sn[k]; P.cam_left[k] = sn[3 + k]; P.cam_up[k] = sn[6 + k]; P.cam_dir[k] = sn[9 + k]; }
+    P.tan_x = sn[12]; P.tan_y = sn[13]; P.width = (int) sn[14]; P.height = (int) sn[15];
+    uint32_t px = (uint32_t)((float) P.width * ux), py = (uint32_t)((float) P.height * uy);
+    if (r == b * spp) {
+        if (sensor_idx) sensor_idx[b] = si;
+        if (pixels) { pixels[2 * b] = px; pixels[2 * b + 1] = py; }
+    }
+    Pcg32 S1; S1.seed(seed_rays, r);
+    float ox = S1.next_1d(), oy = S1.next_1d();
+    V3 o, d;
+    sensor_ray(P, py * (uint32_t) P.width + px, ox, oy, o, d);
+    rays_o[3 * (size_t) r] = o.x; rays_o[3 * (size_t) r + 1] = o.y; rays_o[3 * (size_t) r + 2] = o.z;
+    rays_d[3 * (size_t) r] = d.x; rays_d[3 * (size_t) r + 1] = d.y; rays_d[3 * (size_t) r + 2] = d.z;
+}
+
 // box film: image[p] = mean_spp L (batched.py:176-197)
 __global__ void __launch_bounds__(256) film_develop_kernel(const float *L, uint64_t n_pixels, uint32_t spp, float *image)
 {
@@ -825,6 +859,17 @@ hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(majorant_reduce_kernel, dim3(blocks), dim3(256), 0, stream, sigma_t, n, scratch_bits);
     hipLaunchKernelGGL(majorant_finalize_kernel, dim3(1), dim3(1), 0, stream, scratch_bits, scale, majorant);
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_raygen(const float *sensors, int n_sensors, uint32_t batch_size, uint32_t spp, uint32_t seed_pixels,
+                               uint32_t seed_rays, float *rays_o, float *rays_d, uint32_t *sensor_idx, uint32_t *pixels,
+                               hipStream_t stream)
+{
+    uint64_t n = (uint64_t) batch_size * spp;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(batch_raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sensors, n_sensors,
+                       batch_size, spp, seed_pixels, seed_rays, rays_o, rays_d, sensor_idx, pixels);
     return hipGetLastError();
 }
 

@@ -19,6 +19,9 @@ hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int
 hipError_t launch_untile(const Params &P, hipStream_t stream);
 hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t *scratch_bits,
                            float *majorant, hipStream_t stream);
+hipError_t launch_batch_raygen(const float *sensors, int n_sensors, uint32_t batch_size, uint32_t spp, uint32_t seed_pixels,
+                               uint32_t seed_rays, float *rays_o, float *rays_d, uint32_t *sensor_idx, uint32_t *pixels,
+                               hipStream_t stream);
 hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, float *image,
                                hipStream_t stream);
 hipError_t launch_film_backward(const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL,

@@ -149,6 +149,17 @@ public:
         }
         check(rc, "drt_nerf_render_backward");
     }
+    void batch_sample_rays(uintptr_t sensors, int n_sensors, uint32_t batch, uint32_t spp, uint32_t seed_px, uint32_t seed_rays,
+                           uintptr_t ro, uintptr_t rd, uintptr_t sidx, uintptr_t pix)
+    {
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = drt_batch_sample_rays(h_, ptr<const float>(sensors), n_sensors, batch, spp, seed_px, seed_rays, ptr<float>(ro),
+                                       ptr<float>(rd), ptr<uint32_t>(sidx), ptr<uint32_t>(pix));
+        }
+        check(rc, "drt_batch_sample_rays");
+    }
     void film_develop(uintptr_t L, uint64_t n_pixels, uint32_t spp, uintptr_t image)
     {
         int rc;
@@ -218,6 +229,7 @@ PYBIND11_MODULE(_drt_pybind, m)
         .def("render_backward", &Integrator::render_backward)
         .def("nerf_render_primal", &Integrator::nerf_render_primal)
         .def("nerf_render_backward", &Integrator::nerf_render_backward)
+        .def("batch_sample_rays", &Integrator::batch_sample_rays)
         .def("film_develop", &Integrator::film_develop)
         .def("film_backward", &Integrator::film_backward)
         .def("debug_eval", &Integrator::debug_eval)
