@@ -1,0 +1,99 @@
+"""N2 / N3 host logic that needs no GPU: optimizer, schedules, projection, upsampling, `.vol` IO
+(reference: python/opt_config.py:11-75, python/optimize.py:169-252, python/util.py:55-71)."""
+import numpy as np
+import pytest
+import torch
+from scipy.ndimage import zoom
+
+
+def test_upsample_grid_equals_scipy_zoom(uivr):
+    """optimize.py:217-219: zoom(order=1, mode='nearest', prefilter=False, grid_mode=True)."""
+    rng = np.random.default_rng(0)
+    for shape in [(4, 6, 5, 1), (3, 3, 3, 3), (8, 4, 2, 3)]:
+        a = rng.random(shape, dtype=np.float32)
+        new = tuple(2 * s for s in shape[:3]) + (shape[3],)
+        ref = zoom(a, [2, 2, 2, 1], order=1, mode='nearest', prefilter=False, grid_mode=True)
+        got = uivr.upsample_grid(torch.from_numpy(a), new).numpy()
+        assert got.shape == new
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+    same = uivr.upsample_grid(torch.from_numpy(a), a.shape)
+    assert torch.equal(same, torch.from_numpy(a))
+
+
+def test_adam_matches_reference_formula(uivr):
+    rng = np.random.default_rng(1)
+    p0 = rng.random((4, 3)).astype(np.float32)
+    params = {"a.sigma_t.data": torch.from_numpy(p0.copy()), "a.albedo.data": torch.from_numpy(p0.copy())}
+    opt = uivr.Adam(lr=1e-2, params=params)
+    opt.set_learning_rate({"a.albedo.data": 2e-2})
+    m = np.zeros_like(p0); v = np.zeros_like(p0); ref = p0.astype(np.float64).copy()
+    for t in range(1, 6):
+        g = rng.normal(size=p0.shape).astype(np.float32)
+        opt.step({"a.sigma_t.data": torch.from_numpy(g), "a.albedo.data": torch.from_numpy(g)})
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g * g
+        ref -= 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-8)
+    np.testing.assert_allclose(params["a.sigma_t.data"].numpy(), ref, rtol=1e-5, atol=1e-7)
+    # per-parameter learning rate: twice the step
+    np.testing.assert_allclose(params["a.albedo.data"].numpy() - p0, 2 * (ref - p0), rtol=1e-4, atol=1e-6)
+    # state is dropped when the shape changes (upsampling, optimize.py:241)
+    opt["a.sigma_t.data"] = torch.zeros((8, 3))
+    assert "a.sigma_t.data" not in opt.state
+
+
+def _scene_config(uivr, **kw):
+    scene = uivr.cube_test_scene(8, 8)
+    return uivr.SceneConfig(name="cube", scene=scene, param_keys=[uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY], sensors=[0],
+                            start_from_value={uivr.SIGMA_T_KEY: 0.04, uivr.ALBEDO_KEY: 0.6}, **kw)
+
+
+def test_optimization_config_schedule(uivr):
+    sc = _scene_config(uivr)
+    assert sc.param_lr_factors == {uivr.ALBEDO_KEY: 2.0}                 # scene_config.py:67-71
+    assert sc.max_depth == 64 and sc.max_density == 250 and sc.majorant_resolution_factor == 8
+    oc = uivr.OptimizationConfig("t", spp=16, n_iter=101, lr=5e-3, lr_schedule=uivr.Schedule.Last25, upsample=[0.04, 0.16, 0.36, 0.64])
+    assert oc.primal_spp_factor == 64 and oc.base_seed == 988378 and oc.loss is uivr.losses.l1
+    assert oc.upsample_at == {4, 16, 36, 64} and oc.should_upsample(16) and not oc.should_upsample(17)
+    lr = lambda i: oc.learning_rates(sc, i)
+    assert lr(0)[uivr.SIGMA_T_KEY] == 5e-3 and lr(0)[uivr.ALBEDO_KEY] == 1e-2
+    assert lr(75)[uivr.SIGMA_T_KEY] == 2.5e-3 and lr(85)[uivr.SIGMA_T_KEY] == 1.25e-3 and lr(100)[uivr.SIGMA_T_KEY] == 6.25e-4
+    const = uivr.OptimizationConfig("c", spp=1, n_iter=10, lr=1.0)
+    assert const.learning_rates(sc, 9)[uivr.SIGMA_T_KEY] == 1.0 and not const.should_upsample(3)
+    with pytest.raises(ValueError):
+        uivr.SceneConfig(name="x", scene=sc.scene, param_keys=[uivr.SIGMA_T_KEY], sensors=[0], start_from_value={})
+
+
+def test_projection_and_majorant_factor(uivr):
+    sc = _scene_config(uivr, max_density=3.0)
+    opt = uivr.Adam(1.0, {uivr.SIGMA_T_KEY: torch.tensor([-1.0, 2.0, 9.0]), uivr.ALBEDO_KEY: torch.tensor([-0.5, 0.5, 1.5]),
+                         uivr.EMISSION_KEY: torch.tensor([-2.0, 7.0])})
+    uivr.enforce_valid_params(sc, opt)
+    assert opt[uivr.SIGMA_T_KEY].tolist() == [0.0, 2.0, 3.0] and opt[uivr.ALBEDO_KEY].tolist() == [0.0, 0.5, 1.0]
+    assert opt[uivr.EMISSION_KEY].tolist() == [0.0, 7.0]
+    with pytest.raises(ValueError):
+        uivr.enforce_valid_params(sc, uivr.Adam(1.0, {"foo": torch.zeros(1)}))
+    f = uivr.adjusted_majorant_res_factor                               # optimize.py:182-193
+    assert f(8, (256, 256, 256, 1)) == 8 and f(8, (16, 16, 16, 1)) == 4 and f(8, (8, 8, 8, 1)) == 2
+    assert f(8, (4, 4, 4, 1)) == 0 and f(0, (64, 64, 64, 1)) == 0 and f(1, (64, 64, 64, 1)) == 0
+
+
+def test_vol_roundtrip(uivr, tmp_path):
+    rng = np.random.default_rng(2)
+    for c in (1, 3):
+        a = rng.random((3, 4, 5, c), dtype=np.float32)
+        path = str(tmp_path / f"g{c}.vol")
+        uivr.write_vol(path, a, (-1, -2, -3), (1, 2, 3))
+        raw = open(path, "rb").read()
+        assert raw[:4] == b"VOL\x03" and len(raw) == 48 + a.size * 4
+        assert np.frombuffer(raw[4:24], "<i4").tolist() == [1, 5, 4, 3, c]      # type, xres, yres, zres, channels
+        b, lo, hi = uivr.read_vol(path)
+        np.testing.assert_array_equal(a, b)
+        assert lo == (-1, -2, -3) and hi == (1, 2, 3)
+    sc = _scene_config(uivr)
+    uivr.save_params(str(tmp_path), sc, {k: torch.from_numpy(np.asarray(v)) for k, v in sc.scene.params().items()}, "final", sc.scene.medium)
+    d, lo, hi = uivr.read_vol(str(tmp_path / "final-medium1_sigma_t.vol"))       # util.py:64-68 naming
+    np.testing.assert_array_equal(d, sc.scene.medium.sigma_t)
+    assert lo == (-0.5, -0.5, -0.5)
+    with pytest.raises(ValueError):
+        open(tmp_path / "bad.vol", "wb").write(b"NOPE" + b"\0" * 60)
+        uivr.read_vol(str(tmp_path / "bad.vol"))

@@ -14,6 +14,9 @@ from .distributed import ShardSpec, allreduce_gradients, allreduce_scalar, from_
 from .render import alloc_grads, render, render_backward, render_primal
 from .batched import gather_ref_values, render_batch, sample_batch, sensors_to_device
 from . import losses
+from .optimize import (Adam, OptimizationConfig, SGD, SceneConfig, Schedule, adjusted_majorant_res_factor,
+                       enforce_valid_params, run_optimization, save_params, upsample_grid)
+from .volume_io import read_vol, write_vol
 
 __all__ = [
     "ALBEDO_KEY", "EMISSION_KEY", "SIGMA_T_KEY", "ConstantEmitter", "GridMedium", "PerspectiveSensor",
@@ -21,5 +24,7 @@ __all__ = [
     "VolpathSimpleIntegrator", "NeRFIntegrator", "load_dict", "register_integrator", "sample_tea_32", "IntegratorConfig",
     "add_int_config", "get_int_config", "ShardSpec", "allreduce_gradients", "allreduce_scalar",
     "from_environment", "alloc_grads", "render", "render_backward", "render_primal", "render_batch",
-    "gather_ref_values", "sample_batch", "sensors_to_device", "losses",
+    "gather_ref_values", "sample_batch", "sensors_to_device", "losses", "Adam", "SGD", "OptimizationConfig",
+    "SceneConfig", "Schedule", "adjusted_majorant_res_factor", "enforce_valid_params", "run_optimization",
+    "save_params", "upsample_grid", "read_vol", "write_vol",
 ]

@@ -1,0 +1,313 @@
+"""The inverse-rendering loop around the hot path (N2; reference: python/optimize.py,
+python/opt_config.py:11-75): Adam with per-parameter learning rates and the `Last25` schedule,
+projection of the parameters onto their legal range, x2 trilinear grid upsampling, majorant
+supergrid adjustment, `.vol` checkpoints - all on the device (the reference round-trips the grids
+through scipy on the host for upsampling, optimize.py:217-223).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from enum import IntEnum
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import losses
+from .batched import gather_ref_values, render_batch, sensors_to_device
+from .integrators import sample_tea_32
+from .opt_config import get_int_config
+from .render import render, render_primal
+from .scene import ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, GridMedium, Scene
+from .volume_io import write_vol
+
+
+class Schedule(IntEnum):
+    Constant = 0
+    Last25 = 1
+
+
+@dataclass
+class OptimizationConfig:
+    """python/opt_config.py:11-75 (same fields and defaults)."""
+    name: str
+    spp: int
+    n_iter: int
+    lr: float
+    primal_spp_factor: int = 64
+    batch_size: Optional[int] = None
+    lr_schedule: Optional[Schedule] = None
+    upsample: Optional[List[float]] = None
+    base_seed: int = 988378
+    render_initial: bool = True
+    render_final: bool = True
+    preview_stride: int = 100
+    checkpoint_initial: bool = True
+    checkpoint_final: bool = True
+    checkpoint_stride: int = 1000
+    preview_spp: Optional[int] = None
+    opt_type: str = 'adam'
+    opt_args: Optional[Dict] = None
+    loss: Callable = losses.l1
+
+    def __post_init__(self):
+        self.upsample_at = set()
+        if self.upsample:
+            for t in self.upsample:
+                assert t >= 0 and t <= 1
+                self.upsample_at.add(int(t * self.n_iter))
+
+    def optimizer(self, params):
+        opt_type = {'sgd': SGD, 'adam': Adam}[self.opt_type]
+        return opt_type(lr=self.lr, params=params, **(self.opt_args or {}))
+
+    def learning_rates(self, scene_config, it_i):
+        schedule_factor = 1.0
+        if self.lr_schedule not in (None, Schedule.Constant):
+            t = it_i / (self.n_iter - 1)
+            if self.lr_schedule == Schedule.Last25:
+                steps = [0.75, 0.85, 0.95]
+            else:
+                raise ValueError(f'Unsupported schedule: {self.lr_schedule}')
+            for s in steps:
+                if t >= s:
+                    schedule_factor *= 0.5
+        upsampling_factor = 1.0
+        return {k: (schedule_factor * upsampling_factor * scene_config.param_lr_factors.get(k, 1.0) * self.lr)
+                for k in scene_config.param_keys}
+
+    def should_upsample(self, it_i):
+        if not self.upsample_at:
+            return False
+        return it_i in self.upsample_at
+
+
+@dataclass
+class SceneConfig:
+    """The data fields of python/scene_config.py:9-72 for scenes given as objects (the reference's
+    registry points at XML files and assets that are not part of its repository)."""
+    name: str
+    scene: Scene
+    param_keys: List[str]
+    sensors: List[int]
+    start_from_value: Dict[str, Optional[float]]
+    max_depth: int = 64
+    ref_spp: int = 8192
+    ref_integrator: str = 'volpathsimple-drt'
+    preview_sensors: Optional[List[int]] = None
+    max_density: float = 250
+    majorant_resolution_factor: int = 8
+    param_lr_factors: Optional[Dict[str, float]] = None
+
+    def __post_init__(self):
+        for k in self.param_keys:
+            if k not in self.start_from_value:
+                raise ValueError(f'Parameter "{k}" will be optimized but was not given an initial value in `start_from_value`')
+        if not self.preview_sensors:
+            self.preview_sensors = [self.sensors[0]]
+        if not self.param_lr_factors:
+            self.param_lr_factors = {k: 2.0 for k in self.param_keys if '.albedo.' in k}   # scene_config.py:67-71
+
+
+class Adam:
+    """mi.ad.Adam [M3-ext] as the reference uses it (opt_config.py:46-48, optimize.py:329,352-354):
+    bias-corrected Adam (beta1 0.9, beta2 0.999, epsilon 1e-8), per-parameter learning rates, state
+    dropped when a parameter changes shape (upsampling)."""
+
+    def __init__(self, lr, params: Dict[str, torch.Tensor], beta_1=0.9, beta_2=0.999, epsilon=1e-8):
+        self.lr_default = lr
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+        self.variables: Dict[str, torch.Tensor] = dict(params)
+        self.lr: Dict[str, float] = {}
+        self.state: Dict[str, tuple] = {}
+
+    def __getitem__(self, k):
+        return self.variables[k]
+
+    def __setitem__(self, k, v):
+        if k in self.state and self.state[k][1].shape != v.shape:
+            del self.state[k]
+        self.variables[k] = v
+
+    def items(self):
+        return self.variables.items()
+
+    def set_learning_rate(self, lr):
+        if isinstance(lr, dict):
+            self.lr.update(lr)
+        else:
+            self.lr_default = lr
+
+    @torch.no_grad()
+    def step(self, grads: Dict[str, torch.Tensor]):
+        for k, p in self.variables.items():
+            g = grads.get(k)
+            if g is None:
+                continue
+            t, m, v = self.state.get(k, (0, torch.zeros_like(p), torch.zeros_like(p)))
+            t += 1
+            m.mul_(self.beta_1).add_(g, alpha=1 - self.beta_1)
+            v.mul_(self.beta_2).addcmul_(g, g, value=1 - self.beta_2)
+            lr = self.lr.get(k, self.lr_default)
+            lr_t = lr * (1 - self.beta_2 ** t) ** 0.5 / (1 - self.beta_1 ** t)
+            p.addcdiv_(m, v.sqrt().add_(self.epsilon), value=-lr_t)        # in place: bumps the tensor version
+            self.state[k] = (t, m, v)
+
+
+class SGD(Adam):
+    """mi.ad.SGD without momentum."""
+
+    @torch.no_grad()
+    def step(self, grads):
+        for k, p in self.variables.items():
+            if grads.get(k) is not None:
+                p.add_(grads[k], alpha=-self.lr.get(k, self.lr_default))
+
+
+@torch.no_grad()
+def enforce_valid_params(scene_config: SceneConfig, opt) -> None:
+    """optimize.py:169-179."""
+    for k, v in opt.items():
+        if k.endswith('sigma_t.data'):
+            v.clamp_(0, scene_config.max_density)
+        elif k.endswith('emission.data'):
+            v.clamp_(min=0)
+        elif k.endswith('albedo.data'):
+            v.clamp_(0, 1)
+        else:
+            raise ValueError(k)
+
+
+def adjusted_majorant_res_factor(res_factor: int, density_res) -> int:
+    """optimize.py:182-193: the largest factor <= the configured one that leaves >= 4 supergrid cells
+    along the shortest side, else 0 (supergrid disabled)."""
+    if res_factor > 1:
+        min_side = min(density_res[:3])
+        while res_factor > 1 and (min_side // res_factor) < 4:
+            res_factor -= 1
+    if res_factor <= 1:
+        res_factor = 0
+    return res_factor
+
+
+@torch.no_grad()
+def upsample_grid(values: torch.Tensor, new_res) -> torch.Tensor:
+    """optimize.py:203-225: first-order interpolation identical to
+    `scipy.ndimage.zoom(order=1, mode='nearest', prefilter=False, grid_mode=True)` = trilinear
+    resampling with half-voxel-centred coordinates and edge replication, on the device."""
+    z, y, x, c = values.shape
+    if tuple(new_res) == (z, y, x, c):
+        return values.detach().clone()
+    assert new_res[-1] == c
+    v = values.permute(3, 0, 1, 2).unsqueeze(0)                       # (1, C, Z, Y, X)
+    out = F.interpolate(v, size=tuple(new_res[:3]), mode='trilinear', align_corners=False)
+    return out[0].permute(1, 2, 3, 0).contiguous()
+
+
+def save_params(output_dir: str, scene_config: SceneConfig, params: Dict[str, torch.Tensor], name: str, medium: GridMedium) -> None:
+    """python/util.py:55-71: one `.vol` per parameter, `<name>-medium1_sigma_t.vol`."""
+    for key in scene_config.param_keys:
+        if not key.endswith('.data'):
+            raise NotImplementedError(f'Checkpointing of parameter {key}')
+        var_name = '_'.join(key[:-len('.data')].strip().split('.'))
+        write_vol(os.path.join(output_dir, f'{name}-{var_name}.vol'), params[key], medium.bbox_min, medium.bbox_max)
+
+
+def _scene_with(scene: Scene, params: Dict[str, torch.Tensor], factor: int) -> Scene:
+    m = scene.medium
+    medium = GridMedium(sigma_t=params.get(SIGMA_T_KEY, m.sigma_t), albedo=params.get(ALBEDO_KEY, m.albedo),
+                        bbox_min=m.bbox_min, bbox_max=m.bbox_max, scale=m.scale, majorant_resolution_factor=factor,
+                        emission=params.get(EMISSION_KEY, m.emission))
+    return Scene(medium=medium, emitter=scene.emitter, sensors=scene.sensors)
+
+
+def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, scene_config: SceneConfig,
+                     int_config, ref_images: Optional[torch.Tensor] = None, progress: Optional[Callable] = None):
+    """python/optimize.py:275-365.  `ref_images`: (n_sensors, H, W, 3) reference tensor; rendered from
+    `scene_config.scene` at `ref_spp` with `ref_integrator` when None (optimize.py:24-87).
+    Returns (scene, params, opt, losses)."""
+    int_config = get_int_config(int_config)
+    scene0 = scene_config.scene
+    dev = scene0.medium.sigma_t.device
+    integrator = int_config.create(max_depth=scene_config.max_depth)
+    keys = list(scene_config.param_keys)
+    sensors = [scene0.sensors[i] for i in scene_config.sensors]
+    n_sensors = len(sensors)
+    film = (sensors[0].width, sensors[0].height)
+    spp_grad = opt_config.spp
+    spp_primal = spp_grad * opt_config.primal_spp_factor
+
+    if ref_images is None:                                             # reference renderings
+        ref_int = get_int_config(scene_config.ref_integrator).create(max_depth=scene_config.max_depth)
+        ref_scene = Scene(medium=scene0.medium, emitter=scene0.emitter, sensors=sensors)
+        imgs = []
+        for s in range(n_sensors):
+            passes = max(1, scene_config.ref_spp // 2048)
+            acc = 0
+            for p in range(passes):                                    # multi-pass (optimize.py:24-50)
+                acc = acc + render_primal(ref_scene, ref_int, s, scene_config.ref_spp // passes, 1234 + p) / passes
+            imgs.append(acc.view(film[1], film[0], 3))
+        ref_images = torch.stack(imgs)
+
+    # --- initialisation (optimize.py:134-166)
+    full = {SIGMA_T_KEY: scene0.medium.sigma_t, ALBEDO_KEY: scene0.medium.albedo, EMISSION_KEY: scene0.medium.emission}
+    n_up = len(opt_config.upsample) if opt_config.upsample else 0
+    params: Dict[str, torch.Tensor] = {}
+    for k in keys:
+        shape = tuple(full[k].shape)
+        init_res = tuple(max(1, s // (2 ** n_up)) for s in shape[:3]) + (shape[-1],)
+        if n_up and 1 in init_res[:3]:
+            raise ValueError(f'Initial resolution not supported: {init_res}. Maybe reduce upsample_steps?')
+        v = scene_config.start_from_value[k]
+        if v is None:
+            assert not opt_config.upsample
+            params[k] = full[k].detach().clone()
+        else:
+            params[k] = torch.full(init_res, float(v), dtype=torch.float32, device=dev)
+    factor = adjusted_majorant_res_factor(scene_config.majorant_resolution_factor, params[SIGMA_T_KEY].shape)
+    opt = opt_config.optimizer(params)
+    scene = _scene_with(Scene(scene0.medium, scene0.emitter, sensors), params, factor)
+    table = sensors_to_device(sensors, dev)
+    if output_dir and opt_config.checkpoint_initial:
+        os.makedirs(os.path.join(output_dir, 'params'), exist_ok=True)
+        save_params(os.path.join(output_dir, 'params'), scene_config, params, 'initial', scene.medium)
+
+    host_rng = torch.Generator().manual_seed(93483)                    # sensor choice (optimize.py:291,344)
+    history = []
+    for it_i in range(opt_config.n_iter):
+        seed = sample_tea_32(2 * it_i + 0, opt_config.base_seed)[0]
+        seed_grad = sample_tea_32(2 * it_i + 1, opt_config.base_seed)[0]
+        opt.set_learning_rate(opt_config.learning_rates(scene_config, it_i))
+        if opt_config.should_upsample(it_i):                           # optimize.py:228-252
+            for k in keys:
+                old = opt[k]
+                new_res = tuple(2 * r for r in old.shape[:3]) + (old.shape[-1],)
+                opt[k] = upsample_grid(old, new_res)
+                params[k] = opt[k]
+            factor = adjusted_majorant_res_factor(scene_config.majorant_resolution_factor, params[SIGMA_T_KEY].shape)
+            scene = _scene_with(scene, params, factor)
+        leaves = {k: params[k].detach().requires_grad_(True) for k in integrator.param_keys}
+        if opt_config.batch_size is not None:                          # batched rendering (:332-341)
+            image, _, _, sensor_idx, pixel_idx = render_batch(
+                opt_config.batch_size, scene, sensors=sensors, params=leaves, integrator=integrator,
+                spp=spp_primal, spp_grad=spp_grad, seed=seed, seed_grad=seed_grad, sensor_table=table)
+            ref_values = gather_ref_values(ref_images, sensor_idx, pixel_idx)
+        else:                                                          # sensor-based rendering (:342-348)
+            s_i = int(torch.rand((), generator=host_rng).item() * n_sensors)
+            image = render(scene, params=leaves, integrator=integrator, sensor=s_i, spp=spp_primal,
+                           spp_grad=spp_grad, seed=seed, seed_grad=seed_grad)
+            ref_values = ref_images[s_i].reshape(-1, 3)
+        loss_value = opt_config.loss(image, ref_values)
+        loss_value.backward()                                          # dr.backward (:350)
+        opt.step({k: leaves[k].grad for k in keys if k in leaves})     # :352
+        enforce_valid_params(scene_config, opt)                        # :353
+        history.append(float(loss_value.detach()))
+        if output_dir and it_i > 0 and opt_config.checkpoint_stride and it_i % opt_config.checkpoint_stride == 0:
+            save_params(os.path.join(output_dir, 'params'), scene_config, params, f'{it_i:08d}', scene.medium)
+        if progress:
+            progress(it_i, history[-1])
+    if output_dir and opt_config.checkpoint_final:
+        os.makedirs(os.path.join(output_dir, 'params'), exist_ok=True)
+        save_params(os.path.join(output_dir, 'params'), scene_config, params, 'final', scene.medium)
+    return scene, params, opt, history
