@@ -372,11 +372,15 @@ __device__ __forceinline__ void stencil_indices(const Stencil &s, int idx[8])
 constexpr int kCoopDwords = 32;   // per lane: 8 indices + 3 x 8 values
 constexpr int kOccWords = 1024;   // empty-space bitmask: at most 32768 cells = 4 KiB of LDS per workgroup
 
+// Lanes of ONE wavefront exchange records through LDS.  The hardware executes a wave's DS
+// instructions in order, so all that is needed is (1) that the compiler neither reorders nor caches
+// LDS accesses across this point - wavefront-scope fences alone were observed NOT to guarantee that
+// (stale records, wrong gradients) - and (2) that outstanding LDS operations have landed.
 __device__ __forceinline__ void coop_stage_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 template <int NCH>
@@ -410,6 +414,7 @@ __device__ __forceinline__ void coop_scatter(float *dst, uint32_t chan_stride, c
 
 __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, uint32_t *rec)
 {
+    if (g == 0.0f) return;            // adding exact zeros changes nothing: skip the requests
     float w[8]; int idx[8];
     make_grad_indices(P, p, idx, w);
     float gs = g * P.scale;
@@ -427,6 +432,7 @@ __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, ui
 
 __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float g[3], uint32_t *rec)
 {
+    if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) return;   // e.g. nerf queries in empty space (weight 0)
     float w[8]; int idx[8];
     make_grad_indices(P, p, idx, w);
     if (P.debug_flags & 1u) return;

@@ -114,6 +114,7 @@ __device__ __forceinline__ float collide(const Params &P, float maj, float inv_m
 // splat share one 64-byte line: one atomic request per splat.
 __device__ __forceinline__ void wave_splat_sigma(const Params &P, bool pending, V3 p, float g, uint32_t *rec)
 {
+    pending = pending && g != 0.0f;   // exact zeros change nothing
     const uint64_t mask = __ballot(pending);
     if (!mask) return;
     const uint32_t lane = __lane_id();
