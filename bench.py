@@ -70,11 +70,18 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the DRT integrator has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DRT_BENCH_SAME_DEVICE=1 (with DRT_BENCH_BACKEND=gloo) lets the multi-rank path be smoke-tested on
+    # a single-GPU box; real runs use one GPU per rank over RCCL ("nccl")
+    dev_index = 0 if os.environ.get("DRT_BENCH_SAME_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("DRT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     # ---- workload (synthetic, seeded; resident in HBM) ---------------------------------
     if args.workload == "dust-devil":
