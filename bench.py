@@ -134,8 +134,9 @@ def main():
         step(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
-    t_primal = h.read_timings(False)
-    t_adjoint = h.read_timings(True)
+    t_primal = h.read_timings(0)
+    t_adjoint = h.read_timings(1)
+    t_untile = h.read_timings(2)
     h.enable_timing(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -228,6 +229,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "t_primal_ms": round(avg_p, 3), "t_adjoint_ms": round(avg_a, 3),
+            "t_grad_reduce_ms": round(sum(t_untile) / max(1, len(t_untile)), 3),
             "counters_primal": cnt_p, "counters_adjoint": cnt_a,
         }
         if args.debug_flags:

@@ -40,7 +40,7 @@ struct drt_handle_s {
     int occ_z = 0;
     bool timing = false;
     // HIP event pairs around every tracing launch while timing is on: [0] primal, [1] backward
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[2];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[3];   // primal, adjoint, gradient reduction
     std::string error;
 };
 
@@ -156,6 +156,22 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
         h->timed[which].emplace_back(a, b);
+    }
+    return DRT_OK;
+}
+
+int timed_untile(drt_handle h, const drt::Params &P)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventCreate(&a));
+        DRT_HIP_CHECK(h, hipEventCreate(&b));
+        DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
+    }
+    DRT_HIP_CHECK(h, drt::launch_untile(P, h->stream));
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
+        h->timed[2].emplace_back(a, b);
     }
     return DRT_OK;
 }
@@ -401,8 +417,7 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
     rc = timed_launch(h, 1, P, true);
     if (rc) return rc;
-    DRT_HIP_CHECK(h, drt::launch_untile(P, h->stream));
-    return DRT_OK;
+    return timed_untile(h, P);
 }
 
 static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, const float *emission)
@@ -448,8 +463,7 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
     if (rc) return rc;
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_emission;
     DRT_HIP_CHECK(h, drt::launch_nerf(P, true, h->counting, h->stream));
-    DRT_HIP_CHECK(h, drt::launch_untile(P, h->stream));
-    return DRT_OK;
+    return timed_untile(h, P);
 }
 
 int drt_batch_sample_rays(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_size, uint32_t spp,
@@ -548,7 +562,8 @@ int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity)
     if (capacity > 0 && !out_ms) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null out_ms");
     DeviceGuard g(h->device);
     DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    auto &v = h->timed[backward ? 1 : 0];
+    if (backward < 0 || backward > 2) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_read_timings: kind must be 0, 1 or 2");
+    auto &v = h->timed[backward];
     int n = (int) v.size();
     for (int i = 0; i < n && i < capacity; ++i)
         DRT_HIP_CHECK(h, hipEventElapsedTime(out_ms + i, v[i].first, v[i].second));

@@ -657,36 +657,123 @@ __global__ void __launch_bounds__(256) brick_sigma_kernel(const float *src, floa
 
 // Gradient scratch (apron layout, make_grad_indices) -> caller's (Z,Y,X,1) / (Z,Y,X,3) buffers:
 // sum the up to 8 slots of every voxel, += into the caller's grids (the ABI accumulates) and reset
-// the scratch for the next launch.  One thread per voxel; each slot belongs to exactly one voxel.
-__global__ void __launch_bounds__(256) untile_gradients_kernel(const Params P, uint32_t n_voxels)
+// the scratch for the next launch.  Each slot belongs to exactly one voxel.
+//
+// Streaming form: a thread owns the LINE column (bx, y_begin..y_end, Z), i.e. the voxels
+// X = 3bx..3bx+2 of row Z, and marches y along consecutive line-rows with 16-byte loads.  Line
+// (z, y, bx) holds contributions to voxel rows (y, z) [quad 0], (y+1, z) [quad 1], (y, z+1)
+// [quad 2] and (y+1, z+1) [quad 3]: the thread reads quads 0/1 of its own line and quads 2/3 of
+// line (Z-1, y, bx) (the neighbour wave's own line: L1 hit), carries the dy = 1 quads in registers
+// to the next step, and takes the seam slot (slot 3 of line bx-1 is voxel 3bx) from the previous
+// lane.  Every 64-byte line crosses the L1 four times (one-dword-per-voxel gathers crossed it 16
+// times and were bound by that, 2 TB/s) and HBM about once.  The summation order per voxel is
+// fixed (dz, dy, own slot before seam slot): the result does not depend on the decomposition.
+constexpr int kUntileLanes = 32;                    // lines along x per workgroup row
+constexpr int kUntileRows = 8;                      // z rows per workgroup
+
+struct Quad { float v[4]; };
+
+// read a 16-byte quad and reset it; the consumer of slot 3 is the next line's thread: when that is
+// another wave (`keep3`), slot 3 is left for it to reset
+__device__ __forceinline__ Quad take_quad(float *p, bool keep3, bool wr)
 {
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;                       // plane: 0 sigma_t, 1..3 albedo / emission rgb
-    if (v >= n_voxels) return;
-    const int X = (int)(v % (uint32_t) P.rx); uint32_t t = v / (uint32_t) P.rx;
-    const int Y = (int)(t % (uint32_t) P.ry), Z = (int)(t / (uint32_t) P.ry);
-    const int bx0 = X / 3, ox = X - 3 * bx0;
-    float *plane = P.gt + (size_t) c * P.gt_plane;
-    float acc = 0.0f;
+    const float4 q = *reinterpret_cast<const float4 *>(p);
+    if (wr && (q.x != 0.0f || q.y != 0.0f || q.z != 0.0f || q.w != 0.0f)) {
+        if (!keep3) *reinterpret_cast<float4 *>(p) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        else { p[0] = 0.0f; p[1] = 0.0f; p[2] = 0.0f; }
+    }
+    Quad r; r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+    return r;
+}
+
+__device__ __forceinline__ float take_slot(float *p, bool wr)
+{
+    float g = *p;
+    if (wr && g != 0.0f) *p = 0.0f;
+    return g;
+}
+
+// slot 3 of the previous line: from the previous lane, or (first lane of a row segment) from memory
+__device__ __forceinline__ float seam_value(const Quad &q, float *line, int quad, bool first, bool have_prev, bool active, bool wr)
+{
+    float s = __shfl_up(q.v[3], 1);
+    if (first) s = (have_prev && active) ? take_slot(line - 16 + 4 * quad + 3, wr) : 0.0f;
+    return s;
+}
+
+template <int NPL>
+__device__ __forceinline__ void untile_march(const Params &P, int plane0, int bx, int Z, int y_begin, int y_end, bool valid)
+{
+    const bool first = (threadIdx.x & (kUntileLanes - 1)) == 0;
+    const bool last_lane = (threadIdx.x & (kUntileLanes - 1)) == kUntileLanes - 1;
+    const bool have_prev = bx > 0;
+    const bool keep3 = last_lane && bx + 1 < P.gt_nbx;      // slot 3 is read by another wave's first lane
+    const bool has_z = Z > 0;
+    const bool wr = !(P.debug_flags & 64u);
+    const size_t row = (size_t) P.gt_nbx << 4;              // floats per line-row
+    const int X = 3 * bx, nvx = min(3, P.rx - X);           // voxels of this line that exist
+    Quad c1[NPL], c3[NPL];                                  // dy = 1 quads of the previous step
+    float s1[NPL], s3[NPL];                                 // ... and their seam values
+    const Quad zero = {{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
-    for (int dz = 0; dz < 2; ++dz) {
+    for (int k = 0; k < NPL; ++k) { c1[k] = zero; c3[k] = zero; s1[k] = 0.0f; s3[k] = 0.0f; }
+    for (int y = max(y_begin - 1, 0); y < y_end; ++y) {
+        const bool out = valid && y >= y_begin;             // dy = 0 quads feed voxel row Y = y (ours)
+        const bool keep = valid && y + 1 < y_end;           // dy = 1 quads feed voxel row Y = y + 1 (ours?)
+        const size_t offA = ((size_t) Z * P.ry + y) * row + ((size_t) bx << 4);     // line (Z, y, bx)
+        const size_t offB = offA - (size_t) P.ry * row;                             // line (Z - 1, y, bx)
+        float acc[NPL][3];
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            const int z = Z - dz, y = Y - dy;
-            if (z < 0 || y < 0) continue;
-            float *line = plane + ((((size_t) z * P.ry + y) * P.gt_nbx + bx0) << 4) + (dz * 2 + dy) * 4;
-            float g = line[ox];
-            if (g != 0.0f) { acc += g; line[ox] = 0.0f; }
-            if (ox == 0 && bx0 > 0) {               // slot 3 of the previous block is this voxel too
-                float g3 = line[-13];               // (line - 16)[3]
-                if (g3 != 0.0f) { acc += g3; line[-13] = 0.0f; }
+        for (int k = 0; k < NPL; ++k) {
+            float *plane = P.gt + (size_t) (plane0 + k) * P.gt_plane;
+            float *A = plane + offA, *B = plane + offB;
+            Quad q0 = zero, q1 = zero, q2 = zero, q3 = zero;
+            if (out) q0 = take_quad(A, keep3, wr);
+            if (keep) q1 = take_quad(A + 4, keep3, wr);
+            if (out && has_z) q2 = take_quad(B + 8, keep3, wr);
+            if (keep && has_z) q3 = take_quad(B + 12, keep3, wr);
+            const float e0 = seam_value(q0, A, 0, first, have_prev, out, wr);
+            const float e1 = seam_value(q1, A, 1, first, have_prev, keep, wr);
+            const float e2 = seam_value(q2, B, 2, first, have_prev, out && has_z, wr);
+            const float e3 = seam_value(q3, B, 3, first, have_prev, keep && has_z, wr);
+            // fixed order: (dz0,dy0) (dz0,dy1) (dz1,dy0) (dz1,dy1), own slot then seam slot
+            float a0 = 0.0f;
+            a0 += q0.v[0]; a0 += e0; a0 += c1[k].v[0]; a0 += s1[k]; a0 += q2.v[0]; a0 += e2; a0 += c3[k].v[0]; a0 += s3[k];
+            acc[k][0] = a0;
+#pragma unroll
+            for (int j = 1; j < 3; ++j) {
+                float a = 0.0f;
+                a += q0.v[j]; a += c1[k].v[j]; a += q2.v[j]; a += c3[k].v[j];
+                acc[k][j] = a;
+            }
+            c1[k] = q1; c3[k] = q3; s1[k] = e1; s3[k] = e3;
+        }
+        if (out) {
+            const size_t v = ((size_t) Z * P.ry + y) * P.rx + X;
+            for (int j = 0; j < nvx; ++j) {
+                if (NPL == 1) {
+                    if (acc[0][j] != 0.0f) P.g_sigma[v + j] += acc[0][j];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k)
+                        if (acc[k][j] != 0.0f) P.g_albedo[3 * (v + j) + k] += acc[k][j];
+                }
             }
         }
     }
-    if (acc != 0.0f) {
-        if (c == 0) P.g_sigma[v] += acc;
-        else P.g_albedo[3 * (size_t) v + (c - 1)] += acc;
-    }
+}
+
+__global__ void __launch_bounds__(kUntileLanes * kUntileRows) untile_gradients_kernel(const Params P, int n_chunks, int chunk)
+{
+    const int bx = blockIdx.x * kUntileLanes + (threadIdx.x & (kUntileLanes - 1));
+    const int Z = blockIdx.y * kUntileRows + (threadIdx.x / kUntileLanes);
+    const int group = blockIdx.z / n_chunks;        // 0: sigma_t plane, 1: the three colour planes
+    const int y_begin = (blockIdx.z - group * n_chunks) * chunk;
+    const int y_end = min(y_begin + chunk, P.ry);
+    const bool valid = bx < P.gt_nbx && Z < P.rz;   // invalid lanes stay for the shuffles
+    const int bxc = valid ? bx : 0, Zc = valid ? Z : 0;
+    if (group == 0) untile_march<1>(P, 0, bxc, Zc, y_begin, y_end, valid);
+    else untile_march<3>(P, 1, bxc, Zc, y_begin, y_end, valid);
 }
 
 // sample_batch_pixels + sample_batch_rays (python/batched.py:397-467): one thread per ray r of the
@@ -844,8 +931,11 @@ hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t st
 
 hipError_t launch_untile(const Params &P, hipStream_t stream)
 {
-    uint32_t n = (uint32_t) P.rx * P.ry * P.rz;
-    hipLaunchKernelGGL(untile_gradients_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, stream, P, n);
+    static const int chunk = [] { const char *e = getenv("DRT_UNTILE_CHUNK"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
+    const int nc = (P.ry + chunk - 1) / chunk;
+    hipLaunchKernelGGL(untile_gradients_kernel,
+                       dim3((P.gt_nbx + kUntileLanes - 1) / kUntileLanes, (P.rz + kUntileRows - 1) / kUntileRows, nc * 2),
+                       dim3(kUntileLanes * kUntileRows), 0, stream, P, nc, chunk);
     return hipGetLastError();
 }
 

@@ -194,13 +194,13 @@ public:
         return d;
     }
     void enable_timing(bool on) { check(drt_enable_timing(h_, on ? 1 : 0), "drt_enable_timing"); }
-    std::vector<float> read_timings(bool backward)
+    std::vector<float> read_timings(int kind)
     {
-        int n = drt_read_timings(h_, backward ? 1 : 0, nullptr, 0);
+        int n = drt_read_timings(h_, kind, nullptr, 0);
         if (n < 0) check(n, "drt_read_timings");
         std::vector<float> out((size_t) n);
         if (n > 0) {
-            int rc = drt_read_timings(h_, backward ? 1 : 0, out.data(), n);
+            int rc = drt_read_timings(h_, kind, out.data(), n);
             if (rc < 0) check(rc, "drt_read_timings");
         }
         return out;
