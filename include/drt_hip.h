@@ -99,6 +99,18 @@ int drt_params_changed(drt_handle h);
  * supports infinite emitters (volpathsimple.py:16). */
 int drt_set_emitter_constant(drt_handle h, const float radiance[3]);
 
+/* `envmap` emitter (python/scene_config.py:102,152,210,262,313; used at
+ * volpathsimple.py:273 pdf_direction, :284 eval, :419 sample_emitter_direction).
+ * `pixels`: DEVICE pointer to a lat-long RGB bitmap [height][width][3] f32 (row 0 =
+ * the +Y pole); the library takes its own copy and builds the importance-sampling
+ * tables (synchronises the stream), so the caller's buffer may be released.
+ * `to_world`: row-major 3x3 rotation; radiance = bilinear lookup x scale.
+ * Local direction (sin phi sin theta, cos theta, -cos phi sin theta) <-> uv =
+ * (phi / 2pi, theta / pi).  Replaces a previously set constant emitter and vice
+ * versa.  No envmap gradients (volpathsimple.py:283 TODO). */
+int drt_set_emitter_envmap(drt_handle h, const float *pixels, int32_t width, int32_t height,
+                           const float to_world[9], float scale);
+
 /* `perspective` sensor + box-filter hdrfilm used by mi.render
  * (tests/test_integrators.py:46-67; python/optimize.py:44,129,345). */
 int drt_set_sensor_perspective(drt_handle h, const float origin[3], const float left[3],
@@ -182,7 +194,8 @@ int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity);
  * the oracle.  op: 0 log, 1 sincos(2 pi u), 2 square_to_uniform_sphere, 3 sigma_t(p),
  * 4 albedo(p), 5 box hit (o,d) -> valid,t,n, 6 PCG32 floats of (seed,index) bit
  * patterns, 7 sensor ray (pixel bits, ux, uy), 8 mis_weight / div / sqrt / fma,
- * 9 majorant supergrid cell (index bits), 10 exp. */
+ * 9 majorant supergrid cell (index bits), 10 exp, 11 atan2(y, x), 12 envmap eval(d)
+ * rgb + pdf_direction(d), 13 envmap sample_direction(u1, u2) -> d, pdf. */
 int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out);
 
 /* Profiling ablations / kernel selection for experiments; 0 in production.

@@ -31,7 +31,20 @@ class Medium(C.Structure):
 
 
 class Emitter(C.Structure):
-    _fields_ = [("radiance", C.c_float * 3)]
+    _fields_ = [("radiance", C.c_float * 3), ("pixels", C.POINTER(C.c_float)), ("width", C.c_int32),
+                ("height", C.c_int32), ("to_world", C.c_float * 9), ("scale", C.c_float)]
+
+
+def make_emitter(emitter):
+    """drto_emitter of a scene emitter (ConstantEmitter / EnvmapEmitter); returns (struct, keepalive)."""
+    if hasattr(emitter, "pixels"):
+        pix = _f32(emitter.pixels)
+        assert pix.ndim == 3 and pix.shape[2] == 3
+        e = Emitter((C.c_float * 3)(0, 0, 0), _fp(pix), pix.shape[1], pix.shape[0],
+                    (C.c_float * 9)(*emitter.to_world_flat()), float(emitter.scale))
+        return e, pix
+    e = Emitter((C.c_float * 3)(*emitter.radiance))
+    return e, None
 
 
 class Sensor(C.Structure):
@@ -62,7 +75,10 @@ class Job(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH):
+    src_newer = (not os.path.exists(_LIB_PATH) or
+                 any(os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+                     for f in ("drt_oracle.c", "drt_oracle.h", "Makefile")))
+    if force or src_newer:
         subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True,
                        stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -113,6 +129,13 @@ def lib():
         L.drto_sensor_ray.restype = None
         L.drto_alt_seed.argtypes = [C.c_uint32, C.c_int]
         L.drto_alt_seed.restype = C.c_uint32
+        L.drto_atan2f.argtypes = [C.c_float, C.c_float]
+        L.drto_atan2f.restype = C.c_float
+        L.drto_envmap_eval.argtypes = [C.POINTER(Emitter), fp, fp]
+        L.drto_envmap_pdf.argtypes = [C.POINTER(Emitter), fp]
+        L.drto_envmap_pdf.restype = C.c_float
+        L.drto_envmap_sample.argtypes = [C.POINTER(Emitter), C.c_float, C.c_float, fp, fp, fp]
+        L.drto_envmap_tables.argtypes = [C.POINTER(Emitter), fp, fp]
         _lib = L
     return _lib
 
@@ -156,7 +179,7 @@ class OracleScene:
         self.medium = Medium(_fp(self.sigma_t), _fp(self.albedo), (C.c_int32 * 3)(x, y, z),
                              (C.c_float * 3)(*m.bbox_min), (C.c_float * 3)(*m.bbox_max),
                              float(m.scale), int(getattr(m, "majorant_resolution_factor", 0)))
-        self.emitter = Emitter((C.c_float * 3)(*scene.emitter.radiance))
+        self.emitter, self._emitter_pixels = make_emitter(scene.emitter)
         self.sensor = None
         self.film = None
         if sensor_index is not None and scene.sensors:
@@ -315,3 +338,37 @@ def bytes_per_sample(cnt: dict, n_samples: int) -> float:
     b = (60 * n + 32 * (cnt["n_dt"] + cnt["n_rt"] + cnt["n_drt"]) + 96 * cnt["n_alb"]
          + 64 * (cnt["n_tr"] + cnt["n_rt_adj"] + cnt["n_sc"]) + 192 * cnt["n_sc_alb"])
     return b / n
+
+
+# ---- envmap emitter primitives (test hooks) ---------------------------------------------------
+def envmap_eval(emitter, d):
+    e, keep = make_emitter(emitter)
+    dd = np.ascontiguousarray(d, dtype=np.float32)
+    out = np.zeros(3, np.float32)
+    lib().drto_envmap_eval(C.byref(e), _fp(dd), _fp(out))
+    return out
+
+
+def envmap_pdf(emitter, d):
+    e, keep = make_emitter(emitter)
+    dd = np.ascontiguousarray(d, dtype=np.float32)
+    return float(lib().drto_envmap_pdf(C.byref(e), _fp(dd)))
+
+
+def envmap_sample(emitter, u1, u2):
+    """-> (direction[3], pdf, radiance / pdf [3])"""
+    e, keep = make_emitter(emitter)
+    d, w, pdf = np.zeros(3, np.float32), np.zeros(3, np.float32), C.c_float(0)
+    rc = lib().drto_envmap_sample(C.byref(e), float(u1), float(u2), _fp(d), C.byref(pdf), _fp(w))
+    assert rc == 0
+    return d, float(pdf.value), w
+
+
+def envmap_tables(emitter):
+    """-> (marginal CDF [h+1], conditional CDFs [h, w+1])"""
+    e, keep = make_emitter(emitter)
+    marg = np.zeros(e.height + 1, np.float32)
+    cond = np.zeros((e.height, e.width + 1), np.float32)
+    rc = lib().drto_envmap_tables(C.byref(e), _fp(marg), _fp(cond))
+    assert rc == 0
+    return marg, cond

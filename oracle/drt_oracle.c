@@ -183,6 +183,209 @@ static inline float mis_weight(float a, float b)
     return isfinite(w) ? w : 0.0f;
 }
 
+/* atan2 with a specified instruction sequence (Cephes atanf polynomial on min/max in [0,1]); the
+ * HIP kernels evaluate the same sequence, so envmap lookups are bit-identical.  atan2(0,0) = 0. */
+static inline float drt_atan2f(float y, float x)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float t = mx != 0.0f ? mn / mx : 0.0f;
+    float y0 = 0.0f, z = t;
+    if (t > 0.4142135624f) { y0 = 0.78539816339744831f; z = (t - 1.0f) / (t + 1.0f); }
+    float zz = z * z;
+    float p = fmaf(fmaf(fmaf(8.05374449538e-2f, zz, -1.38776856032e-1f), zz, 1.99777106478e-1f), zz, -3.33329491539e-1f);
+    float a = y0 + fmaf(p * zz, z, z);
+    if (ay > ax) a = 1.57079632679489662f - a;
+    if (x < 0.0f) a = 3.14159265358979323846f - a;
+    return y < 0.0f ? -a : a;
+}
+
+/* ------------------------------------------------------------------------- */
+/* envmap emitter (E5) [M3-ext]: see drto_emitter in drt_oracle.h             */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    const float *pix;            /* [h][w][3], NULL = constant emitter */
+    int w, h;
+    float R[9];                  /* to_world, row-major */
+    float scale;
+    float *marg;                 /* [h+1] marginal CDF over rows */
+    float *cond;                 /* [h][w+1] conditional CDFs over columns */
+} envmap_t;
+
+#define DRT_INV_TWOPI 0.15915494309189535f
+#define DRT_INV_PI    0.31830988618379069f
+#define DRT_TWO_PI_SQ 19.739208802178716f    /* 2 pi^2 */
+#define DRT_ONE_MINUS_EPS 0.99999994f
+
+/* Importance-sampling tables.  Double accumulation, one rounding to float per entry; the HIP
+ * library's host code (drt_capi.cpp) performs the same loop. */
+static int envmap_build(envmap_t *e)
+{
+    const int w = e->w, h = e->h;
+    e->marg = (float *) malloc(sizeof(float) * (size_t)(h + 1));
+    e->cond = (float *) malloc(sizeof(float) * (size_t) h * (size_t)(w + 1));
+    double *lum = (double *) malloc(sizeof(double) * (size_t) w * h);
+    double *rowsum = (double *) malloc(sizeof(double) * (size_t) h);
+    if (!e->marg || !e->cond || !lum || !rowsum) { free(lum); free(rowsum); return -4; }
+    double lmax = 0.0;
+    for (size_t i = 0; i < (size_t) w * h; ++i) {
+        const float *p = e->pix + 3 * i;
+        double l = 0.212671 * (double) p[0] + 0.715160 * (double) p[1] + 0.072169 * (double) p[2];
+        lum[i] = l > 0.0 ? l : 0.0;
+        if (lum[i] > lmax) lmax = lum[i];
+    }
+    const int uniform = !(lmax > 0.0);                   /* all-black map: uniform weights */
+    double total = 0.0;
+    for (int j = 0; j < h; ++j) {
+        const double st = sin(3.14159265358979323846 * ((double) j + 0.5) / (double) h);
+        float *c = e->cond + (size_t) j * (w + 1);
+        double run = 0.0;
+        for (int i = 0; i < w; ++i) {
+            double m = uniform ? 1.0 : 0.0;
+            if (!uniform)
+                for (int dj = -1; dj <= 1; ++dj) for (int di = -1; di <= 1; ++di) {
+                    int jj = j + dj, ii = (i + di + w) % w;
+                    jj = jj < 0 ? 0 : (jj > h - 1 ? h - 1 : jj);
+                    double l = lum[(size_t) jj * w + ii];
+                    if (l > m) m = l;
+                }
+            run += m * st;
+            c[i + 1] = (float) run;                      /* unnormalised for now */
+        }
+        rowsum[j] = run;
+        total += run;
+        c[0] = 0.0f;
+        for (int i = 0; i < w; ++i)
+            c[i + 1] = run > 0.0 ? (float)((double) c[i + 1] / run) : (float)((double)(i + 1) / (double) w);
+        c[w] = 1.0f;
+    }
+    double run = 0.0;
+    e->marg[0] = 0.0f;
+    for (int j = 0; j < h; ++j) { run += rowsum[j]; e->marg[j + 1] = (float)(run / total); }
+    e->marg[h] = 1.0f;
+    free(lum); free(rowsum);
+    return 0;
+}
+
+static void envmap_free(envmap_t *e) { free(e->marg); free(e->cond); e->marg = e->cond = NULL; }
+
+/* bilinear lookup at uv in [0,1)^2: texel centres at ((i+.5)/w, (j+.5)/h), wrap in u, clamp in v */
+static inline void envmap_lookup(const envmap_t *e, float u, float v, float out[3])
+{
+    float px = fmaf(u, (float) e->w, -0.5f), py = fmaf(v, (float) e->h, -0.5f);
+    float fx0 = floorf(px), fy0 = floorf(py);
+    float fx = px - fx0, fy = py - fy0;
+    int i0 = (int) fx0, j0 = (int) fy0;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    if (i0 < 0) i0 += e->w;
+    if (i1 >= e->w) i1 -= e->w;
+    j0 = j0 < 0 ? 0 : (j0 > e->h - 1 ? e->h - 1 : j0);
+    j1 = j1 < 0 ? 0 : (j1 > e->h - 1 ? e->h - 1 : j1);
+    const float *p00 = e->pix + 3 * ((size_t) j0 * e->w + i0), *p01 = e->pix + 3 * ((size_t) j0 * e->w + i1);
+    const float *p10 = e->pix + 3 * ((size_t) j1 * e->w + i0), *p11 = e->pix + 3 * ((size_t) j1 * e->w + i1);
+    float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+    for (int k = 0; k < 3; ++k) {
+        float a = fmaf(wx0, p00[k], fx * p01[k]);
+        float b = fmaf(wx0, p10[k], fx * p11[k]);
+        out[k] = fmaf(wy0, a, fy * b) * e->scale;
+    }
+}
+
+/* world direction -> uv, sin(theta) */
+static inline void envmap_dir_to_uv(const envmap_t *e, v3 d, float *u, float *v, float *sin_theta)
+{
+    const float *R = e->R;                               /* local = R^T d */
+    float lx = fmaf(R[6], d.z, fmaf(R[3], d.y, R[0] * d.x));
+    float ly = fmaf(R[7], d.z, fmaf(R[4], d.y, R[1] * d.x));
+    float lz = fmaf(R[8], d.z, fmaf(R[5], d.y, R[2] * d.x));
+    float st = sqrtf(fmaf(lx, lx, lz * lz));
+    float uu = drt_atan2f(lx, -lz) * DRT_INV_TWOPI;
+    if (uu < 0.0f) uu += 1.0f;
+    if (uu >= 1.0f) uu = 0.0f;
+    float vv = drt_atan2f(st, ly) * DRT_INV_PI;
+    vv = fminf(fmaxf(vv, 0.0f), DRT_ONE_MINUS_EPS);
+    *u = uu; *v = vv; *sin_theta = st;
+}
+
+/* texel probability density in uv space: pmf(row) * pmf(col | row) * w * h */
+static inline float envmap_pdf_uv(const envmap_t *e, int i, int j)
+{
+    const float *c = e->cond + (size_t) j * (e->w + 1);
+    float pm = e->marg[j + 1] - e->marg[j], pc = c[i + 1] - c[i];
+    return (pm * pc) * ((float) e->w * (float) e->h);
+}
+
+/* Emitter::eval for an escaped ray of direction d (volpathsimple.py:284) */
+static inline void envmap_eval(const envmap_t *e, v3 d, float out[3])
+{
+    float u, v, st;
+    envmap_dir_to_uv(e, d, &u, &v, &st);
+    envmap_lookup(e, u, v, out);
+}
+
+/* Emitter::pdf_direction (volpathsimple.py:273) */
+static inline float envmap_pdf(const envmap_t *e, v3 d)
+{
+    float u, v, st;
+    envmap_dir_to_uv(e, d, &u, &v, &st);
+    int i = (int)(u * (float) e->w), j = (int)(v * (float) e->h);
+    if (i > e->w - 1) i = e->w - 1;
+    if (j > e->h - 1) j = e->h - 1;
+    float den = DRT_TWO_PI_SQ * st;
+    return den > 0.0f ? envmap_pdf_uv(e, i, j) / den : 0.0f;
+}
+
+/* largest k in [0, n-1] with cdf[k] <= x (cdf[0] = 0, cdf[n] = 1, x in [0,1)) */
+static inline int cdf_find(const float *cdf, int n, float x)
+{
+    int lo = 0, hi = n;                                  /* invariant: cdf[lo] <= x < cdf[hi] */
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+/* Scene::sample_emitter_direction (volpathsimple.py:419): direction, pdf, radiance / pdf.  The pdf
+ * and the radiance are evaluated FROM THE DIRECTION (as pdf_direction / eval do for an escaped
+ * ray), so NEE and the escape-side MIS weight see the same density. */
+static inline v3 envmap_sample_dir(const envmap_t *e, float u1, float u2)
+{
+    int j = cdf_find(e->marg, e->h, u2);
+    const float *c = e->cond + (size_t) j * (e->w + 1);
+    int i = cdf_find(c, e->w, u1);
+    float dv = fminf((u2 - e->marg[j]) / (e->marg[j + 1] - e->marg[j]), DRT_ONE_MINUS_EPS);
+    float du = fminf((u1 - c[i]) / (c[i + 1] - c[i]), DRT_ONE_MINUS_EPS);
+    float u = ((float) i + du) / (float) e->w, v = ((float) j + dv) / (float) e->h;
+    float sp, cp, st, ct;
+    drt_sincos_2pi(u, &sp, &cp);
+    drt_sincos_2pi(0.5f * v, &st, &ct);
+    float lx = sp * st, ly = ct, lz = -(cp * st);
+    const float *R = e->R;                               /* world = R local */
+    v3 d;
+    d.x = fmaf(R[2], lz, fmaf(R[1], ly, R[0] * lx));
+    d.y = fmaf(R[5], lz, fmaf(R[4], ly, R[3] * lx));
+    d.z = fmaf(R[8], lz, fmaf(R[7], ly, R[6] * lx));
+    return d;
+}
+
+static inline void envmap_sample(const envmap_t *e, float u1, float u2, v3 *d, float *pdf, float weight[3])
+{
+    *d = envmap_sample_dir(e, u1, u2);
+    float p = envmap_pdf(e, *d), Le[3];
+    envmap_eval(e, *d, Le);
+    *pdf = p;
+    for (int k = 0; k < 3; ++k) weight[k] = p > 0.0f ? Le[k] / p : 0.0f;
+}
+
+static int envmap_from_emitter(envmap_t *e, const drto_emitter *em)
+{
+    if (em->width < 2 || em->height < 2) return -2;
+    e->pix = em->pixels; e->w = em->width; e->h = em->height; e->scale = em->scale;
+    for (int k = 0; k < 9; ++k) e->R[k] = em->to_world[k];
+    return envmap_build(e);
+}
+
 /* ------------------------------------------------------------------------- */
 /* scene                                                                      */
 /* ------------------------------------------------------------------------- */
@@ -197,6 +400,7 @@ typedef struct {
     int gx, gy, gz;
     float *mgrid;
     float Le[3];
+    envmap_t env;                /* env.pix != NULL: envmap emitter instead of the constant Le */
 } scene_t;
 
 typedef struct {
@@ -437,17 +641,28 @@ static float estimate_transmittance(ctx_t *c, v3 o, v3 d, float tmax, pcg32 *S, 
     return T;
 }
 
-/* A7: sample_emitter (volpathsimple.py:406-433), constant emitter. Returns
- * emitter_val * transmittance (RGB) in out[]. */
-static void sample_emitter(ctx_t *c, v3 p, pcg32 *S, const float *adj, float out[3])
+/* A7: sample_emitter (volpathsimple.py:406-433).  Returns emitter_val * transmittance (RGB) in
+ * out[] and ds.pdf in *ds_pdf. */
+static void sample_emitter(ctx_t *c, v3 p, pcg32 *S, const float *adj, float out[3], float *ds_pdf)
 {
     const scene_t *sc = c->sc;
     float ux = next_1d(S), uy = next_1d(S);              /* :418 */
-    v3 wd = square_to_uniform_sphere(ux, uy);            /* constant::sample_direction */
-    si_t si = box_hit(sc, p, wd);                        /* mei.spawn_ray: no offset (n=0) :427-428 */
+    v3 wd;
+    float pdf, val[3];
+    if (sc->env.pix) {
+        envmap_sample(&sc->env, ux, uy, &wd, &pdf, val); /* envmap::sample_direction */
+    } else {
+        wd = square_to_uniform_sphere(ux, uy);           /* constant::sample_direction */
+        pdf = DRT_INV_FOURPI;
+        for (int k = 0; k < 3; ++k) val[k] = sc->Le[k] * DRT_FOURPI;    /* radiance / pdf */
+    }
+    *ds_pdf = pdf;
     float T = 0.0f;
-    if (si.valid) T = estimate_transmittance(c, p, wd, si.t, S, adj);
-    for (int k = 0; k < 3; ++k) out[k] = (sc->Le[k] * DRT_FOURPI) * T;  /* radiance / pdf */
+    if (pdf != 0.0f) {                                   /* sampling_worked :421-423 */
+        si_t si = box_hit(sc, p, wd);                    /* mei.spawn_ray: no offset (n=0) :427-428 */
+        if (si.valid) T = estimate_transmittance(c, p, wd, si.t, S, adj);
+    }
+    for (int k = 0; k < 3; ++k) out[k] = val[k] * T;
 }
 
 /* A7: sample_emitter_for_nee (volpathsimple.py:380-403) */
@@ -455,15 +670,15 @@ static void sample_emitter_for_nee(ctx_t *c, v3 p, pcg32 *S, const float beta[3]
                                    float contrib[3])
 {
     pcg32 clone = *S;                                    /* :383 */
-    float emitted[3];
-    sample_emitter(c, p, S, NULL, emitted);              /* :385 */
-    float w = mis_weight(DRT_INV_FOURPI, DRT_INV_FOURPI);/* ds.pdf vs phase_pdf :391 */
+    float emitted[3], ds_pdf;
+    sample_emitter(c, p, S, NULL, emitted, &ds_pdf);     /* :385 */
+    float w = mis_weight(ds_pdf, DRT_INV_FOURPI);        /* ds.pdf vs phase_pdf :391 */
     for (int k = 0; k < 3; ++k)
         contrib[k] = ((beta[k] * DRT_INV_FOURPI) * w) * emitted[k];
     if (dL) {                                            /* :393-401 */
         float adj[3] = { dL[0] * contrib[0], dL[1] * contrib[1], dL[2] * contrib[2] };
-        float unused[3];
-        sample_emitter(c, p, &clone, adj, unused);
+        float unused[3], unused_pdf;
+        sample_emitter(c, p, &clone, adj, unused, &unused_pdf);
     }
 }
 
@@ -741,12 +956,14 @@ static void drt_sample(ctx_t *c, pcg32 *S, int adjoint, ray_t ray, const float *
 
     if (!adjoint) {                                      /* :263-287 envmap, primal only */
         if (escaped && !(depth <= 0 && cfg->hide_emitters)) {
-            float w = 1.0f;
+            float w = 1.0f, Le[3] = { sc->Le[0], sc->Le[1], sc->Le[2] };
             if (cfg->use_nee) {
-                float epdf = has_scattered ? DRT_INV_FOURPI : 0.0f;    /* :273-277 */
+                float epdf = 0.0f;                                      /* :273-277 */
+                if (has_scattered) epdf = sc->env.pix ? envmap_pdf(&sc->env, ray.d) : DRT_INV_FOURPI;
                 w = mis_weight(last_pdf, epdf);
             }
-            for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * sc->Le[k];
+            if (sc->env.pix) envmap_eval(&sc->env, ray.d, Le);          /* :284 */
+            for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
         }
     }
     out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
@@ -833,7 +1050,11 @@ static void nerf_sample(ctx_t *c, const nerf_t *nf, pcg32 *S, int adjoint, ray_t
     /* composite with the background emitter (:131-146; executes in both modes, :144) */
     int active_e = escaped || active;
     if (nf->hide_emitters) active_e = active_e && (weights_sum > 0.0f);
-    if (active_e) for (int k = 0; k < 3; ++k) result[k] += (1.0f - weights_sum) * sc->Le[k];
+    if (active_e) {
+        float Le[3] = { sc->Le[0], sc->Le[1], sc->Le[2] };
+        if (sc->env.pix) envmap_eval(&sc->env, ray.d, Le);
+        for (int k = 0; k < 3; ++k) result[k] += (1.0f - weights_sum) * Le[k];
+    }
     out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
 }
 
@@ -904,6 +1125,11 @@ static int scene_init(scene_t *sc, const drto_job *job)
     sc->inv_majorant = sc->majorant != 0.0f ? 1.0f / sc->majorant : 0.0f;
     for (int k = 0; k < 3; ++k) sc->Le[k] = job->emitter->radiance[k];
     sc->mgrid = NULL; sc->gx = sc->gy = sc->gz = 0;
+    memset(&sc->env, 0, sizeof(sc->env));
+    if (job->emitter->pixels) {
+        int rc = envmap_from_emitter(&sc->env, job->emitter);
+        if (rc) return rc;
+    }
     if (m->majorant_factor > 0) {
         /* cell (I,J,K) covers 1/G of the box per axis; its majorant is scale * max over every
          * voxel a trilinear lookup inside the cell can touch, padded by one voxel:
@@ -933,7 +1159,7 @@ static int scene_init(scene_t *sc, const drto_job *job)
     return 0;
 }
 
-static void scene_free(scene_t *sc) { free(sc->mgrid); sc->mgrid = NULL; }
+static void scene_free(scene_t *sc) { free(sc->mgrid); sc->mgrid = NULL; envmap_free(&sc->env); }
 
 /* perspective sensor (tests/test_integrators.py:46-67): sample position in
  * [0,1]^2, (0,0) = top-left; camera x axis = `left`. */
@@ -1110,7 +1336,11 @@ int drto_render_textbook(const drto_job *job, float *L_out)
             if (!sn.valid) { alive = 0; break; }
             ray.maxt = sn.t;
         }
-        if (alive) for (int k = 0; k < 3; ++k) L[k] = beta[k] * sc.Le[k];
+        if (alive) {
+            float Le[3] = { sc.Le[0], sc.Le[1], sc.Le[2] };
+            if (sc.env.pix) envmap_eval(&sc.env, ray.d, Le);
+            for (int k = 0; k < 3; ++k) L[k] = beta[k] * Le[k];
+        }
         L_out[3 * i] = L[0]; L_out[3 * i + 1] = L[1]; L_out[3 * i + 2] = L[2];
     }
     scene_free(&sc);
@@ -1123,7 +1353,7 @@ int drto_render_textbook(const drto_job *job, float *L_out)
 static void scene_from_medium(scene_t *sc, const drto_medium *m)
 {
     drto_config cfg; memset(&cfg, 0, sizeof cfg);
-    drto_emitter em = { { 0, 0, 0 } };
+    drto_emitter em; memset(&em, 0, sizeof em);
     drto_job job; memset(&job, 0, sizeof job);
     job.cfg = &cfg; job.medium = m; job.emitter = &em;
     scene_init(sc, &job);
@@ -1175,6 +1405,44 @@ void drto_uniform_sphere(float ux, float uy, float out[3])
 {
     v3 d = square_to_uniform_sphere(ux, uy);
     out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+float drto_atan2f(float y, float x) { return drt_atan2f(y, x); }
+int drto_envmap_eval(const drto_emitter *em, const float d[3], float out[3])
+{
+    envmap_t e; memset(&e, 0, sizeof(e));
+    e.pix = em->pixels; e.w = em->width; e.h = em->height; e.scale = em->scale;
+    for (int k = 0; k < 9; ++k) e.R[k] = em->to_world[k];
+    envmap_eval(&e, v3_make(d[0], d[1], d[2]), out);
+    return 0;
+}
+float drto_envmap_pdf(const drto_emitter *em, const float d[3])
+{
+    envmap_t e;
+    if (envmap_from_emitter(&e, em)) return -1.0f;
+    float p = envmap_pdf(&e, v3_make(d[0], d[1], d[2]));
+    envmap_free(&e);
+    return p;
+}
+int drto_envmap_sample(const drto_emitter *em, float u1, float u2, float d[3], float *pdf, float weight[3])
+{
+    envmap_t e;
+    int rc = envmap_from_emitter(&e, em);
+    if (rc) return rc;
+    v3 dd;
+    envmap_sample(&e, u1, u2, &dd, pdf, weight);
+    d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
+    envmap_free(&e);
+    return 0;
+}
+int drto_envmap_tables(const drto_emitter *em, float *marginal, float *conditional)
+{
+    envmap_t e;
+    int rc = envmap_from_emitter(&e, em);
+    if (rc) return rc;
+    if (marginal) memcpy(marginal, e.marg, sizeof(float) * (size_t)(e.h + 1));
+    if (conditional) memcpy(conditional, e.cond, sizeof(float) * (size_t) e.h * (size_t)(e.w + 1));
+    envmap_free(&e);
+    return 0;
 }
 float drto_logf(float x) { return drt_logf(x); }
 float drto_expf(float x) { return drt_expf(x); }

@@ -7,7 +7,7 @@
  *     /root/reference/python/batched.py:212-326             (primal -> dL -> adjoint sequence)
  * plus the slice of the Mitsuba 3 branch `unbiased-inverse-volume-rendering`
  * that those files call (Medium::sample_interaction[_drt], GridVolume::eval,
- * PCG32 `independent` sampler, sample_tea_32, constant emitter, isotropic
+ * PCG32 `independent` sampler, sample_tea_32, constant / envmap emitter, isotropic
  * phase, AABB fast-path intersection).
  *
  * PARITY UNPINNED: Mitsuba 3 / Dr.Jit are third-party dependencies that are
@@ -57,9 +57,22 @@ typedef struct drto_medium {
     int32_t majorant_factor; /* majorant_resolution_factor (scene_config.py:36); 0 = global majorant */
 } drto_medium;
 
-/* `constant` emitter (tests/test_integrators.py:73-77). */
+/* The scene's single infinite emitter (volpathsimple.py:16).
+ *   pixels == NULL : `constant` emitter of `radiance` (tests/test_integrators.py:73-77).
+ *   pixels != NULL : `envmap` emitter (scene_config.py:102,152,210,262,313) [M3-ext]: lat-long RGB
+ *                    bitmap [height][width][3] (row 0 = +Y pole), times `scale`, rotated by the 3x3
+ *                    row-major `to_world`.  Local direction (sin phi sin theta, cos theta,
+ *                    -cos phi sin theta) <-> uv = (phi / 2pi, theta / pi), bilinear lookup (wrap in u,
+ *                    clamp in v).  Importance sampling: piecewise-constant over texels, weight =
+ *                    max luminance of the 3x3 neighbourhood x sin(theta_row) (the build's own
+ *                    marginal/conditional CDF; Mitsuba's Hierarchical2D warp is not restated -
+ *                    same estimator expectation, different sample placement). */
 typedef struct drto_emitter {
     float radiance[3];
+    const float *pixels;
+    int32_t width, height;
+    float to_world[9];
+    float scale;
 } drto_emitter;
 
 /* Perspective sensor after look_at: world-space orthonormal frame.
@@ -152,6 +165,14 @@ void     drto_uniform_sphere(float ux, float uy, float out[3]);
 float    drto_logf(float x);
 float    drto_expf(float x);
 void     drto_sincos_2pi(float u, float *s, float *c);
+float    drto_atan2f(float y, float x);
+/* envmap primitives (test hooks): radiance towards world direction d; solid-angle pdf of sampling d;
+ * sample_direction(u1, u2) -> d, pdf, radiance / pdf; the importance-sampling tables
+ * (marginal [h+1], conditional [h][w+1]; either may be NULL). */
+int      drto_envmap_eval(const drto_emitter *e, const float d[3], float out[3]);
+float    drto_envmap_pdf(const drto_emitter *e, const float d[3]);
+int      drto_envmap_sample(const drto_emitter *e, float u1, float u2, float d[3], float *pdf, float weight[3]);
+int      drto_envmap_tables(const drto_emitter *e, float *marginal, float *conditional);
 float    drto_eval_sigma_t(const drto_medium *m, const float p[3]);
 void     drto_eval_albedo(const drto_medium *m, const float p[3], float out[3]);
 float    drto_majorant(const drto_medium *m);

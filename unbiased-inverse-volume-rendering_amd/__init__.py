@@ -5,7 +5,7 @@ Host-side mirror of the reference's plugin surface for the hot path
 hand-written HIP library (csrc/, C ABI in include/drt_hip.h).  Importing this
 package does not need a GPU; creating an integrator handle does.
 """
-from .scene import (ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, ConstantEmitter, GridMedium,
+from .scene import (ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, ConstantEmitter, EnvmapEmitter, GridMedium,
                     PerspectiveSensor, Scene, cube_test_scene, scene_to)
 from .integrators import (ADMode, IndependentSampler, NeRFIntegrator, RayBatch, VolpathSimpleIntegrator, load_dict,
                           register_integrator, sample_tea_32)
@@ -19,7 +19,7 @@ from .optimize import (Adam, OptimizationConfig, SGD, SceneConfig, Schedule, adj
 from .volume_io import read_vol, write_vol
 
 __all__ = [
-    "ALBEDO_KEY", "EMISSION_KEY", "SIGMA_T_KEY", "ConstantEmitter", "GridMedium", "PerspectiveSensor",
+    "ALBEDO_KEY", "EMISSION_KEY", "SIGMA_T_KEY", "ConstantEmitter", "EnvmapEmitter", "GridMedium", "PerspectiveSensor",
     "Scene", "cube_test_scene", "scene_to", "ADMode", "IndependentSampler", "RayBatch",
     "VolpathSimpleIntegrator", "NeRFIntegrator", "load_dict", "register_integrator", "sample_tea_32", "IntegratorConfig",
     "add_int_config", "get_int_config", "ShardSpec", "allreduce_gradients", "allreduce_scalar",

@@ -31,6 +31,7 @@ struct drt_handle_s {
     float *d_sigma_b = nullptr;    // bricked copy of sigma_t (refreshed by drt_params_changed)
     uint32_t *d_occ = nullptr;     // empty-space bitmask (kOccWords words)
     float *d_mgrid = nullptr;      // majorant supergrid (refreshed by drt_params_changed)
+    float *d_env = nullptr;        // envmap emitter: pixels | marginal CDF | conditional CDFs (one allocation)
     size_t mgrid_cells = 0;
     size_t sigma_b_floats = 0;
     size_t gt_floats = 0;
@@ -232,6 +233,7 @@ int drt_destroy(drt_handle h)
     if (h->d_sigma_b) (void) hipFree(h->d_sigma_b);
     if (h->d_mgrid) (void) hipFree(h->d_mgrid);
     if (h->d_occ) (void) hipFree(h->d_occ);
+    if (h->d_env) (void) hipFree(h->d_env);
     clear_timings(h);
     delete h;
     return DRT_OK;
@@ -368,6 +370,79 @@ int drt_set_emitter_constant(drt_handle h, const float radiance[3])
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
     if (!radiance) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null radiance");
     for (int k = 0; k < 3; ++k) h->base.Le[k] = radiance[k];
+    h->base.env_pix = h->base.env_marg = h->base.env_cond = nullptr;
+    h->have_emitter = true;
+    return DRT_OK;
+}
+
+int drt_set_emitter_envmap(drt_handle h, const float *pixels, int32_t width, int32_t height,
+                           const float to_world[9], float scale)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!pixels || !to_world) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_set_emitter_envmap: null argument");
+    if (width < 2 || height < 2 || (int64_t) width * height > (1 << 28))
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_set_emitter_envmap: bad resolution %d x %d", width, height);
+    DeviceGuard g(h->device);
+    const size_t w = (size_t) width, hh = (size_t) height, n_pix = 3 * w * hh;
+    std::vector<float> pix(n_pix);
+    DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));          // a previous map may still be in use
+    DRT_HIP_CHECK(h, hipMemcpy(pix.data(), pixels, n_pix * sizeof(float), hipMemcpyDeviceToHost));
+
+    // Importance-sampling tables (DESIGN.md "envmap"): piecewise constant over texels, weight = peak
+    // luminance of the 3x3 neighbourhood (covers the bilinear footprint: pdf > 0 wherever the lookup
+    // can be > 0) x sin(theta_row); double accumulation, one rounding to float per entry.
+    std::vector<float> marg(hh + 1), cond(hh * (w + 1));
+    std::vector<double> lum(w * hh), rowsum(hh);
+    double lmax = 0.0;
+    for (size_t i = 0; i < w * hh; ++i) {
+        const float *p = pix.data() + 3 * i;
+        double l = 0.212671 * (double) p[0] + 0.715160 * (double) p[1] + 0.072169 * (double) p[2];
+        lum[i] = l > 0.0 ? l : 0.0;
+        if (lum[i] > lmax) lmax = lum[i];
+    }
+    const bool uniform = !(lmax > 0.0);                          // all-black map: uniform weights
+    double total = 0.0;
+    for (int j = 0; j < height; ++j) {
+        const double st = sin(3.14159265358979323846 * ((double) j + 0.5) / (double) height);
+        float *c = cond.data() + (size_t) j * (w + 1);
+        double run = 0.0;
+        for (int i = 0; i < width; ++i) {
+            double m = uniform ? 1.0 : 0.0;
+            if (!uniform)
+                for (int dj = -1; dj <= 1; ++dj)
+                    for (int di = -1; di <= 1; ++di) {
+                        int jj = j + dj, ii = (i + di + width) % width;
+                        jj = jj < 0 ? 0 : (jj > height - 1 ? height - 1 : jj);
+                        double l = lum[(size_t) jj * w + ii];
+                        if (l > m) m = l;
+                    }
+            run += m * st;
+            c[i + 1] = (float) run;
+        }
+        rowsum[j] = run;
+        total += run;
+        c[0] = 0.0f;
+        for (int i = 0; i < width; ++i)
+            c[i + 1] = run > 0.0 ? (float)((double) c[i + 1] / run) : (float)((double)(i + 1) / (double) width);
+        c[w] = 1.0f;
+    }
+    double run = 0.0;
+    marg[0] = 0.0f;
+    for (int j = 0; j < height; ++j) { run += rowsum[j]; marg[j + 1] = (float)(run / total); }
+    marg[hh] = 1.0f;
+
+    if (h->d_env) { (void) hipFree(h->d_env); h->d_env = nullptr; }
+    const size_t n_all = n_pix + marg.size() + cond.size();
+    DRT_HIP_CHECK(h, hipMalloc(&h->d_env, n_all * sizeof(float)));
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env, pix.data(), n_pix * sizeof(float), hipMemcpyHostToDevice));
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + n_pix, marg.data(), marg.size() * sizeof(float), hipMemcpyHostToDevice));
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + n_pix + marg.size(), cond.data(), cond.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->base.env_pix = h->d_env;
+    h->base.env_marg = h->d_env + n_pix;
+    h->base.env_cond = h->d_env + n_pix + marg.size();
+    h->base.env_w = width; h->base.env_h = height; h->base.env_scale = scale;
+    for (int k = 0; k < 9; ++k) h->base.env_R[k] = to_world[k];
+    for (int k = 0; k < 3; ++k) h->base.Le[k] = 0.0f;
     h->have_emitter = true;
     return DRT_OK;
 }

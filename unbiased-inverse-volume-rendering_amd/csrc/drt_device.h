@@ -163,6 +163,23 @@ __device__ __forceinline__ V3 square_to_uniform_sphere(float ux, float uy)
     return V3{ r * c, r * s, z };
 }
 
+// atan2 with a specified instruction sequence (Cephes atanf polynomial on min/max in [0,1]);
+// atan2(0,0) = 0.  Same sequence as the oracle's, so envmap lookups are bit-identical.
+__device__ __forceinline__ float drt_atan2f(float y, float x)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float t = mx != 0.0f ? mn / mx : 0.0f;
+    float y0 = 0.0f, z = t;
+    if (t > 0.4142135624f) { y0 = 0.78539816339744831f; z = (t - 1.0f) / (t + 1.0f); }
+    float zz = z * z;
+    float p = fmaf(fmaf(fmaf(8.05374449538e-2f, zz, -1.38776856032e-1f), zz, 1.99777106478e-1f), zz, -3.33329491539e-1f);
+    float a = y0 + fmaf(p * zz, z, z);
+    if (ay > ax) a = 1.57079632679489662f - a;
+    if (x < 0.0f) a = 3.14159265358979323846f - a;
+    return y < 0.0f ? -a : a;
+}
+
 // mi.ad.common.mis_weight: power heuristic, non-finite -> 0 (volpathsimple.py:278,391)
 __device__ __forceinline__ float mis_weight(float a, float b)
 {
@@ -191,6 +208,12 @@ struct Params {
     float bmin[3], bmax[3], inv_ext[3];
     float scale;
     float Le[3];
+    // `envmap` emitter (env_pix != nullptr) instead of the constant Le: lat-long RGB bitmap
+    // [env_h][env_w][3] (library-owned device copy), row-major to_world rotation, scale, and the
+    // importance-sampling tables (marginal CDF over rows [h+1], conditional CDFs [h][w+1])
+    const float *env_pix, *env_marg, *env_cond;
+    int env_w, env_h;
+    float env_R[9], env_scale;
     // nerf integrator (python/integrators/nerf.py): emission grid (Z,Y,X,3) and properties
     const float *emission;
     int nerf_queries, nerf_jitter, nerf_relu;
@@ -221,6 +244,157 @@ struct Params {
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
 };
+
+// ---------------------------------------------------------------------------
+// envmap emitter [M3-ext] (volpathsimple.py:273,284,419; include/drt_hip.h: drt_set_emitter_envmap)
+// local direction (sin phi sin theta, cos theta, -cos phi sin theta) <-> uv = (phi/2pi, theta/pi)
+// ---------------------------------------------------------------------------
+constexpr float kInvTwoPi = 0.15915494309189535f;
+constexpr float kInvPi = 0.31830988618379069f;
+constexpr float kTwoPiSq = 19.739208802178716f;
+constexpr float kOneMinusEps = 0.99999994f;
+
+// bilinear lookup at uv in [0,1)^2: texel centres at ((i+.5)/w, (j+.5)/h), wrap in u, clamp in v
+__device__ __forceinline__ void envmap_lookup(const Params &P, float u, float v, float out[3])
+{
+    const int w = P.env_w, h = P.env_h;
+    float px = fmaf(u, (float) w, -0.5f), py = fmaf(v, (float) h, -0.5f);
+    float fx0 = floorf(px), fy0 = floorf(py);
+    float fx = px - fx0, fy = py - fy0;
+    int i0 = (int) fx0, j0 = (int) fy0;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    if (i0 < 0) i0 += w;
+    if (i1 >= w) i1 -= w;
+    j0 = min(max(j0, 0), h - 1);
+    j1 = min(max(j1, 0), h - 1);
+    const float *p00 = P.env_pix + 3 * ((size_t) j0 * w + i0), *p01 = P.env_pix + 3 * ((size_t) j0 * w + i1);
+    const float *p10 = P.env_pix + 3 * ((size_t) j1 * w + i0), *p11 = P.env_pix + 3 * ((size_t) j1 * w + i1);
+    float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float a = fmaf(wx0, p00[k], fx * p01[k]);
+        float b = fmaf(wx0, p10[k], fx * p11[k]);
+        out[k] = fmaf(wy0, a, fy * b) * P.env_scale;
+    }
+}
+
+__device__ __forceinline__ void envmap_dir_to_uv(const Params &P, V3 d, float &u, float &v, float &sin_theta)
+{
+    const float *R = P.env_R;                                // local = R^T d
+    float lx = fmaf(R[6], d.z, fmaf(R[3], d.y, R[0] * d.x));
+    float ly = fmaf(R[7], d.z, fmaf(R[4], d.y, R[1] * d.x));
+    float lz = fmaf(R[8], d.z, fmaf(R[5], d.y, R[2] * d.x));
+    float st = sqrtf(fmaf(lx, lx, lz * lz));
+    float uu = drt_atan2f(lx, -lz) * kInvTwoPi;
+    if (uu < 0.0f) uu += 1.0f;
+    if (uu >= 1.0f) uu = 0.0f;
+    float vv = drt_atan2f(st, ly) * kInvPi;
+    vv = fminf(fmaxf(vv, 0.0f), kOneMinusEps);
+    u = uu; v = vv; sin_theta = st;
+}
+
+// texel probability density in uv space: pmf(row) * pmf(col | row) * w * h
+__device__ __forceinline__ float envmap_pdf_uv(const Params &P, int i, int j)
+{
+    const float *c = P.env_cond + (size_t) j * (P.env_w + 1);
+    float pm = P.env_marg[j + 1] - P.env_marg[j], pc = c[i + 1] - c[i];
+    return (pm * pc) * ((float) P.env_w * (float) P.env_h);
+}
+
+// Emitter::eval for an escaped ray of direction d (volpathsimple.py:284)
+__device__ __forceinline__ void envmap_eval(const Params &P, V3 d, float out[3])
+{
+    float u, v, st;
+    envmap_dir_to_uv(P, d, u, v, st);
+    envmap_lookup(P, u, v, out);
+}
+
+// Emitter::pdf_direction (volpathsimple.py:273)
+__device__ __forceinline__ float envmap_pdf(const Params &P, V3 d)
+{
+    float u, v, st;
+    envmap_dir_to_uv(P, d, u, v, st);
+    int i = min((int)(u * (float) P.env_w), P.env_w - 1), j = min((int)(v * (float) P.env_h), P.env_h - 1);
+    float den = kTwoPiSq * st;
+    return den > 0.0f ? envmap_pdf_uv(P, i, j) / den : 0.0f;
+}
+
+// largest k in [0, n-1] with cdf[k] <= x (cdf[0] = 0, cdf[n] = 1, x in [0,1))
+__device__ __forceinline__ int cdf_find(const float *cdf, int n, float x)
+{
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Scene::sample_emitter_direction (volpathsimple.py:419).  The pdf and the radiance are evaluated
+// FROM THE DIRECTION (envmap_pdf / envmap_eval, as for an escaped ray), so NEE and the escape-side
+// MIS weight see the same density and the state machine only has to keep the direction.
+__device__ __forceinline__ V3 envmap_sample_dir(const Params &P, float u1, float u2)
+{
+    const int w = P.env_w, h = P.env_h;
+    int j = cdf_find(P.env_marg, h, u2);
+    const float *c = P.env_cond + (size_t) j * (w + 1);
+    int i = cdf_find(c, w, u1);
+    float dv = fminf((u2 - P.env_marg[j]) / (P.env_marg[j + 1] - P.env_marg[j]), kOneMinusEps);
+    float du = fminf((u1 - c[i]) / (c[i + 1] - c[i]), kOneMinusEps);
+    float u = ((float) i + du) / (float) w, v = ((float) j + dv) / (float) h;
+    float sp, cp, st, ct;
+    drt_sincos_2pi(u, sp, cp);
+    drt_sincos_2pi(0.5f * v, st, ct);
+    float lx = sp * st, ly = ct, lz = -(cp * st);
+    const float *R = P.env_R;                                // world = R local
+    V3 d;
+    d.x = fmaf(R[2], lz, fmaf(R[1], ly, R[0] * lx));
+    d.y = fmaf(R[5], lz, fmaf(R[4], ly, R[3] * lx));
+    d.z = fmaf(R[8], lz, fmaf(R[7], ly, R[6] * lx));
+    return d;
+}
+
+// The emitter dispatch is a compile-time switch (ENV = an envmap is bound): the constant-emitter
+// kernels - every BASELINE configuration - carry none of the envmap code or its registers.
+// emitter direction sample: the direction for (u1, u2) ...
+template <bool ENV>
+__device__ __forceinline__ V3 emitter_sample_dir(const Params &P, float u1, float u2)
+{
+    if constexpr (ENV) return envmap_sample_dir(P, u1, u2);
+    else return square_to_uniform_sphere(u1, u2);
+}
+
+// ... and, from the direction, ds.pdf and radiance / pdf
+template <bool ENV>
+__device__ __forceinline__ float emitter_sample_value(const Params &P, V3 d, float val[3])
+{
+    if constexpr (ENV) {
+        float p = envmap_pdf(P, d), Le[3];
+        envmap_eval(P, d, Le);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) val[k] = p > 0.0f ? Le[k] / p : 0.0f;
+        return p;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) val[k] = P.Le[k] * kFourPi;
+        return kInvFourPi;
+    }
+}
+
+template <bool ENV>
+__device__ __forceinline__ float emitter_pdf(const Params &P, V3 d)
+{
+    if constexpr (ENV) return envmap_pdf(P, d);
+    else return kInvFourPi;
+}
+
+// emitter radiance towards an escaped ray
+template <bool ENV>
+__device__ __forceinline__ void emitter_eval(const Params &P, V3 d, float Le[3])
+{
+    if constexpr (ENV) envmap_eval(P, d, Le);
+    else { Le[0] = P.Le[0]; Le[1] = P.Le[1]; Le[2] = P.Le[2]; }
+}
 
 enum CounterSlot { C_RAYS = 0, C_DT, C_RT, C_DRT, C_ALB, C_TR, C_RT_ADJ, C_SC, C_SC_ALB, C_COUNT };
 

@@ -19,7 +19,7 @@ struct Ray { V3 o, d; float maxt; };
 struct Mei { bool valid; float t; V3 p; float sigma_t; };
 struct PathState { int depth; Hit si; float last_pdf; bool escaped; bool active; };
 
-template <bool COUNT>
+template <bool COUNT, bool ENV>
 struct Tracer {
     const Params &P;
     float maj, inv_maj;
@@ -120,17 +120,22 @@ struct Tracer {
         return T;
     }
 
-    // sample_emitter (volpathsimple.py:406-433), `constant` emitter
+    // sample_emitter (volpathsimple.py:406-433): emitter_val * transmittance in out[], ds.pdf returned
     template <bool ADJ>
-    __device__ void sample_emitter(V3 p, Pcg32 &S, const float *adj, float out[3])
+    __device__ float sample_emitter(V3 p, Pcg32 &S, const float *adj, float out[3])
     {
         float ux = S.next_1d(), uy = S.next_1d();                       // :418
-        V3 wd = square_to_uniform_sphere(ux, uy);
-        Hit si = box_hit(P, p, wd);                                     // :427-428
+        float val[3];
+        V3 wd = emitter_sample_dir<ENV>(P, ux, uy);                          // Scene::sample_emitter_direction
+        float pdf = emitter_sample_value<ENV>(P, wd, val);                   // ds.pdf, radiance / pdf
         float T = 0.0f;
-        if (si.valid) T = estimate_transmittance<ADJ>(p, wd, si.t, S, adj);
+        if (pdf != 0.0f) {                                              // sampling_worked :421-423
+            Hit si = box_hit(P, p, wd);                                 // :427-428
+            if (si.valid) T = estimate_transmittance<ADJ>(p, wd, si.t, S, adj);
+        }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) out[k] = (P.Le[k] * kFourPi) * T;
+        for (int k = 0; k < 3; ++k) out[k] = val[k] * T;
+        return pdf;
     }
 
     // sample_emitter_for_nee (volpathsimple.py:380-403)
@@ -140,14 +145,14 @@ struct Tracer {
     {
         Pcg32 clone = S;                                                // :383
         float emitted[3];
-        sample_emitter<false>(p, S, nullptr, emitted);                  // :385
-        float w = mis_weight(kInvFourPi, kInvFourPi);                   // :391
+        float ds_pdf = sample_emitter<false>(p, S, nullptr, emitted);   // :385
+        float w = mis_weight(ds_pdf, kInvFourPi);                       // :391
 #pragma unroll
         for (int k = 0; k < 3; ++k) contrib[k] = ((beta[k] * kInvFourPi) * w) * emitted[k];
         if constexpr (ADJ) {                                            // :393-401
             float adj[3] = { dL[0] * contrib[0], dL[1] * contrib[1], dL[2] * contrib[2] };
             float unused[3];
-            sample_emitter<true>(p, clone, adj, unused);
+            (void) sample_emitter<true>(p, clone, adj, unused);
         }
     }
 
@@ -393,20 +398,22 @@ struct Tracer {
             }
         } else {                                                        // :263-287
             if (escaped && !(depth <= 0 && P.hide_emitters)) {
-                float w = 1.0f;
+                float w = 1.0f, Le[3];
                 if (P.use_nee) {
-                    float epdf = has_scattered ? kInvFourPi : 0.0f;     // :273-277
+                    float epdf = 0.0f;                                  // :273-277
+                    if (has_scattered) epdf = emitter_pdf<ENV>(P, ray.d);
                     w = mis_weight(last_pdf, epdf);
                 }
+                emitter_eval<ENV>(P, ray.d, Le);                        // :284
 #pragma unroll
-                for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * P.Le[k];
+                for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
             }
         }
         out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
     }
 };
 
-template <bool ADJ, bool COUNT>
+template <bool ADJ, bool COUNT, bool ENV>
 __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Params P)
 {
     // XCD-aware block -> ray-chunk map.  Workgroup b runs on XCD b % 8 (observed dispatch
@@ -425,7 +432,7 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
     }
 #endif
     uint64_t i = (uint64_t) b * blockDim.x + threadIdx.x;
-    Tracer<COUNT> tr(P);
+    Tracer<COUNT, ENV> tr(P);
     if constexpr (ADJ) {
         __shared__ uint32_t coop_rec[4 * 64 * kCoopDwords];
         tr.rec = coop_rec + (threadIdx.x >> 6) * (64 * kCoopDwords);
@@ -561,8 +568,10 @@ __global__ void __launch_bounds__(256) nerf_kernel(const Params P)
         bool active_e = escaped || active;                                   // :131-146
         if (P.hide_emitters) active_e = active_e && (weights_sum > 0.0f);
         if (active_e) {
+            float Le[3];
+            if (P.env_pix) emitter_eval<true>(P, d, Le); else emitter_eval<false>(P, d, Le);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) result[k] += (1.0f - weights_sum) * P.Le[k];
+            for (int k = 0; k < 3; ++k) result[k] += (1.0f - weights_sum) * Le[k];
         }
         if constexpr (!ADJ) { P.L_out[3 * i] = result[0]; P.L_out[3 * i + 1] = result[1]; P.L_out[3 * i + 2] = result[2]; }
     }
@@ -859,6 +868,15 @@ __global__ void __launch_bounds__(256) debug_eval_kernel(const Params P, int op,
             o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
         } break;
         case 10: o[0] = drt_expf(a[0]); break;
+        case 11: o[0] = drt_atan2f(a[0], a[1]); break;
+        case 12: if (P.env_pix) {                       // envmap: eval(d) rgb, pdf_direction(d)
+            V3 d = v3(a[0], a[1], a[2]); float Le[3];
+            envmap_eval(P, d, Le); o[0] = Le[0]; o[1] = Le[1]; o[2] = Le[2]; o[3] = envmap_pdf(P, d);
+        } break;
+        case 13: if (P.env_pix) {                       // envmap: sample_direction(u1, u2) -> d, pdf
+            V3 d = envmap_sample_dir(P, a[0], a[1]);
+            o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = envmap_pdf(P, d);
+        } break;
         case 9: if (P.mgrid) { o[0] = P.mgrid[__float_as_uint(a[0])]; } break;
         case 8: o[0] = mis_weight(a[0], a[1]); o[1] = a[0] / a[1]; o[2] = sqrtf(a[0]); o[3] = fmaf(a[0], a[1], a[2]); break;
         default: break;
@@ -879,12 +897,16 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
 {
     if (P.n_rays == 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((P.n_rays + 255) / 256));
-    if (adjoint) {
-        if (count) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, stream, P);
-        else       hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, stream, P);
-    } else {
-        if (count) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, P);
-        else       hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, P);
+    const int variant = (adjoint ? 4 : 0) | (count ? 2 : 0) | (P.env_pix ? 1 : 0);
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((trace_kernel<false, false, false>), grid, block, 0, stream, P); break;
+        case 1: hipLaunchKernelGGL((trace_kernel<false, false, true>), grid, block, 0, stream, P); break;
+        case 2: hipLaunchKernelGGL((trace_kernel<false, true, false>), grid, block, 0, stream, P); break;
+        case 3: hipLaunchKernelGGL((trace_kernel<false, true, true>), grid, block, 0, stream, P); break;
+        case 4: hipLaunchKernelGGL((trace_kernel<true, false, false>), grid, block, 0, stream, P); break;
+        case 5: hipLaunchKernelGGL((trace_kernel<true, false, true>), grid, block, 0, stream, P); break;
+        case 6: hipLaunchKernelGGL((trace_kernel<true, true, false>), grid, block, 0, stream, P); break;
+        default: hipLaunchKernelGGL((trace_kernel<true, true, true>), grid, block, 0, stream, P); break;
     }
     return hipGetLastError();
 }

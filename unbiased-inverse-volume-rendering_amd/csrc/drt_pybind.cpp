@@ -85,6 +85,15 @@ public:
     {
         check(drt_set_emitter_constant(h_, rgb.data()), "drt_set_emitter_constant");
     }
+    void set_emitter_envmap(uintptr_t pixels, int w, int hgt, std::array<float, 9> to_world, float scale)
+    {
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = drt_set_emitter_envmap(h_, (const float *) pixels, w, hgt, to_world.data(), scale);
+        }
+        check(rc, "drt_set_emitter_envmap");
+    }
     void set_sensor_perspective(std::array<float, 3> o, std::array<float, 3> left, std::array<float, 3> up,
                                 std::array<float, 3> dir, float tan_x, float tan_y, int w, int hgt)
     {
@@ -224,6 +233,7 @@ PYBIND11_MODULE(_drt_pybind, m)
         .def("set_medium", &Integrator::set_medium)
         .def("params_changed", &Integrator::params_changed)
         .def("set_emitter_constant", &Integrator::set_emitter_constant)
+        .def("set_emitter_envmap", &Integrator::set_emitter_envmap)
         .def("set_sensor_perspective", &Integrator::set_sensor_perspective)
         .def("render_primal", &Integrator::render_primal)
         .def("render_backward", &Integrator::render_backward)

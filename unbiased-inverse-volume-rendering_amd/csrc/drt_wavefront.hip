@@ -139,7 +139,7 @@ __device__ __forceinline__ void wave_splat_sigma(const Params &P, bool pending, 
 
 }  // namespace
 
-template <bool ADJ, bool COUNT>
+template <bool ADJ, bool COUNT, bool ENV>
 __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(const Params P)
 {
     __shared__ uint32_t occ_lds[kOccWords];
@@ -271,10 +271,11 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                 if (ph == PH_END) {
                     if (!ADJ || rec_mode) {                                     // envmap block, primal only
                         if (escaped && !(depth <= 0 && P.hide_emitters)) {
-                            float w = 1.0f;
-                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? kInvFourPi : 0.0f);
+                            float w = 1.0f, Le[3];
+                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? emitter_pdf<ENV>(P, rd) : 0.0f);
+                            emitter_eval<ENV>(P, rd, Le);
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * P.Le[k];
+                            for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
                         }
                     }
                     if constexpr (!ADJ) {
@@ -420,11 +421,12 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
 
                 // ---- NEE walk finished (:388-403) -------------------------------------------------------------
                 if (ph == PH_RT_END) {
-                    const float w = mis_weight(kInvFourPi, kInvFourPi);         // :391
-                    float contrib[3];
+                    float val[3], contrib[3];
+                    const float ds_pdf = emitter_sample_value<ENV>(P, nd, val);      // recomputed from the direction
+                    const float w = mis_weight(ds_pdf, kInvFourPi);             // :391
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        contrib[k] = ((beta[k] * kInvFourPi) * w) * ((P.Le[k] * kFourPi) * wt);
+                        contrib[k] = ((beta[k] * kInvFourPi) * w) * (val[k] * wt);
                         result[k] = adj_lane ? result[k] - contrib[k] : result[k] + contrib[k];   // :211-214
                     }
                     ph = PH_PHASE;
@@ -446,8 +448,9 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                 if (ph == PH_NEE) {
                     if (adj_lane) Cst = S.state;                                // :383
                     float ux = S.next_1d(), uy = S.next_1d();                   // :418
-                    nd = square_to_uniform_sphere(ux, uy);
+                    nd = emitter_sample_dir<ENV>(P, ux, uy);
                     Hit h = box_hit(P, mp, nd);                                 // :427-428
+                    if constexpr (ENV) { if (envmap_pdf(P, nd) == 0.0f) h.valid = false; }   // sampling_worked :421-423
                     if (h.valid) { nt0 = h.t; wo = mp; wmax = h.t; wt = 1.0f; ph = PH_RT; }
                     else { nt0 = kInf; wt = 0.0f; ph = PH_RT_END; }
                 }
@@ -567,12 +570,16 @@ hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int
     uint64_t need = (P.n_rays + 255) / 256;
     if (need < blocks) blocks = (unsigned) need;
     dim3 block(256), grid(blocks);
-    if (adjoint) {
-        if (count) hipLaunchKernelGGL((trace_wavefront_kernel<true, true>), grid, block, 0, stream, P);
-        else       hipLaunchKernelGGL((trace_wavefront_kernel<true, false>), grid, block, 0, stream, P);
-    } else {
-        if (count) hipLaunchKernelGGL((trace_wavefront_kernel<false, true>), grid, block, 0, stream, P);
-        else       hipLaunchKernelGGL((trace_wavefront_kernel<false, false>), grid, block, 0, stream, P);
+    const int variant = (adjoint ? 4 : 0) | (count ? 2 : 0) | (P.env_pix ? 1 : 0);
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((trace_wavefront_kernel<false, false, false>), grid, block, 0, stream, P); break;
+        case 1: hipLaunchKernelGGL((trace_wavefront_kernel<false, false, true>), grid, block, 0, stream, P); break;
+        case 2: hipLaunchKernelGGL((trace_wavefront_kernel<false, true, false>), grid, block, 0, stream, P); break;
+        case 3: hipLaunchKernelGGL((trace_wavefront_kernel<false, true, true>), grid, block, 0, stream, P); break;
+        case 4: hipLaunchKernelGGL((trace_wavefront_kernel<true, false, false>), grid, block, 0, stream, P); break;
+        case 5: hipLaunchKernelGGL((trace_wavefront_kernel<true, false, true>), grid, block, 0, stream, P); break;
+        case 6: hipLaunchKernelGGL((trace_wavefront_kernel<true, true, false>), grid, block, 0, stream, P); break;
+        default: hipLaunchKernelGGL((trace_wavefront_kernel<true, true, true>), grid, block, 0, stream, P); break;
     }
     return hipGetLastError();
 }

@@ -160,17 +160,37 @@ class _DeviceIntegrator:
         h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         al_key = (al.data_ptr(), al._version) if isinstance(al, torch.Tensor) else (0, 0)
         key = (st.data_ptr(), st._version) + al_key + (tuple(st.shape),
-               tuple(m.bbox_min), tuple(m.bbox_max), float(m.scale), int(m.majorant_resolution_factor),
-               tuple(scene.emitter.radiance))
+               tuple(m.bbox_min), tuple(m.bbox_max), float(m.scale), int(m.majorant_resolution_factor))
+        self._bind_emitter(h, idx, scene.emitter, dev)
         if self._bound.get(idx) != key:
             z, y, x = st.shape[:3]
             h.set_medium(st.data_ptr(), al.data_ptr() if isinstance(al, torch.Tensor) else 0,
                          [int(x), int(y), int(z)],
                          [float(v) for v in m.bbox_min], [float(v) for v in m.bbox_max],
                          float(m.scale), int(m.majorant_resolution_factor))
-            h.set_emitter_constant([float(v) for v in scene.emitter.radiance])
             self._bound[idx] = key
         return h, dev
+
+    def _bind_emitter(self, h, idx, emitter, dev):
+        """`constant` or `envmap` (the only legal emitters, volpathsimple.py:16); the envmap upload
+        builds the importance-sampling tables, so it is redone only when the map itself changes."""
+        if hasattr(emitter, "pixels"):
+            px = emitter.pixels
+            if not isinstance(px, torch.Tensor):
+                raise TypeError("envmap pixels must be a torch device tensor (use scene_to(scene, device))")
+            if px.dim() != 3 or px.shape[-1] != 3:
+                raise ValueError(f"envmap pixels must have shape (H, W, 3), got {tuple(px.shape)}")
+            _check(px, tuple(px.shape), dev, "envmap pixels")
+            R = emitter.to_world_flat()
+            ekey = ("envmap", px.data_ptr(), px._version, tuple(px.shape), float(emitter.scale), tuple(R))
+            if self._bound_emitter.get(idx) != ekey:
+                h.set_emitter_envmap(px.data_ptr(), int(px.shape[1]), int(px.shape[0]), R, float(emitter.scale))
+                self._bound_emitter[idx] = ekey
+        else:
+            ekey = ("constant",) + tuple(float(v) for v in emitter.radiance)
+            if self._bound_emitter.get(idx) != ekey:
+                h.set_emitter_constant([float(v) for v in emitter.radiance])
+                self._bound_emitter[idx] = ekey
 
     @staticmethod
     def _set_rays(h, ray: RayBatch):
@@ -218,6 +238,7 @@ class VolpathSimpleIntegrator(_DeviceIntegrator):
             raise ValueError("max_depth must be >= 0 (unbounded depth is not supported)")
         self._handles: Dict[int, object] = {}
         self._bound: Dict[int, tuple] = {}
+        self._bound_emitter: Dict[int, tuple] = {}
 
     # -- reference surface ---------------------------------------------------
     def aovs(self):
@@ -301,6 +322,7 @@ class NeRFIntegrator(_DeviceIntegrator):
             raise ValueError("queries_per_ray must be >= 2")
         self._handles: Dict[int, object] = {}
         self._bound: Dict[int, tuple] = {}
+        self._bound_emitter: Dict[int, tuple] = {}
 
     def aovs(self):
         return []

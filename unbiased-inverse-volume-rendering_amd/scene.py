@@ -61,6 +61,37 @@ class ConstantEmitter:
 
 
 @dataclass
+class EnvmapEmitter:
+    """`envmap` environment emitter (python/scene_config.py:102,152,210,262,313): a lat-long RGB
+    bitmap of shape (H, W, 3) float32 (row 0 = the +Y pole; numpy array or torch tensor - a device
+    tensor for the HIP path), multiplied by `scale` and rotated by the 3x3 `to_world`.
+
+    Local direction (sin phi sin theta, cos theta, -cos phi sin theta) <-> uv = (phi / 2pi,
+    theta / pi); bilinear lookup (wrap in u, clamp in v); importance sampling proportional to the
+    texel's 3x3-neighbourhood peak luminance x sin(theta) (piecewise constant), combined with
+    phase-function sampling by the power heuristic (volpathsimple.py:273-278,391)."""
+    pixels: object
+    scale: float = 1.0
+    to_world: Sequence[Sequence[float]] = ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0))
+
+    @property
+    def resolution(self):
+        h, w = self.pixels.shape[:2]
+        return int(w), int(h)
+
+    def to_world_flat(self):
+        R = np.asarray(self.to_world, dtype=np.float32).reshape(3, 3)
+        return [float(v) for v in R.reshape(-1)]
+
+    @staticmethod
+    def rotation_y(degrees: float):
+        """`rotate(y, angle)` as the reference's scene files orient their environment maps."""
+        a = np.deg2rad(degrees)
+        c, s = float(np.cos(a)), float(np.sin(a))
+        return ((c, 0.0, s), (0.0, 1.0, 0.0), (-s, 0.0, c))
+
+
+@dataclass
 class GridMedium:
     """`heterogeneous` medium with `gridvolume` sigma_t / albedo and an isotropic
     phase function, bounded by an axis-aligned box (tests/test_integrators.py:79-111).
@@ -145,4 +176,7 @@ def scene_to(scene: Scene, device) -> Scene:
     medium = GridMedium(sigma_t=conv(m.sigma_t), albedo=conv(m.albedo), bbox_min=tuple(m.bbox_min),
                         bbox_max=tuple(m.bbox_max), scale=m.scale,
                         majorant_resolution_factor=m.majorant_resolution_factor, emission=conv(m.emission))
-    return Scene(medium=medium, emitter=scene.emitter, sensors=list(scene.sensors))
+    emitter = scene.emitter
+    if isinstance(emitter, EnvmapEmitter):
+        emitter = EnvmapEmitter(pixels=conv(emitter.pixels), scale=emitter.scale, to_world=emitter.to_world)
+    return Scene(medium=medium, emitter=emitter, sensors=list(scene.sensors))
