@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -32,6 +33,14 @@ struct drt_handle_s {
     uint32_t *d_occ = nullptr;     // empty-space bitmask (kOccWords words)
     float *d_mgrid = nullptr;      // majorant supergrid (refreshed by drt_params_changed)
     float *d_env = nullptr;        // envmap emitter: pixels | marginal CDF | conditional CDFs (one allocation)
+    // deferred splatting (drt_deferred.hip): record streams in / tile-sorted, chunk fills, partition tables
+    void *d_rec = nullptr;         // one allocation, carved up in ensure_deferred
+    size_t rec_bytes = 0;
+    uint64_t rec_rays = 0;         // ray count the current carving was sized for
+    int rec_bins = 0;
+    bool rec_tiny = false;
+    drt::DeferredPlan plan{};
+    size_t rec_clear_bytes = 0;    // chunk fills + cursors: the prefix of d_rec zeroed before every launch
     size_t mgrid_cells = 0;
     size_t sigma_b_floats = 0;
     size_t gt_floats = 0;
@@ -161,6 +170,104 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     return DRT_OK;
 }
 
+// Deferred splatting is used for the one-ray-per-lane adjoint kernel when the grid has at most kMaxBins
+// tiles and the record streams fit the memory budget; otherwise (and with debug bit 128) the tracer
+// adds its splats to the apron scratch with atomics and untile_gradients_kernel reduces that.
+constexpr uint64_t kRecBudgetBytes = 64ull << 30;
+
+bool want_deferred(drt_handle h, const drt::Params &P, uint64_t n_rays)
+{
+    if (h->debug_flags & (128u | 2u | 32u)) return false;          // 128: atomic path; 2: per-lane atomics; 32: state machine
+    const int ntx = (P.rx + drt::kTileX - 1) / drt::kTileX, nty = (P.ry + drt::kTileY - 1) / drt::kTileY,
+              ntz = (P.rz + drt::kTileZ - 1) / drt::kTileZ;
+    if ((int64_t) ntx * nty * ntz > drt::kMaxBins) return false;
+    return n_rays * 3200ull < kRecBudgetBytes;                       // ~3.1 kB of record space per ray (in + sorted)
+}
+
+int ensure_deferred(drt_handle h, drt::Params &P, uint64_t n_rays)
+{
+    using namespace drt;
+    DeferredPlan &D = h->plan;
+    const int ntx = (P.rx + kTileX - 1) / kTileX, nty = (P.ry + kTileY - 1) / kTileY, ntz = (P.rz + kTileZ - 1) / kTileZ;
+    const int n_bins = ntx * nty * ntz;
+    const bool tiny_now = (h->debug_flags & 256u) != 0;
+    if (!h->d_rec || n_rays > h->rec_rays || n_bins != h->rec_bins || tiny_now != h->rec_tiny) {
+        // capacity: every wave may leave one chunk partly filled per stream, plus the expected volume
+        // (headline workload: 12.3 sigma_t and 1.4 colour splats per ray) with a wide margin; beyond it the
+        // tracer falls back to direct atomics (emit_record), so this is a performance choice only
+        const uint64_t waves = (n_rays + 63) / 64;
+        const bool tiny = (h->debug_flags & 256u) != 0;            // test hook: force the overflow path
+        uint64_t chunks[4];
+        chunks[0] = tiny ? 2 : 2 * waves + (n_rays * 48 + kRecChunk - 1) / kRecChunk;
+        for (int s = 1; s < 4; ++s) chunks[s] = tiny ? 1 : 2 * waves + (n_rays * 6 + kRecChunk - 1) / kRecChunk;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
+        size_t o_cursor = carve(12 * sizeof(uint32_t));          // cursors [8] + vmax [4]
+        size_t o_count[4], o_in[4], o_out[4];
+        for (int s = 0; s < 4; ++s) o_count[s] = carve(chunks[s] * sizeof(uint32_t));
+        const size_t clear = off;
+        size_t o_hist = carve((size_t) 4 * kPartWGs * n_bins * sizeof(uint32_t));
+        size_t o_base = carve((size_t) 4 * (n_bins + 1) * sizeof(uint32_t));
+        size_t o_unit = carve((size_t) 4 * (n_bins + 1) * sizeof(uint32_t));
+        for (int s = 0; s < 4; ++s) { o_in[s] = carve(chunks[s] * kRecChunk * sizeof(float4)); o_out[s] = carve(chunks[s] * kRecChunk * sizeof(float4)); }
+        if (off > h->rec_bytes) {
+            if (h->d_rec) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_rec); h->d_rec = nullptr; h->rec_bytes = 0; }
+            DRT_HIP_CHECK(h, hipMalloc(&h->d_rec, off));
+            h->rec_bytes = off;
+        }
+        char *b = (char *) h->d_rec;
+        D.cursor = (uint32_t *) (b + o_cursor);
+        D.vmax = D.cursor + 8;
+        uint64_t max_chunks = 0;
+        for (int s = 0; s < 4; ++s) {
+            D.chunk_count[s] = (uint32_t *) (b + o_count[s]);
+            D.in[s] = (float4 *) (b + o_in[s]); D.out[s] = (float4 *) (b + o_out[s]);
+            D.cap_chunks[s] = (uint32_t) chunks[s];
+            if (chunks[s] > max_chunks) max_chunks = chunks[s];
+        }
+        D.hist = (uint32_t *) (b + o_hist); D.bin_base = (uint32_t *) (b + o_base); D.unit_start = (uint32_t *) (b + o_unit);
+        D.n_bins = n_bins; D.ntx = ntx; D.nty = nty; D.ntz = ntz;
+        D.max_units = (uint32_t) (max_chunks * kRecChunk / kUnitRecords + (uint64_t) n_bins + 1);
+        h->rec_clear_bytes = clear; h->rec_rays = n_rays; h->rec_bins = n_bins; h->rec_tiny = tiny;
+    }
+    DRT_HIP_CHECK(h, hipMemsetAsync(h->d_rec, 0, h->rec_clear_bytes, h->stream));
+    for (int s = 0; s < 4; ++s) { P.rec_buf[s] = D.in[s]; P.rec_chunk_count[s] = D.chunk_count[s]; P.rec_cap_chunks[s] = D.cap_chunks[s]; }
+    P.rec_cursor = D.cursor;
+    return DRT_OK;
+}
+
+int timed_reduce(drt_handle h, const drt::Params &P)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventCreate(&a));
+        DRT_HIP_CHECK(h, hipEventCreate(&b));
+        DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
+    }
+    static const bool profile = getenv("DRT_REDUCE_PROFILE") != nullptr;   // stage timings to stderr (synchronises)
+    if (profile) {
+        hipEvent_t ev[5];
+        for (auto &e : ev) DRT_HIP_CHECK(h, hipEventCreate(&e));
+        DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, h->plan, h->stream, ev));
+        DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        float ms[4];
+        for (int k = 0; k < 4; ++k) DRT_HIP_CHECK(h, hipEventElapsedTime(ms + k, ev[k], ev[k + 1]));
+        uint32_t cur[8];
+        DRT_HIP_CHECK(h, hipMemcpy(cur, h->plan.cursor, sizeof cur, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[drt] reduce: histogram %.3f offsets %.3f scatter %.3f tiles %.3f ms; chunks %u %u %u %u (cap %u %u) overflow %u %u %u %u\n",
+                ms[0], ms[1], ms[2], ms[3], cur[0], cur[1], cur[2], cur[3], h->plan.cap_chunks[0], h->plan.cap_chunks[1],
+                cur[4], cur[5], cur[6], cur[7]);
+        for (auto &e : ev) (void) hipEventDestroy(e);
+    } else {
+        DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, h->plan, h->stream));
+    }
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
+        h->timed[2].emplace_back(a, b);
+    }
+    return DRT_OK;
+}
+
 int timed_untile(drt_handle h, const drt::Params &P)
 {
     hipEvent_t a = nullptr, b = nullptr;
@@ -234,6 +341,7 @@ int drt_destroy(drt_handle h)
     if (h->d_mgrid) (void) hipFree(h->d_mgrid);
     if (h->d_occ) (void) hipFree(h->d_occ);
     if (h->d_env) (void) hipFree(h->d_env);
+    if (h->d_rec) (void) hipFree(h->d_rec);
     clear_timings(h);
     delete h;
     return DRT_OK;
@@ -490,9 +598,14 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     drt::Params P;
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
+    const bool defer = want_deferred(h, P, n_rays);
+    if (defer) {
+        rc = ensure_deferred(h, P, n_rays);
+        if (rc) return rc;
+    }
     rc = timed_launch(h, 1, P, true);
     if (rc) return rc;
-    return timed_untile(h, P);
+    return defer ? timed_reduce(h, P) : timed_untile(h, P);
 }
 
 static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, const float *emission)

@@ -1,0 +1,250 @@
+// drt_deferred.hip -- deferred, tile-binned gradient splatting for the adjoint pass.
+//
+// The adjoint tracer emits ~14 trilinear splats per ray (volpathsimple.py:170,489,580,594,607).  As
+// global fp32 atomics they cost one L2 atomic request per splat and plane, and the chip retires only
+// ~21 G requests/s: 8.6 of the adjoint's 21.8 ms.  Here the tracer appends
+// 16-byte records {p, value} to per-plane streams instead (emit_record, drt_device.h) and this file
+// turns them into gradients with streaming passes only:
+//
+//   bin_histogram  records -> per-(workgroup, tile) counts            (LDS histogram)
+//   bin_offsets    counts  -> exclusive offsets, tile bases, reduce units
+//   bin_scatter    records -> tile-sorted copy                         (LDS cursors)
+//   tile_reduce    workgroups walk runs of <= kUnitRecords-record units of ONE tile: trilinear weights
+//                  recomputed (same axis_setup / stencil_weights as the lookup), 8 LDS adds per record
+//                  into a (32+1)x(16+1)x(16+1) tile, then one coalesced flush of the non-zero tile
+//                  entries into the caller's gradient grid (+=, fp32 atomics: ~10^7 per launch instead
+//                  of ~10^9 lane-atomics).
+//
+// The LDS accumulators are 64-bit FIXED POINT: on gfx950 ds_add_f32 retires 0.2 T lane-atomics/s but
+// ds_add_u64 3.4 T/s (tools/ubench/lds_atomic_rate.hip; the fp32 version of this kernel took 5.3 ms,
+// 4.9 of them in ds_add_f32).  Every float product w*v is scaled by a power of two chosen from the
+// stream's max |v| (found by the histogram pass) so that |w*v| * scale < 2^40 and rounded to an
+// integer: quantisation 2^-41 max|v| per add, exact and order-independent sums inside a tile.
+//
+// A tile is addressed by the BASE corner cell of the splat, so its footprint is the tile plus a
+// one-voxel apron on the high side.  Streams: 0 = sigma_t (value already times `scale`), 1..3 = the
+// colour planes of albedo / emission.  Sum order differs from the atomic path (as it does between
+// two runs of the atomic path); the parity tolerance on gradients is unchanged.
+#include "drt_device.h"
+#include "drt_launch.h"
+
+namespace drt {
+
+namespace {
+
+constexpr int kLdsTile = (kTileX + 1) * (kTileY + 1) * (kTileZ + 1);
+constexpr uint32_t kReduceWGs = 1024;   // per stream: 4 workgroups per CU, looping over the reduce units
+
+struct Cell { int x0, x1, y0, y1, z0, z1; float w[8]; };
+
+// base corner cell + weights of a record position: the SAME arithmetic as the lookups / the atomic path
+__device__ __forceinline__ void cell_of(const Params &P, float px, float py, float pz, int &x0, int &y0, int &z0)
+{
+    int i1; float w0, w1;
+    axis_setup(px, P.bmin[0], P.inv_ext[0], P.rx, x0, i1, w0, w1);
+    axis_setup(py, P.bmin[1], P.inv_ext[1], P.ry, y0, i1, w0, w1);
+    axis_setup(pz, P.bmin[2], P.inv_ext[2], P.rz, z0, i1, w0, w1);
+}
+
+__device__ __forceinline__ int bin_of(const Params &P, const DeferredPlan &D, float4 r)
+{
+    int x0, y0, z0;
+    cell_of(P, r.x, r.y, r.z, x0, y0, z0);
+    return ((z0 / kTileZ) * D.nty + (y0 / kTileY)) * D.ntx + (x0 / kTileX);
+}
+
+__global__ void __launch_bounds__(256) bin_histogram_kernel(const Params P, const DeferredPlan D)
+{
+    extern __shared__ uint32_t h[];
+    const int s = blockIdx.y;
+    for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    const uint32_t used = min(D.cursor[s], D.cap_chunks[s]);
+    float vmax = 0.0f;
+    for (uint32_t c = blockIdx.x; c < used; c += gridDim.x) {
+        const uint32_t cnt = D.chunk_count[s][c];
+        const float4 *src = D.in[s] + (size_t) c * kRecChunk;
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float4 r = src[i];
+            atomicAdd(&h[bin_of(P, D, r)], 1u);
+            const float a = fabsf(r.w);
+            if (a > vmax && a <= 3.0e38f) vmax = a;               // finite values only
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(D.vmax + s, __float_as_uint(vmax));
+    __syncthreads();
+    uint32_t *dst = D.hist + ((size_t) s * gridDim.x + blockIdx.x) * D.n_bins;
+    for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) dst[b] = h[b];
+}
+
+// per tile: exclusive prefix over the partition workgroups (in place) and the tile total.  One wave
+// per (stream, tile): lane l owns workgroups [l * per, (l + 1) * per) - independent loads, a wave scan
+// of the lane sums, independent stores.
+__global__ void __launch_bounds__(256) bin_offsets_kernel(const DeferredPlan D, int n_wgs)
+{
+    const int lane = threadIdx.x & 63, s = blockIdx.y;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= D.n_bins) return;
+    uint32_t *col = D.hist + (size_t) s * n_wgs * D.n_bins + b;
+    constexpr int kPer = kPartWGs / 64;
+    uint32_t v[kPer], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { v[k] = col[(size_t) (lane * kPer + k) * D.n_bins]; sum += v[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { col[(size_t) (lane * kPer + k) * D.n_bins] = run; run += v[k]; }
+    if (lane == 63) D.bin_base[(size_t) s * (D.n_bins + 1) + b] = incl;      // total for now
+}
+
+// one workgroup per stream: exclusive scan of the tile totals -> bin_base, and of the reduce-unit counts
+__global__ void __launch_bounds__(1024) bin_scan_kernel(const DeferredPlan D)
+{
+    __shared__ uint32_t sa[1024], sb[1024];
+    const int s = blockIdx.x, t = threadIdx.x;
+    uint32_t *base = D.bin_base + (size_t) s * (D.n_bins + 1);
+    uint32_t *ustart = D.unit_start + (size_t) s * (D.n_bins + 1);
+    const int per = (D.n_bins + 1023) / 1024;
+    uint32_t tot[4], ua = 0, ub = 0;
+    for (int k = 0; k < per; ++k) {
+        const int b = t * per + k;
+        tot[k] = b < D.n_bins ? base[b] : 0u;
+        ua += tot[k]; ub += (tot[k] + kUnitRecords - 1) / kUnitRecords;
+    }
+    sa[t] = ua; sb[t] = ub;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t a = t >= off ? sa[t - off] : 0u, b = t >= off ? sb[t - off] : 0u;
+        __syncthreads();
+        sa[t] += a; sb[t] += b;
+        __syncthreads();
+    }
+    uint32_t ra = sa[t] - ua, rb = sb[t] - ub;                    // exclusive
+    for (int k = 0; k < per; ++k) {
+        const int b = t * per + k;
+        if (b < D.n_bins) { base[b] = ra; ustart[b] = rb; }
+        ra += tot[k]; rb += (tot[k] + kUnitRecords - 1) / kUnitRecords;
+    }
+    if (t == 1023) { base[D.n_bins] = sa[t]; ustart[D.n_bins] = sb[t]; }
+}
+
+__global__ void __launch_bounds__(256) bin_scatter_kernel(const Params P, const DeferredPlan D)
+{
+    extern __shared__ uint32_t cur[];
+    const int s = blockIdx.y;
+    const uint32_t *off = D.hist + ((size_t) s * gridDim.x + blockIdx.x) * D.n_bins;
+    const uint32_t *base = D.bin_base + (size_t) s * (D.n_bins + 1);
+    for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) cur[b] = base[b] + off[b];
+    __syncthreads();
+    const uint32_t used = min(D.cursor[s], D.cap_chunks[s]);
+    float4 *dst = D.out[s];
+    for (uint32_t c = blockIdx.x; c < used; c += gridDim.x) {
+        const uint32_t cnt = D.chunk_count[s][c];
+        const float4 *src = D.in[s] + (size_t) c * kRecChunk;
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float4 r = src[i];
+            dst[atomicAdd(&cur[bin_of(P, D, r)], 1u)] = r;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const DeferredPlan D)
+{
+    extern __shared__ unsigned long long tile[];                 // kLdsTile signed 64-bit fixed-point accumulators
+    const int s = blockIdx.y;
+    // scale = 2^(40 - e) with max|v| < 2^e: |w * v| * scale < 2^40, 2^23 such adds fit an int64
+    const float vmax = __uint_as_float(D.vmax[s]);
+    int e = 0;
+    (void) frexpf(vmax, &e);
+    const double scale = ldexp(1.0, 40 - e), inv_scale = ldexp(1.0, e - 40);
+    const uint32_t *base = D.bin_base + (size_t) s * (D.n_bins + 1);
+    const uint32_t *ustart = D.unit_start + (size_t) s * (D.n_bins + 1);
+    const uint32_t n_units = ustart[D.n_bins];
+    // persistent workgroups (empty ones are not free to dispatch), each a CONTIGUOUS run of units: the
+    // units of a heavy tile follow one another, so the LDS tile is zeroed / flushed once per run
+    const uint32_t u_begin = (uint32_t) (((uint64_t) n_units * blockIdx.x) / gridDim.x);
+    const uint32_t u_end = (uint32_t) (((uint64_t) n_units * (blockIdx.x + 1)) / gridDim.x);
+    float *dst = s == 0 ? P.g_sigma : P.g_albedo + (s - 1);
+    const int stride = s == 0 ? 1 : 3;
+    const float4 *src = D.out[s];
+    int b = -1, X0 = 0, Y0 = 0, Z0 = 0;
+    for (uint32_t u = u_begin; u <= u_end; ++u) {
+        int nb = -1;
+        if (u < u_end) {
+            int lo = b < 0 ? 0 : b, hi = D.n_bins;                // largest tile with ustart[tile] <= u
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (ustart[mid] <= u) lo = mid; else hi = mid; }
+            nb = lo;
+        }
+        if (nb == b && nb < 0) break;                             // no units at all for this workgroup
+        if (nb != b) {
+            if (b >= 0 && !(P.debug_flags & 1024u)) {             // flush the finished tile (+=)
+                __syncthreads();
+                for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) {
+                    const long long q = (long long) tile[j];
+                    if (q == 0) continue;
+                    const float v = (float) ((double) q * inv_scale);
+                    const int lx = j % (kTileX + 1), ly = (j / (kTileX + 1)) % (kTileY + 1), lz = j / ((kTileX + 1) * (kTileY + 1));
+                    const size_t vox = ((size_t) (Z0 + lz) * P.ry + (Y0 + ly)) * P.rx + (X0 + lx);
+                    atomicAdd(dst + (size_t) stride * vox, v);
+                }
+                __syncthreads();
+            }
+            if (nb < 0) break;
+            b = nb;
+            X0 = (b % D.ntx) * kTileX; Y0 = ((b / D.ntx) % D.nty) * kTileY; Z0 = (b / (D.ntx * D.nty)) * kTileZ;
+            for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) tile[j] = 0ull;
+            __syncthreads();
+        }
+        const uint32_t first = base[b] + (u - ustart[b]) * kUnitRecords;
+        const uint32_t last = min(first + kUnitRecords, base[b + 1]);
+        for (uint32_t i = first + threadIdx.x; i < last; i += blockDim.x) {
+            const float4 r = src[i];
+            Stencil st;
+            axis_setup(r.x, P.bmin[0], P.inv_ext[0], P.rx, st.x0, st.x1, st.wx0, st.wx1);
+            axis_setup(r.y, P.bmin[1], P.inv_ext[1], P.ry, st.y0, st.y1, st.wy0, st.wy1);
+            axis_setup(r.z, P.bmin[2], P.inv_ext[2], P.rz, st.z0, st.z1, st.wz0, st.wz1);
+            float w[8];
+            stencil_weights(st, w);
+            const int x0 = st.x0 - X0, x1 = st.x1 - X0;
+            const int y0 = (st.y0 - Y0) * (kTileX + 1), y1 = (st.y1 - Y0) * (kTileX + 1);
+            const int z0 = (st.z0 - Z0) * ((kTileX + 1) * (kTileY + 1)), z1 = (st.z1 - Z0) * ((kTileX + 1) * (kTileY + 1));
+            const int o[8] = { z0 + y0 + x0, z0 + y0 + x1, z0 + y1 + x0, z0 + y1 + x1,
+                               z1 + y0 + x0, z1 + y0 + x1, z1 + y1 + x0, z1 + y1 + x1 };
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float pv = w[c] * r.w;                       // the float product the atomic path adds
+                const float pc = fminf(fmaxf(pv, -vmax), vmax);    // non-finite input cannot wrap the accumulator
+                atomicAdd(&tile[o[c]], (unsigned long long) __double2ll_rn((double) pc * scale));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev)
+{
+    const size_t lds = (size_t) D.n_bins * sizeof(uint32_t);
+    auto mark = [&](int k) { if (ev) (void) hipEventRecord(ev[k], stream); };
+    mark(0);
+    hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, 4), dim3(256), lds, stream, P, D);
+    mark(1);
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3((D.n_bins + 3) / 4, 4), dim3(256), 0, stream, D, kPartWGs);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(4), dim3(1024), 0, stream, D);
+    mark(2);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(kPartWGs, 4), dim3(256), lds, stream, P, D);
+    mark(3);
+    static const hipError_t attr = hipFuncSetAttribute((const void *) tile_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       kLdsTile * (int) sizeof(unsigned long long));
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(tile_reduce_kernel, dim3(D.max_units < kReduceWGs ? D.max_units : kReduceWGs, 4), dim3(256),
+                       kLdsTile * sizeof(unsigned long long), stream, P, D);
+    mark(4);
+    return hipGetLastError();
+}
+
+}  // namespace drt

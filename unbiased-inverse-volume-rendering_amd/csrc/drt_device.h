@@ -240,6 +240,14 @@ struct Params {
     float *gt;                 // plane c at gt + c * gt_plane
     uint32_t gt_plane;         // floats per plane = nbx * ry * rz * 16
     int gt_nbx;                // lines per grid row = ceil(rx / 3)
+    // Deferred splatting (adjoint, drt_deferred.hip): instead of atomics the tracer appends 16-byte
+    // records {p.x, p.y, p.z, value} to stream 0 (sigma_t) / 1..3 (colour planes), in chunks of
+    // kRecChunk records handed out by rec_cursor[s]; the records are then partitioned by grid tile and
+    // reduced in LDS.  rec_buf[0] == nullptr: the atomic path (apron scratch) is used.
+    float4 *rec_buf[4];
+    uint32_t *rec_chunk_count[4];   // valid records per chunk (zeroed per launch)
+    uint32_t rec_cap_chunks[4];     // chunks available per stream
+    uint32_t *rec_cursor;           // [0..3] chunks handed out, [4..7] splats that overflowed (direct atomics)
     unsigned long long *queues;     // 8 per-XCD ray queue heads (wavefront kernel), zeroed per launch
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
@@ -586,9 +594,84 @@ __device__ __forceinline__ void coop_scatter(float *dst, uint32_t chan_stride, c
     coop_stage_sync();
 }
 
+// ---------------------------------------------------------------------------
+// Deferred splatting: record append.  `st` = the wave's LDS state {cur[4], end[4]} (absolute record
+// slots of the stream's open chunk).  Called under divergence: the active lanes compact themselves
+// (ballot / prefix), the first one advances the cursor - taking a fresh chunk from the global counter
+// when the open one fills up, so chunks are always full except each wave's last - and every lane
+// stores its record with one 16-byte write.  Out of chunks: the splat goes straight to the caller's
+// grid with 8 atomics (slow, correct; counted in rec_cursor[4+s]).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRecChunk = 256;
+
+__device__ __forceinline__ void splat_direct(const Params &P, int s, V3 p, float v)
+{
+    Stencil st = make_stencil(P, p);
+    float w[8];
+    stencil_weights(st, w);
+    float *dst = s == 0 ? P.g_sigma : P.g_albedo + (s - 1);
+    const int stride = s == 0 ? 1 : 3;
+    const int idx[8] = { st.z0 + st.y0 + st.x0, st.z0 + st.y0 + st.x1, st.z0 + st.y1 + st.x0, st.z0 + st.y1 + st.x1,
+                         st.z1 + st.y0 + st.x0, st.z1 + st.y0 + st.x1, st.z1 + st.y1 + st.x0, st.z1 + st.y1 + st.x1 };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(dst + (size_t) stride * idx[k], w[k] * v);
+}
+
+__device__ __forceinline__ void emit_record(const Params &P, int s, V3 p, float v, uint32_t *st_)
+{
+    volatile uint32_t *st = st_;
+    const uint64_t mask = __ballot(1);
+    const uint32_t lane = __lane_id();
+    const uint32_t rank = (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+    const uint32_t n = (uint32_t) __popcll(mask);
+    uint32_t base0 = 0, base1 = 0, split = 0;
+    if (rank == 0) {
+        const uint32_t cur = st[s], end = st[4 + s];
+        base0 = cur;
+        if (cur + n <= end) { split = n; st[s] = cur + n; }
+        else {
+            split = end - cur;
+            if (end) P.rec_chunk_count[s][(end - 1u) / kRecChunk] = kRecChunk;      // the open chunk is full
+            const uint32_t c = atomicAdd(P.rec_cursor + s, 1u);
+            if (c < P.rec_cap_chunks[s]) {
+                base1 = c * kRecChunk;
+                st[s] = base1 + (n - split); st[4 + s] = base1 + kRecChunk;
+            } else {
+                base1 = 0xffffffffu;                                                // out of chunks
+                st[s] = end;
+                atomicAdd(P.rec_cursor + 4 + s, n - split);
+            }
+        }
+    }
+    base0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base0);
+    base1 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base1);
+    split = (uint32_t) __builtin_amdgcn_readfirstlane((int) split);
+    if (rank < split) P.rec_buf[s][base0 + rank] = make_float4(p.x, p.y, p.z, v);
+    else if (base1 != 0xffffffffu) P.rec_buf[s][base1 + (rank - split)] = make_float4(p.x, p.y, p.z, v);
+    else splat_direct(P, s, p, v);
+}
+
+// end of the wave: publish the fill of the chunks still open
+__device__ __forceinline__ void close_records(const Params &P, uint32_t *st_)
+{
+    volatile uint32_t *st = st_;
+    if (__lane_id() < 4) {
+        const int s = (int) __lane_id();
+        const uint32_t cur = st[s], end = st[4 + s];
+        if (end) P.rec_chunk_count[s][(end - 1u) / kRecChunk] = cur - (end - kRecChunk);
+    }
+}
+
+// DEFER: `rec` is the wave's record state (emit_record); otherwise the cooperative-scatter staging area
+template <bool DEFER = false>
 __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, uint32_t *rec)
 {
     if (g == 0.0f) return;            // adding exact zeros changes nothing: skip the requests
+    if constexpr (DEFER) {
+        if (P.debug_flags & 1u) return;
+        emit_record(P, 0, p, g * P.scale, rec);
+        return;
+    }
     float w[8]; int idx[8];
     make_grad_indices(P, p, idx, w);
     float gs = g * P.scale;
@@ -604,9 +687,17 @@ __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, ui
     coop_scatter<1>(P.gt, 0, idx, val, rec);
 }
 
+template <bool DEFER = false>
 __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float g[3], uint32_t *rec)
 {
     if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) return;   // e.g. nerf queries in empty space (weight 0)
+    if constexpr (DEFER) {
+        if (P.debug_flags & 1u) return;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (g[k] != 0.0f) emit_record(P, 1 + k, p, g[k], rec);
+        return;
+    }
     float w[8]; int idx[8];
     make_grad_indices(P, p, idx, w);
     if (P.debug_flags & 1u) return;

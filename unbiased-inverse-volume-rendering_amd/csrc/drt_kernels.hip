@@ -19,12 +19,12 @@ struct Ray { V3 o, d; float maxt; };
 struct Mei { bool valid; float t; V3 p; float sigma_t; };
 struct PathState { int depth; Hit si; float last_pdf; bool escaped; bool active; };
 
-template <bool COUNT, bool ENV>
+template <bool COUNT, bool ENV, bool DEFER = false>
 struct Tracer {
     const Params &P;
     float maj, inv_maj;
     uint32_t ray_index;
-    uint32_t *rec;          // wave-private LDS staging area of the cooperative scatter
+    uint32_t *rec;          // wave-private LDS: staging area of the cooperative scatter, or (DEFER) the record-stream state
     const uint32_t *occ;    // empty-space bitmask (LDS copy) or nullptr
     const float *mg;        // majorant supergrid as the DDA reads it (global memory, L2-resident; an LDS copy
                             // was measured slower: it costs a wave per SIMD of occupancy)
@@ -110,7 +110,7 @@ struct Tracer {
             count(C_RT);
             if constexpr (ADJ) if (tr > 0.0f) {                         // :487-492
                 float a = (adj[0] + adj[1]) + adj[2];
-                splat_sigma_t(P, p, -(a * lim) / tr, rec);
+                splat_sigma_t<DEFER>(P, p, -(a * lim) / tr, rec);
                 count(C_RT_ADJ);
             }
             T *= tr;                                                    // :495
@@ -255,8 +255,8 @@ struct Tracer {
             gs += a * alb[k];
             ga[k] = a * sig;
         }
-        splat_sigma_t(P, p, gs, rec); count(C_SC);                           // :577-581
-        splat_albedo(P, p, ga, rec);  count(C_SC_ALB);
+        splat_sigma_t<DEFER>(P, p, gs, rec); count(C_SC);                           // :577-581
+        splat_albedo<DEFER>(P, p, ga, rec);  count(C_SC_ALB);
     }
 
     // backpropagate_transmittance (volpathsimple.py:584-607)
@@ -267,7 +267,7 @@ struct Tracer {
         float g = -(adjw * (interval / 4.0f));
         for (int j = 0; j < 4; ++j) {
             float t = A.next_1d() * interval;                           // :595
-            splat_sigma_t(P, ray_at(ray.o, ray.d, t), g, rec);
+            splat_sigma_t<DEFER>(P, ray_at(ray.o, ray.d, t), g, rec);
             count(C_TR);
         }
     }
@@ -355,8 +355,8 @@ struct Tracer {
                         gs += a * albedo[k];
                         ga[k] = a * mei.sigma_t;
                     }
-                    splat_sigma_t(P, mei.p, gs, rec); count(C_SC);
-                    splat_albedo(P, mei.p, ga, rec);  count(C_SC_ALB);
+                    splat_sigma_t<DEFER>(P, mei.p, gs, rec); count(C_SC);
+                    splat_albedo<DEFER>(P, mei.p, ga, rec);  count(C_SC_ALB);
                 }
                 backprop_transmittance(A, ray, did_escape ? si.t : mei.t, dL, result);   // :181-189
             }
@@ -413,7 +413,7 @@ struct Tracer {
     }
 };
 
-template <bool ADJ, bool COUNT, bool ENV>
+template <bool ADJ, bool COUNT, bool ENV, bool DEFER>
 __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Params P)
 {
     // XCD-aware block -> ray-chunk map.  Workgroup b runs on XCD b % 8 (observed dispatch
@@ -432,8 +432,13 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
     }
 #endif
     uint64_t i = (uint64_t) b * blockDim.x + threadIdx.x;
-    Tracer<COUNT, ENV> tr(P);
-    if constexpr (ADJ) {
+    Tracer<COUNT, ENV, DEFER> tr(P);
+    if constexpr (ADJ && DEFER) {
+        __shared__ uint32_t rec_state[4 * 8];                   // per wave: cur[4], end[4]
+        tr.rec = rec_state + (threadIdx.x >> 6) * 8;
+        if ((threadIdx.x & 63) < 8) tr.rec[threadIdx.x & 63] = 0;
+        coop_stage_sync();
+    } else if constexpr (ADJ) {
         __shared__ uint32_t coop_rec[4 * 64 * kCoopDwords];
         tr.rec = coop_rec + (threadIdx.x >> 6) * (64 * kCoopDwords);
     }
@@ -469,6 +474,7 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
             P.L_out[3 * i] = L[0]; P.L_out[3 * i + 1] = L[1]; P.L_out[3 * i + 2] = L[2];
         }
     }
+    if constexpr (ADJ && DEFER) close_records(P, tr.rec);
     if (COUNT) {
         // wave reduction, then one device atomic per wave and slot
 #pragma unroll
@@ -898,15 +904,24 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
     if (P.n_rays == 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((P.n_rays + 255) / 256));
     const int variant = (adjoint ? 4 : 0) | (count ? 2 : 0) | (P.env_pix ? 1 : 0);
+    const bool defer = adjoint && P.rec_buf[0] != nullptr;
     switch (variant) {
-        case 0: hipLaunchKernelGGL((trace_kernel<false, false, false>), grid, block, 0, stream, P); break;
-        case 1: hipLaunchKernelGGL((trace_kernel<false, false, true>), grid, block, 0, stream, P); break;
-        case 2: hipLaunchKernelGGL((trace_kernel<false, true, false>), grid, block, 0, stream, P); break;
-        case 3: hipLaunchKernelGGL((trace_kernel<false, true, true>), grid, block, 0, stream, P); break;
-        case 4: hipLaunchKernelGGL((trace_kernel<true, false, false>), grid, block, 0, stream, P); break;
-        case 5: hipLaunchKernelGGL((trace_kernel<true, false, true>), grid, block, 0, stream, P); break;
-        case 6: hipLaunchKernelGGL((trace_kernel<true, true, false>), grid, block, 0, stream, P); break;
-        default: hipLaunchKernelGGL((trace_kernel<true, true, true>), grid, block, 0, stream, P); break;
+        case 0: hipLaunchKernelGGL((trace_kernel<false, false, false, false>), grid, block, 0, stream, P); break;
+        case 1: hipLaunchKernelGGL((trace_kernel<false, false, true, false>), grid, block, 0, stream, P); break;
+        case 2: hipLaunchKernelGGL((trace_kernel<false, true, false, false>), grid, block, 0, stream, P); break;
+        case 3: hipLaunchKernelGGL((trace_kernel<false, true, true, false>), grid, block, 0, stream, P); break;
+        case 4: if (defer) hipLaunchKernelGGL((trace_kernel<true, false, false, true>), grid, block, 0, stream, P);
+                else hipLaunchKernelGGL((trace_kernel<true, false, false, false>), grid, block, 0, stream, P);
+                break;
+        case 5: if (defer) hipLaunchKernelGGL((trace_kernel<true, false, true, true>), grid, block, 0, stream, P);
+                else hipLaunchKernelGGL((trace_kernel<true, false, true, false>), grid, block, 0, stream, P);
+                break;
+        case 6: if (defer) hipLaunchKernelGGL((trace_kernel<true, true, false, true>), grid, block, 0, stream, P);
+                else hipLaunchKernelGGL((trace_kernel<true, true, false, false>), grid, block, 0, stream, P);
+                break;
+        default: if (defer) hipLaunchKernelGGL((trace_kernel<true, true, true, true>), grid, block, 0, stream, P);
+                 else hipLaunchKernelGGL((trace_kernel<true, true, true, false>), grid, block, 0, stream, P);
+                 break;
     }
     return hipGetLastError();
 }

@@ -17,6 +17,26 @@ hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int 
 hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
 hipError_t launch_untile(const Params &P, hipStream_t stream);
+
+// Deferred splatting (drt_deferred.hip): record streams -> tile partition -> LDS reduction.
+constexpr int kTileX = 32, kTileY = 16, kTileZ = 16;   // base-corner cells per tile; LDS tile = 33 x 17 x 17 floats
+constexpr int kMaxBins = 4096;                           // tiles per grid the one-pass partition handles
+constexpr uint32_t kUnitRecords = 16384;                 // records per reduce workgroup
+constexpr int kPartWGs = 1024;                           // partition workgroups (histogram / scatter)
+struct DeferredPlan {
+    float4 *in[4], *out[4];          // record streams as emitted / tile-sorted
+    uint32_t *chunk_count[4];        // valid records per chunk of in[s]
+    uint32_t cap_chunks[4];
+    uint32_t *cursor;                // [0..3] chunks handed out (may exceed the capacity), [4..7] overflowed splats
+    uint32_t *hist;                  // [4][kPartWGs][n_bins] counts, then exclusive offsets
+    uint32_t *bin_base;              // [4][n_bins + 1]
+    uint32_t *unit_start;            // [4][n_bins + 1] first reduce unit of every tile
+    uint32_t *vmax;                  // [4] bit pattern of max |value| per stream (zeroed per launch)
+    int n_bins, ntx, nty, ntz;
+    uint32_t max_units;              // launch bound of the reduce kernel (any stream)
+};
+// ev: optional 5 events recorded before/after the stages (histogram | offsets+scan | scatter | reduce)
+hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev = nullptr);
 hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t *scratch_bits,
                            float *majorant, hipStream_t stream);
 hipError_t launch_batch_raygen(const float *sensors, int n_sensors, uint32_t batch_size, uint32_t spp, uint32_t seed_pixels,
