@@ -201,7 +201,10 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
 /* Profiling ablations / kernel selection for experiments; 0 in production.
  * bit 0 (1): skip the gradient atomics; bit 1 (2): per-lane (uncoalesced) atomics; bit 3 (8): force the
  * one-ray-per-lane tracing kernels; bit 4 (16): no empty-space bitmask; bit 5 (32): state-machine
- * kernel for the adjoint too. */
+ * kernel for the adjoint too; bit 7 (128): gradient splats as atomics into the apron scratch (the path
+ * used when the grid has more than 4096 tiles or the record streams exceed the memory budget) instead
+ * of deferred records; bit 8 (256): two-chunk record streams (exercises the out-of-chunks fallback);
+ * bits 9, 10 (512, 1024): reduction without LDS adds / without the flush (timing only). */
 int drt_set_debug_flags(drt_handle h, uint32_t flags);
 
 const char *drt_version(void);

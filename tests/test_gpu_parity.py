@@ -365,12 +365,15 @@ def test_sigma_t_gradient_vs_finite_differences(uivr, gpu, variant):
 
 
 @pytest.mark.parametrize("flags,variant", [(8, "drt"), (8, "basic"), (32, "drt"), (32, "drt-nomis"), (32, "basic"),
-                                           (2, "drt"), (16, "drt")])
+                                           (2, "drt"), (16, "drt"), (128, "drt"), (128, "quadratic"), (256, "drt"),
+                                           (256, "basic")])
 def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     """The production path uses the wave-synchronous state machine for the primal and the
     one-ray-per-lane kernel for the adjoint (measured faster).  The other combinations
     stay verified: 8 = per-lane kernels everywhere, 32 = state machine for the adjoint too,
-    2 = uncoalesced per-lane atomics, 16 = no empty-space bitmask."""
+    2 = uncoalesced per-lane atomics, 16 = no empty-space bitmask, 128 = gradient splats as atomics
+    into the apron scratch instead of deferred records, 256 = record streams of two chunks, so
+    almost every splat takes the out-of-chunks fallback (direct atomics into the caller's grid)."""
     props = props_for(variant)
     scene = uivr.cube_test_scene(32, 32, density_scale=2.0)
     spp, seed = 16, 777

@@ -33,6 +33,7 @@ namespace drt {
 namespace {
 
 constexpr int kLdsTile = (kTileX + 1) * (kTileY + 1) * (kTileZ + 1);
+constexpr int kPartUnroll = 4;          // chunks a partition workgroup keeps in flight
 constexpr uint32_t kReduceWGs = 1024;   // per stream: 4 workgroups per CU, looping over the reduce units
 
 struct Cell { int x0, x1, y0, y1, z0, z1; float w[8]; };
@@ -61,13 +62,20 @@ __global__ void __launch_bounds__(256) bin_histogram_kernel(const Params P, cons
     __syncthreads();
     const uint32_t used = min(D.cursor[s], D.cap_chunks[s]);
     float vmax = 0.0f;
-    for (uint32_t c = blockIdx.x; c < used; c += gridDim.x) {
-        const uint32_t cnt = D.chunk_count[s][c];
-        const float4 *src = D.in[s] + (size_t) c * kRecChunk;
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const float4 r = src[i];
-            atomicAdd(&h[bin_of(P, D, r)], 1u);
-            const float a = fabsf(r.w);
+    static_assert(kRecChunk == 256, "one record per thread and chunk");
+    for (uint32_t c0 = blockIdx.x; c0 < used; c0 += kPartUnroll * gridDim.x) {
+        float4 r[kPartUnroll]; bool ok[kPartUnroll];
+#pragma unroll
+        for (int k = 0; k < kPartUnroll; ++k) {                   // kPartUnroll chunks in flight per workgroup
+            const uint32_t c = c0 + k * gridDim.x;
+            ok[k] = c < used && threadIdx.x < D.chunk_count[s][c];
+            if (ok[k]) r[k] = D.in[s][(size_t) c * kRecChunk + threadIdx.x];
+        }
+#pragma unroll
+        for (int k = 0; k < kPartUnroll; ++k) {
+            if (!ok[k]) continue;
+            atomicAdd(&h[bin_of(P, D, r[k])], 1u);
+            const float a = fabsf(r[k].w);
             if (a > vmax && a <= 3.0e38f) vmax = a;               // finite values only
         }
     }
@@ -142,13 +150,19 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(const Params P, const 
     __syncthreads();
     const uint32_t used = min(D.cursor[s], D.cap_chunks[s]);
     float4 *dst = D.out[s];
-    for (uint32_t c = blockIdx.x; c < used; c += gridDim.x) {
-        const uint32_t cnt = D.chunk_count[s][c];
-        const float4 *src = D.in[s] + (size_t) c * kRecChunk;
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const float4 r = src[i];
-            dst[atomicAdd(&cur[bin_of(P, D, r)], 1u)] = r;
+    for (uint32_t c0 = blockIdx.x; c0 < used; c0 += kPartUnroll * gridDim.x) {   // same chunk -> workgroup map as the histogram
+        float4 r[kPartUnroll]; bool ok[kPartUnroll];
+#pragma unroll
+        for (int k = 0; k < kPartUnroll; ++k) {
+            const uint32_t c = c0 + k * gridDim.x;
+            ok[k] = c < used && threadIdx.x < D.chunk_count[s][c];
+            if (ok[k]) r[k] = D.in[s][(size_t) c * kRecChunk + threadIdx.x];
         }
+        uint32_t slot[kPartUnroll];
+#pragma unroll
+        for (int k = 0; k < kPartUnroll; ++k) if (ok[k]) slot[k] = atomicAdd(&cur[bin_of(P, D, r[k])], 1u);
+#pragma unroll
+        for (int k = 0; k < kPartUnroll; ++k) if (ok[k]) dst[slot[k]] = r[k];
     }
 }
 
@@ -201,8 +215,14 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
         }
         const uint32_t first = base[b] + (u - ustart[b]) * kUnitRecords;
         const uint32_t last = min(first + kUnitRecords, base[b + 1]);
-        for (uint32_t i = first + threadIdx.x; i < last; i += blockDim.x) {
-            const float4 r = src[i];
+        for (uint32_t i0 = first + threadIdx.x; i0 < last; i0 += 4 * blockDim.x) {
+            float4 rr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + k * blockDim.x < last) rr[k] = src[i0 + k * blockDim.x];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+            if (i0 + k * blockDim.x >= last) break;
+            const float4 r = rr[k];
             Stencil st;
             axis_setup(r.x, P.bmin[0], P.inv_ext[0], P.rx, st.x0, st.x1, st.wx0, st.wx1);
             axis_setup(r.y, P.bmin[1], P.inv_ext[1], P.ry, st.y0, st.y1, st.wy0, st.wy1);
@@ -219,6 +239,7 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
                 const float pv = w[c] * r.w;                       // the float product the atomic path adds
                 const float pc = fminf(fmaxf(pv, -vmax), vmax);    // non-finite input cannot wrap the accumulator
                 atomicAdd(&tile[o[c]], (unsigned long long) __double2ll_rn((double) pc * scale));
+            }
             }
         }
     }
