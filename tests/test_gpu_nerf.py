@@ -26,9 +26,12 @@ def _h1(uivr, sg, integ, spp, seed):
     return img, grads
 
 
+@pytest.mark.parametrize("flags", [0, 128, 256])
 @pytest.mark.parametrize("props", [dict(), dict(queries_per_ray=64, activation="relu"),
                                    dict(queries_per_ray=17, jittering_enabled=False, hide_emitters=True)])
-def test_nerf_matches_oracle(uivr, oracle, gpu, props):
+def test_nerf_matches_oracle(uivr, oracle, gpu, props, flags):
+    """flags: 0 = deferred tile-binned splatting (production), 128 = atomics into the apron scratch,
+    256 = two-chunk record streams (out-of-chunks fallback)."""
     scene = uivr.cube_test_scene(32, 32, density_scale=1.5)
     if props.get("activation") == "relu":
         scene.medium.sigma_t[1, 1, 1, 0] = -0.3          # exercise the clamped branch
@@ -45,6 +48,7 @@ def test_nerf_matches_oracle(uivr, oracle, gpu, props):
     batch = uivr.RayBatch(n_rays=32 * 32 * spp, spp=spp, sensor=sg.sensors[0])
     samp = uivr.IndependentSampler(seed, spp)
     h = integ.native_handle(sg)
+    h.set_debug_flags(flags)
     h.enable_counters(True)
     h.reset_counters()
     L, _, state = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
@@ -54,6 +58,7 @@ def test_nerf_matches_oracle(uivr, oracle, gpu, props):
     assert cnt == cr
     grads = uivr.alloc_grads(sg, integ.param_keys)
     integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=state, grads=grads)
+    h.set_debug_flags(0)
     _close(grads[uivr.SIGMA_T_KEY], gs, "grad sigma_t")
     _close(grads[uivr.EMISSION_KEY], ge, "grad emission")
 

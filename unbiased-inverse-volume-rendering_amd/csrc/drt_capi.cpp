@@ -39,6 +39,7 @@ struct drt_handle_s {
     uint64_t rec_rays = 0;         // ray count the current carving was sized for
     int rec_bins = 0;
     bool rec_tiny = false;
+    uint32_t rec_per_ray[2] = {0, 0};   // record capacity per ray (sigma_t, each colour plane) of the current carving
     drt::DeferredPlan plan{};
     size_t rec_clear_bytes = 0;    // chunk fills + cursors: the prefix of d_rec zeroed before every launch
     size_t mgrid_cells = 0;
@@ -173,33 +174,33 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
 // Deferred splatting is used for the one-ray-per-lane adjoint kernel when the grid has at most kMaxBins
 // tiles and the record streams fit the memory budget; otherwise (and with debug bit 128) the tracer
 // adds its splats to the apron scratch with atomics and untile_gradients_kernel reduces that.
-constexpr uint64_t kRecBudgetBytes = 64ull << 30;
+constexpr uint64_t kRecBudgetBytes = 48ull << 30;               // record streams (emitted + tile-sorted) per sub-batch
 
-bool want_deferred(drt_handle h, const drt::Params &P, uint64_t n_rays)
+bool want_deferred(drt_handle h, const drt::Params &P)
 {
     if (h->debug_flags & (128u | 2u | 32u)) return false;          // 128: atomic path; 2: per-lane atomics; 32: state machine
     const int ntx = (P.rx + drt::kTileX - 1) / drt::kTileX, nty = (P.ry + drt::kTileY - 1) / drt::kTileY,
               ntz = (P.rz + drt::kTileZ - 1) / drt::kTileZ;
-    if ((int64_t) ntx * nty * ntz > drt::kMaxBins) return false;
-    return n_rays * 3200ull < kRecBudgetBytes;                       // ~3.1 kB of record space per ray (in + sorted)
+    return (int64_t) ntx * nty * ntz <= drt::kMaxBins;
 }
 
-int ensure_deferred(drt_handle h, drt::Params &P, uint64_t n_rays)
+int ensure_deferred(drt_handle h, drt::Params &P, uint64_t n_rays, uint32_t per_ray_sigma, uint32_t per_ray_colour)
 {
     using namespace drt;
     DeferredPlan &D = h->plan;
     const int ntx = (P.rx + kTileX - 1) / kTileX, nty = (P.ry + kTileY - 1) / kTileY, ntz = (P.rz + kTileZ - 1) / kTileZ;
     const int n_bins = ntx * nty * ntz;
     const bool tiny_now = (h->debug_flags & 256u) != 0;
-    if (!h->d_rec || n_rays > h->rec_rays || n_bins != h->rec_bins || tiny_now != h->rec_tiny) {
+    if (!h->d_rec || n_rays > h->rec_rays || n_bins != h->rec_bins || tiny_now != h->rec_tiny ||
+        per_ray_sigma > h->rec_per_ray[0] || per_ray_colour > h->rec_per_ray[1]) {
         // capacity: every wave may leave one chunk partly filled per stream, plus the expected volume
         // (headline workload: 12.3 sigma_t and 1.4 colour splats per ray) with a wide margin; beyond it the
         // tracer falls back to direct atomics (emit_record), so this is a performance choice only
         const uint64_t waves = (n_rays + 63) / 64;
         const bool tiny = (h->debug_flags & 256u) != 0;            // test hook: force the overflow path
         uint64_t chunks[4];
-        chunks[0] = tiny ? 2 : 2 * waves + (n_rays * 48 + kRecChunk - 1) / kRecChunk;
-        for (int s = 1; s < 4; ++s) chunks[s] = tiny ? 1 : 2 * waves + (n_rays * 6 + kRecChunk - 1) / kRecChunk;
+        chunks[0] = tiny ? 2 : 2 * waves + (n_rays * per_ray_sigma + kRecChunk - 1) / kRecChunk;
+        for (int s = 1; s < 4; ++s) chunks[s] = tiny ? 1 : 2 * waves + (n_rays * per_ray_colour + kRecChunk - 1) / kRecChunk;
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
         size_t o_cursor = carve(12 * sizeof(uint32_t));          // cursors [8] + vmax [4]
@@ -229,10 +230,43 @@ int ensure_deferred(drt_handle h, drt::Params &P, uint64_t n_rays)
         D.n_bins = n_bins; D.ntx = ntx; D.nty = nty; D.ntz = ntz;
         D.max_units = (uint32_t) (max_chunks * kRecChunk / kUnitRecords + (uint64_t) n_bins + 1);
         h->rec_clear_bytes = clear; h->rec_rays = n_rays; h->rec_bins = n_bins; h->rec_tiny = tiny;
+        h->rec_per_ray[0] = per_ray_sigma; h->rec_per_ray[1] = per_ray_colour;
     }
     DRT_HIP_CHECK(h, hipMemsetAsync(h->d_rec, 0, h->rec_clear_bytes, h->stream));
     for (int s = 0; s < 4; ++s) { P.rec_buf[s] = D.in[s]; P.rec_chunk_count[s] = D.chunk_count[s]; P.rec_cap_chunks[s] = D.cap_chunks[s]; }
     P.rec_cursor = D.cursor;
+    return DRT_OK;
+}
+
+int timed_reduce(drt_handle h, const drt::Params &P);
+int timed_untile(drt_handle h, const drt::Params &P);
+
+// Adjoint launch + gradient reduction of one job.  Deferred path: the job is cut into sub-batches of
+// rays whose record streams fit the memory budget (each: clear fills, trace, partition + reduce).
+template <class Launch>
+int run_backward(drt_handle h, drt::Params &P, bool allow_defer, uint32_t per_ray_sigma, uint32_t per_ray_colour, Launch launch)
+{
+    if (!allow_defer || !want_deferred(h, P)) {
+        int rc = launch(P);
+        if (rc) return rc;
+        return timed_untile(h, P);
+    }
+    const uint64_t n_rays = P.n_rays;
+    const uint64_t bytes_per_ray = 32ull * ((uint64_t) per_ray_sigma + 3ull * per_ray_colour) + 1024ull;   // streams in + sorted, chunk slack
+    uint64_t batch = kRecBudgetBytes / bytes_per_ray;
+    batch = batch / 4096 * 4096;                                   // keeps whole workgroups (and XCD runs) per sub-batch
+    if (batch == 0) batch = 4096;
+    for (uint64_t first = 0; first < n_rays; first += batch) {
+        const uint64_t count = n_rays - first < batch ? n_rays - first : batch;
+        int rc = ensure_deferred(h, P, count, per_ray_sigma, per_ray_colour);
+        if (rc) return rc;
+        P.ray_first = first; P.n_rays = first + count;
+        rc = launch(P);
+        if (rc) return rc;
+        rc = timed_reduce(h, P);
+        if (rc) return rc;
+    }
+    P.ray_first = 0; P.n_rays = n_rays;
     return DRT_OK;
 }
 
@@ -264,6 +298,22 @@ int timed_reduce(drt_handle h, const drt::Params &P)
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
         h->timed[2].emplace_back(a, b);
+    }
+    return DRT_OK;
+}
+
+int timed_nerf(drt_handle h, int which, const drt::Params &P, bool adjoint)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventCreate(&a));
+        DRT_HIP_CHECK(h, hipEventCreate(&b));
+        DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
+    }
+    DRT_HIP_CHECK(h, drt::launch_nerf(P, adjoint, h->counting, h->stream));
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
+        h->timed[which].emplace_back(a, b);
     }
     return DRT_OK;
 }
@@ -598,14 +648,9 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     drt::Params P;
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
-    const bool defer = want_deferred(h, P, n_rays);
-    if (defer) {
-        rc = ensure_deferred(h, P, n_rays);
-        if (rc) return rc;
-    }
-    rc = timed_launch(h, 1, P, true);
-    if (rc) return rc;
-    return defer ? timed_reduce(h, P) : timed_untile(h, P);
+    // capacity: 48 sigma_t and 6 colour records per ray (headline workload: 12.3 and 1.4); beyond it the
+    // tracer falls back to direct atomics (emit_record), so this is a performance choice only
+    return run_backward(h, P, true, 48, 6, [&](drt::Params &Q) { return timed_launch(h, 1, Q, true); });
 }
 
 static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, const float *emission)
@@ -631,8 +676,7 @@ int drt_nerf_render_primal(drt_handle h, const drt_nerf_config *cfg, const float
     rc = nerf_fill(h, P, cfg, emission);
     if (rc) return rc;
     P.L_out = L_out;
-    DRT_HIP_CHECK(h, drt::launch_nerf(P, false, h->counting, h->stream));
-    return DRT_OK;
+    return timed_nerf(h, 0, P, false);
 }
 
 int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
@@ -650,8 +694,8 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
     rc = nerf_fill(h, P, cfg, emission);
     if (rc) return rc;
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_emission;
-    DRT_HIP_CHECK(h, drt::launch_nerf(P, true, h->counting, h->stream));
-    return timed_untile(h, P);
+    const uint32_t q = (uint32_t) cfg->queries_per_ray;          // at most one splat per query and plane
+    return run_backward(h, P, true, q, q, [&](drt::Params &Q) { return timed_nerf(h, 1, Q, true); });
 }
 
 int drt_batch_sample_rays(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_size, uint32_t spp,

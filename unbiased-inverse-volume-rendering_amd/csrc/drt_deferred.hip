@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const DeferredPlan D)
     uint32_t *base = D.bin_base + (size_t) s * (D.n_bins + 1);
     uint32_t *ustart = D.unit_start + (size_t) s * (D.n_bins + 1);
     const int per = (D.n_bins + 1023) / 1024;
-    uint32_t tot[4], ua = 0, ub = 0;
+    uint32_t tot[kMaxBins / 1024], ua = 0, ub = 0;
     for (int k = 0; k < per; ++k) {
         const int b = t * per + k;
         tot[k] = b < D.n_bins ? base[b] : 0u;

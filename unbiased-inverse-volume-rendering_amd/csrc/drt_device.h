@@ -226,7 +226,8 @@ struct Params {
     int width, height;
     // job
     const float *rays_o, *rays_d;
-    uint64_t n_rays, ray_offset;
+    uint64_t n_rays, ray_offset;   // local rays [ray_first, n_rays) are traced by this launch (sub-batches of one job)
+    uint64_t ray_first;
     uint64_t chunk, stride;    // global index of local ray i = ray_offset + (i/chunk)*stride + i%chunk (chunk 0: + i)
     uint32_t spp, seed, alt_seed;
     // outputs / adjoint inputs

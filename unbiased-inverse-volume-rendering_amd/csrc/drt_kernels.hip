@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
         }
     }
 #endif
-    uint64_t i = (uint64_t) b * blockDim.x + threadIdx.x;
+    uint64_t i = P.ray_first + (uint64_t) b * blockDim.x + threadIdx.x;
     Tracer<COUNT, ENV, DEFER> tr(P);
     if constexpr (ADJ && DEFER) {
         __shared__ uint32_t rec_state[4 * 8];                   // per wave: cur[4], end[4]
@@ -492,10 +492,10 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
 // queries_per_ray jittered queries per ray, PRB-style backward.  One ray per lane; the loop is
 // regular (no divergence besides rays that miss the box).
 // ---------------------------------------------------------------------------
-template <bool ADJ, bool COUNT>
+template <bool ADJ, bool COUNT, bool DEFER>
 __global__ void __launch_bounds__(256) nerf_kernel(const Params P)
 {
-    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = P.ray_first + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t occ_lds[kOccWords];
     const uint32_t *occ = nullptr;
     if (P.occ) {
@@ -504,7 +504,12 @@ __global__ void __launch_bounds__(256) nerf_kernel(const Params P)
         occ = occ_lds;
     }
     uint32_t *rec = nullptr;
-    if constexpr (ADJ) {
+    if constexpr (ADJ && DEFER) {
+        __shared__ uint32_t rec_state[4 * 8];                   // per wave: cur[4], end[4]
+        rec = rec_state + (threadIdx.x >> 6) * 8;
+        if ((threadIdx.x & 63) < 8) rec[threadIdx.x & 63] = 0;
+        coop_stage_sync();
+    } else if constexpr (ADJ) {
         __shared__ uint32_t coop_rec[4 * 64 * kCoopDwords];
         rec = coop_rec + (threadIdx.x >> 6) * (64 * kCoopDwords);
     }
@@ -564,8 +569,8 @@ __global__ void __launch_bounds__(256) nerf_kernel(const Params P)
                         ge[k] = dL[k] * weight;
                     }
                     if (P.nerf_relu && !(raw > 0.0f)) gs = 0.0f;
-                    splat_sigma_t(P, p, gs, rec);
-                    splat_albedo(P, p, ge, rec);       // planes 1..3 of the scratch = emission gradients here
+                    splat_sigma_t<DEFER>(P, p, gs, rec);
+                    splat_albedo<DEFER>(P, p, ge, rec);    // colour planes = emission gradients here
                 }
                 t_a = t_b;
                 if (!last) { throughput *= safe_a; weights_sum += weight; }  // :117-120
@@ -581,6 +586,7 @@ __global__ void __launch_bounds__(256) nerf_kernel(const Params P)
         }
         if constexpr (!ADJ) { P.L_out[3 * i] = result[0]; P.L_out[3 * i + 1] = result[1]; P.L_out[3 * i + 2] = result[2]; }
     }
+    if constexpr (ADJ && DEFER) close_records(P, rec);
     if (COUNT) {
         uint32_t vals[C_COUNT] = { n_rays, n_q, 0, 0, n_q, 0, 0, ADJ ? n_q : 0u, ADJ ? n_q : 0u };
 #pragma unroll
@@ -901,8 +907,8 @@ hipError_t launch_debug_eval(const Params &P, int op, const float *in, uint64_t 
 // ---------------------------------------------------------------------------
 hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t stream)
 {
-    if (P.n_rays == 0) return hipSuccess;
-    dim3 block(256), grid((unsigned)((P.n_rays + 255) / 256));
+    if (P.n_rays <= P.ray_first) return hipSuccess;
+    dim3 block(256), grid((unsigned)((P.n_rays - P.ray_first + 255) / 256));
     const int variant = (adjoint ? 4 : 0) | (count ? 2 : 0) | (P.env_pix ? 1 : 0);
     const bool defer = adjoint && P.rec_buf[0] != nullptr;
     switch (variant) {
@@ -954,14 +960,18 @@ hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int 
 
 hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream)
 {
-    if (P.n_rays == 0) return hipSuccess;
-    dim3 block(256), grid((unsigned)((P.n_rays + 255) / 256));
-    if (adjoint) {
-        if (count) hipLaunchKernelGGL((nerf_kernel<true, true>), grid, block, 0, stream, P);
-        else       hipLaunchKernelGGL((nerf_kernel<true, false>), grid, block, 0, stream, P);
+    if (P.n_rays <= P.ray_first) return hipSuccess;
+    dim3 block(256), grid((unsigned)((P.n_rays - P.ray_first + 255) / 256));
+    const bool defer = adjoint && P.rec_buf[0] != nullptr;
+    if (adjoint && defer) {
+        if (count) hipLaunchKernelGGL((nerf_kernel<true, true, true>), grid, block, 0, stream, P);
+        else       hipLaunchKernelGGL((nerf_kernel<true, false, true>), grid, block, 0, stream, P);
+    } else if (adjoint) {
+        if (count) hipLaunchKernelGGL((nerf_kernel<true, true, false>), grid, block, 0, stream, P);
+        else       hipLaunchKernelGGL((nerf_kernel<true, false, false>), grid, block, 0, stream, P);
     } else {
-        if (count) hipLaunchKernelGGL((nerf_kernel<false, true>), grid, block, 0, stream, P);
-        else       hipLaunchKernelGGL((nerf_kernel<false, false>), grid, block, 0, stream, P);
+        if (count) hipLaunchKernelGGL((nerf_kernel<false, true, false>), grid, block, 0, stream, P);
+        else       hipLaunchKernelGGL((nerf_kernel<false, false, false>), grid, block, 0, stream, P);
     }
     return hipGetLastError();
 }

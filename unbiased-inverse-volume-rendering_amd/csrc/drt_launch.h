@@ -20,7 +20,7 @@ hipError_t launch_untile(const Params &P, hipStream_t stream);
 
 // Deferred splatting (drt_deferred.hip): record streams -> tile partition -> LDS reduction.
 constexpr int kTileX = 32, kTileY = 16, kTileZ = 16;   // base-corner cells per tile; LDS tile = 33 x 17 x 17 floats
-constexpr int kMaxBins = 4096;                           // tiles per grid the one-pass partition handles
+constexpr int kMaxBins = 16384;                          // tiles per grid the one-pass partition handles (64 KiB LDS histogram): 512^3
 constexpr uint32_t kUnitRecords = 16384;                 // records per reduce workgroup
 constexpr int kPartWGs = 1024;                           // partition workgroups (histogram / scatter)
 struct DeferredPlan {
