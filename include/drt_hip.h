@@ -184,8 +184,10 @@ int drt_get_counters(drt_handle h, drt_counters *out);   /* synchronises the str
  * drt_enable_timing (either value) synchronises and discards recorded pairs.
  * drt_read_timings synchronises, writes up to `capacity` durations (ms, launch
  * order) of the primal (backward = 0) or adjoint (backward = 1) tracing launches
- * or of the gradient-scratch reduction that follows each adjoint (backward = 2)
- * and returns the number recorded (>= 0) or a negative drt_status. */
+ * or of the gradient reductions that follow each adjoint launch (backward = 2; on
+ * a side stream when sub-batches are pipelined) or of whole backward passes,
+ * first launch to last reduction (backward = 3), and returns the number recorded
+ * (>= 0) or a negative drt_status. */
 int drt_enable_timing(drt_handle h, int enable);
 int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity);
 

@@ -58,7 +58,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     tp, ta, tr = h.read_timings(0), h.read_timings(1), h.read_timings(2)
     h.enable_timing(False)
-    mean = lambda v: round(sum(v) / max(1, len(v)), 3)
+    mean = lambda v: round(sum(v) / args.steps, 3)       # per step (sub-batch launches summed)
     print(json.dumps({"workload": f"nerf {args.res}^3 {'dense' if args.dense else 'dust-devil'}, {args.film}^2 x {spp} spp, {args.queries} queries/ray",
                       "Msamples_per_s": round(n * spp / dt / 1e6, 2), "ms_per_step": round(1e3 * dt, 3),
                       "t_primal_ms": mean(tp), "t_adjoint_ms": mean(ta), "t_grad_reduce_ms": mean(tr),

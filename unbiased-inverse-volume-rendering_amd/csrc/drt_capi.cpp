@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -33,15 +34,21 @@ struct drt_handle_s {
     uint32_t *d_occ = nullptr;     // empty-space bitmask (kOccWords words)
     float *d_mgrid = nullptr;      // majorant supergrid (refreshed by drt_params_changed)
     float *d_env = nullptr;        // envmap emitter: pixels | marginal CDF | conditional CDFs (one allocation)
-    // deferred splatting (drt_deferred.hip): record streams in / tile-sorted, chunk fills, partition tables
-    void *d_rec = nullptr;         // one allocation, carved up in ensure_deferred
-    size_t rec_bytes = 0;
-    uint64_t rec_rays = 0;         // ray count the current carving was sized for
-    int rec_bins = 0;
-    bool rec_tiny = false;
-    uint32_t rec_per_ray[2] = {0, 0};   // record capacity per ray (sigma_t, each colour plane) of the current carving
-    drt::DeferredPlan plan{};
-    size_t rec_clear_bytes = 0;    // chunk fills + cursors: the prefix of d_rec zeroed before every launch
+    // deferred splatting (drt_deferred.hip): record streams in / tile-sorted, chunk fills, partition tables.
+    // Two slots: sub-batch b traces into slot b % 2 while slot (b - 1) % 2 is reduced on the side stream.
+    struct RecSlot {
+        void *mem = nullptr;           // one allocation, carved up in ensure_deferred
+        size_t bytes = 0;
+        uint64_t rays = 0;             // ray count the current carving was sized for
+        int bins = 0;
+        bool tiny = false;
+        uint32_t per_ray[2] = {0, 0};  // record capacity per ray (sigma_t, each colour plane) of the current carving
+        drt::DeferredPlan plan{};
+        size_t clear_bytes = 0;        // chunk fills + cursors: the prefix of mem zeroed before every launch
+        hipEvent_t traced = nullptr, reduced = nullptr;
+        bool busy = false;             // `reduced` is pending on the side stream
+    } rec[2];
+    hipStream_t side = nullptr;        // high-priority stream of the overlapped reductions
     size_t mgrid_cells = 0;
     size_t sigma_b_floats = 0;
     size_t gt_floats = 0;
@@ -51,7 +58,7 @@ struct drt_handle_s {
     int occ_z = 0;
     bool timing = false;
     // HIP event pairs around every tracing launch while timing is on: [0] primal, [1] backward
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[3];   // primal, adjoint, gradient reduction
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed[4];   // primal, adjoint, gradient reduction, whole backward pass
     std::string error;
 };
 
@@ -184,26 +191,25 @@ bool want_deferred(drt_handle h, const drt::Params &P)
     return (int64_t) ntx * nty * ntz <= drt::kMaxBins;
 }
 
-int ensure_deferred(drt_handle h, drt::Params &P, uint64_t n_rays, uint32_t per_ray_sigma, uint32_t per_ray_colour)
+int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint64_t n_rays, uint32_t per_ray_sigma,
+                    uint32_t per_ray_colour)
 {
     using namespace drt;
-    DeferredPlan &D = h->plan;
+    DeferredPlan &D = R.plan;
     const int ntx = (P.rx + kTileX - 1) / kTileX, nty = (P.ry + kTileY - 1) / kTileY, ntz = (P.rz + kTileZ - 1) / kTileZ;
     const int n_bins = ntx * nty * ntz;
-    const bool tiny_now = (h->debug_flags & 256u) != 0;
-    if (!h->d_rec || n_rays > h->rec_rays || n_bins != h->rec_bins || tiny_now != h->rec_tiny ||
-        per_ray_sigma > h->rec_per_ray[0] || per_ray_colour > h->rec_per_ray[1]) {
-        // capacity: every wave may leave one chunk partly filled per stream, plus the expected volume
-        // (headline workload: 12.3 sigma_t and 1.4 colour splats per ray) with a wide margin; beyond it the
-        // tracer falls back to direct atomics (emit_record), so this is a performance choice only
+    const bool tiny = (h->debug_flags & 256u) != 0;                // test hook: force the out-of-chunks path
+    if (!R.mem || n_rays > R.rays || n_bins != R.bins || tiny != R.tiny || per_ray_sigma > R.per_ray[0] ||
+        per_ray_colour > R.per_ray[1]) {
+        // capacity: every wave may leave one chunk partly filled per stream, plus the expected volume;
+        // beyond it the tracer falls back to direct atomics (emit_record): a performance choice only
         const uint64_t waves = (n_rays + 63) / 64;
-        const bool tiny = (h->debug_flags & 256u) != 0;            // test hook: force the overflow path
         uint64_t chunks[4];
         chunks[0] = tiny ? 2 : 2 * waves + (n_rays * per_ray_sigma + kRecChunk - 1) / kRecChunk;
         for (int s = 1; s < 4; ++s) chunks[s] = tiny ? 1 : 2 * waves + (n_rays * per_ray_colour + kRecChunk - 1) / kRecChunk;
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
-        size_t o_cursor = carve(12 * sizeof(uint32_t));          // cursors [8] + vmax [4]
+        size_t o_cursor = carve(20 * sizeof(uint32_t));          // cursors [8] + vmax [4] + debug checksums [4 x u64]
         size_t o_count[4], o_in[4], o_out[4];
         for (int s = 0; s < 4; ++s) o_count[s] = carve(chunks[s] * sizeof(uint32_t));
         const size_t clear = off;
@@ -211,12 +217,16 @@ int ensure_deferred(drt_handle h, drt::Params &P, uint64_t n_rays, uint32_t per_
         size_t o_base = carve((size_t) 4 * (n_bins + 1) * sizeof(uint32_t));
         size_t o_unit = carve((size_t) 4 * (n_bins + 1) * sizeof(uint32_t));
         for (int s = 0; s < 4; ++s) { o_in[s] = carve(chunks[s] * kRecChunk * sizeof(float4)); o_out[s] = carve(chunks[s] * kRecChunk * sizeof(float4)); }
-        if (off > h->rec_bytes) {
-            if (h->d_rec) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_rec); h->d_rec = nullptr; h->rec_bytes = 0; }
-            DRT_HIP_CHECK(h, hipMalloc(&h->d_rec, off));
-            h->rec_bytes = off;
+        if (off > R.bytes) {
+            if (R.mem) {
+                DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+                if (h->side) DRT_HIP_CHECK(h, hipStreamSynchronize(h->side));
+                (void) hipFree(R.mem); R.mem = nullptr; R.bytes = 0;
+            }
+            DRT_HIP_CHECK(h, hipMalloc(&R.mem, off));
+            R.bytes = off;
         }
-        char *b = (char *) h->d_rec;
+        char *b = (char *) R.mem;
         D.cursor = (uint32_t *) (b + o_cursor);
         D.vmax = D.cursor + 8;
         uint64_t max_chunks = 0;
@@ -229,74 +239,164 @@ int ensure_deferred(drt_handle h, drt::Params &P, uint64_t n_rays, uint32_t per_
         D.hist = (uint32_t *) (b + o_hist); D.bin_base = (uint32_t *) (b + o_base); D.unit_start = (uint32_t *) (b + o_unit);
         D.n_bins = n_bins; D.ntx = ntx; D.nty = nty; D.ntz = ntz;
         D.max_units = (uint32_t) (max_chunks * kRecChunk / kUnitRecords + (uint64_t) n_bins + 1);
-        h->rec_clear_bytes = clear; h->rec_rays = n_rays; h->rec_bins = n_bins; h->rec_tiny = tiny;
-        h->rec_per_ray[0] = per_ray_sigma; h->rec_per_ray[1] = per_ray_colour;
+        R.clear_bytes = clear; R.rays = n_rays; R.bins = n_bins; R.tiny = tiny;
+        R.per_ray[0] = per_ray_sigma; R.per_ray[1] = per_ray_colour;
     }
-    DRT_HIP_CHECK(h, hipMemsetAsync(h->d_rec, 0, h->rec_clear_bytes, h->stream));
+    DRT_HIP_CHECK(h, hipMemsetAsync(R.mem, 0, R.clear_bytes, h->stream));
     for (int s = 0; s < 4; ++s) { P.rec_buf[s] = D.in[s]; P.rec_chunk_count[s] = D.chunk_count[s]; P.rec_cap_chunks[s] = D.cap_chunks[s]; }
     P.rec_cursor = D.cursor;
     return DRT_OK;
 }
 
-int timed_reduce(drt_handle h, const drt::Params &P);
+int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream);
 int timed_untile(drt_handle h, const drt::Params &P);
 
-// Adjoint launch + gradient reduction of one job.  Deferred path: the job is cut into sub-batches of
-// rays whose record streams fit the memory budget (each: clear fills, trace, partition + reduce).
+// Adjoint launch + gradient reduction of one job.  Deferred path: the job is cut into sub-batches of rays
+// whose record streams fit the memory budget.  With DRT_PIPELINE set, large jobs are cut into
+// >= kPipeBatches pieces and pipelined over two record slots (tracer of sub-batch b on the caller's stream,
+// partition + reduction of sub-batch b - 1 on a side stream; the caller's stream waits for every
+// reduction at the end) - an experiment that measured slower than running them back to back.
+constexpr uint64_t kPipeBatches = 4, kPipeMinRays = 1ull << 20;
+
 template <class Launch>
-int run_backward(drt_handle h, drt::Params &P, bool allow_defer, uint32_t per_ray_sigma, uint32_t per_ray_colour, Launch launch)
+int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t per_ray_colour, Launch launch)
 {
-    if (!allow_defer || !want_deferred(h, P)) {
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventCreate(&t0));
+        DRT_HIP_CHECK(h, hipEventCreate(&t1));
+        DRT_HIP_CHECK(h, hipEventRecord(t0, h->stream));
+    }
+    if (!want_deferred(h, P)) {
         int rc = launch(P);
         if (rc) return rc;
-        return timed_untile(h, P);
+        rc = timed_untile(h, P);
+        if (rc) return rc;
+    } else {
+        const uint64_t n_rays = P.n_rays;
+        const uint64_t bytes_per_ray = 32ull * ((uint64_t) per_ray_sigma + 3ull * per_ray_colour) + 1024ull;   // streams in + sorted, chunk slack
+        // measured on the headline workload: overlapping costs more than it hides (tracer 15.0 -> 19.8 ms
+        // with the reductions alongside, step 22.1 -> 24.7 ms), so the overlap is opt-in
+        static const bool want_pipe = getenv("DRT_PIPELINE") != nullptr;
+        const uint64_t want_pipe_slots = want_pipe ? 2 : 1;
+        uint64_t batch = (kRecBudgetBytes / want_pipe_slots) / bytes_per_ray;
+        const bool pipe = want_pipe && n_rays >= kPipeMinRays;
+        if (pipe && batch > (n_rays + kPipeBatches - 1) / kPipeBatches) batch = (n_rays + kPipeBatches - 1) / kPipeBatches;
+        batch = (batch + 65535) / 65536 * 65536;                   // whole workgroups and XCD runs per sub-batch
+        const bool overlap = pipe;
+        if (overlap && !h->side) {
+            int lo = 0, hi = 0;
+            DRT_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            DRT_HIP_CHECK(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
+        }
+        int b = 0;
+        for (uint64_t first = 0; first < n_rays; first += batch, ++b) {
+            auto &R = h->rec[overlap ? (b & 1) : 0];
+            const uint64_t count = n_rays - first < batch ? n_rays - first : batch;
+            if (R.busy) { DRT_HIP_CHECK(h, hipStreamWaitEvent(h->stream, R.reduced, 0)); R.busy = false; }
+            int rc = ensure_deferred(h, R, P, count, per_ray_sigma, per_ray_colour);
+            if (rc) return rc;
+            P.ray_first = first; P.n_rays = first + count;
+            rc = launch(P);
+            if (rc) return rc;
+            if (!overlap) {
+                rc = timed_reduce(h, P, R.plan, h->stream);
+                if (rc) return rc;
+                continue;
+            }
+            if (!R.traced) { DRT_HIP_CHECK(h, hipEventCreateWithFlags(&R.traced, hipEventDisableTiming)); DRT_HIP_CHECK(h, hipEventCreateWithFlags(&R.reduced, hipEventDisableTiming)); }
+            DRT_HIP_CHECK(h, hipEventRecord(R.traced, h->stream));
+            DRT_HIP_CHECK(h, hipStreamWaitEvent(h->side, R.traced, 0));
+            rc = timed_reduce(h, P, R.plan, h->side);
+            if (rc) return rc;
+            DRT_HIP_CHECK(h, hipEventRecord(R.reduced, h->side));
+            R.busy = true;
+        }
+        for (auto &R : h->rec)
+            if (R.busy) { DRT_HIP_CHECK(h, hipStreamWaitEvent(h->stream, R.reduced, 0)); R.busy = false; }
+        P.ray_first = 0; P.n_rays = n_rays;
     }
-    const uint64_t n_rays = P.n_rays;
-    const uint64_t bytes_per_ray = 32ull * ((uint64_t) per_ray_sigma + 3ull * per_ray_colour) + 1024ull;   // streams in + sorted, chunk slack
-    uint64_t batch = kRecBudgetBytes / bytes_per_ray;
-    batch = batch / 4096 * 4096;                                   // keeps whole workgroups (and XCD runs) per sub-batch
-    if (batch == 0) batch = 4096;
-    for (uint64_t first = 0; first < n_rays; first += batch) {
-        const uint64_t count = n_rays - first < batch ? n_rays - first : batch;
-        int rc = ensure_deferred(h, P, count, per_ray_sigma, per_ray_colour);
-        if (rc) return rc;
-        P.ray_first = first; P.n_rays = first + count;
-        rc = launch(P);
-        if (rc) return rc;
-        rc = timed_reduce(h, P);
-        if (rc) return rc;
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventRecord(t1, h->stream));
+        h->timed[3].emplace_back(t0, t1);
     }
-    P.ray_first = 0; P.n_rays = n_rays;
     return DRT_OK;
 }
 
-int timed_reduce(drt_handle h, const drt::Params &P)
+int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream)
 {
     hipEvent_t a = nullptr, b = nullptr;
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventCreate(&a));
         DRT_HIP_CHECK(h, hipEventCreate(&b));
-        DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
+        DRT_HIP_CHECK(h, hipEventRecord(a, stream));
     }
     static const bool profile = getenv("DRT_REDUCE_PROFILE") != nullptr;   // stage timings to stderr (synchronises)
+    static const bool checksum = getenv("DRT_RECORD_CHECKSUM") != nullptr;   // debugging aid: order-independent sums of the record streams
+    if (checksum) {
+        DRT_HIP_CHECK(h, hipStreamSynchronize(stream));
+        for (int s2 = 0; s2 < 4; ++s2) {
+            uint32_t used = 0;
+            DRT_HIP_CHECK(h, hipMemcpy(&used, D.cursor + s2, 4, hipMemcpyDeviceToHost));
+            if (used > D.cap_chunks[s2]) used = D.cap_chunks[s2];
+            std::vector<uint32_t> cnt(used);
+            std::vector<float> recs((size_t) used * drt::kRecChunk * 4);
+            if (used) {
+                DRT_HIP_CHECK(h, hipMemcpy(cnt.data(), D.chunk_count[s2], used * 4, hipMemcpyDeviceToHost));
+                DRT_HIP_CHECK(h, hipMemcpy(recs.data(), D.in[s2], recs.size() * 4, hipMemcpyDeviceToHost));
+            }
+            double sv = 0, sx = 0, sa = 0; uint64_t n = 0, xr = 0;
+            for (uint32_t c = 0; c < used; ++c)
+                for (uint32_t i = 0; i < cnt[c]; ++i) {
+                    const float *r = recs.data() + ((size_t) c * drt::kRecChunk + i) * 4;
+                    sv += r[3]; sx += (double) r[0] * r[3] + 2.0 * r[1] * r[3] + 3.0 * r[2] * r[3]; sa += fabs((double) r[3]); ++n;
+                    uint32_t b[4]; memcpy(b, r, 16); xr ^= ((uint64_t) (b[0] * 2654435761u) << 32) ^ (b[1] * 40503u) ^ ((uint64_t) b[2] << 17) ^ b[3];
+                }
+            fprintf(stderr, "[drt] stream %d emitted: n %llu sum %.12e mom %.12e abs %.12e xor %016llx\n", s2, (unsigned long long) n, sv, sx, sa, (unsigned long long) xr);
+        }
+    }
     if (profile) {
         hipEvent_t ev[5];
         for (auto &e : ev) DRT_HIP_CHECK(h, hipEventCreate(&e));
-        DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, h->plan, h->stream, ev));
-        DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+        DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, D, stream, ev));
+        DRT_HIP_CHECK(h, hipStreamSynchronize(stream));
         float ms[4];
         for (int k = 0; k < 4; ++k) DRT_HIP_CHECK(h, hipEventElapsedTime(ms + k, ev[k], ev[k + 1]));
         uint32_t cur[8];
-        DRT_HIP_CHECK(h, hipMemcpy(cur, h->plan.cursor, sizeof cur, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[drt] reduce: histogram %.3f offsets %.3f scatter %.3f tiles %.3f ms; chunks %u %u %u %u (cap %u %u) overflow %u %u %u %u\n",
-                ms[0], ms[1], ms[2], ms[3], cur[0], cur[1], cur[2], cur[3], h->plan.cap_chunks[0], h->plan.cap_chunks[1],
-                cur[4], cur[5], cur[6], cur[7]);
+        DRT_HIP_CHECK(h, hipMemcpy(cur, D.cursor, sizeof cur, hipMemcpyDeviceToHost));
+        uint32_t tot[4], units[4];
+        for (int k = 0; k < 4; ++k) {
+            DRT_HIP_CHECK(h, hipMemcpy(tot + k, D.bin_base + (size_t) k * (D.n_bins + 1) + D.n_bins, 4, hipMemcpyDeviceToHost));
+            DRT_HIP_CHECK(h, hipMemcpy(units + k, D.unit_start + (size_t) k * (D.n_bins + 1) + D.n_bins, 4, hipMemcpyDeviceToHost));
+        }
+        fprintf(stderr, "[drt] reduce: histogram %.3f offsets %.3f scatter %.3f tiles %.3f ms; chunks %u %u %u %u (cap %u %u) overflow %u %u %u %u; records %u %u %u %u units %u %u %u %u\n",
+                ms[0], ms[1], ms[2], ms[3], cur[0], cur[1], cur[2], cur[3], D.cap_chunks[0], D.cap_chunks[1],
+                cur[4], cur[5], cur[6], cur[7], tot[0], tot[1], tot[2], tot[3], units[0], units[1], units[2], units[3]);
         for (auto &e : ev) (void) hipEventDestroy(e);
     } else {
-        DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, h->plan, h->stream));
+        DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, D, stream));
+    }
+    if (checksum) {
+        DRT_HIP_CHECK(h, hipStreamSynchronize(stream));
+        unsigned long long fl[4];
+        DRT_HIP_CHECK(h, hipMemcpy(fl, D.cursor + 12, sizeof fl, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[drt] flushed fixed-point sums: %lld %lld %lld %lld\n", (long long) fl[0], (long long) fl[1], (long long) fl[2], (long long) fl[3]);
+        for (int s2 = 0; s2 < 4; ++s2) {
+            uint32_t tot = 0;
+            DRT_HIP_CHECK(h, hipMemcpy(&tot, D.bin_base + (size_t) s2 * (D.n_bins + 1) + D.n_bins, 4, hipMemcpyDeviceToHost));
+            std::vector<float> recs((size_t) tot * 4);
+            if (tot) DRT_HIP_CHECK(h, hipMemcpy(recs.data(), D.out[s2], recs.size() * 4, hipMemcpyDeviceToHost));
+            double sv = 0, sx = 0, sa = 0; uint64_t xr = 0;
+            for (uint32_t i = 0; i < tot; ++i) {
+                const float *r = recs.data() + (size_t) i * 4;
+                sv += r[3]; sx += (double) r[0] * r[3] + 2.0 * r[1] * r[3] + 3.0 * r[2] * r[3]; sa += fabs((double) r[3]);
+                uint32_t b[4]; memcpy(b, r, 16); xr ^= ((uint64_t) (b[0] * 2654435761u) << 32) ^ (b[1] * 40503u) ^ ((uint64_t) b[2] << 17) ^ b[3];
+            }
+            fprintf(stderr, "[drt] stream %d sorted : n %u sum %.12e mom %.12e abs %.12e xor %016llx\n", s2, tot, sv, sx, sa, (unsigned long long) xr);
+        }
     }
     if (h->timing) {
-        DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
+        DRT_HIP_CHECK(h, hipEventRecord(b, stream));
         h->timed[2].emplace_back(a, b);
     }
     return DRT_OK;
@@ -391,7 +491,12 @@ int drt_destroy(drt_handle h)
     if (h->d_mgrid) (void) hipFree(h->d_mgrid);
     if (h->d_occ) (void) hipFree(h->d_occ);
     if (h->d_env) (void) hipFree(h->d_env);
-    if (h->d_rec) (void) hipFree(h->d_rec);
+    for (auto &R : h->rec) {
+        if (R.mem) (void) hipFree(R.mem);
+        if (R.traced) (void) hipEventDestroy(R.traced);
+        if (R.reduced) (void) hipEventDestroy(R.reduced);
+    }
+    if (h->side) (void) hipStreamDestroy(h->side);
     clear_timings(h);
     delete h;
     return DRT_OK;
@@ -650,7 +755,7 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
     // capacity: 48 sigma_t and 6 colour records per ray (headline workload: 12.3 and 1.4); beyond it the
     // tracer falls back to direct atomics (emit_record), so this is a performance choice only
-    return run_backward(h, P, true, 48, 6, [&](drt::Params &Q) { return timed_launch(h, 1, Q, true); });
+    return run_backward(h, P, 48, 6, [&](drt::Params &Q) { return timed_launch(h, 1, Q, true); });
 }
 
 static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, const float *emission)
@@ -695,7 +800,7 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
     if (rc) return rc;
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_emission;
     const uint32_t q = (uint32_t) cfg->queries_per_ray;          // at most one splat per query and plane
-    return run_backward(h, P, true, q, q, [&](drt::Params &Q) { return timed_nerf(h, 1, Q, true); });
+    return run_backward(h, P, q, q, [&](drt::Params &Q) { return timed_nerf(h, 1, Q, true); });
 }
 
 int drt_batch_sample_rays(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_size, uint32_t spp,
@@ -794,7 +899,7 @@ int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity)
     if (capacity > 0 && !out_ms) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null out_ms");
     DeviceGuard g(h->device);
     DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    if (backward < 0 || backward > 2) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_read_timings: kind must be 0, 1 or 2");
+    if (backward < 0 || backward > 3) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_read_timings: kind must be 0..3");
     auto &v = h->timed[backward];
     int n = (int) v.size();
     for (int i = 0; i < n && i < capacity; ++i)

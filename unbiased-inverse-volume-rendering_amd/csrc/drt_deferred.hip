@@ -28,12 +28,26 @@
 #include "drt_device.h"
 #include "drt_launch.h"
 
+#ifndef DRT_PART_UNROLL
+#define DRT_PART_UNROLL 4
+#endif
+
 namespace drt {
 
 namespace {
 
 constexpr int kLdsTile = (kTileX + 1) * (kTileY + 1) * (kTileZ + 1);
-constexpr int kPartUnroll = 4;          // chunks a partition workgroup keeps in flight
+
+// Workgroup barrier AFTER no-return LDS atomics.  __syncthreads() alone compiles to a bare s_barrier here
+// (the memory model treats LDS as in-order and waits for nothing), and the reads that follow were
+// observed to overtake ds_add_u64 operations still in flight: a few records' worth of gradient lost per
+// launch, one launch in ten.  Drain this wave's LDS queue first.
+__device__ __forceinline__ void lds_atomics_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+constexpr int kPartUnroll = DRT_PART_UNROLL;   // chunks a partition thread keeps in flight
 constexpr uint32_t kReduceWGs = 1024;   // per stream: 4 workgroups per CU, looping over the reduce units
 
 struct Cell { int x0, x1, y0, y1, z0, z1; float w[8]; };
@@ -54,7 +68,7 @@ __device__ __forceinline__ int bin_of(const Params &P, const DeferredPlan &D, fl
     return ((z0 / kTileZ) * D.nty + (y0 / kTileY)) * D.ntx + (x0 / kTileX);
 }
 
-__global__ void __launch_bounds__(256) bin_histogram_kernel(const Params P, const DeferredPlan D)
+__global__ void __launch_bounds__(kPartThreads) bin_histogram_kernel(const Params P, const DeferredPlan D)
 {
     extern __shared__ uint32_t h[];
     const int s = blockIdx.y;
@@ -63,13 +77,16 @@ __global__ void __launch_bounds__(256) bin_histogram_kernel(const Params P, cons
     const uint32_t used = min(D.cursor[s], D.cap_chunks[s]);
     float vmax = 0.0f;
     static_assert(kRecChunk == 256, "one record per thread and chunk");
-    for (uint32_t c0 = blockIdx.x; c0 < used; c0 += kPartUnroll * gridDim.x) {
+    // chunk -> workgroup map (shared with the scatter pass): workgroup g owns chunks g*kSub + sub (mod stride)
+    constexpr uint32_t kSub = kPartThreads / 256;                  // chunks a workgroup reads side by side
+    const uint32_t sub = threadIdx.x >> 8, rec = threadIdx.x & 255u;
+    for (uint32_t c0 = blockIdx.x * kSub + sub; c0 < used; c0 += kPartUnroll * kSub * gridDim.x) {
         float4 r[kPartUnroll]; bool ok[kPartUnroll];
 #pragma unroll
-        for (int k = 0; k < kPartUnroll; ++k) {                   // kPartUnroll chunks in flight per workgroup
-            const uint32_t c = c0 + k * gridDim.x;
-            ok[k] = c < used && threadIdx.x < D.chunk_count[s][c];
-            if (ok[k]) r[k] = D.in[s][(size_t) c * kRecChunk + threadIdx.x];
+        for (int k = 0; k < kPartUnroll; ++k) {                   // kPartUnroll chunks in flight per thread
+            const uint32_t c = c0 + k * kSub * gridDim.x;
+            ok[k] = c < used && rec < D.chunk_count[s][c];
+            if (ok[k]) r[k] = D.in[s][(size_t) c * kRecChunk + rec];
         }
 #pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) {
@@ -82,7 +99,7 @@ __global__ void __launch_bounds__(256) bin_histogram_kernel(const Params P, cons
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
     if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(D.vmax + s, __float_as_uint(vmax));
-    __syncthreads();
+    lds_atomics_barrier();
     uint32_t *dst = D.hist + ((size_t) s * gridDim.x + blockIdx.x) * D.n_bins;
     for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) dst[b] = h[b];
 }
@@ -140,7 +157,7 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const DeferredPlan D)
     if (t == 1023) { base[D.n_bins] = sa[t]; ustart[D.n_bins] = sb[t]; }
 }
 
-__global__ void __launch_bounds__(256) bin_scatter_kernel(const Params P, const DeferredPlan D)
+__global__ void __launch_bounds__(kPartThreads) bin_scatter_kernel(const Params P, const DeferredPlan D)
 {
     extern __shared__ uint32_t cur[];
     const int s = blockIdx.y;
@@ -150,13 +167,15 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(const Params P, const 
     __syncthreads();
     const uint32_t used = min(D.cursor[s], D.cap_chunks[s]);
     float4 *dst = D.out[s];
-    for (uint32_t c0 = blockIdx.x; c0 < used; c0 += kPartUnroll * gridDim.x) {   // same chunk -> workgroup map as the histogram
+    constexpr uint32_t kSub = kPartThreads / 256;
+    const uint32_t sub = threadIdx.x >> 8, rec = threadIdx.x & 255u;
+    for (uint32_t c0 = blockIdx.x * kSub + sub; c0 < used; c0 += kPartUnroll * kSub * gridDim.x) {   // same map as the histogram
         float4 r[kPartUnroll]; bool ok[kPartUnroll];
 #pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) {
-            const uint32_t c = c0 + k * gridDim.x;
-            ok[k] = c < used && threadIdx.x < D.chunk_count[s][c];
-            if (ok[k]) r[k] = D.in[s][(size_t) c * kRecChunk + threadIdx.x];
+            const uint32_t c = c0 + k * kSub * gridDim.x;
+            ok[k] = c < used && rec < D.chunk_count[s][c];
+            if (ok[k]) r[k] = D.in[s][(size_t) c * kRecChunk + rec];
         }
         uint32_t slot[kPartUnroll];
 #pragma unroll
@@ -196,13 +215,19 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
         if (nb == b && nb < 0) break;                             // no units at all for this workgroup
         if (nb != b) {
             if (b >= 0 && !(P.debug_flags & 1024u)) {             // flush the finished tile (+=)
-                __syncthreads();
+                lds_atomics_barrier();
                 for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) {
                     const long long q = (long long) tile[j];
                     if (q == 0) continue;
+                    if (P.debug_flags & 8192u) atomicAdd((unsigned long long *) (D.cursor + 12) + s, (unsigned long long) q);   // exact checksum of what is flushed
                     const float v = (float) ((double) q * inv_scale);
                     const int lx = j % (kTileX + 1), ly = (j / (kTileX + 1)) % (kTileY + 1), lz = j / ((kTileX + 1) * (kTileY + 1));
                     const size_t vox = ((size_t) (Z0 + lz) * P.ry + (Y0 + ly)) * P.rx + (X0 + lx);
+                    if (P.debug_flags & 4096u) {                      // experiment: compare-and-swap loop instead of the hardware fp32 add
+                        unsigned int *a = (unsigned int *) (dst + (size_t) stride * vox);
+                        unsigned int old = *a, assumed;
+                        do { assumed = old; old = atomicCAS(a, assumed, __float_as_uint(__uint_as_float(assumed) + v)); } while (old != assumed);
+                    } else
                     atomicAdd(dst + (size_t) stride * vox, v);
                 }
                 __syncthreads();
@@ -252,18 +277,20 @@ hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStr
     const size_t lds = (size_t) D.n_bins * sizeof(uint32_t);
     auto mark = [&](int k) { if (ev) (void) hipEventRecord(ev[k], stream); };
     mark(0);
-    hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, 4), dim3(256), lds, stream, P, D);
+    hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, 4), dim3(kPartThreads), lds, stream, P, D);
     mark(1);
     hipLaunchKernelGGL(bin_offsets_kernel, dim3((D.n_bins + 3) / 4, 4), dim3(256), 0, stream, D, kPartWGs);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(4), dim3(1024), 0, stream, D);
     mark(2);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(kPartWGs, 4), dim3(256), lds, stream, P, D);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(kPartWGs, 4), dim3(kPartThreads), lds, stream, P, D);
     mark(3);
-    static const hipError_t attr = hipFuncSetAttribute((const void *) tile_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       kLdsTile * (int) sizeof(unsigned long long));
+    static const int lds_tile = [] { const char *e = getenv("DRT_REDUCE_LDS"); int v = e ? atoi(e) : 0; return v > kLdsTile * 8 ? v : kLdsTile * 8; }();
+    static const hipError_t attr = hipFuncSetAttribute((const void *) tile_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tile);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(tile_reduce_kernel, dim3(D.max_units < kReduceWGs ? D.max_units : kReduceWGs, 4), dim3(256),
-                       kLdsTile * sizeof(unsigned long long), stream, P, D);
+    static const uint32_t wgs_env = [] { const char *e = getenv("DRT_REDUCE_WGS"); return e ? (uint32_t) atoi(e) : 0u; }();
+    const uint32_t wgs = wgs_env ? wgs_env : (D.max_units < kReduceWGs ? D.max_units : kReduceWGs);
+    hipLaunchKernelGGL(tile_reduce_kernel, dim3(wgs, 4), dim3(256),
+                       (size_t) lds_tile, stream, P, D);
     mark(4);
     return hipGetLastError();
 }

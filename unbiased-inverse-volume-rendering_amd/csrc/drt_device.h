@@ -618,9 +618,14 @@ __device__ __forceinline__ void splat_direct(const Params &P, int s, V3 p, float
     for (int k = 0; k < 8; ++k) atomicAdd(dst + (size_t) stride * idx[k], w[k] * v);
 }
 
+// The wave state lives in LDS; the pointer arrives as a generic one (it travels through a struct), so it
+// is cast back to the LDS address space: plain ds_read / ds_write, which one wave executes in order,
+// instead of FLAT accesses (observed to lose an update now and then under the nerf kernel's emission rate).
+typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
+
 __device__ __forceinline__ void emit_record(const Params &P, int s, V3 p, float v, uint32_t *st_)
 {
-    volatile uint32_t *st = st_;
+    lds_u32 *st = (lds_u32 *) st_;
     const uint64_t mask = __ballot(1);
     const uint32_t lane = __lane_id();
     const uint32_t rank = (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
@@ -655,7 +660,7 @@ __device__ __forceinline__ void emit_record(const Params &P, int s, V3 p, float 
 // end of the wave: publish the fill of the chunks still open
 __device__ __forceinline__ void close_records(const Params &P, uint32_t *st_)
 {
-    volatile uint32_t *st = st_;
+    lds_u32 *st = (lds_u32 *) st_;
     if (__lane_id() < 4) {
         const int s = (int) __lane_id();
         const uint32_t cur = st[s], end = st[4 + s];

@@ -22,7 +22,17 @@ hipError_t launch_untile(const Params &P, hipStream_t stream);
 constexpr int kTileX = 32, kTileY = 16, kTileZ = 16;   // base-corner cells per tile; LDS tile = 33 x 17 x 17 floats
 constexpr int kMaxBins = 16384;                          // tiles per grid the one-pass partition handles (64 KiB LDS histogram): 512^3
 constexpr uint32_t kUnitRecords = 16384;                 // records per reduce workgroup
-constexpr int kPartWGs = 1024;                           // partition workgroups (histogram / scatter)
+#ifndef DRT_PART_WGS
+#define DRT_PART_WGS 256
+#endif
+#ifndef DRT_PART_THREADS
+#define DRT_PART_THREADS 1024
+#endif
+// Partition workgroups (histogram / scatter): every (workgroup, tile) pair owns an output sub-range, i.e.
+// one partially written line at a time; few, large workgroups keep that working set (WGs x tiles x 128 B)
+// inside the 256 MB memory-side cache.
+constexpr int kPartWGs = DRT_PART_WGS;
+constexpr int kPartThreads = DRT_PART_THREADS;
 struct DeferredPlan {
     float4 *in[4], *out[4];          // record streams as emitted / tile-sorted
     uint32_t *chunk_count[4];        // valid records per chunk of in[s]
