@@ -8,7 +8,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "drt::" not in k: continue
-        short = k.split("(")[0].replace("void ", "")
+        short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         per[(short, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (k, d, c), v in per.items():
         acc[k][c].append(v)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc CSVs (tools/pmc_traffic.txt passes) -> profiles/roofline_traffic.json.
+
+HBM-side bytes per launch = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B + 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B)
+(request-size counters; FETCH_SIZE under-reports 128-B requests by 2x on gfx950, MI355X_MICROARCH.md).
+The adjoint PASS is the adjoint tracer plus the gradient reduction kernels that finish its splats.
+
+    python tools/pmc_to_traffic.py <dir with *counter_collection.csv> <workload key> [out.json]
+"""
+import collections, csv, glob, json, sys
+
+root, key = sys.argv[1], sys.argv[2]
+out = sys.argv[3] if len(sys.argv) > 3 else "profiles/roofline_traffic.json"
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    per = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "drt::" not in k:
+            continue
+        short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        per[(short, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    for (k, d, c), v in per.items():
+        acc[k][c].append(v)
+
+
+def mean(k, c):
+    v = acc[k].get(c, [])
+    return sum(v) / len(v) if v else 0.0
+
+
+detail = {}
+for k in acc:
+    rd = 128 * mean(k, "TCC_EA0_RDREQ_128B_sum") + 64 * mean(k, "TCC_EA0_RDREQ_64B_sum") + 32 * mean(k, "TCC_EA0_RDREQ_32B_sum")
+    wr = 64 * mean(k, "TCC_EA0_WRREQ_64B_sum") + 32 * (mean(k, "TCC_EA0_WRREQ_sum") - mean(k, "TCC_EA0_WRREQ_64B_sum"))
+    detail[k] = {"read_bytes": rd, "write_bytes": wr, "total": rd + wr, "fetch_size_kib": mean(k, "FETCH_SIZE"),
+                 "write_size_kib": mean(k, "WRITE_SIZE"), "atomics": mean(k, "TCC_EA0_ATOMIC_sum"),
+                 "launches_seen": len(acc[k].get("TCC_EA0_RDREQ_sum", []))}
+adj = [k for k in detail if "trace_kernel<true, false" in k or "bin_" in k or "tile_reduce" in k or "untile" in k]
+pri = [k for k in detail if "trace_wavefront_kernel<false, false" in k]
+res = {key: sum(detail[k]["total"] for k in adj),
+       key + ":primal": sum(detail[k]["total"] for k in pri),
+       "_adjoint_pass_kernels": adj, "_detail": detail,
+       "_method": __doc__.split("\n\n")[1]}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1))
+for k in adj + pri:
+    print(f"{k:70s} read {detail[k]['read_bytes'] / 1e9:7.2f} GB  write {detail[k]['write_bytes'] / 1e9:7.2f} GB  atomics {detail[k]['atomics']:.3g}")
