@@ -206,7 +206,11 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
  * kernel for the adjoint too; bit 7 (128): gradient splats as atomics into the apron scratch (the path
  * used when the grid has more than 4096 tiles or the record streams exceed the memory budget) instead
  * of deferred records; bit 8 (256): two-chunk record streams (exercises the out-of-chunks fallback);
- * bits 9, 10 (512, 1024): reduction without LDS adds / without the flush (timing only). */
+ * bits 9, 10 (512, 1024): reduction without LDS adds / without the flush (timing only); bit 11 (2048):
+ * overlap the tracer of ray sub-batch b with the reduction of sub-batch b - 1 on a side stream (also
+ * DRT_PIPELINE in the environment; measured slower); bit 12 (4096): compare-and-swap flush; bit 13
+ * (8192): exact checksum of the flushed sums; bit 14 (16384): 8 MB record budget, i.e. many ray
+ * sub-batches (test hook). */
 int drt_set_debug_flags(drt_handle h, uint32_t flags);
 
 const char *drt_version(void);

@@ -277,12 +277,15 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
         const uint64_t bytes_per_ray = 32ull * ((uint64_t) per_ray_sigma + 3ull * per_ray_colour) + 1024ull;   // streams in + sorted, chunk slack
         // measured on the headline workload: overlapping costs more than it hides (tracer 15.0 -> 19.8 ms
         // with the reductions alongside, step 22.1 -> 24.7 ms), so the overlap is opt-in
-        static const bool want_pipe = getenv("DRT_PIPELINE") != nullptr;
+        static const bool env_pipe = getenv("DRT_PIPELINE") != nullptr;
+        const bool forced = (h->debug_flags & 2048u) != 0;         // test hook: overlap whatever the job size
+        const bool want_pipe = env_pipe || forced;
         const uint64_t want_pipe_slots = want_pipe ? 2 : 1;
-        uint64_t batch = (kRecBudgetBytes / want_pipe_slots) / bytes_per_ray;
-        const bool pipe = want_pipe && n_rays >= kPipeMinRays;
+        const uint64_t budget = (h->debug_flags & 16384u) ? (8ull << 20) : kRecBudgetBytes;   // test hook: 8 MB -> many sub-batches
+        uint64_t batch = (budget / want_pipe_slots) / bytes_per_ray;
+        const bool pipe = want_pipe && (forced || n_rays >= kPipeMinRays);
         if (pipe && batch > (n_rays + kPipeBatches - 1) / kPipeBatches) batch = (n_rays + kPipeBatches - 1) / kPipeBatches;
-        batch = (batch + 65535) / 65536 * 65536;                   // whole workgroups and XCD runs per sub-batch
+        batch = (h->debug_flags & 16384u) ? (batch + 255) / 256 * 256 : (batch + 65535) / 65536 * 65536;   // whole workgroups (and XCD runs) per sub-batch
         const bool overlap = pipe;
         if (overlap && !h->side) {
             int lo = 0, hi = 0;
