@@ -163,7 +163,13 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     // debug bit 8 forces the per-lane kernel everywhere.
     const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
     const bool wavefront = !(h->debug_flags & 8u) && (!adjoint || ((h->debug_flags & 32u) && !quadratic));
-    if (!wavefront) {
+    // wave-cooperative tracking loops (drt_coop.hip): the adjoint by default, the primal with debug bit 65536;
+    // supergrid scenes and debug bit 32768 keep the plain per-lane kernel
+    const bool coop = !wavefront && !P.mgrid && !(h->debug_flags & 32768u);
+    const bool coop_primal = !adjoint && !P.mgrid && (h->debug_flags & 65536u) && !(h->debug_flags & 8u);
+    if (coop || coop_primal) {
+        DRT_HIP_CHECK(h, drt::launch_trace_coop(P, adjoint, h->counting, h->stream));
+    } else if (!wavefront) {
         DRT_HIP_CHECK(h, drt::launch_trace(P, adjoint, h->counting, h->stream));
     } else {
         drt::Params Q = P;

@@ -16,6 +16,8 @@ hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int 
                               hipStream_t stream);
 hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
+// one ray per lane with wave-cooperative tracking loops (drt_coop.hip); global majorant only (P.mgrid == nullptr)
+hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_untile(const Params &P, hipStream_t stream);
 
 // Deferred splatting (drt_deferred.hip): record streams -> tile partition -> LDS reduction.
