@@ -210,7 +210,9 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
  * overlap the tracer of ray sub-batch b with the reduction of sub-batch b - 1 on a side stream (also
  * DRT_PIPELINE in the environment; measured slower); bit 12 (4096): compare-and-swap flush; bit 13
  * (8192): exact checksum of the flushed sums; bit 14 (16384): 8 MB record budget, i.e. many ray
- * sub-batches (test hook). */
+ * sub-batches (test hook); bit 15 (32768): plain one-ray-per-lane adjoint kernel instead of the
+ * wave-cooperative tracking loops (drt_coop.hip); bit 16 (65536): wave-cooperative kernel for the
+ * primal too (default: the state-machine kernel, same speed). */
 int drt_set_debug_flags(drt_handle h, uint32_t flags);
 
 const char *drt_version(void);

@@ -9,14 +9,19 @@
 //
 // Here every tracking loop is entered by ALL 64 lanes of the wave (the bounce loop is wave-uniform, lanes
 // without a live ray carry job = false) and executed in rounds: the J pending walks share the wave,
-// m = min(16, 2^floor(log2(64 / J))) candidate steps each; lane L serves walk L / m, step L % m.  What the
-// sequential algorithm computes in order - the moving origin o_{k+1} = fma(d, dt_k, o_k), the remaining
-// length, the running transmittance product, "first accepted / first outside" - is resolved by a chain over
-// the m lanes in the SAME order with the SAME operations, so every walk returns bit for bit what the
-// per-lane loop (and the oracle) returns; only the grid lookups, the logarithms and the random numbers, i.e.
-// the expensive part, run in parallel.  Speculative steps behind a walk's end are discarded (and not
-// counted).  Supergrid scenes (majorant_resolution_factor > 0: the distance depends on the position) keep
-// the per-lane kernels.
+// m = min(DRT_COOP_MAXM, 2^floor(log2(64 / J))) candidate steps each; lane L serves walk L / m, step L % m.
+// What the sequential algorithm computes in order - the moving origin o_{k+1} = fma(d, dt_k, o_k), the
+// remaining length, the running transmittance product, "first accepted / first outside" - every lane
+// recomputes for its own step by replaying the earlier steps of the round in the SAME order with the SAME
+// operations (their distances / transmittance factors gathered from the lanes that produced them), so every
+// walk returns bit for bit what the per-lane loop (and the oracle) returns; only the grid lookups, the
+// logarithms and the random numbers, i.e. the expensive part, run in parallel.  Speculative steps behind a
+// walk's end are discarded (and not counted).  Supergrid scenes (majorant_resolution_factor > 0: the
+// distance depends on the position) keep the per-lane kernels.
+//
+// Headline workload, adjoint tracer: 44.7 M wave-level loop iterations -> 16.4 M rounds, VALU lane
+// utilisation 15 % -> 64 %, 8.4 G -> 6.1 G wave instructions (still VALU-issue-bound: the replay and the
+// round set-up are pure overhead), 13.9 -> 11.0 ms.
 //
 // Same algorithm and line references as Tracer in drt_kernels.hip (volpathsimple.py:38-655).
 #include "drt_device.h"
@@ -29,7 +34,7 @@
 #define DRT_XCD_RUN 256
 #endif
 #ifndef DRT_COOP_MAXM
-#define DRT_COOP_MAXM 16       // candidate steps per walk and round (chain length)
+#define DRT_COOP_MAXM 8        // candidate steps per walk and round = chain length (swept 4 / 8 / 16: 11.7 / 11.0 / 11.5 ms)
 #endif
 
 namespace drt {
@@ -62,15 +67,6 @@ __device__ __forceinline__ float pcg_float(uint64_t old)
     uint32_t bits = (((xs >> rot) | (xs << ((0u - rot) & 31u))) >> 9) | 0x3f800000u;
     return __uint_as_float(bits) - 1.0f;
 }
-
-// value of the previous lane within the 16-lane row (DPP row_shr:1, a VALU move: the chains below are
-// serial and ds_bpermute latency would dominate them); lane 0 of a row gets 0.  Walk groups are at most
-// 16 lanes wide and row-aligned, and the first lane of a group never uses what it receives.
-__device__ __forceinline__ float row_prev(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
-}
-__device__ __forceinline__ int row_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); }
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 {
@@ -152,13 +148,16 @@ struct CoopTracer {
             const float dt = sample_distance(pcg_float(sc));
             // chain 1 (sequential semantics): origin and remaining length before step c; reached = every
             // earlier step of the round found its tentative collision inside the segment
+            // (every lane replays the earlier steps of its walk itself, in order, with their distances
+            // gathered from the lanes that drew them: independent ds_bpermutes instead of a dependent chain)
             bool reached = serve;
-            for (int s = 1; s < m; ++s) {
-                const float nx = fmaf(dx, dt, cx), ny = fmaf(dy, dt, cy), nz = fmaf(dz, dt, cz), nt = ct - dt;
-                const int cont = (reached && dt <= ct) ? 1 : 0;
-                const float px = row_prev(nx), py = row_prev(ny), pz = row_prev(nz), pt = row_prev(nt);
-                const int pc = row_prev(cont);
-                if (c == s) { cx = px; cy = py; cz = pz; ct = pt; reached = pc != 0; }
+            const int gb = (int) __lane_id() - c;                               // first lane of my group
+            for (int k = 0; k + 1 < m; ++k) {
+                const float dk = __shfl(dt, gb + k);
+                if (k < c) {
+                    reached = reached && dk <= ct;
+                    cx = fmaf(dx, dk, cx); cy = fmaf(dy, dk, cy); cz = fmaf(dz, dk, cz); ct = ct - dk;
+                }
             }
             const bool inside = reached && dt <= ct;                            // :480-481
             const V3 p = v3(fmaf(dx, dt, cx), fmaf(dy, dt, cy), fmaf(dz, dt, cz));
@@ -166,12 +165,9 @@ struct CoopTracer {
             const float tr = (maj - sig) * inv_maj;                             // :473-476
             // chain 2: running product before step c; a step is executed iff the product is still non-zero
             bool live = reached;                                                // step c is started (its draw is consumed)
-            for (int s = 1; s < m; ++s) {
-                const float nT = Tin * tr;
-                const int cont = (live && inside && nT != 0.0f) ? 1 : 0;        // :495, :502
-                const float pT = row_prev(nT);
-                const int pc = row_prev(cont);
-                if (c == s) { Tin = pT; live = pc != 0; }
+            for (int k = 0; k + 1 < m; ++k) {
+                const float trk = __shfl(tr, gb + k);
+                if (k < c) { Tin = Tin * trk; live = live && Tin != 0.0f; }       // :495, :502
             }
             const bool exec = live && inside;
             const float Tout = exec ? Tin * tr : Tin;
@@ -225,14 +221,13 @@ struct CoopTracer {
             const float dt = sample_distance(pcg_float(s0));                    // :348
             const float u2 = pcg_float(s1);                                     // :359
             bool reached = serve;
-            for (int s = 1; s < m; ++s) {
-                const float nx = fmaf(dx, dt, cx), ny = fmaf(dy, dt, cy), nz = fmaf(dz, dt, cz);
-                const float nt = ct - dt, nr = crun + dt;                       // :364-367
-                const int cont = (reached && dt <= ct) ? 1 : 0;
-                const float px = row_prev(nx), py = row_prev(ny), pz = row_prev(nz);
-                const float pt = row_prev(nt), pr = row_prev(nr);
-                const int pc = row_prev(cont);
-                if (c == s) { cx = px; cy = py; cz = pz; ct = pt; crun = pr; reached = pc != 0; }
+            const int gb = (int) __lane_id() - c;                               // first lane of my group
+            for (int k = 0; k + 1 < m; ++k) {
+                const float dk = __shfl(dt, gb + k);
+                if (k < c) {                                                    // :364-367
+                    reached = reached && dk <= ct;
+                    cx = fmaf(dx, dk, cx); cy = fmaf(dy, dk, cy); cz = fmaf(dz, dk, cz); ct = ct - dk; crun = crun + dk;
+                }
             }
             const bool inside = reached && dt <= ct;                            // :358
             const V3 p = v3(fmaf(dx, dt, cx), fmaf(dy, dt, cy), fmaf(dz, dt, cz));
