@@ -112,7 +112,7 @@ struct CoopTracer {
     {
         const uint32_t lane = __lane_id();
         const int J = __popcll(pending);
-        lg = 31 - __clz(64 / J);
+        lg = J > 1 ? __clz(J - 1) - 26 : 6;                 // floor(log2(64 / J)) = 6 - ceil(log2(J)), no division
         if (lg > (31 - __clz(DRT_COOP_MAXM))) lg = 31 - __clz(DRT_COOP_MAXM);
         m = 1 << lg;
         my_rank = (int) __popcll(pending & ((1ull << lane) - 1ull));
