@@ -212,7 +212,8 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
  * (8192): exact checksum of the flushed sums; bit 14 (16384): 8 MB record budget, i.e. many ray
  * sub-batches (test hook); bit 15 (32768): plain one-ray-per-lane adjoint kernel instead of the
  * wave-cooperative tracking loops (drt_coop.hip); bit 16 (65536): wave-cooperative kernel for the
- * primal too (default: the state-machine kernel, same speed). */
+ * primal too (default: the state-machine kernel, same speed); bit 18 (262144): pretend that the record
+ * streams cannot be allocated (the job then takes the atomic path, as it does when hipMalloc fails). */
 int drt_set_debug_flags(drt_handle h, uint32_t flags);
 
 const char *drt_version(void);

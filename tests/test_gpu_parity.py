@@ -368,7 +368,7 @@ def test_sigma_t_gradient_vs_finite_differences(uivr, gpu, variant):
                                            (2, "drt"), (16, "drt"), (128, "drt"), (128, "quadratic"), (256, "drt"),
                                            (256, "basic"), (16384, "drt"), (16384 + 2048, "drt"), (2048, "basic"),
                                            (32768, "drt"), (32768, "quadratic"), (65536, "drt"), (65536, "basic"),
-                                           (65536, "quadratic-nomis")])
+                                           (65536, "quadratic-nomis"), (262144, "drt")])
 def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     """The production path uses the wave-synchronous state machine for the primal and the
     one-ray-per-lane kernel for the adjoint (measured faster).  The other combinations
@@ -379,7 +379,8 @@ def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     16384 = 8 MB record budget (the 16 k rays are traced in sub-batches of 2560), 2048 = the reduction
     of sub-batch b - 1 overlapped with the tracer of sub-batch b on a side stream, 32768 = plain per-lane
     adjoint kernel instead of the wave-cooperative tracking loops (production default for the adjoint),
-    65536 = wave-cooperative kernel for the primal too."""
+    65536 = wave-cooperative kernel for the primal too, 262144 = record streams "cannot be allocated"
+    (fallback to the atomic path)."""
     props = props_for(variant)
     scene = uivr.cube_test_scene(32, 32, density_scale=2.0)
     spp, seed = 16, 777

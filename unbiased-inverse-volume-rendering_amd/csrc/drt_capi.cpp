@@ -187,6 +187,7 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
 // Deferred splatting is used for the one-ray-per-lane adjoint kernel when the grid has at most kMaxBins
 // tiles and the record streams fit the memory budget; otherwise (and with debug bit 128) the tracer
 // adds its splats to the apron scratch with atomics and untile_gradients_kernel reduces that.
+constexpr int kNoRecordMemory = -1000;                           // internal: record streams could not be allocated
 constexpr uint64_t kRecBudgetBytes = 48ull << 30;               // record streams (emitted + tile-sorted) per sub-batch
 
 bool want_deferred(drt_handle h, const drt::Params &P)
@@ -229,7 +230,11 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
                 if (h->side) DRT_HIP_CHECK(h, hipStreamSynchronize(h->side));
                 (void) hipFree(R.mem); R.mem = nullptr; R.bytes = 0;
             }
-            DRT_HIP_CHECK(h, hipMalloc(&R.mem, off));
+            if ((h->debug_flags & 262144u) || hipMalloc(&R.mem, off) != hipSuccess) {   // not enough memory for the record streams (bit 262144: simulate):
+                (void) hipGetLastError();                         // this job uses the atomic path instead
+                R.mem = nullptr; R.rays = 0;
+                return kNoRecordMemory;
+            }
             R.bytes = off;
         }
         char *b = (char *) R.mem;
@@ -304,6 +309,15 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
             const uint64_t count = n_rays - first < batch ? n_rays - first : batch;
             if (R.busy) { DRT_HIP_CHECK(h, hipStreamWaitEvent(h->stream, R.reduced, 0)); R.busy = false; }
             int rc = ensure_deferred(h, R, P, count, per_ray_sigma, per_ray_colour);
+            if (rc == kNoRecordMemory && first == 0) {       // fall back to atomics into the apron scratch
+                for (int s2 = 0; s2 < 4; ++s2) P.rec_buf[s2] = nullptr;
+                P.rec_cursor = nullptr; P.ray_first = 0; P.n_rays = n_rays;
+                rc = launch(P);
+                if (rc) return rc;
+                rc = timed_untile(h, P);
+                if (rc) return rc;
+                break;
+            }
             if (rc) return rc;
             P.ray_first = first; P.n_rays = first + count;
             rc = launch(P);
