@@ -49,6 +49,12 @@ struct drt_handle_s {
         bool busy = false;             // `reduced` is pending on the side stream
     } rec[2];
     hipStream_t side = nullptr;        // high-priority stream of the overlapped reductions
+    // path cache (drt_coop.hip): written by the primal launch of an H1 step, read by the adjoint launch of the
+    // same job if nothing happened to the handle in between
+    void *d_pcache = nullptr;          // [rays][kPathCacheCap][2] uint4 | [rays] hash words
+    size_t pcache_bytes = 0;
+    struct JobSig { uint64_t n_rays, ray_offset, chunk, stride; uint32_t spp, seed; const void *rays_o, *rays_d; uint64_t scene_version; bool valid; } pcache_sig{};
+    uint64_t scene_version = 0;        // bumped by every call that changes the medium / emitter / sensor / integrator state
     size_t mgrid_cells = 0;
     size_t sigma_b_floats = 0;
     size_t gt_floats = 0;
@@ -147,6 +153,48 @@ void clear_timings(drt_handle h)
 }
 
 // launch bracketed by an event pair on the handle's stream when timing is enabled
+constexpr uint32_t kPathCacheCap = 4;                 // bounce-loop iterations cached per ray (headline: 2.4 on average)
+constexpr uint64_t kPathCacheMaxRays = 1ull << 24;     // larger primal launches (reference renders) skip the cache
+
+bool same_job(const drt_handle_s::JobSig &a, const drt_handle_s::JobSig &b)
+{
+    return a.n_rays == b.n_rays && a.ray_offset == b.ray_offset && a.chunk == b.chunk && a.stride == b.stride &&
+           a.spp == b.spp && a.seed == b.seed && a.rays_o == b.rays_o && a.rays_d == b.rays_d && a.scene_version == b.scene_version;
+}
+
+drt_handle_s::JobSig job_sig(drt_handle h, const drt::Params &P)
+{
+    return drt_handle_s::JobSig{ P.n_rays, P.ray_offset, P.chunk, P.stride, P.spp, P.seed, P.rays_o, P.rays_d, h->scene_version, true };
+}
+
+// primal launch of the cooperative kernel: bind the cache for writing (best effort)
+void bind_path_cache_write(drt_handle h, drt::Params &P)
+{
+    h->pcache_sig.valid = false;
+    if ((h->debug_flags & 1048576u) || P.n_rays > kPathCacheMaxRays) return;
+    const size_t entries = (size_t) P.n_rays * kPathCacheCap * 2 * sizeof(uint4), need = entries + (size_t) P.n_rays * sizeof(uint32_t);
+    if (need > h->pcache_bytes) {
+        if (h->d_pcache) { if (hipStreamSynchronize(h->stream) != hipSuccess) return; (void) hipFree(h->d_pcache); h->d_pcache = nullptr; h->pcache_bytes = 0; }
+        if (hipMalloc(&h->d_pcache, need) != hipSuccess) { (void) hipGetLastError(); h->d_pcache = nullptr; return; }
+        h->pcache_bytes = need;
+    }
+    P.path_cache = (uint4 *) h->d_pcache;
+    P.ray_hash = (uint32_t *) ((char *) h->d_pcache + entries);
+    P.path_cache_cap = kPathCacheCap; P.path_cache_mode = 1;
+    h->pcache_sig = job_sig(h, P);
+}
+
+// adjoint launch: read the cache if it was written by the primal pass of this very job
+void bind_path_cache_read(drt_handle h, drt::Params &P, uint64_t job_rays)
+{
+    drt::Params J = P; J.n_rays = job_rays;
+    if (!h->pcache_sig.valid || (h->debug_flags & 1048576u) || !same_job(h->pcache_sig, job_sig(h, J))) return;
+    const size_t entries = (size_t) job_rays * kPathCacheCap * 2 * sizeof(uint4);
+    P.path_cache = (uint4 *) h->d_pcache;
+    P.ray_hash = (uint32_t *) ((char *) h->d_pcache + entries);
+    P.path_cache_cap = kPathCacheCap; P.path_cache_mode = 2;
+}
+
 int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
 {
     hipEvent_t a = nullptr, b = nullptr;
@@ -156,17 +204,19 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
     }
     // Kernel choice (measured on MI355X, headline workload):
-    //   primal : wave-synchronous state machine (drt_wavefront.hip) - 3.2 ms vs 3.4 ms
-    //   adjoint: one ray per lane (drt_kernels.hip)                 - 22.4 ms vs 24-26 ms; the state
-    //            machine also serves the adjoint (debug bit 32) but its transition blocks run at
-    //            too low a lane occupancy to win; quadratic DRT exists only in the per-lane kernel.
-    // debug bit 8 forces the per-lane kernel everywhere.
+    //   global majorant: one ray per lane with wave-cooperative tracking loops (drt_coop.hip) for both passes;
+    //                    the primal pass writes the path cache that the adjoint pass of the same job reads.
+    //                    The wave-synchronous state machine (drt_wavefront.hip) is as fast for the primal
+    //                    (debug bit 65536 selects it) but cannot feed the cache; for the adjoint (bit 32) it
+    //                    is slower (its transition blocks run with ~3 lanes).
+    //   supergrid      : plain one-ray-per-lane kernels (drt_kernels.hip; also debug bits 8 / 32768):
+    //                    the free-flight distance depends on the position, the cooperative loops do not apply.
     const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
-    const bool wavefront = !(h->debug_flags & 8u) && (!adjoint || ((h->debug_flags & 32u) && !quadratic));
-    // wave-cooperative tracking loops (drt_coop.hip): the adjoint by default, the primal with debug bit 65536;
-    // supergrid scenes and debug bit 32768 keep the plain per-lane kernel
-    const bool coop = !wavefront && !P.mgrid && !(h->debug_flags & 32768u);
-    const bool coop_primal = !adjoint && !P.mgrid && (h->debug_flags & 65536u) && !(h->debug_flags & 8u);
+    const bool sm_primal = !adjoint && (P.mgrid != nullptr || (h->debug_flags & 65536u)) && !(h->debug_flags & 8u);
+    const bool sm_adjoint = adjoint && (h->debug_flags & 32u) && !quadratic && !(h->debug_flags & 8u);
+    const bool wavefront = sm_primal || sm_adjoint;
+    const bool coop = !wavefront && !P.mgrid && !(h->debug_flags & (adjoint ? 32768u : 8u));
+    const bool coop_primal = false;
     if (coop || coop_primal) {
         DRT_HIP_CHECK(h, drt::launch_trace_coop(P, adjoint, h->counting, h->stream));
     } else if (!wavefront) {
@@ -520,6 +570,7 @@ int drt_destroy(drt_handle h)
         if (R.reduced) (void) hipEventDestroy(R.reduced);
     }
     if (h->side) (void) hipStreamDestroy(h->side);
+    if (h->d_pcache) (void) hipFree(h->d_pcache);
     clear_timings(h);
     delete h;
     return DRT_OK;
@@ -552,6 +603,7 @@ int drt_synchronize(drt_handle h)
 int drt_params_changed(drt_handle h)
 {
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    h->scene_version++;
     if (!h->have_medium) return fail(h, DRT_ERR_NOT_CONFIGURED, "no medium set");
     DeviceGuard g(h->device);
     size_t n = (size_t) h->base.rx * h->base.ry * h->base.rz;
@@ -647,7 +699,7 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         B.sigma_b = h->d_sigma_b;
         B.sb_ystride = (int) nbx; B.sb_zstride = (int) (nby * nbx);
     }
-    h->have_medium = true;
+    h->have_medium = true; h->scene_version++;
     return drt_params_changed(h);
 }
 
@@ -657,7 +709,7 @@ int drt_set_emitter_constant(drt_handle h, const float radiance[3])
     if (!radiance) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null radiance");
     for (int k = 0; k < 3; ++k) h->base.Le[k] = radiance[k];
     h->base.env_pix = h->base.env_marg = h->base.env_cond = nullptr;
-    h->have_emitter = true;
+    h->have_emitter = true; h->scene_version++;
     return DRT_OK;
 }
 
@@ -729,7 +781,7 @@ int drt_set_emitter_envmap(drt_handle h, const float *pixels, int32_t width, int
     h->base.env_w = width; h->base.env_h = height; h->base.env_scale = scale;
     for (int k = 0; k < 9; ++k) h->base.env_R[k] = to_world[k];
     for (int k = 0; k < 3; ++k) h->base.Le[k] = 0.0f;
-    h->have_emitter = true;
+    h->have_emitter = true; h->scene_version++;
     return DRT_OK;
 }
 
@@ -741,11 +793,15 @@ int drt_set_sensor_perspective(drt_handle h, const float origin[3], const float 
     if (!origin || !left || !up || !dir) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null sensor frame");
     if (width < 1 || height < 1) return fail(h, DRT_ERR_INVALID_ARGUMENT, "film size must be >= 1");
     drt::Params &B = h->base;
+    bool same = h->have_sensor && B.tan_x == tan_x && B.tan_y == tan_y && B.width == width && B.height == height;
+    for (int k = 0; k < 3; ++k)
+        same = same && B.cam_o[k] == origin[k] && B.cam_left[k] == left[k] && B.cam_up[k] == up[k] && B.cam_dir[k] == dir[k];
     for (int k = 0; k < 3; ++k) {
         B.cam_o[k] = origin[k]; B.cam_left[k] = left[k]; B.cam_up[k] = up[k]; B.cam_dir[k] = dir[k];
     }
     B.tan_x = tan_x; B.tan_y = tan_y; B.width = width; B.height = height;
     h->have_sensor = true;
+    if (!same) h->scene_version++;                              // (the host layer re-sends the sensor with every sample())
     return DRT_OK;
 }
 
@@ -760,6 +816,8 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     drt::Params P;
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
     P.L_out = L_out;
+    h->pcache_sig.valid = false;
+    if (!P.mgrid && !(h->debug_flags & (8u | 65536u))) bind_path_cache_write(h, P);
     return timed_launch(h, 0, P, false);
 }
 
@@ -778,7 +836,13 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
     // capacity: 48 sigma_t and 6 colour records per ray (headline workload: 12.3 and 1.4); beyond it the
     // tracer falls back to direct atomics (emit_record), so this is a performance choice only
-    return run_backward(h, P, 48, 6, [&](drt::Params &Q) { return timed_launch(h, 1, Q, true); });
+    const uint64_t job_rays = n_rays;
+    rc = run_backward(h, P, 48, 6, [&](drt::Params &Q) {
+        if (!Q.mgrid && !(h->debug_flags & (8u | 32u | 32768u))) bind_path_cache_read(h, Q, job_rays);
+        return timed_launch(h, 1, Q, true);
+    });
+    h->pcache_sig.valid = false;
+    return rc;
 }
 
 static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, const float *emission)
@@ -804,6 +868,7 @@ int drt_nerf_render_primal(drt_handle h, const drt_nerf_config *cfg, const float
     rc = nerf_fill(h, P, cfg, emission);
     if (rc) return rc;
     P.L_out = L_out;
+    h->pcache_sig.valid = false;
     return timed_nerf(h, 0, P, false);
 }
 
@@ -874,7 +939,7 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
 int drt_set_debug_flags(drt_handle h, uint32_t flags)
 {
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
-    h->debug_flags = flags;
+    h->debug_flags = flags; h->scene_version++;
     return DRT_OK;
 }
 

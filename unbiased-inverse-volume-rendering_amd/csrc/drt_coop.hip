@@ -83,12 +83,13 @@ struct CoopTracer {
     uint32_t *slots;        // wave-private LDS, 64 words: walk slot -> owner lane
     const uint64_t *jump;   // LDS copy of the jump-ahead table: A_k at [2k], G_k at [2k + 1]
     const uint32_t *occ;
+    uint4 *pc;              // this ray's path-cache entries (2 x uint4 per bounce-loop iteration) or nullptr
     uint32_t cnt[C_COUNT];
 
     __device__ __forceinline__ CoopTracer(const Params &p) : P(p)
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
-        ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr;
+        ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr;
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
@@ -129,9 +130,10 @@ struct CoopTracer {
     // estimate_transmittance: ratio tracking (volpathsimple.py:436-504), all lanes of the wave call it
     // ---------------------------------------------------------------------------------------------
     template <bool ADJ>
-    __device__ float coop_rt(bool job, V3 o, V3 d, float tmax, Pcg32 &S, float a_sum)
+    __device__ float coop_rt(bool job, V3 o, V3 d, float tmax, Pcg32 &S, float a_sum, uint32_t *steps_out = nullptr)
     {
         float T = 1.0f;
+        uint32_t steps = 0;
         uint64_t pending = __ballot(job);
         while (pending) {
             int m, lg, js, c, owner, my_rank; bool serve;
@@ -189,24 +191,27 @@ struct CoopTracer {
             const float rT = __shfl(Tout, src), rx = __shfl(p.x, src), ry = __shfl(p.y, src), rz = __shfl(p.z, src);
             const float rt = __shfl(ct - dt, src);
             const int rend = __shfl(ends ? 1 : 0, src);
+            const int rout = __shfl((live && !inside) ? 1 : 0, src);
             const uint64_t rs = shfl64(sc * kPcgMul + inc, src);               // stream after the last started step's draw
             if (job) {
                 T = rT; o = v3(rx, ry, rz); tmax = rt;
                 S.state = rs;
+                steps += (uint32_t) (src - base + 1 - rout);                    // executed steps of my walk in this round
                 if (rend) job = false;
             }
             pending = __ballot(job);
         }
+        if (steps_out) *steps_out = steps;
         return T;
     }
 
     // ---------------------------------------------------------------------------------------------
     // sample_real_interaction: delta tracking (volpathsimple.py:323-377), all lanes of the wave call it
     // ---------------------------------------------------------------------------------------------
-    template <bool ATTACHED>
-    __device__ Mei coop_dt(bool job, const Ray &ray, Pcg32 &S)
+    __device__ Mei coop_dt(bool job, const Ray &ray, Pcg32 &S, uint32_t &steps)
     {
         Mei mei; mei.valid = false; mei.t = kInf; mei.p = v3(0, 0, 0); mei.sigma_t = 0.0f;
+        steps = 0;
         V3 ro = ray.o; float rmaxt = ray.maxt, running_t = 0.0f;
         uint64_t pending = __ballot(job);
         while (pending) {
@@ -256,20 +261,19 @@ struct CoopTracer {
                 if (oterm) {
                     job = false;
                     if (racc) { mei.valid = true; mei.t = rtm; }
-                } else { ro = v3(rx, ry, rz); rmaxt = rt; running_t = rtm; }
+                    steps += (uint32_t) (racc ? oe + 1 : oe);
+                } else { ro = v3(rx, ry, rz); rmaxt = rt; running_t = rtm; steps += (uint32_t) m; }
             }
             pending = __ballot(job);
         }
-        if (mei.valid) {
-            mei.p = ray_at(ray.o, ray.d, mei.t);                                // :371
-            if (ATTACHED) { mei.sigma_t = eval_sigma_t(P, mei.p, occ); count(C_DT); }   // :373-375
-        }
-        return mei;
+        return mei;                                                             // mei.p / attached sigma_t: the caller (:371-375)
     }
 
-    // sample_emitter (volpathsimple.py:406-433): emitter_val * transmittance in out[], ds.pdf returned
+    // sample_emitter (volpathsimple.py:406-433): emitter_val * transmittance in out[], ds.pdf returned.
+    // cache (value walk only): mode 1 stores {T, sampler state behind the walk, steps} into *ce, mode 2 takes
+    // them from it instead of walking.
     template <bool ADJ>
-    __device__ float sample_emitter(bool job, V3 p, Pcg32 &S, const float *adj, float out[3])
+    __device__ float sample_emitter(bool job, V3 p, Pcg32 &S, const float *adj, float out[3], int cmode = 0, uint4 *ce = nullptr)
     {
         float val[3] = { 0.0f, 0.0f, 0.0f }, pdf = 0.0f, tmax = 0.0f;
         V3 wd = v3(0, 0, 1);
@@ -278,14 +282,21 @@ struct CoopTracer {
             float ux = S.next_1d(), uy = S.next_1d();                           // :418
             wd = emitter_sample_dir<ENV>(P, ux, uy);
             pdf = emitter_sample_value<ENV>(P, wd, val);
-            if (pdf != 0.0f) {                                                  // sampling_worked :421-423
+            if (pdf != 0.0f && cmode != 2) {                                    // sampling_worked :421-423
                 Hit si = box_hit(P, p, wd);                                     // :427-428
                 walk = si.valid; tmax = si.t;
             }
         }
         const float a_sum = (ADJ && job) ? (adj[0] + adj[1]) + adj[2] : 0.0f;
-        float T = coop_rt<ADJ>(walk, p, wd, tmax, S, a_sum);
+        uint32_t steps = 0;
+        float T = coop_rt<ADJ>(walk, p, wd, tmax, S, a_sum, &steps);
         if (!walk) T = 0.0f;
+        if (job && cmode == 1) *ce = make_uint4(__float_as_uint(T), (uint32_t) S.state, (uint32_t) (S.state >> 32), steps);
+        if (job && cmode == 2) {
+            const uint4 e = *ce;
+            T = __uint_as_float(e.x); S.state = ((uint64_t) e.z << 32) | e.y;
+            if (COUNT) cnt[C_RT] += e.w;
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) out[k] = val[k] * T;
         return pdf;
@@ -293,11 +304,12 @@ struct CoopTracer {
 
     // sample_emitter_for_nee (volpathsimple.py:380-403)
     template <bool ADJ>
-    __device__ void sample_emitter_for_nee(bool job, V3 p, Pcg32 &S, const float beta[3], const float *dL, float contrib[3])
+    __device__ void sample_emitter_for_nee(bool job, V3 p, Pcg32 &S, const float beta[3], const float *dL, float contrib[3],
+                                           int cmode = 0, uint4 *ce = nullptr)
     {
         Pcg32 clone = S;                                                        // :383
         float emitted[3];
-        float ds_pdf = sample_emitter<false>(job, p, S, nullptr, emitted);      // :385
+        float ds_pdf = sample_emitter<false>(job, p, S, nullptr, emitted, cmode, ce);   // :385
         float w = mis_weight(ds_pdf, kInvFourPi);                               // :391
 #pragma unroll
         for (int k = 0; k < 3; ++k) contrib[k] = job ? ((beta[k] * kInvFourPi) * w) * emitted[k] : 0.0f;
@@ -443,6 +455,7 @@ struct CoopTracer {
         if (active) (void) S.next_1d();                                         // :99
         if constexpr (ADJ) { if (job) A.seed(P.alt_seed, ray_index); }          // :100-107
 
+        int it = 0;                                                             // bounce-loop iterations this ray has run
         while (__ballot(active)) {                                              // :114, wave-uniform
             bool run = active;
             if (run) {
@@ -454,7 +467,23 @@ struct CoopTracer {
                 run = active;
             }
 
-            Mei mei = coop_dt<ADJ>(run, ray, S);                                // :126
+            // path cache (main path only): the adjoint takes this iteration's walk from the primal pass
+            const int cmode = (!RECURSIVE && pc && run && it < (int) P.path_cache_cap) ? (int) P.path_cache_mode : 0;
+            uint4 *ce = cmode ? pc + 2 * it : nullptr;
+            uint32_t dt_steps = 0;
+            Mei mei = coop_dt(run && cmode != 2, ray, S, dt_steps);             // :126
+            if (cmode == 2) {
+                const uint4 e = ce[0];
+                mei.t = __uint_as_float(e.x); mei.valid = mei.t < kInf;
+                S.state = ((uint64_t) e.z << 32) | e.y;
+                if (COUNT) cnt[C_DT] += e.w;
+            } else if (cmode == 1) {
+                ce[0] = make_uint4(__float_as_uint(mei.valid ? mei.t : kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), dt_steps);
+            }
+            if (run && mei.valid) {
+                mei.p = ray_at(ray.o, ray.d, mei.t);                            // :371
+                if (ADJ) { mei.sigma_t = eval_sigma_t(P, mei.p, occ); count(C_DT); }   // :373-375
+            }
             const bool did_escape = run && !mei.valid, did_scatter = run && mei.valid;   // :130-134
             has_scattered |= did_scatter;
 
@@ -511,7 +540,7 @@ struct CoopTracer {
             }
             if (P.use_nee) {
                 float nee[3];
-                sample_emitter_for_nee<ADJ>(nee_job, mei.p, S, beta, dL, nee);
+                sample_emitter_for_nee<ADJ>(nee_job, mei.p, S, beta, dL, nee, nee_job ? cmode : 0, ce ? ce + 1 : nullptr);
                 if (nee_job) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) result[k] = ADJ ? result[k] - nee[k] : result[k] + nee[k];
@@ -532,6 +561,7 @@ struct CoopTracer {
                     if (si.valid) ray.o = offset_p(si, ray.d);
                     escaped = true;
                 }
+                ++it;
             }
         }
 
@@ -618,6 +648,19 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
             ray.d = v3(P.rays_d[3 * i], P.rays_d[3 * i + 1], P.rays_d[3 * i + 2]);
         }
         tr.count(C_RAYS);
+        if (P.path_cache_mode) {
+            // one word per ray ties the entries to THIS ray: explicit rays are hashed (the buffers may have
+            // been refilled between the two passes), sensor rays are determined by the job signature
+            uint32_t hsh = 0x9e3779b9u ^ gi;
+            if (!P.sensor_flow) {
+                const uint32_t w[6] = { __float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z),
+                                        __float_as_uint(ray.d.x), __float_as_uint(ray.d.y), __float_as_uint(ray.d.z) };
+#pragma unroll
+                for (int k = 0; k < 6; ++k) hsh = (hsh ^ w[k]) * 0x01000193u + (hsh >> 15);
+            }
+            if (P.path_cache_mode == 1) { P.ray_hash[i] = hsh; tr.pc = P.path_cache + (size_t) i * P.path_cache_cap * 2; }
+            else if (P.ray_hash[i] == hsh) tr.pc = P.path_cache + (size_t) i * P.path_cache_cap * 2;
+        }
         if (ADJ) {
             dL[0] = P.dL[3 * i]; dL[1] = P.dL[3 * i + 1]; dL[2] = P.dL[3 * i + 2];
             Lin[0] = P.L_in[3 * i]; Lin[1] = P.L_in[3 * i + 1]; Lin[2] = P.L_in[3 * i + 2];

@@ -249,6 +249,14 @@ struct Params {
     uint32_t *rec_chunk_count[4];   // valid records per chunk (zeroed per launch)
     uint32_t rec_cap_chunks[4];     // chunks available per stream
     uint32_t *rec_cursor;           // [0..3] chunks handed out, [4..7] splats that overflowed (direct atomics)
+    // Path cache (drt_coop.hip): the primal pass of an H1 step records, per ray and bounce-loop iteration,
+    // what its delta-tracking walk and its NEE transmittance walk returned (distance / transmittance, the
+    // sampler state behind them, their step counts); the adjoint pass of the SAME job reads them instead of
+    // walking again.  [n_rays][path_cache_cap][2] uint4; mode 0 off, 1 write, 2 read.  ray_hash: one word
+    // per ray (explicit rays: hash of origin and direction) that must match for a ray's entries to be used.
+    uint4 *path_cache;
+    uint32_t *ray_hash;
+    uint32_t path_cache_cap, path_cache_mode;
     unsigned long long *queues;     // 8 per-XCD ray queue heads (wavefront kernel), zeroed per launch
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
