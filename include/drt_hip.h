@@ -211,8 +211,9 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
  * DRT_PIPELINE in the environment; measured slower); bit 12 (4096): compare-and-swap flush; bit 13
  * (8192): exact checksum of the flushed sums; bit 14 (16384): 8 MB record budget, i.e. many ray
  * sub-batches (test hook); bit 15 (32768): plain one-ray-per-lane adjoint kernel instead of the
- * wave-cooperative tracking loops (drt_coop.hip); bit 16 (65536): wave-cooperative kernel for the
- * primal too (default: the state-machine kernel, same speed); bit 18 (262144): pretend that the record
+ * wave-cooperative tracking loops (drt_coop.hip); bit 16 (65536): state-machine kernel for the primal
+ * (default: the cooperative kernel, which also writes the path cache); bit 20 (1048576): no path
+ * cache (the adjoint pass walks its primal path again); bit 18 (262144): pretend that the record
  * streams cannot be allocated (the job then takes the atomic path, as it does when hipMalloc fails). */
 int drt_set_debug_flags(drt_handle h, uint32_t flags);
 

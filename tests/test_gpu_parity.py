@@ -116,6 +116,60 @@ def test_heterogeneous_grid_explicit_rays(uivr, oracle, gpu):
     _assert_grads_close(grads[uivr.ALBEDO_KEY], ga, "grad albedo")
 
 
+def test_path_cache_is_tied_to_the_rays(uivr, oracle, gpu):
+    """The adjoint pass reuses the walks its primal pass recorded (path cache, drt_coop.hip).  Refill the
+    ray buffers in place between the two passes: job signature and pointers still match, the per-ray hash
+    does not, so every ray must be walked again - gradients of the NEW rays, as the oracle computes them.
+    Also: cache on / off give the same gradients and counters."""
+    rng = np.random.default_rng(11)
+    scene = uivr.cube_test_scene(16, 16, density_scale=2.0)
+    props = props_for("drt")
+    n, spp, seed = 2048, 4, 99
+
+    def rays():
+        o = rng.normal(size=(n, 3)).astype(np.float32) * 0.2 + np.array([3.5, 3.0, 3.5], dtype=np.float32)
+        tgt = rng.random((n, 3), dtype=np.float32) * 2.0 - 0.5
+        d = tgt - o
+        return o, (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+
+    oa, da = rays()
+    ob, db = rays()
+    osc = oracle.OracleScene(scene, sensor_index=None)
+    Lb, _ = oracle.render_primal(osc, props, spp, seed, rays_o=ob, rays_d=db)
+    dL = (rng.random((n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    gs, ga, cb = oracle.render_backward(osc, props, spp, seed, dL, Lb, rays_o=ob, rays_d=db)
+
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props)
+    to, td = torch.from_numpy(oa).to(gpu), torch.from_numpy(da).to(gpu)
+    batch = uivr.RayBatch(n_rays=n, spp=spp, o=to, d=td)
+    samp = uivr.IndependentSampler(seed, spp)
+    integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)            # cache written for rays A
+    to.copy_(torch.from_numpy(ob).to(gpu)); td.copy_(torch.from_numpy(db).to(gpu))   # same buffers, rays B
+    grads = uivr.alloc_grads(sg)
+    integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu),
+                 state_in=torch.from_numpy(Lb).to(gpu), grads=grads)
+    _assert_grads_close(grads[uivr.SIGMA_T_KEY], gs, "stale cache: grad sigma_t")
+    _assert_grads_close(grads[uivr.ALBEDO_KEY], ga, "stale cache: grad albedo")
+
+    # proper sequence, cache on (0) and off (1048576): same gradients, adjoint counters equal to the oracle's
+    h = integ.native_handle(sg)
+    for flags in (0, 1048576):
+        h.set_debug_flags(flags)
+        L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+        np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), Lb.view(np.uint32))
+        h.enable_counters(True)
+        h.reset_counters()
+        grads = uivr.alloc_grads(sg)
+        integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=st, grads=grads)
+        cnt = {k: int(v) for k, v in h.get_counters().items()}
+        h.enable_counters(False)
+        assert cnt == cb, flags
+        _assert_grads_close(grads[uivr.SIGMA_T_KEY], gs, f"flags {flags}: grad sigma_t")
+        _assert_grads_close(grads[uivr.ALBEDO_KEY], ga, f"flags {flags}: grad albedo")
+    h.set_debug_flags(0)
+
+
 @pytest.mark.parametrize("factor", [2, 4, 5])
 def test_majorant_supergrid(uivr, oracle, gpu, factor):
     """majorant_resolution_factor > 0 (scene_config.py:36): supergrid values, primal bit-exact,
@@ -368,7 +422,7 @@ def test_sigma_t_gradient_vs_finite_differences(uivr, gpu, variant):
                                            (2, "drt"), (16, "drt"), (128, "drt"), (128, "quadratic"), (256, "drt"),
                                            (256, "basic"), (16384, "drt"), (16384 + 2048, "drt"), (2048, "basic"),
                                            (32768, "drt"), (32768, "quadratic"), (65536, "drt"), (65536, "basic"),
-                                           (65536, "quadratic-nomis"), (262144, "drt")])
+                                           (65536, "quadratic-nomis"), (262144, "drt"), (1048576, "drt")])
 def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     """The production path uses the wave-synchronous state machine for the primal and the
     one-ray-per-lane kernel for the adjoint (measured faster).  The other combinations
@@ -379,8 +433,8 @@ def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     16384 = 8 MB record budget (the 16 k rays are traced in sub-batches of 2560), 2048 = the reduction
     of sub-batch b - 1 overlapped with the tracer of sub-batch b on a side stream, 32768 = plain per-lane
     adjoint kernel instead of the wave-cooperative tracking loops (production default for the adjoint),
-    65536 = wave-cooperative kernel for the primal too, 262144 = record streams "cannot be allocated"
-    (fallback to the atomic path)."""
+    65536 = state-machine kernel for the primal (no path cache), 262144 = record streams "cannot be
+    allocated" (fallback to the atomic path), 1048576 = path cache off."""
     props = props_for(variant)
     scene = uivr.cube_test_scene(32, 32, density_scale=2.0)
     spp, seed = 16, 777

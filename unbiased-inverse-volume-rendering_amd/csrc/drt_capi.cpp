@@ -153,7 +153,7 @@ void clear_timings(drt_handle h)
 }
 
 // launch bracketed by an event pair on the handle's stream when timing is enabled
-constexpr uint32_t kPathCacheCap = 4;                 // bounce-loop iterations cached per ray (headline: 2.4 on average)
+constexpr uint32_t kPathCacheCap = 16;                 // bounce-loop iterations cached per ray (headline: 2.4 on average)
 constexpr uint64_t kPathCacheMaxRays = 1ull << 24;     // larger primal launches (reference renders) skip the cache
 
 bool same_job(const drt_handle_s::JobSig &a, const drt_handle_s::JobSig &b)
