@@ -37,7 +37,7 @@ for k in acc:
                  "write_size_kib": mean(k, "WRITE_SIZE"), "atomics": mean(k, "TCC_EA0_ATOMIC_sum"),
                  "launches_seen": len(acc[k].get("TCC_EA0_RDREQ_sum", []))}
 adj = [k for k in detail if "trace_kernel<true, false" in k or "trace_coop_kernel<true, false" in k or "bin_" in k or "tile_reduce" in k or "untile" in k]
-pri = [k for k in detail if "trace_wavefront_kernel<false, false" in k]
+pri = [k for k in detail if "trace_wavefront_kernel<false, false" in k or "trace_coop_kernel<false, false" in k]
 res = {key: sum(detail[k]["total"] for k in adj),
        key + ":primal": sum(detail[k]["total"] for k in pri),
        "_adjoint_pass_kernels": adj, "_detail": detail,
