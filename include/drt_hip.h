@@ -131,7 +131,12 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
 /* sample(mode=Backward, dL, state_in=L_in): render_batch_backward step (2)
  * (batched.py:309-326).  Same rays / seed as the primal call that produced L_in.
  * ACCUMULATES (+=) into grad_sigma_t (Z,Y,X,1) and grad_albedo (Z,Y,X,3) - the
- * reference's dr.grad(params[k]) after scatter_reduce(Add) (volpathsimple.py:170,489,580,607). */
+ * reference's dr.grad(params[k]) after scatter_reduce(Add) (volpathsimple.py:170,489,580,607).
+ * When this call directly follows the drt_render_primal call of the same job on this handle (same
+ * ray range, seed, spp, interleave and ray buffers, no set_* / params_changed call in between - the
+ * H1 sequence of batched.py:255-326), the walks recorded by that primal pass are reused instead
+ * of being traced again (path cache; per-ray hashes guard explicit ray buffers that were refilled).
+ * Any other order is equally valid and simply traces the paths again. */
 int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
                         uint64_t ray_offset, uint32_t spp, uint32_t seed, const float *dL,
                         const float *L_in, float *grad_sigma_t, float *grad_albedo);
