@@ -207,10 +207,11 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     //   global majorant: one ray per lane with wave-cooperative tracking loops (drt_coop.hip) for both passes;
     //                    the primal pass writes the path cache that the adjoint pass of the same job reads.
     //                    The wave-synchronous state machine (drt_wavefront.hip) is as fast for the primal
-    //                    (debug bit 65536 selects it) but cannot feed the cache; for the adjoint (bit 32) it
-    //                    is slower (its transition blocks run with ~3 lanes).
-    //   supergrid      : plain one-ray-per-lane kernels (drt_kernels.hip; also debug bits 8 / 32768):
-    //                    the free-flight distance depends on the position, the cooperative loops do not apply.
+    //                    (debug bit 65536 selects it); for the adjoint (bit 32) it is slower (its transition
+    //                    blocks run with ~3 lanes).
+    //   supergrid      : state machine for the primal, plain one-ray-per-lane kernel (drt_kernels.hip; also debug
+    //                    bits 8 / 32768) for the adjoint, path cache included: the free-flight distance depends
+    //                    on the position, the cooperative loops do not apply.
     const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
     const bool sm_primal = !adjoint && (P.mgrid != nullptr || (h->debug_flags & 65536u)) && !(h->debug_flags & 8u);
     const bool sm_adjoint = adjoint && (h->debug_flags & 32u) && !quadratic && !(h->debug_flags & 8u);
@@ -817,7 +818,7 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
     P.L_out = L_out;
     h->pcache_sig.valid = false;
-    if (!P.mgrid && !(h->debug_flags & (8u | 65536u))) bind_path_cache_write(h, P);
+    bind_path_cache_write(h, P);                                 // every primal kernel records its walks
     return timed_launch(h, 0, P, false);
 }
 
@@ -838,7 +839,7 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     // tracer falls back to direct atomics (emit_record), so this is a performance choice only
     const uint64_t job_rays = n_rays;
     rc = run_backward(h, P, 48, 6, [&](drt::Params &Q) {
-        if (!Q.mgrid && !(h->debug_flags & (8u | 32u | 32768u))) bind_path_cache_read(h, Q, job_rays);
+        if (!(h->debug_flags & 32u) || (h->debug_flags & 8u)) bind_path_cache_read(h, Q, job_rays);      // ... and every adjoint kernel but it
         return timed_launch(h, 1, Q, true);
     });
     h->pcache_sig.valid = false;

@@ -28,12 +28,13 @@ struct Tracer {
     const uint32_t *occ;    // empty-space bitmask (LDS copy) or nullptr
     const float *mg;        // majorant supergrid as the DDA reads it (global memory, L2-resident; an LDS copy
                             // was measured slower: it costs a wave per SIMD of occupancy)
+    uint4 *pc;              // this ray's path-cache entries (drt_device.h: Params::path_cache) or nullptr
     uint32_t cnt[C_COUNT];
 
     __device__ __forceinline__ Tracer(const Params &p) : P(p)
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
-        ray_index = 0; rec = nullptr; mg = p.mgrid; occ = nullptr;
+        ray_index = 0; rec = nullptr; mg = p.mgrid; occ = nullptr; pc = nullptr;
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
@@ -97,9 +98,10 @@ struct Tracer {
 
     // estimate_transmittance: ratio tracking (volpathsimple.py:436-504)
     template <bool ADJ>
-    __device__ float estimate_transmittance(V3 o, V3 d, float tmax, Pcg32 &S, const float *adj)
+    __device__ float estimate_transmittance(V3 o, V3 d, float tmax, Pcg32 &S, const float *adj, uint32_t *steps_out = nullptr)
     {
         float T = 1.0f;
+        uint32_t steps = 0;
         for (;;) {
             float lm, lim;
             float dt = sample_collision(o, d, tmax, S.next_1d(), lm, lim);
@@ -114,24 +116,34 @@ struct Tracer {
                 count(C_RT_ADJ);
             }
             T *= tr;                                                    // :495
+            ++steps;
             o = p; tmax -= dt;                                          // :497-499
             if (T == 0.0f) break;                                       // :502
         }
+        if (steps_out) *steps_out = steps;
         return T;
     }
 
     // sample_emitter (volpathsimple.py:406-433): emitter_val * transmittance in out[], ds.pdf returned
     template <bool ADJ>
-    __device__ float sample_emitter(V3 p, Pcg32 &S, const float *adj, float out[3])
+    __device__ float sample_emitter(V3 p, Pcg32 &S, const float *adj, float out[3], int cmode = 0, uint4 *ce = nullptr)
     {
         float ux = S.next_1d(), uy = S.next_1d();                       // :418
         float val[3];
         V3 wd = emitter_sample_dir<ENV>(P, ux, uy);                          // Scene::sample_emitter_direction
         float pdf = emitter_sample_value<ENV>(P, wd, val);                   // ds.pdf, radiance / pdf
         float T = 0.0f;
-        if (pdf != 0.0f) {                                              // sampling_worked :421-423
-            Hit si = box_hit(P, p, wd);                                 // :427-428
-            if (si.valid) T = estimate_transmittance<ADJ>(p, wd, si.t, S, adj);
+        if (cmode == 2) {                                               // path cache: the primal pass walked this
+            const uint4 e = *ce;
+            T = __uint_as_float(e.x); S.state = ((uint64_t) e.z << 32) | e.y;
+            if (COUNT) cnt[C_RT] += e.w;
+        } else {
+            uint32_t steps = 0;
+            if (pdf != 0.0f) {                                          // sampling_worked :421-423
+                Hit si = box_hit(P, p, wd);                             // :427-428
+                if (si.valid) T = estimate_transmittance<ADJ>(p, wd, si.t, S, adj, &steps);
+            }
+            if (cmode == 1) *ce = make_uint4(__float_as_uint(T), (uint32_t) S.state, (uint32_t) (S.state >> 32), steps);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) out[k] = val[k] * T;
@@ -141,11 +153,11 @@ struct Tracer {
     // sample_emitter_for_nee (volpathsimple.py:380-403)
     template <bool ADJ>
     __device__ void sample_emitter_for_nee(V3 p, Pcg32 &S, const float beta[3], const float *dL,
-                                           float contrib[3])
+                                           float contrib[3], int cmode = 0, uint4 *ce = nullptr)
     {
         Pcg32 clone = S;                                                // :383
         float emitted[3];
-        float ds_pdf = sample_emitter<false>(p, S, nullptr, emitted);   // :385
+        float ds_pdf = sample_emitter<false>(p, S, nullptr, emitted, cmode, ce);   // :385
         float w = mis_weight(ds_pdf, kInvFourPi);                       // :391
 #pragma unroll
         for (int k = 0; k < 3; ++k) contrib[k] = ((beta[k] * kInvFourPi) * w) * emitted[k];
@@ -158,22 +170,30 @@ struct Tracer {
 
     // sample_real_interaction: delta tracking (volpathsimple.py:323-377)
     template <bool ATTACHED>
-    __device__ Mei sample_real_interaction(const Ray &ray, Pcg32 &S)
+    __device__ Mei sample_real_interaction(const Ray &ray, Pcg32 &S, int cmode = 0, uint4 *ce = nullptr)
     {
         Mei mei; mei.valid = false; mei.t = kInf; mei.p = v3(0, 0, 0); mei.sigma_t = 0.0f;
         V3 ro = ray.o; float rmaxt = ray.maxt, running_t = 0.0f;
+        uint32_t steps = 0;
+        if (cmode == 2) {                                               // path cache: the primal pass walked this
+            const uint4 e = *ce;
+            mei.t = __uint_as_float(e.x); mei.valid = mei.t < kInf;
+            S.state = ((uint64_t) e.z << 32) | e.y;
+            if (COUNT) cnt[C_DT] += e.w;
+        } else
         for (;;) {
             float lm, lim;
             float dt = sample_collision(ro, ray.d, rmaxt, S.next_1d(), lm, lim);   // :348
             if (!(dt <= rmaxt)) break;                                  // :358
             V3 p = ray_at(ro, ray.d, dt);
             float sig = eval_sigma_t(P, p, occ);
-            count(C_DT);
+            count(C_DT); ++steps;
             float r = sig * lim;                                        // :354
             float u = S.next_1d();                                      // :359
             if (!(u >= r)) { mei.valid = true; mei.t = running_t + dt; break; }   // :351
             ro = p; rmaxt -= dt; running_t += dt;                       // :364-367
         }
+        if (cmode == 1) *ce = make_uint4(__float_as_uint(mei.valid ? mei.t : kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), steps);
         if (mei.valid) {
             mei.p = ray_at(ray.o, ray.d, mei.t);                        // :371
             if (ATTACHED) { mei.sigma_t = eval_sigma_t(P, mei.p, occ); count(C_DT); }   // :373-375
@@ -307,6 +327,7 @@ struct Tracer {
         if (active) (void) S.next_1d();                                 // :99
         if constexpr (ADJ) A.seed(P.alt_seed, ray_index);               // :100-107
 
+        int it = 0;                                                     // bounce-loop iterations that reached their walk
         while (active) {                                                // :114
             float q = fminf(fmaxf(beta[0], fmaxf(beta[1], beta[2])), 0.99f);   // :117-121
             bool perform_rr = depth > P.rr_depth;
@@ -316,7 +337,10 @@ struct Tracer {
             if (perform_rr) { float iq = 1.0f / q; beta[0] *= iq; beta[1] *= iq; beta[2] *= iq; }
             if (!active) break;
 
-            Mei mei = sample_real_interaction<ADJ>(ray, S);             // :126
+            const int cmode = (!RECURSIVE && pc && it < (int) P.path_cache_cap) ? (int) P.path_cache_mode : 0;
+            uint4 *ce = cmode ? pc + 2 * it : nullptr;
+            ++it;
+            Mei mei = sample_real_interaction<ADJ>(ray, S, cmode, ce);  // :126
             bool did_escape = !mei.valid, did_scatter = mei.valid;      // :130-134
             has_scattered |= did_scatter;
 
@@ -367,7 +391,7 @@ struct Tracer {
 
             if (P.use_nee && did_scatter && active) {                   // :206-215
                 float nee[3];
-                sample_emitter_for_nee<ADJ>(mei.p, S, beta, dL, nee);
+                sample_emitter_for_nee<ADJ>(mei.p, S, beta, dL, nee, cmode, ce ? ce + 1 : nullptr);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) result[k] = ADJ ? result[k] - nee[k] : result[k] + nee[k];
             }
@@ -464,6 +488,17 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
         }
         ray.maxt = kLargest;
         tr.count(C_RAYS);
+        if (P.path_cache_mode) {                                        // see trace_coop_kernel
+            uint32_t hsh = 0x9e3779b9u ^ gi;
+            if (!P.sensor_flow) {
+                const uint32_t w[6] = { __float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z),
+                                        __float_as_uint(ray.d.x), __float_as_uint(ray.d.y), __float_as_uint(ray.d.z) };
+#pragma unroll
+                for (int k = 0; k < 6; ++k) hsh = (hsh ^ w[k]) * 0x01000193u + (hsh >> 15);
+            }
+            if (P.path_cache_mode == 1) { P.ray_hash[i] = hsh; tr.pc = P.path_cache + (size_t) i * P.path_cache_cap * 2; }
+            else if (P.ray_hash[i] == hsh) tr.pc = P.path_cache + (size_t) i * P.path_cache_cap * 2;
+        }
         float L[3];
         if (ADJ) {
             float dL[3] = { P.dL[3 * i], P.dL[3 * i + 1], P.dL[3 * i + 2] };

@@ -192,6 +192,8 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
     int r_depth = -1; float r_si_t = kInf; V3 r_o = ro, r_d = rd;
     float r_wsum[3] = { 0, 0, 0 }, r_cw[3] = { 0, 0, 0 };
     float xp_sig = 0.0f, xp_coef[3] = { 0, 0, 0 };
+    // path cache (primal pass only, Params::path_cache): bounce-loop iteration of this ray, steps of the current walk
+    int pc_it = 0; uint32_t pc_steps = 0; bool pc_on = false;
 
     for (;;) {
         // ================= (A) regeneration ===========================================================
@@ -230,6 +232,19 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                             rd = v3(P.rays_d[3 * i], P.rays_d[3 * i + 1], P.rays_d[3 * i + 2]);
                         }
                         DRT_COUNT(C_RAYS);
+                        if constexpr (!ADJ) {
+                            pc_on = P.path_cache_mode == 1; pc_it = 0;
+                            if (pc_on) {                                        // see trace_coop_kernel
+                                uint32_t hsh = 0x9e3779b9u ^ gi;
+                                if (!P.sensor_flow) {
+                                    const uint32_t w[6] = { __float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z),
+                                                            __float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z) };
+#pragma unroll
+                                    for (int k = 0; k < 6; ++k) hsh = (hsh ^ w[k]) * 0x01000193u + (hsh >> 15);
+                                }
+                                P.ray_hash[i] = hsh;
+                            }
+                        }
                         beta[0] = beta[1] = beta[2] = 1.0f;
                         result[0] = result[1] = result[2] = 0.0f;
                         if constexpr (ADJ) {
@@ -336,6 +351,11 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                 }
 
                 // ---- real collision found (:130-189) ----------------------------------------------------
+                if constexpr (!ADJ) {                                           // path cache: what this iteration's walk returned
+                    if ((ph == PH_SCAT || ph == PH_ESC) && pc_on && pc_it < (int) P.path_cache_cap)
+                        P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2] =
+                            make_uint4(__float_as_uint(ph == PH_SCAT ? mei_t : kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
+                }
                 if (ph == PH_SCAT) {
                     mp = ray_at(ro, rd, mei_t);                                 // :371
                     if (adj_lane) { mei_sig = eval_sigma_t(P, mp, occ); DRT_COUNT(C_DT); }   // :373-375
@@ -420,6 +440,11 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                 }
 
                 // ---- NEE walk finished (:388-403) -------------------------------------------------------------
+                if constexpr (!ADJ) {
+                    if (ph == PH_RT_END && pc_on && pc_it < (int) P.path_cache_cap)
+                        P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1] =
+                            make_uint4(__float_as_uint(wt), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
+                }
                 if (ph == PH_RT_END) {
                     float val[3], contrib[3];
                     const float ds_pdf = emitter_sample_value<ENV>(P, nd, val);      // recomputed from the direction
@@ -451,12 +476,14 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                     nd = emitter_sample_dir<ENV>(P, ux, uy);
                     Hit h = box_hit(P, mp, nd);                                 // :427-428
                     if constexpr (ENV) { if (envmap_pdf(P, nd) == 0.0f) h.valid = false; }   // sampling_worked :421-423
+                    pc_steps = 0;
                     if (h.valid) { nt0 = h.t; wo = mp; wmax = h.t; wt = 1.0f; ph = PH_RT; }
                     else { nt0 = kInf; wt = 0.0f; ph = PH_RT_END; }
                 }
 
                 // ---- phase sampling + new segment (:221-246) -------------------------------------------------------
                 if (ph == PH_PHASE) {
+                    ++pc_it;                                                    // next bounce-loop iteration (path cache index)
                     (void) S.next_1d();
                     float ux = S.next_1d(), uy = S.next_1d();
                     ro = mp; rd = square_to_uniform_sphere(ux, uy);
@@ -480,7 +507,7 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                     float u_rr = S.next_1d();
                     bool active = (beta[0] != 0.0f || beta[1] != 0.0f || beta[2] != 0.0f) && (!perform_rr || (u_rr < q));
                     if (perform_rr) { float iq = 1.0f / q; beta[0] *= iq; beta[1] *= iq; beta[2] *= iq; }
-                    if (active) { wo = ro; wmax = si_t; wt = 0.0f; ph = PH_DT; }
+                    if (active) { wo = ro; wmax = si_t; wt = 0.0f; ph = PH_DT; pc_steps = 0; }
                     else ph = PH_END;
                 }
             }
@@ -528,13 +555,13 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                             dT *= (lm - sig) * lim;
                             if (dT == 0.0f) ph = PH_DRT_END;
                         } else if (ph == PH_DT) {                               // :348-367
-                            DRT_COUNT(C_DT);
+                            DRT_COUNT(C_DT); ++pc_steps;
                             float r = sig * lim;
                             float u2 = R.next_1d();
                             if (!(u2 >= r)) { mei_t = wt + dt; ph = PH_SCAT; }
                             else { wo = p; wmax -= dt; wt += dt; }
                         } else {                                                // ratio tracking :465-502
-                            DRT_COUNT(C_RT);
+                            DRT_COUNT(C_RT); ++pc_steps;
                             float tr = (lm - sig) * lim;
                             if (ph == PH_RTA && tr > 0.0f) {                    // :487-492
                                 sp = p; sg = -(adjsum * lim) / tr; splat = true;
