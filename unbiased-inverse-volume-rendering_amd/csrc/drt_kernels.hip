@@ -586,13 +586,15 @@ __global__ void __launch_bounds__(256) nerf_kernel(const Params P)
                 V3 p = ray_at(o, d, t_b);                                    // query_medium :151-165
                 float raw = eval_sigma_t(P, p, occ);
                 float sigma = P.nerf_relu ? fmaxf(0.0f, raw) : raw;
-                float em[3];
-                eval_rgb(P, P.emission, p, em);
                 n_q++;
                 bool last = !(j + 1 < N);
                 float a = last ? 1.0f : drt_expf(-sigma * dt);               // :104-106
                 float weight = (1.0f - a) * throughput;
                 float safe_a = a + 1e-10f;
+                // the primal only needs the emission where the query has weight (adding weight * em with
+                // weight == 0 changes nothing); the adjoint's sigma_t gradient needs it everywhere
+                float em[3] = { 0.0f, 0.0f, 0.0f };
+                if (ADJ || weight != 0.0f) eval_rgb(P, P.emission, p, em);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) result[k] = ADJ ? result[k] - weight * em[k] : result[k] + weight * em[k];
                 if constexpr (ADJ) {                                         // :122-129
