@@ -84,12 +84,13 @@ struct CoopTracer {
     const uint64_t *jump;   // LDS copy of the jump-ahead table: A_k at [2k], G_k at [2k + 1]
     const uint32_t *occ;
     uint4 *pc;              // this ray's path-cache entries (2 x uint4 per bounce-loop iteration) or nullptr
+    uint32_t work;          // tracking steps of this ray's main path (primal pass: feeds block_cost)
     uint32_t cnt[C_COUNT];
 
     __device__ __forceinline__ CoopTracer(const Params &p) : P(p)
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
-        ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr;
+        ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr; work = 0;
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
@@ -472,6 +473,7 @@ struct CoopTracer {
             uint4 *ce = cmode ? pc + 2 * it : nullptr;
             uint32_t dt_steps = 0;
             Mei mei = coop_dt(run && cmode != 2, ray, S, dt_steps);             // :126
+            work += dt_steps + 4u;
             if (cmode == 2) {
                 const uint4 e = ce[0];
                 mei.t = __uint_as_float(e.x); mei.valid = mei.t < kInf;
@@ -598,6 +600,8 @@ template <bool ADJ, bool COUNT, bool ENV, bool DEFER>
 __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const Params P)
 {
     uint32_t b = blockIdx.x;                                    // XCD-aware block -> ray-chunk map (see trace_kernel)
+    if (ADJ && P.block_order) b = P.block_order[blockIdx.x];     // heavy blocks first
+    else
 #if DRT_XCD_RUN > 0
     {
         const uint32_t span = 8u * DRT_XCD_RUN;
@@ -673,6 +677,14 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
         if (job) { P.L_out[3 * i] = L[0]; P.L_out[3 * i + 1] = L[1]; P.L_out[3 * i + 2] = L[2]; }
     }
     if constexpr (ADJ && DEFER) close_records(P, tr.rec);
+    if constexpr (!ADJ) {
+        if (P.block_cost) {
+            uint32_t v = tr.work;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(P.block_cost + b, v);
+        }
+    }
     if (COUNT) {
 #pragma unroll
         for (int s = 0; s < C_COUNT; ++s) {
@@ -685,6 +697,28 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
 }
 
 }  // namespace
+
+namespace {
+// blocks by descending cost: counting sort on floor(log2(cost + 1)), one workgroup
+__global__ void __launch_bounds__(1024) block_order_kernel(const uint32_t *cost, uint32_t n, uint32_t *order)
+{
+    __shared__ uint32_t hist[33], cur[33];
+    if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[32 - __clz(cost[i])], 1u);   // bucket 0..32
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int k = 32; k >= 0; --k) { cur[k] = run; run += hist[k]; } }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&cur[32 - __clz(cost[i])], 1u)] = i;
+}
+}  // namespace
+
+hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t *order, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(block_order_kernel, dim3(1), dim3(1024), 0, stream, cost, n_blocks, order);
+    return hipGetLastError();
+}
 
 hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStream_t stream)
 {

@@ -254,6 +254,10 @@ struct Params {
     // sampler state behind them, their step counts); the adjoint pass of the SAME job reads them instead of
     // walking again.  [n_rays][path_cache_cap][2] uint4; mode 0 off, 1 write, 2 read.  ray_hash: one word
     // per ray (explicit rays: hash of origin and direction) that must match for a ray's entries to be used.
+    // heavy-first scheduling (drt_coop.hip): the primal pass sums the tracking steps of every 256-ray block into
+    // block_cost, block_order (blocks by descending cost) then tells the adjoint launch which block a workgroup takes
+    uint32_t *block_cost;
+    const uint32_t *block_order;
     uint4 *path_cache;
     uint32_t *ray_hash;
     uint32_t path_cache_cap, path_cache_mode;
