@@ -55,6 +55,7 @@ struct drt_handle_s {
     size_t pcache_bytes = 0;
     struct JobSig { uint64_t n_rays, ray_offset, chunk, stride; uint32_t spp, seed; const void *rays_o, *rays_d; uint64_t scene_version; bool valid; } pcache_sig{};
     bool order_valid = false;          // block_order of the last primal launch is usable
+    uint64_t order_rays = 0;           // ray count of the launch that produced the stored order (0: none)
     uint64_t scene_version = 0;        // bumped by every call that changes the medium / emitter / sensor / integrator state
     size_t mgrid_cells = 0;
     size_t sigma_b_floats = 0;
@@ -173,11 +174,13 @@ drt_handle_s::JobSig job_sig(drt_handle h, const drt::Params &P)
 void bind_path_cache_write(drt_handle h, drt::Params &P)
 {
     h->pcache_sig.valid = false;
+    if (P.n_rays != h->order_rays) h->order_rays = 0;           // another launch shape re-carves the buffer: the stored order dies
     if ((h->debug_flags & 1048576u) || P.n_rays > kPathCacheMaxRays) return;
     const size_t entries = (size_t) P.n_rays * kPathCacheCap * 2 * sizeof(uint4), n_blocks = (size_t) ((P.n_rays + 255) / 256);
     const size_t need = entries + (size_t) P.n_rays * sizeof(uint32_t) + 2 * n_blocks * sizeof(uint32_t);
     if (need > h->pcache_bytes) {
         if (h->d_pcache) { if (hipStreamSynchronize(h->stream) != hipSuccess) return; (void) hipFree(h->d_pcache); h->d_pcache = nullptr; h->pcache_bytes = 0; }
+        h->order_rays = 0;
         if (hipMalloc(&h->d_pcache, need) != hipSuccess) { (void) hipGetLastError(); h->d_pcache = nullptr; return; }
         h->pcache_bytes = need;
     }
@@ -829,12 +832,20 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     P.L_out = L_out;
     h->pcache_sig.valid = false;
     bind_path_cache_write(h, P);                                 // every primal kernel records its walks
+    {   // the block order left by the previous primal launch of the same shape predicts this one's heavy blocks
+        // (same sensor, next step); an order is only ever a schedule, never a result
+        static const bool no_lpt = getenv("DRT_NO_HEAVY_FIRST") != nullptr;
+        const uint64_t n_blocks = (n_rays + 255) / 256;
+        if (!no_lpt && P.block_cost && h->order_rays == n_rays && n_blocks <= kHeavyFirstMaxBlocks && !P.mgrid &&
+            !(h->debug_flags & (8u | 65536u)))
+            P.block_order = P.block_cost + n_blocks;
+    }
     rc = timed_launch(h, 0, P, false);
     h->order_valid = false;
     if (rc == DRT_OK && P.block_cost && !P.mgrid && !(h->debug_flags & (8u | 65536u))) {   // cooperative primal: it filled block_cost
         const uint32_t n_blocks = (uint32_t) ((P.n_rays + 255) / 256);
         DRT_HIP_CHECK(h, drt::launch_block_order(P.block_cost, n_blocks, P.block_cost + n_blocks, h->stream));
-        h->order_valid = true;
+        h->order_valid = true; h->order_rays = n_rays;
     }
     return rc;
 }

@@ -600,7 +600,7 @@ template <bool ADJ, bool COUNT, bool ENV, bool DEFER>
 __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const Params P)
 {
     uint32_t b = blockIdx.x;                                    // XCD-aware block -> ray-chunk map (see trace_kernel)
-    if (ADJ && P.block_order) b = P.block_order[blockIdx.x];     // heavy blocks first
+    if (P.block_order) b = P.block_order[blockIdx.x];            // heavy blocks first (adjoint: this job's primal costs; primal: the previous launch's)
     else
 #if DRT_XCD_RUN > 0
     {
