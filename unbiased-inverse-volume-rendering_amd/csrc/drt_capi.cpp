@@ -204,7 +204,7 @@ void bind_path_cache_read(drt_handle h, drt::Params &P, uint64_t job_rays)
     static const bool no_lpt = getenv("DRT_NO_HEAVY_FIRST") != nullptr;
     // (measured: film 184^2 x 32 spp, the per-rank share at 8 GPUs: adjoint 2.22 -> 1.70 ms; 256^2: 3.11 -> 2.85 ms; at
     //  the full 512^2 the XCD-contiguous block map is worth more than the order: 9.48 vs 10.02 ms)
-    if (!no_lpt && P.ray_first == 0 && P.n_rays == job_rays && h->order_valid && (job_rays + 255) / 256 <= kHeavyFirstMaxBlocks)
+    if (!no_lpt && P.ray_first == 0 && P.n_rays == job_rays && h->order_valid)
         P.block_order = P.ray_hash + job_rays + (job_rays + 255) / 256;
 }
 
@@ -836,7 +836,8 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
         // (same sensor, next step); an order is only ever a schedule, never a result
         static const bool no_lpt = getenv("DRT_NO_HEAVY_FIRST") != nullptr;
         const uint64_t n_blocks = (n_rays + 255) / 256;
-        if (!no_lpt && P.block_cost && h->order_rays == n_rays && n_blocks <= kHeavyFirstMaxBlocks && !P.mgrid &&
+        (void) n_blocks;
+        if (!no_lpt && P.block_cost && h->order_rays == n_rays && !P.mgrid &&
             !(h->debug_flags & (8u | 65536u)))
             P.block_order = P.block_cost + n_blocks;
     }
@@ -844,7 +845,7 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     h->order_valid = false;
     if (rc == DRT_OK && P.block_cost && !P.mgrid && !(h->debug_flags & (8u | 65536u))) {   // cooperative primal: it filled block_cost
         const uint32_t n_blocks = (uint32_t) ((P.n_rays + 255) / 256);
-        DRT_HIP_CHECK(h, drt::launch_block_order(P.block_cost, n_blocks, P.block_cost + n_blocks, h->stream));
+        DRT_HIP_CHECK(h, drt::launch_block_order(P.block_cost, n_blocks, P.block_cost + n_blocks, n_blocks <= kHeavyFirstMaxBlocks, h->stream));
         h->order_valid = true; h->order_rays = n_rays;
     }
     return rc;

@@ -711,12 +711,54 @@ __global__ void __launch_bounds__(1024) block_order_kernel(const uint32_t *cost,
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&cur[32 - __clz(cost[i])], 1u)] = i;
 }
+
+// large launches: keep the XCD-contiguous block map (L2 locality is worth more than the order) but move
+// the LIGHT blocks - the cheapest buckets, up to ~1/4 of the launch - to the end of the dispatch order, so
+// that the last workgroups to start are short ones.  Stable partition of the XCD-mapped sequence.
+__global__ void __launch_bounds__(1024) block_light_last_kernel(const uint32_t *cost, uint32_t n, uint32_t *order, uint32_t xcd_run)
+{
+    __shared__ uint32_t hist[33], scan[1024], thr, n_heavy;
+    if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[32 - __clz(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0, t = 0;
+        for (int k = 0; k <= 32; ++k) { if (run + hist[k] > n / 4) break; run += hist[k]; t = (uint32_t) k + 1; }
+        thr = t;                                               // buckets < thr are light
+        n_heavy = n - run;
+    }
+    __syncthreads();
+    const uint32_t T = thr, per = (n + blockDim.x - 1) / blockDim.x, j0 = threadIdx.x * per;
+    auto logical = [&](uint32_t j) {
+        const uint32_t span = 8u * xcd_run, full = xcd_run ? (n / span) * span : 0u;
+        if (j < full) { const uint32_t grp = j / span, r = j % span; return grp * span + (r % 8u) * xcd_run + r / 8u; }
+        return j;
+    };
+    uint32_t heavy = 0;
+    for (uint32_t j = j0; j < j0 + per && j < n; ++j) heavy += (32u - (uint32_t) __clz(cost[logical(j)])) >= T ? 1u : 0u;
+    scan[threadIdx.x] = heavy;
+    __syncthreads();
+    for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
+        const uint32_t v = threadIdx.x >= off ? scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t h = scan[threadIdx.x] - heavy;                      // heavy blocks before my range
+    uint32_t l = n_heavy + (j0 < n ? j0 : n) - h;                // light ones go behind all heavy ones
+    for (uint32_t j = j0; j < j0 + per && j < n; ++j) {
+        const uint32_t b = logical(j);
+        if ((32u - (uint32_t) __clz(cost[b])) >= T) order[h++] = b; else order[l++] = b;
+    }
+}
 }  // namespace
 
-hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t *order, hipStream_t stream)
+hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t *order, bool heavy_first, hipStream_t stream)
 {
     if (n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(block_order_kernel, dim3(1), dim3(1024), 0, stream, cost, n_blocks, order);
+    if (heavy_first) hipLaunchKernelGGL(block_order_kernel, dim3(1), dim3(1024), 0, stream, cost, n_blocks, order);
+    else hipLaunchKernelGGL(block_light_last_kernel, dim3(1), dim3(1024), 0, stream, cost, n_blocks, order, (uint32_t) DRT_XCD_RUN);
     return hipGetLastError();
 }
 
