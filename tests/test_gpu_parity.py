@@ -116,6 +116,49 @@ def test_heterogeneous_grid_explicit_rays(uivr, oracle, gpu):
     _assert_grads_close(grads[uivr.ALBEDO_KEY], ga, "grad albedo")
 
 
+def test_multi_tile_grid_gradients_match_oracle(uivr, oracle, gpu):
+    """A grid that spans several reduction tiles (32x16x16 cells each; 70x40x36 -> 3x3x3 tiles, none of the
+    extents a multiple of the tile): the deferred splat records cross tile borders through the apron and
+    the partition / reduction passes handle many bins.  Gradients and counters against the oracle."""
+    rng = np.random.default_rng(23)
+    rx, ry, rz = 70, 40, 36
+    sigma_t = (rng.random((rz, ry, rx, 1), dtype=np.float32) ** 4 * 8.0).astype(np.float32)
+    sigma_t[:, :, 20:30] = 0.0                                           # an empty slab (bitmask cells)
+    albedo = (rng.random((rz, ry, rx, 3), dtype=np.float32) * 0.9 + 0.05).astype(np.float32)
+    medium = uivr.GridMedium(sigma_t=sigma_t, albedo=albedo, bbox_min=(-1.0, -0.5, 0.0), bbox_max=(2.5, 1.5, 1.8), scale=0.8)
+    scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter((0.9, 1.0, 0.6)), sensors=[])
+    n, spp, seed = 8192, 4, 77
+    o = rng.normal(size=(n, 3)).astype(np.float32) * 0.3 + np.array([0.7, 0.5, -3.0], dtype=np.float32)
+    tgt = rng.random((n, 3), dtype=np.float32) * np.array([3.5, 2.0, 1.8], dtype=np.float32) + np.array([-1.0, -0.5, 0.0], dtype=np.float32)
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    props = props_for("drt")
+    osc = oracle.OracleScene(scene, sensor_index=None)
+    Lr, _ = oracle.render_primal(osc, props, spp, seed, rays_o=o, rays_d=d)
+    dL = (rng.random((n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    gs, ga, cr = oracle.render_backward(osc, props, spp, seed, dL, Lr, rays_o=o, rays_d=d)
+
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props)
+    batch = uivr.RayBatch(n_rays=n, spp=spp, o=torch.from_numpy(o).to(gpu), d=torch.from_numpy(d).to(gpu))
+    samp = uivr.IndependentSampler(seed, spp)
+    h = integ.native_handle(sg)
+    for flags in (0, 128):                                               # deferred records / atomics into the apron scratch
+        h.set_debug_flags(flags)
+        L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+        np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+        h.enable_counters(True)
+        h.reset_counters()
+        grads = uivr.alloc_grads(sg)
+        integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=st, grads=grads)
+        cnt = {k: int(v) for k, v in h.get_counters().items()}
+        h.enable_counters(False)
+        assert cnt == cr, flags
+        _assert_grads_close(grads[uivr.SIGMA_T_KEY], gs, f"flags {flags}: grad sigma_t")
+        _assert_grads_close(grads[uivr.ALBEDO_KEY], ga, f"flags {flags}: grad albedo")
+    h.set_debug_flags(0)
+
+
 def test_path_cache_is_tied_to_the_rays(uivr, oracle, gpu):
     """The adjoint pass reuses the walks its primal pass recorded (path cache, drt_coop.hip).  Refill the
     ray buffers in place between the two passes: job signature and pointers still match, the per-ray hash
