@@ -98,8 +98,12 @@ __global__ void __launch_bounds__(kPartThreads) bin_histogram_kernel(const Param
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(D.vmax + s, __float_as_uint(vmax));
+    __shared__ uint32_t wg_vmax;                                 // one global atomic per workgroup, not per wave
+    if (threadIdx.x == 0) wg_vmax = 0u;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&wg_vmax, __float_as_uint(vmax));
     lds_atomics_barrier();
+    if (threadIdx.x == 0 && wg_vmax) atomicMax(D.vmax + s, wg_vmax);
     uint32_t *dst = D.hist + ((size_t) s * gridDim.x + blockIdx.x) * D.n_bins;
     for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) dst[b] = h[b];
 }
