@@ -276,7 +276,7 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
         // beyond it the tracer falls back to direct atomics (emit_record): a performance choice only
         const uint64_t waves = (n_rays + 63) / 64;
         uint64_t chunks[4];
-        chunks[0] = tiny ? 2 : 2 * waves + (n_rays * per_ray_sigma + kRecChunk - 1) / kRecChunk;
+        chunks[0] = tiny ? 2 * kRecGroup0 : (kRecGroup0 + 1) * waves + (n_rays * per_ray_sigma + kRecChunk - 1) / kRecChunk;   // a wave may leave a group partly used
         for (int s = 1; s < 4; ++s) chunks[s] = tiny ? 1 : 2 * waves + (n_rays * per_ray_colour + kRecChunk - 1) / kRecChunk;
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };

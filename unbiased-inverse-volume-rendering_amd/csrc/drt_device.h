@@ -616,6 +616,7 @@ __device__ __forceinline__ void coop_scatter(float *dst, uint32_t chan_stride, c
 // grid with 8 atomics (slow, correct; counted in rec_cursor[4+s]).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRecChunk = 256;
+constexpr uint32_t kRecGroup0 = 4;      // sigma_t stream: chunks handed out per allocation
 
 __device__ __forceinline__ void splat_direct(const Params &P, int s, V3 p, float v)
 {
@@ -649,11 +650,17 @@ __device__ __forceinline__ void emit_record(const Params &P, int s, V3 p, float 
         if (cur + n <= end) { split = n; st[s] = cur + n; }
         else {
             split = end - cur;
-            if (end) P.rec_chunk_count[s][(end - 1u) / kRecChunk] = kRecChunk;      // the open chunk is full
-            const uint32_t c = atomicAdd(P.rec_cursor + s, 1u);
-            if (c < P.rec_cap_chunks[s]) {
+            // chunks are handed out kRecGroup0 at a time on the busy sigma_t stream (every wave fills several:
+            // fewer same-address returning atomics), one at a time on the colour streams
+            const uint32_t G = s == 0 ? kRecGroup0 : 1u;
+            if (end) {                                                              // the open chunks are full
+                const uint32_t last = (end - 1u) / kRecChunk;
+                for (uint32_t j = 0; j < G; ++j) P.rec_chunk_count[s][last - j] = kRecChunk;
+            }
+            const uint32_t c = atomicAdd(P.rec_cursor + s, G);
+            if (c + G <= P.rec_cap_chunks[s]) {
                 base1 = c * kRecChunk;
-                st[s] = base1 + (n - split); st[4 + s] = base1 + kRecChunk;
+                st[s] = base1 + (n - split); st[4 + s] = base1 + G * kRecChunk;
             } else {
                 base1 = 0xffffffffu;                                                // out of chunks
                 st[s] = end;
@@ -676,7 +683,13 @@ __device__ __forceinline__ void close_records(const Params &P, uint32_t *st_)
     if (__lane_id() < 4) {
         const int s = (int) __lane_id();
         const uint32_t cur = st[s], end = st[4 + s];
-        if (end) P.rec_chunk_count[s][(end - 1u) / kRecChunk] = cur - (end - kRecChunk);
+        if (end) {
+            const uint32_t G = s == 0 ? kRecGroup0 : 1u, first = end / kRecChunk - G;
+            for (uint32_t j = 0; j < G; ++j) {
+                const uint32_t lo = (first + j) * kRecChunk;
+                P.rec_chunk_count[s][first + j] = cur <= lo ? 0u : (cur - lo < kRecChunk ? cur - lo : kRecChunk);
+            }
+        }
     }
 }
 
