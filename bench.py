@@ -40,6 +40,105 @@ def algorithmic_bytes(cnt, n_samples, primal_io=True, adjoint_io=True):
     return b + io * n_samples
 
 
+def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=None):
+    """Msamples/s of H1 steps (primal -> film -> loss gradient -> adjoint) over the local rays of `shard`."""
+    sensor = scene.sensors[0]
+    n_pixels = sensor.width * sensor.height
+    sh = shard or u.ShardSpec()
+    n_local = sh.n_local_pixels(n_pixels)
+    off, inter = sh.ray_mapping(spp)
+    batch = u.RayBatch(n_rays=n_local * spp, spp=spp, sensor=sensor, ray_offset=off, interleave=inter)
+    grads = u.alloc_grads(scene, keys or integ.param_keys)
+    loss_scale = 2.0 / (n_pixels * 3)
+
+    def step(i):
+        sampler = u.IndependentSampler(u.sample_tea_32(2 * i + 1, 988378)[0], spp)
+        grads["_flat"].zero_()
+        L, _, state = integ.sample(u.ADMode.Primal, scene, sampler.clone(), batch)
+        img = integ.develop(scene, L, spp)
+        dL = integ.film_backward(scene, loss_scale * (img - 0.5), spp)
+        integ.sample(u.ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state, grads=grads)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    integ.native_handle(scene).release_scratch()
+    return {"value": round(n_local * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+            "n_samples_per_step": n_local * spp}
+
+
+def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
+    """BASELINE.json `configs` 2-5 and the reference's default majorant_resolution_factor on the headline scene,
+    each at its registered size, a few H1 steps each (wall clock around synchronised steps, 1 GPU)."""
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:                     # a failure here must not take the headline line with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+
+    def cfg2():
+        sc = synthetic.smoke_scene(res=128, film=512, device=dev)
+        r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 16)
+        r["workload"] = "config 2: smoke plume 128^3 (janga-smoke stand-in), 512x512x16spp, majorant_resolution_factor 0"
+        return r
+
+    def factor8():
+        sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+        sc.medium.majorant_resolution_factor = 8
+        r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 32)
+        r["workload"] = "headline scene with the reference's default majorant_resolution_factor 8 (scene_config.py:36)"
+        return r
+
+    def cfg4():
+        sc = synthetic.dust_devil_scene(res=512, film=1024, device=dev)
+        r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 64, steps=3, warmup=1,
+                    shard=u.ShardSpec(0, 8, 2048))
+        r["workload"] = ("config 4: 512^3 grid, rank 0's share (1/8, interleaved 2048-pixel chunks) of 1024x1024x64spp; "
+                         "per-GPU compute only, the 2 GiB gradient all-reduce is not included")
+        return r
+
+    def cfg5():
+        sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+        sc.medium.emission = sc.medium.albedo
+        integ = u.get_int_config("nerf").create(max_depth=64)
+        r = h1_rate(torch, u, sc, integ, 32, steps=3, warmup=1)
+        r["workload"] = "config 5 (nerf IntegratorConfig, 128 queries): 256^3 sigma_t + emission grids, 512x512x32spp"
+        return r
+
+    def cfg3():
+        sc = synthetic.dust_devil_scene(res=256, film=512, device=dev, n_sensors=63)
+        scfg = u.SceneConfig(name="dust-devil", scene=sc, param_keys=[u.SIGMA_T_KEY, u.ALBEDO_KEY], sensors=list(range(63)),
+                             start_from_value={u.SIGMA_T_KEY: 0.04, u.ALBEDO_KEY: 0.6}, majorant_resolution_factor=8)
+        ref = torch.full((63, 512, 512, 3), 0.5, device=dev)
+        res = {}
+        for n_iter in (5, 25):                     # warm-up run, then the timed one
+            oc = u.OptimizationConfig(name="b", spp=16, n_iter=n_iter, lr=5e-3, primal_spp_factor=64, batch_size=32768)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            u.run_optimization(None, oc, scfg, integ_name, ref_images=ref)
+            torch.cuda.synchronize()
+            res = {"value": round(n_iter / (time.perf_counter() - t0), 2), "unit": "iterations/s", "n_iter": n_iter}
+        res["workload"] = ("config 3: full optimisation loop, dust devil 256^3, 63 sensors 512^2, batch 32768 px, spp_grad 16, "
+                           "spp_primal 1024, Adam, l1, constant init, majorant_resolution_factor 8 (reproduce.py:45-59)")
+        res["msamples_per_s"] = round(res["value"] * 32768 * (1024 + 2 * 16) / 1e6, 1)
+        return res
+
+    guarded("config2_smoke128_512x16", cfg2)
+    guarded("headline_majorant_factor8", factor8)
+    guarded("config3_optimize_loop", cfg3)
+    guarded("config4_512_rank_share_1024x64", cfg4)
+    guarded("config5_nerf_256_512x32", cfg5)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +152,8 @@ def main():
     ap.add_argument("--majorant-factor", type=int, default=0,
                     help="majorant_resolution_factor of the medium (reference scenes: 8, scene_config.py:36; 0 = global majorant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the other BASELINE configurations (reported under `other_configs`, outside the timed loop)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU sample (0 = auto)")
     ap.add_argument("--debug-flags", type=int, default=0, help="profiling ablations (drt_set_debug_flags); invalidates the result")
     args = ap.parse_args()
@@ -216,14 +317,32 @@ def main():
             cpu_spp = int(max(1, min(spp, round(15.0 / t1))))
         tc = time.perf_counter()
         ob.h1_step(osc, integ.props(), cpu_spp, seed_c)
-        dt = time.perf_counter() - tc
+        dt_atomic = time.perf_counter() - tc
+        # the same sample with a per-thread write-combining cache (2^16 voxels) in front of the shared gradient
+        # grids: the plain port spends most of its time in contended `omp atomic` adds, which says more about
+        # atomics than about the algorithm.  The better of the two is the stated baseline; both are reported.
+        tc = time.perf_counter()
+        ob.h1_step(osc, integ.props(), cpu_spp, seed_c, grad_cache_log2=16)
+        dt_cached = time.perf_counter() - tc
+        dt = min(dt_atomic, dt_cached)
         cpu_baseline = {
             "value": round(n_pixels * cpu_spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores,
             "kind": "port",
             "sample": f"same workload, full {sensor.width}x{sensor.height} image at {cpu_spp} spp "
-                      f"({n_pixels * cpu_spp} samples, {dt:.1f} s); oracle/drt_oracle.c with OpenMP over rays "
+                      f"({n_pixels * cpu_spp} samples, {dt:.1f} s); oracle/drt_oracle.c with OpenMP over rays, "
+                      f"gradients through a per-thread write-combining cache "
                       f"(the reference's llvm_ad_rgb needs Mitsuba 3 / Dr.Jit, absent here)",
+            "value_shared_atomics": round(n_pixels * cpu_spp / dt_atomic / 1e6, 4),
+            "value_thread_local_cache": round(n_pixels * cpu_spp / dt_cached / 1e6, 4),
         }
+
+    # ---- the other BASELINE configurations (outside the timed loop; N = 1 only) ---------
+    other = None
+    if rank == 0 and world == 1 and not args.no_extra_configs and args.workload == "dust-devil" and args.res == 256:
+        grads = L = state = img = dL = None          # free the headline buffers first
+        torch.cuda.empty_cache()
+        h.release_scratch()
+        other = other_configs(torch, u, synthetic, dev, integ_name=args.integrator)
 
     if rank == 0:
         out = {
@@ -242,6 +361,7 @@ def main():
             "t_primal_ms": round(avg_p, 3), "t_adjoint_ms": round(avg_a, 3),
             "t_grad_reduce_ms": round(avg_r, 3),
             "counters_primal": cnt_p, "counters_adjoint": cnt_a,
+            "other_configs": other,
         }
         if args.debug_flags:
             out["INVALID_ablation_debug_flags"] = args.debug_flags

@@ -71,6 +71,12 @@ int drt_destroy(drt_handle h);
 /* Python exceptions / asserts of the reference (opt_config.py:98-104, util.py:83-85). */
 const char *drt_last_error(drt_handle h);
 
+/* Library-owned scratch grows with the largest job seen (splat record streams: ~2 KB per ray of a backward
+ * sub-batch, capped by what the device has free; path cache: 0.5 KB per ray) and is kept for reuse.  This call
+ * synchronises the stream and returns it to the device (it is re-allocated on demand); results never depend
+ * on it.  drt_destroy frees it too. */
+int drt_release_scratch(drt_handle h);
+
 /* Stream on which all later calls enqueue work (hipStream_t, NULL = default). */
 int drt_set_stream(drt_handle h, void *hip_stream);
 int drt_synchronize(drt_handle h);
@@ -172,6 +178,15 @@ int drt_batch_sample_rays(drt_handle h, const float *sensors, int32_t n_sensors,
                           uint32_t sub_seed_pixels, uint32_t sub_seed_rays, float *rays_o, float *rays_d,
                           uint32_t *sensor_idx, uint32_t *pixels);
 
+/* The same for the batch entries [batch_first, batch_first + batch_count) only: the share of one rank when the
+ * `batch_size` pixel list is dealt across GPUs (no counterpart in the single-GPU reference).
+ * The samplers' lanes stay the GLOBAL entry / ray indices, so the union over ranks equals the unsharded
+ * batch bit for bit; outputs are local: rays_o / rays_d [batch_count*spp][3], sensor_idx [batch_count],
+ * pixels [batch_count][2].  Trace the rays with ray_offset = batch_first * spp. */
+int drt_batch_sample_rays_range(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_first,
+                                uint32_t batch_count, uint32_t spp, uint32_t sub_seed_pixels, uint32_t sub_seed_rays,
+                                float *rays_o, float *rays_d, uint32_t *sensor_idx, uint32_t *pixels);
+
 /* Box-filter film: image[p] = mean over the pixel's spp samples
  * (block.put + film.develop, batched.py:176-197).  L: [n_pixels*spp][3]. */
 int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t spp, float *image);
@@ -202,7 +217,8 @@ int drt_read_timings(drt_handle h, int backward, float *out_ms, int capacity);
  * 4 albedo(p), 5 box hit (o,d) -> valid,t,n, 6 PCG32 floats of (seed,index) bit
  * patterns, 7 sensor ray (pixel bits, ux, uy), 8 mis_weight / div / sqrt / fma,
  * 9 majorant supergrid cell (index bits), 10 exp, 11 atan2(y, x), 12 envmap eval(d)
- * rgb + pdf_direction(d), 13 envmap sample_direction(u1, u2) -> d, pdf. */
+ * rgb + pdf_direction(d), 13 envmap sample_direction(u1, u2) -> d, pdf, 14 Medium::sample_interaction_drt
+ * (E2) from o along d to the box exit with the stream PCG32(tea32(0x5eed, item)) -> valid, t', W, maxt. */
 int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out);
 
 /* Profiling ablations / kernel selection for experiments; 0 in production.

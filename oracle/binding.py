@@ -70,7 +70,7 @@ class Job(C.Structure):
                 ("emitter", C.POINTER(Emitter)), ("sensor", C.POINTER(Sensor)),
                 ("rays_o", C.POINTER(C.c_float)), ("rays_d", C.POINTER(C.c_float)),
                 ("n_rays", C.c_uint64), ("ray_offset", C.c_uint64),
-                ("spp", C.c_uint32), ("seed", C.c_uint32), ("n_threads", C.c_int32)]
+                ("spp", C.c_uint32), ("seed", C.c_uint32), ("n_threads", C.c_int32), ("grad_cache_log2", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -123,6 +123,9 @@ def lib():
         L.drto_majorant_grid.restype = C.c_int
         L.drto_ratio_tracking_mean.argtypes = [C.POINTER(Medium), fp, fp, C.c_float, C.c_uint32, C.c_int]
         L.drto_ratio_tracking_mean.restype = C.c_double
+        L.drto_sample_interaction_drt.argtypes = [C.POINTER(Medium), fp, fp, C.c_uint32, C.c_uint32, C.c_int,
+                                                  C.POINTER(C.c_int32), fp, fp]
+        L.drto_sample_interaction_drt.restype = C.c_float
         L.drto_box_hit.argtypes = [C.POINTER(Medium), fp, fp, fp, fp]
         L.drto_box_hit.restype = C.c_int
         L.drto_sensor_ray.argtypes = [C.POINTER(Sensor), C.c_uint32, C.c_float, C.c_float, fp, fp]
@@ -194,7 +197,7 @@ class OracleScene:
         return self.sigma_t.shape[:3]
 
     def job(self, cfg: Config, spp: int, seed: int, n_rays=None, ray_offset=0,
-            rays_o=None, rays_d=None, n_threads=0) -> Job:
+            rays_o=None, rays_d=None, n_threads=0, grad_cache_log2=0) -> Job:
         self._cfg = cfg
         j = Job()
         j.cfg = C.pointer(cfg)
@@ -213,6 +216,7 @@ class OracleScene:
         j.spp = spp
         j.seed = seed
         j.n_threads = n_threads
+        j.grad_cache_log2 = grad_cache_log2
         return j
 
 
@@ -372,3 +376,13 @@ def envmap_tables(emitter):
     rc = lib().drto_envmap_tables(C.byref(e), _fp(marg), _fp(cond))
     assert rc == 0
     return marg, cond
+
+
+def sample_interaction_drt(oscene: OracleScene, o, d, seed: int, n: int, first: int = 0):
+    """E2 test hook: n independent walks of Medium::sample_interaction_drt from `o` along `d` to the box
+    exit -> (valid [n] bool, t' [n], W [n], maxt)."""
+    o = _f32(np.asarray(o, dtype=np.float32)); d = _f32(np.asarray(d, dtype=np.float32))
+    valid = np.zeros(n, dtype=np.int32); t = np.zeros(n, dtype=np.float32); W = np.zeros(n, dtype=np.float32)
+    maxt = lib().drto_sample_interaction_drt(C.byref(oscene.medium), _fp(o), _fp(d), seed & 0xffffffff, first, n,
+                                             valid.ctypes.data_as(C.POINTER(C.c_int32)), _fp(t), _fp(W))
+    return valid.astype(bool), t, W, float(maxt)

@@ -403,12 +403,20 @@ typedef struct {
     envmap_t env;                /* env.pix != NULL: envmap emitter instead of the constant Le */
 } scene_t;
 
+/* Thread-local write-combining cache in front of the shared gradient grids (job->grad_cache_log2 > 0; used by
+ * the timed CPU-baseline leg only): direct-mapped on the voxel index, a hit accumulates privately, an eviction
+ * costs ONE atomic add.  Rays of neighbouring pixels splat into the same voxels, so most adds never reach the
+ * shared grid - without it 256 threads mostly wait for each other's cache lines (`omp atomic` on doubles). */
+typedef struct { uint32_t tag; double v[4]; } gcache_line;   /* [0] sigma_t, [1..3] albedo rgb of voxel `tag` */
+
 typedef struct {
     const scene_t *sc;
     double *g_sigma, *g_albedo;   /* NULL in primal */
     drto_counters cnt;
     uint32_t alt_seed;
     uint32_t ray_index;
+    gcache_line *gcache;          /* NULL: every splat goes to the shared grids with atomics */
+    uint32_t gcache_mask;
 } ctx_t;
 
 /* E3: GridVolume::eval, trilinear, clamp, cell-centred (q = p*res - 0.5) */
@@ -477,6 +485,33 @@ static inline void stencil_weights(const stencil_t *s, float w[8])
     w[4] = zy10 * s->wx0; w[5] = zy10 * s->wx1; w[6] = zy11 * s->wx0; w[7] = zy11 * s->wx1;
 }
 
+static inline void shared_add(double *dst, double v)
+{
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+    *dst += v;
+}
+static inline void gcache_evict(ctx_t *c, gcache_line *l)
+{
+    if (l->tag == 0xffffffffu) return;
+    if (l->v[0] != 0.0) shared_add(&c->g_sigma[l->tag], l->v[0]);
+    for (int ch = 0; ch < 3; ++ch)
+        if (l->v[1 + ch] != 0.0) shared_add(&c->g_albedo[(size_t) l->tag * 3 + ch], l->v[1 + ch]);
+    l->v[0] = l->v[1] = l->v[2] = l->v[3] = 0.0;
+}
+static inline double *gcache_slot(ctx_t *c, uint32_t voxel)
+{
+    gcache_line *l = &c->gcache[(voxel * 2654435761u >> 7) & c->gcache_mask];
+    if (l->tag != voxel) { gcache_evict(c, l); l->tag = voxel; }
+    return l->v;
+}
+static void gcache_flush(ctx_t *c)
+{
+    if (!c->gcache) return;
+    for (uint32_t i = 0; i <= c->gcache_mask; ++i) { gcache_evict(c, &c->gcache[i]); c->gcache[i].tag = 0xffffffffu; }
+}
+
 /* reverse-mode of the trilinear gather = 8-corner scatter_reduce(Add) (E3/E9) */
 static inline void splat_sigma_t(ctx_t *c, v3 p, float g)
 {
@@ -486,10 +521,8 @@ static inline void splat_sigma_t(ctx_t *c, v3 p, float g)
     float gs = g * c->sc->scale;
     for (int k = 0; k < 8; ++k) {
         double v = (double)(w[k] * gs);
-#ifdef _OPENMP
-#pragma omp atomic
-#endif
-        c->g_sigma[s.idx[k]] += v;
+        if (c->gcache) gcache_slot(c, (uint32_t) s.idx[k])[0] += v;
+        else shared_add(&c->g_sigma[s.idx[k]], v);
     }
 }
 static inline void splat_albedo(ctx_t *c, v3 p, const float g[3])
@@ -497,14 +530,14 @@ static inline void splat_albedo(ctx_t *c, v3 p, const float g[3])
     stencil_t s; float w[8];
     make_stencil(c->sc, p, &s);
     stencil_weights(&s, w);
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < 8; ++k) {
+        double *slot = c->gcache ? gcache_slot(c, (uint32_t) s.idx[k]) : NULL;
         for (int ch = 0; ch < 3; ++ch) {
             double v = (double)(w[k] * g[ch]);
-#ifdef _OPENMP
-#pragma omp atomic
-#endif
-            c->g_albedo[(size_t) s.idx[k] * 3 + ch] += v;
+            if (slot) slot[1 + ch] += v;
+            else shared_add(&c->g_albedo[(size_t) s.idx[k] * 3 + ch], v);
         }
+    }
 }
 
 /* E4: scene.ray_intersect with use_bbox_fast_path: nearest hit with the box
@@ -1228,6 +1261,14 @@ static int run_job(const drto_job *job, int adjoint, const float *dL, const floa
     {
         ctx_t c; memset(&c, 0, sizeof c);
         c.sc = &sc; c.g_sigma = g_sigma; c.g_albedo = g_albedo; c.alt_seed = alt_seed;
+        if (adjoint && job->grad_cache_log2 > 0 && job->grad_cache_log2 <= 24) {
+            const uint32_t lines = 1u << job->grad_cache_log2;
+            c.gcache = (gcache_line *) malloc((size_t) lines * sizeof(gcache_line));
+            if (c.gcache) {
+                c.gcache_mask = lines - 1u;
+                for (uint32_t k = 0; k < lines; ++k) { c.gcache[k].tag = 0xffffffffu; c.gcache[k].v[0] = c.gcache[k].v[1] = c.gcache[k].v[2] = c.gcache[k].v[3] = 0.0; }
+            }
+        }
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 256)
 #endif
@@ -1243,6 +1284,8 @@ static int run_job(const drto_job *job, int adjoint, const float *dL, const floa
                 L_out[3 * i] = L[0]; L_out[3 * i + 1] = L[1]; L_out[3 * i + 2] = L[2];
             }
         }
+        gcache_flush(&c);
+        free(c.gcache);
 #ifdef _OPENMP
 #pragma omp critical
 #endif
@@ -1488,6 +1531,23 @@ double drto_ratio_tracking_mean(const drto_medium *m, const float o[3], const fl
     }
     scene_free(&sc);
     return acc / (double) n;
+}
+/* E2 test hook: n independent walks from o along d to the box exit; walk i draws from the stream
+ * PCG32(tea32(seed, first + i)).  Outputs per walk: valid, t', W.  Returns maxt. */
+float drto_sample_interaction_drt(const drto_medium *m, const float o[3], const float d[3], uint32_t seed,
+                                  uint32_t first, int n, int32_t *valid, float *t_out, float *W_out)
+{
+    scene_t sc; scene_from_medium(&sc, m);
+    ctx_t c; memset(&c, 0, sizeof c); c.sc = &sc;
+    ray_t r; r.o = v3_make(o[0], o[1], o[2]); r.d = v3_make(d[0], d[1], d[2]);
+    si_t si = box_hit(&sc, r.o, r.d);
+    r.maxt = si.valid ? si.t : 0.0f;
+    for (int i = 0; i < n; ++i) {
+        pcg32 A; sampler_seed(&A, seed, first + (uint32_t) i);
+        valid[i] = sample_interaction_drt(&c, &r, &A, &t_out[i], &W_out[i]);
+    }
+    scene_free(&sc);
+    return r.maxt;
 }
 int drto_box_hit(const drto_medium *m, const float o[3], const float d[3], float *t, float n[3])
 {

@@ -117,6 +117,8 @@ typedef struct drto_job {
     uint32_t spp;
     uint32_t seed;
     int32_t  n_threads;     /* OpenMP threads (0 = default) */
+    int32_t  grad_cache_log2; /* > 0: per-thread write-combining cache of 2^n voxels in front of the shared gradient
+                               * grids (timed CPU-baseline leg; changes the fp64 summation order only); 0: atomics */
 } drto_job;
 
 /* sample(Primal): L_out[n][3].  volpathsimple.py:38-290 */
@@ -182,6 +184,10 @@ int      drto_majorant_grid(const drto_medium *m, int32_t dims[3], float *out);
 /* mean ratio-tracking transmittance estimate over n independent walks (A8). */
 double   drto_ratio_tracking_mean(const drto_medium *m, const float o[3], const float d[3],
                                   float tmax, uint32_t seed, int n);
+/* E2 (Medium::sample_interaction_drt, call site volpathsimple.py:549-551): n independent walks from o along
+ * d to the box exit, walk i on the stream PCG32(tea32(seed, first + i)); per walk valid / t' / W; returns maxt. */
+float    drto_sample_interaction_drt(const drto_medium *m, const float o[3], const float d[3], uint32_t seed,
+                                     uint32_t first, int n, int32_t *valid, float *t_out, float *W_out);
 /* returns 1 and fills t / normal if the ray hits the medium box surface (E4). */
 int      drto_box_hit(const drto_medium *m, const float o[3], const float d[3],
                       float *t, float n[3]);

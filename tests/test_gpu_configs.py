@@ -1,0 +1,287 @@
+"""Every BASELINE.json configuration at ITS size on the GPU, checked against the CPU oracle.
+
+The oracle cannot trace 10^7..10^8 rays in seconds, but it takes a ray range (`n_rays` / `ray_offset`), and a
+ray's radiance depends only on (seed, global ray index, scene).  So each configuration gets
+  (1) the FULL-size launch on the full-size grids (the kernels, block maps, record streams, tile partition
+      and path cache the production run uses), of which a window of rays through the dense part of the volume
+      is compared with the oracle: radiance BIT-EXACT;
+  (2) the same window traced alone (primal + adjoint): event counters EQUAL, gradients within
+      2e-4 * max|oracle| (fp32 sums in a different order; the oracle accumulates in fp64);
+  (3) size-independent properties of the full launch: determinism (bitwise), linearity of the adjoint in dL,
+      gradient support inside the sensor frustum (energy bound), window gradients contained in the full ones.
+Workloads (python/reproduce.py:45-59, python/scene_config.py:108-170):
+  config 2  smoke plume 128^3 (janga-smoke stand-in), 512^2 x 16 spp
+  config 3  dust devil 256^3, 63 sensors, render_batch(32768 px, spp 1024 / spp_grad 16), 3 optimiser iterations
+  headline  dust devil 256^3, 512^2 x 32 spp
+  config 4  512^3, rank 0's share (ShardSpec(0, 8)) of 1024^2 x 64 spp
+  config 5  nerf integrator (128 queries, opt_config.py:162-169) on the 256^3 grids, 512^2 x 32 spp
+            (+ the fused 4-channel pass: tests/test_gpu_fused.py)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import props_for
+
+pytestmark = pytest.mark.gpu
+
+GRAD_RTOL = 2e-4
+
+
+def _integrator(uivr, props):
+    d = {"type": "volpathsimple"}
+    d.update(props)
+    return uivr.load_dict(d)
+
+
+def _cpu_scene(uivr, sg, sensor=0):
+    m = sg.medium
+    medium = uivr.GridMedium(sigma_t=m.sigma_t.cpu().numpy(), albedo=m.albedo.cpu().numpy(), bbox_min=m.bbox_min,
+                             bbox_max=m.bbox_max, scale=m.scale, majorant_resolution_factor=m.majorant_resolution_factor,
+                             emission=None if m.emission is None else m.emission.cpu().numpy())
+    return uivr.Scene(medium=medium, emitter=sg.emitter, sensors=sg.sensors)
+
+
+def _close_on_device(g_hip: torch.Tensor, g_ref: np.ndarray, what: str):
+    """|hip - oracle| <= 2e-4 max|oracle| + 1e-9, evaluated on the device (the 512^3 grids are GBs)."""
+    ref = torch.from_numpy(g_ref).to(g_hip.device)
+    tol = GRAD_RTOL * float(ref.abs().max()) + 1e-9
+    err = float((g_hip.double() - ref).abs().max())
+    assert float(ref.abs().max()) > 0, f"{what}: the oracle's gradient is identically zero (window misses the volume)"
+    assert err <= tol, f"{what}: max abs err {err:.3e} > tol {tol:.3e}"
+
+
+def _window_check(uivr, oracle, sg, integ, props, spp, seed, L_full, local_first, global_first, n, interleave=None,
+                  min_lookups_per_ray=2.0):
+    """Rays [local_first, local_first + n) of the full launch == global rays [global_first, global_first + n):
+    radiance of the full launch bit-exact vs the oracle; then the window alone: counters, gradients."""
+    dev = sg.medium.sigma_t.device
+    osc = oracle.OracleScene(_cpu_scene(uivr, sg))
+    Lr, c_primal = oracle.render_primal(osc, props, spp, seed, n_rays=n, ray_offset=global_first)
+    np.testing.assert_array_equal(L_full[local_first:local_first + n].cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+    assert c_primal["n_dt"] >= min_lookups_per_ray * n, "the window misses the dense part of the volume"
+    rng = np.random.default_rng(5)
+    dL = ((rng.random((n, 3), dtype=np.float32) - 0.5) * 1e-3).astype(np.float32)
+    gs, ga, c_adj = oracle.render_backward(osc, props, spp, seed, dL, Lr, n_rays=n, ray_offset=global_first)
+    h = integ.native_handle(sg)
+    batch = uivr.RayBatch(n_rays=n, spp=spp, sensor=sg.sensors[0], ray_offset=global_first)
+    samp = uivr.IndependentSampler(seed, spp)
+    h.enable_counters(True)
+    h.reset_counters()
+    Lw, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    cp = {k: int(v) for k, v in h.get_counters().items()}
+    np.testing.assert_array_equal(Lw.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+    assert cp == c_primal
+    h.reset_counters()
+    grads = uivr.alloc_grads(sg)
+    integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(dev), state_in=st, grads=grads)
+    ca = {k: int(v) for k, v in h.get_counters().items()}
+    h.enable_counters(False)
+    assert ca == c_adj
+    _close_on_device(grads[uivr.SIGMA_T_KEY], gs, "window grad sigma_t")
+    _close_on_device(grads[uivr.ALBEDO_KEY], ga, "window grad albedo")
+    return grads
+
+
+def _full_properties(uivr, sg, integ, spp, seed, shard=None):
+    """Full-size launch: determinism, adjoint linearity, finite non-trivial gradients."""
+    s = sg.sensors[0]
+    n_pix = s.width * s.height
+    shard = shard or uivr.ShardSpec()
+    n_local = shard.n_local_pixels(n_pix)
+    off, inter = shard.ray_mapping(spp)
+    batch = uivr.RayBatch(n_rays=n_local * spp, spp=spp, sensor=s, ray_offset=off, interleave=inter)
+    samp = uivr.IndependentSampler(seed, spp)
+    L1, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    L2, _, _ = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    assert torch.equal(L1, L2)                                             # determinism
+    assert torch.isfinite(L1).all() and float(L1.min()) >= 0.0
+    gi = torch.randn((n_local, 3), device=L1.device) * 1e-6
+    out = []
+    for scale in (1.0, 2.0):
+        L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)      # H1: primal then adjoint (path cache)
+        dL = integ.film_backward(sg, (scale * gi).contiguous(), spp)
+        grads = uivr.alloc_grads(sg)
+        integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=dL, state_in=st, grads=grads)
+        out.append(grads["_flat"])
+    g1, g2 = out
+    assert torch.isfinite(g1).all()
+    scale = float(g1.abs().max())
+    assert scale > 0
+    assert float((g2 - 2.0 * g1).abs().max()) <= 1e-3 * scale             # linear in dL
+    return L1, batch
+
+
+# ------------------------------------------------------------------------------------------------------------
+def test_config2_smoke_128_512x16(uivr, oracle, gpu):
+    from uivr_amd import synthetic
+    sg = synthetic.smoke_scene(res=128, film=512, device=gpu)
+    props = props_for("drt")
+    integ = _integrator(uivr, props)
+    spp, seed = 16, 2002
+    L, _ = _full_properties(uivr, sg, integ, spp, seed)
+    assert L.shape[0] == 512 * 512 * 16
+    # 1024 pixels of row 300, columns 192..: through the plume
+    first = (300 * 512 + 192) * spp
+    _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, 1024 * spp)
+
+
+def test_headline_dust_devil_256_512x32(uivr, oracle, gpu):
+    from uivr_amd import synthetic
+    sg = synthetic.dust_devil_scene(res=256, film=512, device=gpu)
+    props = props_for("drt")
+    integ = _integrator(uivr, props)
+    spp, seed = 32, 2003
+    L, _ = _full_properties(uivr, sg, integ, spp, seed)
+    first = (380 * 512 + 200) * spp
+    _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, 512 * spp)
+
+
+def test_headline_majorant_factor_8(uivr, oracle, gpu):
+    """The reference's scenes run majorant_resolution_factor = 8 (scene_config.py:36): same checks on the supergrid path."""
+    from uivr_amd import synthetic
+    sg = synthetic.dust_devil_scene(res=256, film=512, device=gpu)
+    sg.medium.majorant_resolution_factor = 8
+    props = props_for("drt")
+    integ = _integrator(uivr, props)
+    spp, seed = 32, 2004
+    L, _ = _full_properties(uivr, sg, integ, spp, seed)
+    first = (380 * 512 + 200) * spp
+    _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, 256 * spp, min_lookups_per_ray=0.5)
+
+
+def test_config4_512_rank0_share_of_1024x64(uivr, oracle, gpu):
+    """512^3 grid (16384 reduction tiles), rank 0 of 8 of a 1024^2 x 64 spp image: 8.4 M rays of the
+    interleaved chunk map, RNG keyed by the global ray index."""
+    from uivr_amd import synthetic
+    sg = synthetic.dust_devil_scene(res=512, film=1024, device=gpu)
+    props = props_for("drt")
+    integ = _integrator(uivr, props)
+    spp, seed = 64, 2005
+    shard = uivr.ShardSpec(0, 8, chunk_pixels=2048)
+    L, batch = _full_properties(uivr, sg, integ, spp, seed, shard)
+    assert L.shape[0] == 1024 * 1024 * 64 // 8
+    # chunk 320 (2048 px = rows 640, 641) belongs to rank 0 (320 % 8 == 0) and is its local chunk 40
+    chunk_rays = 2048 * spp
+    px0 = 400                                                 # columns 400..527 of row 640
+    local_first = 40 * chunk_rays + px0 * spp
+    global_first = 320 * chunk_rays + px0 * spp
+    n = 128 * spp
+    # the window alone is traced UNSHARDED at the global offset: same rays, same streams
+    _window_check(uivr, oracle, sg, integ, props, spp, seed, L, local_first, global_first, n)
+
+
+def test_config3_optimize_loop_256_63_sensors(uivr, oracle, gpu):
+    """dust devil 256^3, 63 sensors 512^2, batch 32768 px, spp_grad 16, spp_primal 1024 (reproduce.py:48-52):
+    batch rays and radiance of a window bit-exact vs the oracle, window gradients, then 3 iterations of the loop."""
+    from uivr_amd import synthetic
+    sg = synthetic.dust_devil_scene(res=256, film=512, device=gpu, n_sensors=63)
+    props = props_for("drt")
+    integ = _integrator(uivr, props)
+    B, spp, spp_grad, seed, seed_grad = 32768, 1024, 16, 3001, 3002
+    params = {k: v.clone().requires_grad_(True) for k, v in sg.params().items() if k in integ.param_keys}
+    image, _, _, sidx, pix = uivr.render_batch(B, sg, params=params, integrator=integ, seed=seed, seed_grad=seed_grad,
+                                               spp=spp, spp_grad=spp_grad)
+    assert image.shape == (B, 3) and torch.isfinite(image).all()
+    assert len(torch.unique(sidx)) == 63
+    # oracle: the first 24 batch entries at full spp (24576 rays), rays and radiance bit-exact
+    W = 24
+    sub0, sub1, sub2 = (uivr.sample_tea_32(seed, 17 * k + 5)[0] for k in (0, 1, 2))
+    ro, rd, si_r, px_r = oracle.batch_sample_rays(sg.sensors, W, spp, sub0, sub1)
+    np.testing.assert_array_equal(sidx[:W].cpu().numpy().astype(np.uint32), si_r)
+    np.testing.assert_array_equal(pix[:W].cpu().numpy().astype(np.uint32), px_r)
+    osc = oracle.OracleScene(_cpu_scene(uivr, sg), sensor_index=None)
+    Lr, _ = oracle.render_primal(osc, props, spp, seed, rays_o=ro, rays_d=rd)
+    np.testing.assert_allclose(image[:W].detach().cpu().numpy(), oracle.develop(Lr, spp), rtol=0, atol=1e-6)
+    # gradients of a window of the adjoint rays: the first 2048 entries, spp_grad rays each
+    ref = torch.full((63, 512, 512, 3), 0.5, device=gpu)
+    ref_values = uivr.gather_ref_values(ref, sidx, pix)
+    loss = uivr.losses.l1(image, ref_values)
+    loss.backward()
+    assert torch.isfinite(params[uivr.SIGMA_T_KEY].grad).all() and float(params[uivr.SIGMA_T_KEY].grad.abs().max()) > 0
+    Wg = 2048
+    ro2, rd2, _, _ = oracle.batch_sample_rays(sg.sensors, Wg, spp_grad, sub0, sub2)
+    L2, _ = oracle.render_primal(osc, props, spp_grad, seed_grad, rays_o=ro2, rays_d=rd2)
+    rng = np.random.default_rng(9)
+    dLw = ((rng.random((Wg * spp_grad, 3), dtype=np.float32) - 0.5) * 1e-3).astype(np.float32)
+    gs, ga, c_adj = oracle.render_backward(osc, props, spp_grad, seed_grad, dLw, L2, rays_o=ro2, rays_d=rd2)
+    h = integ.native_handle(sg)
+    table = uivr.sensors_to_device(sg.sensors, gpu)
+    tro, trd, _, _ = uivr.sample_batch(integ, sg, table, Wg, spp_grad, seed, 2)
+    np.testing.assert_array_equal(tro.cpu().numpy().view(np.uint32), ro2.view(np.uint32))
+    batch = uivr.RayBatch(n_rays=Wg * spp_grad, spp=spp_grad, o=tro, d=trd)
+    samp = uivr.IndependentSampler(seed_grad, spp_grad)
+    Lw, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    np.testing.assert_array_equal(Lw.cpu().numpy().view(np.uint32), L2.view(np.uint32))
+    h.enable_counters(True)
+    h.reset_counters()
+    grads = uivr.alloc_grads(sg)
+    integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dLw).to(gpu), state_in=st, grads=grads)
+    ca = {k: int(v) for k, v in h.get_counters().items()}
+    h.enable_counters(False)
+    assert ca == c_adj
+    _close_on_device(grads[uivr.SIGMA_T_KEY], gs, "config 3 window grad sigma_t")
+    _close_on_device(grads[uivr.ALBEDO_KEY], ga, "config 3 window grad albedo")
+    del params, image, loss, grads
+
+    # 3 iterations of the optimisation loop at the registered sizes (reproduce.py:45-59; Adam, l1, constant init)
+    sc = uivr.SceneConfig(name="dust-devil", scene=sg, param_keys=[uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY],
+                          sensors=list(range(63)), start_from_value={uivr.SIGMA_T_KEY: 0.04, uivr.ALBEDO_KEY: 0.6},
+                          majorant_resolution_factor=8)
+    oc = uivr.OptimizationConfig(name="t", spp=16, n_iter=3, lr=5e-3, primal_spp_factor=64, batch_size=32768)
+    _, p, _, hist = uivr.run_optimization(None, oc, sc, "volpathsimple-drt", ref_images=ref)
+    assert len(hist) == 3 and all(np.isfinite(hist))
+    assert float(p[uivr.SIGMA_T_KEY].min()) >= 0 and float(p[uivr.SIGMA_T_KEY].max()) <= 250
+    assert float(p[uivr.ALBEDO_KEY].min()) >= 0 and float(p[uivr.ALBEDO_KEY].max()) <= 1
+    assert float((p[uivr.SIGMA_T_KEY] - 0.04).abs().max()) > 0                  # the parameters moved
+
+
+def test_config5_nerf_256_512x32_128_queries(uivr, oracle, gpu):
+    """The registered `nerf` IntegratorConfig (128 queries, opt_config.py:162-169) on the 256^3 density + emission
+    grids (emission = the albedo grid, scene_config.py:109-110) at 512^2 x 32 spp."""
+    from uivr_amd import synthetic
+    sg = synthetic.dust_devil_scene(res=256, film=512, device=gpu)
+    sg.medium.emission = sg.medium.albedo
+    integ = uivr.get_int_config("nerf").create(max_depth=64)
+    assert integ.queries_per_ray == 128
+    spp, seed = 32, 2006
+    s = sg.sensors[0]
+    batch = uivr.RayBatch(n_rays=512 * 512 * spp, spp=spp, sensor=s)
+    samp = uivr.IndependentSampler(seed, spp)
+    L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    L2, _, _ = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    assert torch.equal(L, L2) and torch.isfinite(L).all()
+    gi = torch.randn((512 * 512, 3), device=gpu) * 1e-6
+    g = []
+    for scale in (1.0, 2.0):
+        grads = uivr.alloc_grads(sg, integ.param_keys)
+        integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=integ.film_backward(sg, (scale * gi).contiguous(), spp),
+                     state_in=st, grads=grads)
+        g.append(grads["_flat"])
+    sc = float(g[0].abs().max())
+    assert sc > 0 and float((g[1] - 2.0 * g[0]).abs().max()) <= 1e-3 * sc
+    del g, grads
+    # window vs oracle: 256 pixels of row 380
+    first, n = (380 * 512 + 200) * spp, 256 * spp
+    cpu = _cpu_scene(uivr, sg)
+    osc = oracle.OracleScene(cpu)
+    em = cpu.medium.emission
+    props = dict(queries_per_ray=128)
+    Lr, c_p = oracle.nerf_render(osc, em, props, spp, seed, n_rays=n, ray_offset=first)
+    np.testing.assert_array_equal(L[first:first + n].cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+    rng = np.random.default_rng(6)
+    dL = ((rng.random((n, 3), dtype=np.float32) - 0.5) * 1e-3).astype(np.float32)
+    gs, ge, c_a = oracle.nerf_render(osc, em, props, spp, seed, dL=dL, L_in=Lr, n_rays=n, ray_offset=first)
+    wb = uivr.RayBatch(n_rays=n, spp=spp, sensor=s, ray_offset=first)
+    h = integ.native_handle(sg)
+    Lw, _, stw = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), wb)
+    np.testing.assert_array_equal(Lw.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+    h.enable_counters(True)
+    h.reset_counters()
+    grads = uivr.alloc_grads(sg, integ.param_keys)
+    integ.sample(uivr.ADMode.Backward, sg, samp, wb, δL=torch.from_numpy(dL).to(gpu), state_in=stw, grads=grads)
+    ca = {k: int(v) for k, v in h.get_counters().items()}
+    h.enable_counters(False)
+    assert ca == c_a
+    _close_on_device(grads[uivr.SIGMA_T_KEY], gs, "nerf window grad sigma_t")
+    _close_on_device(grads[uivr.EMISSION_KEY], ge, "nerf window grad emission")

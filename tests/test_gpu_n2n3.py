@@ -1,0 +1,150 @@
+"""GPU-side parity of the rows either side of the hot path and of the host logic that
+decides WHICH grid the kernels see:
+  * device `upsample_grid` vs `scipy.ndimage.zoom(order=1, mode='nearest', grid_mode=True)` (optimize.py:217-223)
+  * device Adam / projection vs the numpy formula (opt_config.py:46-48, optimize.py:169-179, 352-353)
+  * `write_vol` bytes of a device grid vs a header assembled independently here (util.py:55-71)
+  * the medium binding follows the tensor that is passed, never a recycled address
+  * `run_optimization` with parameter-key subsets / supersets (the reference lists sigma_t, albedo, emission)
+"""
+import struct
+
+import numpy as np
+import pytest
+import torch
+from scipy.ndimage import zoom
+
+from conftest import props_for
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_upsample_equals_scipy_zoom(uivr, gpu):
+    rng = np.random.default_rng(10)
+    for shape in [(4, 6, 5, 1), (3, 3, 3, 3), (16, 8, 12, 3), (32, 32, 32, 1)]:
+        a = rng.random(shape, dtype=np.float32)
+        new = tuple(2 * s for s in shape[:3]) + (shape[3],)
+        ref = zoom(a, [2, 2, 2, 1], order=1, mode='nearest', prefilter=False, grid_mode=True)
+        got = uivr.upsample_grid(torch.from_numpy(a).to(gpu), new)
+        assert got.is_cuda and got.is_contiguous() and tuple(got.shape) == new
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-6)
+    # non-integer factor (a fixed grid resampled next to optimised ones): 6 -> 9
+    a = rng.random((6, 6, 6, 3), dtype=np.float32)
+    ref = zoom(a, [1.5, 1.5, 1.5, 1], order=1, mode='nearest', prefilter=False, grid_mode=True)
+    got = uivr.upsample_grid(torch.from_numpy(a).to(gpu), (9, 9, 9, 3))
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-6)
+
+
+def test_device_adam_and_projection_equal_formula(uivr, gpu):
+    rng = np.random.default_rng(11)
+    shape = (8, 8, 8, 3)
+    p0 = (rng.random(shape) * 2).astype(np.float32)
+    keys = ("medium1.sigma_t.data", "medium1.albedo.data")
+    params = {k: torch.from_numpy(p0.copy()).to(gpu) for k in keys}
+    opt = uivr.Adam(lr=5e-2, params=params)
+    opt.set_learning_rate({keys[1]: 1e-1})
+    sc = uivr.SceneConfig(name="c", scene=uivr.cube_test_scene(8, 8), param_keys=list(keys), sensors=[0],
+                          start_from_value={k: 0.1 for k in keys}, max_density=1.5)
+    ref = {k: p0.astype(np.float64).copy() for k in keys}
+    m = {k: np.zeros(shape) for k in keys}
+    v = {k: np.zeros(shape) for k in keys}
+    lo_hi = {keys[0]: (0.0, 1.5), keys[1]: (0.0, 1.0)}
+    lr = {keys[0]: 5e-2, keys[1]: 1e-1}
+    for t in range(1, 8):
+        g = rng.normal(size=shape).astype(np.float32)
+        opt.step({k: torch.from_numpy(g).to(gpu) for k in keys})
+        uivr.enforce_valid_params(sc, opt)
+        for k in keys:
+            m[k] = 0.9 * m[k] + 0.1 * g
+            v[k] = 0.999 * v[k] + 0.001 * g.astype(np.float64) ** 2
+            ref[k] = ref[k] - lr[k] * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m[k] / (np.sqrt(v[k]) + 1e-8)
+            ref[k] = np.clip(ref[k], *lo_hi[k])
+    for k in keys:
+        np.testing.assert_allclose(params[k].cpu().numpy(), ref[k], rtol=2e-5, atol=2e-6)
+        assert params[k].is_cuda
+
+
+def test_vol_bytes_equal_independent_header(uivr, gpu, tmp_path):
+    """python/util.py:55-71 -> mi.VolumeGrid.write: 'V','O','L', u8 3, i32 1 (float32), i32 xres, yres, zres,
+    i32 channels, 6 x f32 bbox, then the data with x fastest and channels interleaved."""
+    rng = np.random.default_rng(12)
+    for c in (1, 3):
+        z, y, x = 5, 7, 9
+        a = rng.random((z, y, x, c), dtype=np.float32)
+        path = str(tmp_path / f"dev{c}.vol")
+        uivr.write_vol(path, torch.from_numpy(a).to(gpu), (-1.0, -0.5, 0.25), (1.0, 1.5, 3.0))
+        expect = b"VOL" + struct.pack("<B", 3) + struct.pack("<i", 1) + struct.pack("<iii", x, y, z) + struct.pack("<i", c) \
+            + struct.pack("<6f", -1.0, -0.5, 0.25, 1.0, 1.5, 3.0)
+        body = bytearray()
+        for k in range(z):
+            for j in range(y):
+                for i in range(x):
+                    for ch in range(c):
+                        body += struct.pack("<f", float(a[k, j, i, ch]))
+        assert open(path, "rb").read() == expect + bytes(body)
+        back, lo, hi = uivr.read_vol(path)
+        np.testing.assert_array_equal(back, a)
+        assert lo == (-1.0, -0.5, 0.25) and hi == (1.0, 1.5, 3.0)
+
+
+def test_fresh_grids_are_never_mistaken_for_the_bound_one(uivr, oracle, gpu):
+    """A finite-difference loop `render(params={S: st + eps})`, `render(params={S: st - eps})` allocates a new
+    grid for each call; the caching allocator hands a just-freed block back at the same address with version 0.
+    The derived device state (brick copy, majorant, mask) must follow the tensor that is passed."""
+    scene = uivr.cube_test_scene(16, 16, density_scale=2.0)
+    props = props_for("basic")
+    integ = uivr.load_dict(dict(type="volpathsimple", **props))
+    sg = uivr.scene_to(scene, gpu)
+    spp, seed = 8, 77
+    base = sg.medium.sigma_t
+
+    def render_with(delta):
+        st = base + delta                         # fresh tensor, freed at the end of the call
+        img = uivr.render(sg, params={uivr.SIGMA_T_KEY: st, uivr.ALBEDO_KEY: sg.medium.albedo}, integrator=integ,
+                          spp=spp, seed=seed)
+        return img.cpu().numpy()
+
+    imgs = {}
+    for delta in (0.5, -0.25, 0.5, 1.0, -0.25):
+        torch.cuda.synchronize()
+        img = render_with(delta)
+        sc = uivr.cube_test_scene(16, 16, density_scale=2.0)
+        sc.medium.sigma_t = (sc.medium.sigma_t + np.float32(delta)).astype(np.float32)
+        L, _ = oracle.render_primal(oracle.OracleScene(sc), props, spp, seed)
+        np.testing.assert_allclose(img, oracle.develop(L, spp), rtol=0, atol=1e-6, err_msg=str(delta))
+        imgs.setdefault(delta, img)
+        np.testing.assert_array_equal(img, imgs[delta])
+    assert not np.array_equal(imgs[0.5], imgs[-0.25])
+    # in-place edits of the SAME tensor are seen too (version counter)
+    st = base.clone()
+    a = uivr.render(sg, params={uivr.SIGMA_T_KEY: st, uivr.ALBEDO_KEY: sg.medium.albedo}, integrator=integ, spp=spp, seed=seed)
+    st.mul_(0.25)
+    b = uivr.render(sg, params={uivr.SIGMA_T_KEY: st, uivr.ALBEDO_KEY: sg.medium.albedo}, integrator=integ, spp=spp, seed=seed)
+    assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("keys,int_name", [(["sigma_t"], "volpathsimple-drt"), (["albedo"], "volpathsimple-drt"),
+                                           (["sigma_t", "albedo", "emission"], "volpathsimple-drt"),
+                                           (["sigma_t", "albedo"], "nerf"), (["sigma_t", "emission"], "nerf")])
+def test_run_optimization_parameter_key_subsets(uivr, gpu, keys, int_name, tmp_path):
+    """optimize.py:134-166 / scene_config.py:148: the optimised keys need not equal the integrator's."""
+    from uivr_amd import synthetic
+    scene = synthetic.smoke_scene(res=16, film=24, device=gpu, optical_side=8.0)
+    scene.sensors = synthetic.ring_sensors(3, radius=5.0, height=0.8, fov=30.0, width=24, film_height=24)
+    scene.medium.emission = scene.medium.albedo.clone() * 0.5
+    full = {"sigma_t": uivr.SIGMA_T_KEY, "albedo": uivr.ALBEDO_KEY, "emission": uivr.EMISSION_KEY}
+    pk = [full[k] for k in keys]
+    start = {uivr.SIGMA_T_KEY: 0.4, uivr.ALBEDO_KEY: 0.5, uivr.EMISSION_KEY: 0.1}
+    sc = uivr.SceneConfig(name="s", scene=scene, param_keys=pk, sensors=[0, 1, 2], start_from_value={k: start[k] for k in pk},
+                          max_depth=8, ref_spp=256, max_density=20.0, ref_integrator=int_name)
+    oc = uivr.OptimizationConfig("t", spp=2, n_iter=6, lr=2e-2, primal_spp_factor=2, batch_size=256, upsample=[0.5],
+                                 checkpoint_initial=False, checkpoint_final=False, checkpoint_stride=2)
+    _, params, opt, hist = uivr.run_optimization(str(tmp_path / "out"), oc, sc, int_name)
+    assert sorted(params) == sorted(pk) and len(hist) == 6 and np.isfinite(hist).all()
+    for k in pk:
+        assert tuple(params[k].shape[:3]) == (16, 16, 16)           # started at 8^3, upsampled once
+    integ_keys = uivr.get_int_config(int_name).create(max_depth=8).param_keys
+    moved = [k for k in pk if float((params[k] - start[k]).abs().max()) > 0]
+    assert sorted(moved) == sorted(k for k in pk if k in integ_keys)    # keys the integrator does not read stay put
+    # the stride checkpoint is written although checkpoint_initial is off (util.py:57 always creates the directory)
+    import os
+    assert any(f.startswith("00000002-") for f in os.listdir(tmp_path / "out" / "params"))

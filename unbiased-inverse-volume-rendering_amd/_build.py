@@ -42,11 +42,38 @@ def _hipcc():
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """Every translation unit is compiled on its own (in parallel: the tracing kernels take about a minute
+    each) into csrc/_obj/, then linked; only units whose sources changed are recompiled."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(_CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [h if os.path.isabs(h) else os.path.join(_CSRC, h) for h in HIP_HEADERS]
-    if force or _newer(LIB_PATH, deps):
-        extra = [f"-D{k}={v}" for k, v in os.environ.items() if k.startswith("DRT_") and v.lstrip("-").isdigit()]
-        cmd = [_hipcc()] + HIP_FLAGS + extra + srcs + ["-o", LIB_PATH]
+    hdrs = [h if os.path.isabs(h) else os.path.join(_CSRC, h) for h in HIP_HEADERS]
+    extra = [f"-D{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("DRT_") and v.lstrip("-").isdigit()]
+    objdir = os.path.join(_CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    stamp = os.path.join(objdir, "flags.txt")
+    flags_now = " ".join(HIP_FLAGS + extra)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
+    compile_flags = [f for f in HIP_FLAGS if f != "-shared"]
+
+    def obj_of(src):
+        return os.path.join(objdir, os.path.basename(src) + ".o")
+
+    def compile_one(src):
+        cmd = [_hipcc()] + compile_flags + extra + ["-c", src, "-o", obj_of(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=_CSRC)
+
+    todo = [s for s in srcs if force or _newer(obj_of(s), [s] + hdrs)]
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), max(1, (os.cpu_count() or 2) - 1))) as ex:
+            list(ex.map(compile_one, todo))
+        with open(stamp, "w") as f:
+            f.write(flags_now)
+    objs = [obj_of(s) for s in srcs]
+    if todo or _newer(LIB_PATH, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=_CSRC)

@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .distributed import allreduce_gradients
+from .distributed import ShardSpec, allreduce_gradients
 from .integrators import ADMode, IndependentSampler, RayBatch, sample_tea_32
 from .render import _grid, _with_params, alloc_grads
 from .scene import PerspectiveSensor, Scene
@@ -35,9 +35,11 @@ def sensors_to_device(sensors: Sequence[PerspectiveSensor], device) -> torch.Ten
 
 
 def sample_batch(integrator, scene: Scene, sensor_table: torch.Tensor, batch_size: int, spp: int, seed: int,
-                 which: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                 which: int, batch_first: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """sample_batch_pixels + sample_batch_rays (batched.py:397-467) -> rays_o, rays_d, sensor_idx, pixels.
-    `which` = 1 for the primal rays, 2 for the adjoint rays (batch_samplers[which])."""
+    `which` = 1 for the primal rays, 2 for the adjoint rays (batch_samplers[which]).
+    `batch_first` / `batch_size`: the range of GLOBAL batch entries to generate (one rank's share of a
+    sharded batch; the samplers' lanes are the global entry / ray indices)."""
     h, dev = integrator._bind(scene)
     n = batch_size * spp
     ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -47,48 +49,55 @@ def sample_batch(integrator, scene: Scene, sensor_table: torch.Tensor, batch_siz
     sub0 = sample_tea_32(seed, 17 * 0 + 5)[0]
     subk = sample_tea_32(seed, 17 * which + 5)[0]
     h.batch_sample_rays(sensor_table.data_ptr(), int(sensor_table.shape[0]), int(batch_size), int(spp), sub0, subk,
-                        ro.data_ptr(), rd.data_ptr(), sidx.data_ptr(), pix.data_ptr())
+                        ro.data_ptr(), rd.data_ptr(), sidx.data_ptr(), pix.data_ptr(), int(batch_first))
     return ro, rd, sidx, pix
 
 
 class _BatchedRenderOp(torch.autograd.Function):
-    """python/batched.py:13-85."""
+    """python/batched.py:13-85.  With a `shard` (world > 1) the batch entries [first, first + count) of this
+    rank are rendered - random streams keyed by the GLOBAL entry / ray index, so the union over ranks is
+    the unsharded batch bit for bit - and the backward pass sums the gradient grids over the ranks with
+    ONE all-reduce.  Unsharded calls never communicate."""
 
     @staticmethod
-    def forward(ctx, p0, p1, scene, integrator, sensor_table, batch_size, spp, spp_grad, seed, seed_grad):
+    def forward(ctx, p0, p1, scene, integrator, sensor_table, batch_size, spp, spp_grad, seed, seed_grad, shard):
         sc = _with_params(scene, integrator.param_keys, (p0.detach(), p1.detach()))
-        ro, rd, sidx, pix = sample_batch(integrator, sc, sensor_table, batch_size, spp, seed, 1)
-        batch = RayBatch(n_rays=batch_size * spp, spp=spp, o=ro, d=rd)
+        first, count = shard.batch_range(batch_size)
+        ro, rd, sidx, pix = sample_batch(integrator, sc, sensor_table, count, spp, seed, 1, first)
+        batch = RayBatch(n_rays=count * spp, spp=spp, o=ro, d=rd, ray_offset=first * spp)
         L, _, _ = integrator.sample(ADMode.Primal, sc, IndependentSampler(seed, spp), batch)    # :163-173
         image = integrator.develop(sc, L, spp)                                                   # :176-197
         ctx.scene, ctx.integrator, ctx.sensor_table = sc, integrator, sensor_table
-        ctx.batch_size, ctx.spp_grad, ctx.seed, ctx.seed_grad = batch_size, spp_grad, seed, seed_grad
+        ctx.range, ctx.spp_grad, ctx.seed, ctx.seed_grad, ctx.shard = (first, count), spp_grad, seed, seed_grad, shard
         ctx.mark_non_differentiable(sidx, pix)
         return image, sidx, pix
 
     @staticmethod
     def backward(ctx, grad_image, _gs, _gp):
         sc, integ = ctx.scene, ctx.integrator
+        first, count = ctx.range
         # decorrelated rays through the same pixels (:69-82); same pixel sampler 0 => same pixels
-        ro, rd, _, _ = sample_batch(integ, sc, ctx.sensor_table, ctx.batch_size, ctx.spp_grad, ctx.seed, 2)
-        batch = RayBatch(n_rays=ctx.batch_size * ctx.spp_grad, spp=ctx.spp_grad, o=ro, d=rd)
+        ro, rd, _, _ = sample_batch(integ, sc, ctx.sensor_table, count, ctx.spp_grad, ctx.seed, 2, first)
+        batch = RayBatch(n_rays=count * ctx.spp_grad, spp=ctx.spp_grad, o=ro, d=rd, ray_offset=first * ctx.spp_grad)
         sampler = IndependentSampler(ctx.seed_grad, ctx.spp_grad)
         L, _, state = integ.sample(ADMode.Primal, sc, sampler.clone(), batch)                    # :255-264
         dL = integ.film_backward(sc, grad_image.contiguous(), ctx.spp_grad)                      # :272-306
         grads = alloc_grads(sc, integ.param_keys)
         integ.sample(ADMode.Backward, sc, sampler, batch, δL=dL, state_in=state, grads=grads)    # :309-318
-        allreduce_gradients(grads)
+        allreduce_gradients(grads, shard=ctx.shard)
         k0, k1 = integ.param_keys
-        return (grads[k0], grads[k1]) + (None,) * 8
+        return (grads[k0], grads[k1]) + (None,) * 9
 
 
 def render_batch(batch_size: int, scene: Scene, sensors=None, film_size=None,
                  params: Optional[Dict[str, torch.Tensor]] = None, integrator=None, film=None,
                  pixel_format=None, sampler=None, seed: int = 0, seed_grad: int = 0, spp: int = 0,
-                 spp_grad: int = 0, sensor_table: Optional[torch.Tensor] = None):
+                 spp_grad: int = 0, sensor_table: Optional[torch.Tensor] = None, shard: Optional[ShardSpec] = None):
     """Batched (ray-centric) alternative to `render` (python/batched.py:88-131).
     -> (image [batch_size, 3], film, sampler, sensor_idx [batch_size], pixel_idx [batch_size, 2])
-    (`film` / `sampler` are returned as given: the device film is stateless here)."""
+    (`film` / `sampler` are returned as given: the device film is stateless here).
+    `shard` (world > 1): the outputs hold this rank's entries `shard.batch_range(batch_size)` only and the
+    backward pass all-reduces the gradient grids; scale the local loss by `local_loss_scale`."""
     if integrator is None:
         raise ValueError("render_batch: an integrator is required")
     if spp <= 0:
@@ -112,7 +121,8 @@ def render_batch(batch_size: int, scene: Scene, sensors=None, film_size=None,
     if sensor_table is None:
         sensor_table = sensors_to_device(sensors, params[keys[0]].device)
     image, sidx, pix = _BatchedRenderOp.apply(params[keys[0]], params[keys[1]], scene, integrator, sensor_table,
-                                              int(batch_size), int(spp), int(spp_grad), int(seed), int(seed_grad))
+                                              int(batch_size), int(spp), int(spp_grad), int(seed), int(seed_grad),
+                                              shard or ShardSpec())
     return image, film, sampler, sidx, pix
 
 

@@ -263,9 +263,10 @@ bool want_deferred(drt_handle h, const drt::Params &P)
 }
 
 int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint64_t n_rays, uint32_t per_ray_sigma,
-                    uint32_t per_ray_colour)
+                    uint32_t per_ray_colour, bool simulate_no_memory = false)
 {
     using namespace drt;
+    if (simulate_no_memory) return kNoRecordMemory;
     DeferredPlan &D = R.plan;
     const int ntx = (P.rx + kTileX - 1) / kTileX, nty = (P.ry + kTileY - 1) / kTileY, ntz = (P.rz + kTileZ - 1) / kTileZ;
     const int n_bins = ntx * nty * ntz;
@@ -356,7 +357,18 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
         const bool forced = (h->debug_flags & 2048u) != 0;         // test hook: overlap whatever the job size
         const bool want_pipe = env_pipe || forced;
         const uint64_t want_pipe_slots = want_pipe ? 2 : 1;
-        const uint64_t budget = (h->debug_flags & 16384u) ? (8ull << 20) : kRecBudgetBytes;   // test hook: 8 MB -> many sub-batches
+        uint64_t budget = (h->debug_flags & 16384u) ? (8ull << 20) : kRecBudgetBytes;   // test hook: 8 MB -> many sub-batches
+        {   // never ask for more than the device can give next to the caller's (torch's) allocations: what the slots
+            // hold already plus 80 % of what is free now; smaller budgets only mean more ray sub-batches
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const uint64_t have = (uint64_t) h->rec[0].bytes + (uint64_t) h->rec[1].bytes;
+                const uint64_t room = have + (uint64_t) ((double) free_b * 0.8);
+                if (room < budget) budget = room;
+            } else (void) hipGetLastError();
+            const uint64_t floor_b = 256ull * bytes_per_ray * want_pipe_slots;     // at least one workgroup of rays per slot
+            if (budget < floor_b) budget = floor_b;
+        }
         uint64_t batch = (budget / want_pipe_slots) / bytes_per_ray;
         const bool pipe = want_pipe && (forced || n_rays >= kPipeMinRays);
         if (pipe && batch > (n_rays + kPipeBatches - 1) / kPipeBatches) batch = (n_rays + kPipeBatches - 1) / kPipeBatches;
@@ -372,10 +384,13 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
             auto &R = h->rec[overlap ? (b & 1) : 0];
             const uint64_t count = n_rays - first < batch ? n_rays - first : batch;
             if (R.busy) { DRT_HIP_CHECK(h, hipStreamWaitEvent(h->stream, R.reduced, 0)); R.busy = false; }
-            int rc = ensure_deferred(h, R, P, count, per_ray_sigma, per_ray_colour);
-            if (rc == kNoRecordMemory && first == 0) {       // fall back to atomics into the apron scratch
+            int rc = ensure_deferred(h, R, P, count, per_ray_sigma, per_ray_colour,
+                                     (h->debug_flags & 524288u) && first > 0);   // test hook: memory runs out after the first sub-batch
+            if (rc == kNoRecordMemory) {
+                // no memory for the record streams (now): the rays that are left, [first, n_rays), take the
+                // atomic path (splats into the apron scratch + untile) - slower, same gradients
                 for (int s2 = 0; s2 < 4; ++s2) P.rec_buf[s2] = nullptr;
-                P.rec_cursor = nullptr; P.ray_first = 0; P.n_rays = n_rays;
+                P.rec_cursor = nullptr; P.ray_first = first; P.n_rays = n_rays;
                 rc = launch(P);
                 if (rc) return rc;
                 rc = timed_untile(h, P);
@@ -587,6 +602,21 @@ int drt_destroy(drt_handle h)
     if (h->d_pcache) (void) hipFree(h->d_pcache);
     clear_timings(h);
     delete h;
+    return DRT_OK;
+}
+
+int drt_release_scratch(drt_handle h)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->side) DRT_HIP_CHECK(h, hipStreamSynchronize(h->side));
+    for (auto &R : h->rec) {
+        if (R.mem) (void) hipFree(R.mem);
+        R.mem = nullptr; R.bytes = 0; R.rays = 0; R.bins = 0; R.busy = false;
+    }
+    if (h->d_pcache) (void) hipFree(h->d_pcache);
+    h->d_pcache = nullptr; h->pcache_bytes = 0; h->pcache_sig.valid = false; h->order_valid = false; h->order_rays = 0;
     return DRT_OK;
 }
 
@@ -921,18 +951,27 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
     return run_backward(h, P, q, q, [&](drt::Params &Q) { return timed_nerf(h, 1, Q, true); });
 }
 
+int drt_batch_sample_rays_range(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_first,
+                                uint32_t batch_count, uint32_t spp, uint32_t sub_seed_pixels, uint32_t sub_seed_rays,
+                                float *rays_o, float *rays_d, uint32_t *sensor_idx, uint32_t *pixels)
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!sensors || n_sensors < 1 || spp == 0) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_batch_sample_rays: bad sensors / spp");
+    if (((uint64_t) batch_first + batch_count) * spp > 0xffffffffull)
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "batch_size * spp exceeds 2^32 - 1");
+    if (batch_count && (!rays_o || !rays_d)) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null ray buffers");
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, drt::launch_batch_raygen(sensors, n_sensors, batch_first, batch_count, spp, sub_seed_pixels, sub_seed_rays,
+                                              rays_o, rays_d, sensor_idx, pixels, h->stream));
+    return DRT_OK;
+}
+
 int drt_batch_sample_rays(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_size, uint32_t spp,
                           uint32_t sub_seed_pixels, uint32_t sub_seed_rays, float *rays_o, float *rays_d,
                           uint32_t *sensor_idx, uint32_t *pixels)
 {
-    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
-    if (!sensors || n_sensors < 1 || spp == 0) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_batch_sample_rays: bad sensors / spp");
-    if ((uint64_t) batch_size * spp > 0xffffffffull) return fail(h, DRT_ERR_INVALID_ARGUMENT, "batch_size * spp exceeds 2^32 - 1");
-    if (batch_size && (!rays_o || !rays_d)) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null ray buffers");
-    DeviceGuard g(h->device);
-    DRT_HIP_CHECK(h, drt::launch_batch_raygen(sensors, n_sensors, batch_size, spp, sub_seed_pixels, sub_seed_rays, rays_o, rays_d,
-                                              sensor_idx, pixels, h->stream));
-    return DRT_OK;
+    return drt_batch_sample_rays_range(h, sensors, n_sensors, 0, batch_size, spp, sub_seed_pixels, sub_seed_rays, rays_o,
+                                       rays_d, sensor_idx, pixels);
 }
 
 int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t spp, float *image)

@@ -838,13 +838,17 @@ __global__ void __launch_bounds__(kUntileLanes * kUntileRows) untile_gradients_k
 // batch; b = r / spp picks (sensor, pixel) from sampler 0's lane b, the sub-pixel offset comes from
 // the ray sampler's lane r.  `sensors`: n_sensors x 16 floats {origin3, left3, up3, dir3, tan_x,
 // tan_y, width, height}.
-__global__ void __launch_bounds__(256) batch_raygen_kernel(const float *sensors, int n_sensors, uint32_t batch_size,
+// `batch_first`: first batch entry of this rank's share (sharded batches): the samplers' lanes are
+// the GLOBAL batch entry / ray index, the outputs are local (entry b - batch_first, ray r - batch_first * spp).
+__global__ void __launch_bounds__(256) batch_raygen_kernel(const float *sensors, int n_sensors, uint32_t batch_first,
+                                                           uint32_t batch_size,
                                                            uint32_t spp, uint32_t seed_pixels, uint32_t seed_rays,
                                                            float *rays_o, float *rays_d, uint32_t *sensor_idx,
                                                            uint32_t *pixels)
 {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= batch_size * spp) return;
+    const uint32_t rl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rl >= batch_size * spp) return;
+    const uint32_t r = rl + batch_first * spp;
     uint32_t b = r / spp;
     Pcg32 S0; S0.seed(seed_pixels, b);
     float us = S0.next_1d(), ux = S0.next_1d(), uy = S0.next_1d();
@@ -857,15 +861,16 @@ __global__ void __launch_bounds__(256) batch_raygen_kernel(const float *sensors,
     P.tan_x = sn[12]; P.tan_y = sn[13]; P.width = (int) sn[14]; P.height = (int) sn[15];
     uint32_t px = (uint32_t)((float) P.width * ux), py = (uint32_t)((float) P.height * uy);
     if (r == b * spp) {
-        if (sensor_idx) sensor_idx[b] = si;
-        if (pixels) { pixels[2 * b] = px; pixels[2 * b + 1] = py; }
+        const uint32_t bl = b - batch_first;
+        if (sensor_idx) sensor_idx[bl] = si;
+        if (pixels) { pixels[2 * bl] = px; pixels[2 * bl + 1] = py; }
     }
     Pcg32 S1; S1.seed(seed_rays, r);
     float ox = S1.next_1d(), oy = S1.next_1d();
     V3 o, d;
     sensor_ray(P, py * (uint32_t) P.width + px, ox, oy, o, d);
-    rays_o[3 * (size_t) r] = o.x; rays_o[3 * (size_t) r + 1] = o.y; rays_o[3 * (size_t) r + 2] = o.z;
-    rays_d[3 * (size_t) r] = d.x; rays_d[3 * (size_t) r + 1] = d.y; rays_d[3 * (size_t) r + 2] = d.z;
+    rays_o[3 * (size_t) rl] = o.x; rays_o[3 * (size_t) rl + 1] = o.y; rays_o[3 * (size_t) rl + 2] = o.z;
+    rays_d[3 * (size_t) rl] = d.x; rays_d[3 * (size_t) rl + 1] = d.y; rays_d[3 * (size_t) rl + 2] = d.z;
 }
 
 // box film: image[p] = mean_spp L (batched.py:176-197)
@@ -925,6 +930,17 @@ __global__ void __launch_bounds__(256) debug_eval_kernel(const Params P, int op,
         case 13: if (P.env_pix) {                       // envmap: sample_direction(u1, u2) -> d, pdf
             V3 d = envmap_sample_dir(P, a[0], a[1]);
             o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = envmap_pdf(P, d);
+        } break;
+        case 14: {                                      // E2: sample_interaction_drt from o along d to the box exit
+            Tracer<false, false, false> tr(P);
+            tr.occ = P.occ;
+            Ray r; r.o = v3(a[0], a[1], a[2]); r.d = v3(a[3], a[4], a[5]);
+            Hit h = box_hit(P, r.o, r.d);
+            r.maxt = h.valid ? h.t : 0.0f;
+            Pcg32 A; A.seed(0x5eedu, (uint32_t) i);
+            float t = kInf, W = 0.0f;
+            bool ok = tr.sample_interaction_drt(r, A, t, W);
+            o[0] = ok ? 1.0f : 0.0f; o[1] = t; o[2] = W; o[3] = r.maxt;
         } break;
         case 9: if (P.mgrid) { o[0] = P.mgrid[__float_as_uint(a[0])]; } break;
         case 8: o[0] = mis_weight(a[0], a[1]); o[1] = a[0] / a[1]; o[2] = sqrtf(a[0]); o[3] = fmaf(a[0], a[1], a[2]); break;
@@ -1036,14 +1052,14 @@ hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_batch_raygen(const float *sensors, int n_sensors, uint32_t batch_size, uint32_t spp, uint32_t seed_pixels,
-                               uint32_t seed_rays, float *rays_o, float *rays_d, uint32_t *sensor_idx, uint32_t *pixels,
-                               hipStream_t stream)
+hipError_t launch_batch_raygen(const float *sensors, int n_sensors, uint32_t batch_first, uint32_t batch_size, uint32_t spp,
+                               uint32_t seed_pixels, uint32_t seed_rays, float *rays_o, float *rays_d, uint32_t *sensor_idx,
+                               uint32_t *pixels, hipStream_t stream)
 {
     uint64_t n = (uint64_t) batch_size * spp;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(batch_raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sensors, n_sensors,
-                       batch_size, spp, seed_pixels, seed_rays, rays_o, rays_d, sensor_idx, pixels);
+                       batch_first, batch_size, spp, seed_pixels, seed_rays, rays_o, rays_d, sensor_idx, pixels);
     return hipGetLastError();
 }
 

@@ -52,6 +52,12 @@ public:
         if (rc) throw std::runtime_error(std::string(what) + ": " + drt_last_error(h_));
     }
 
+    void release_scratch()
+    {
+        int rc;
+        { py::gil_scoped_release nogil; rc = drt_release_scratch(h_); }
+        check(rc, "drt_release_scratch");
+    }
     void set_stream(uintptr_t s) { check(drt_set_stream(h_, ptr<void>(s)), "drt_set_stream"); }
     void synchronize()
     {
@@ -159,15 +165,15 @@ public:
         check(rc, "drt_nerf_render_backward");
     }
     void batch_sample_rays(uintptr_t sensors, int n_sensors, uint32_t batch, uint32_t spp, uint32_t seed_px, uint32_t seed_rays,
-                           uintptr_t ro, uintptr_t rd, uintptr_t sidx, uintptr_t pix)
+                           uintptr_t ro, uintptr_t rd, uintptr_t sidx, uintptr_t pix, uint32_t batch_first)
     {
         int rc;
         {
             py::gil_scoped_release nogil;
-            rc = drt_batch_sample_rays(h_, ptr<const float>(sensors), n_sensors, batch, spp, seed_px, seed_rays, ptr<float>(ro),
-                                       ptr<float>(rd), ptr<uint32_t>(sidx), ptr<uint32_t>(pix));
+            rc = drt_batch_sample_rays_range(h_, ptr<const float>(sensors), n_sensors, batch_first, batch, spp, seed_px, seed_rays,
+                                             ptr<float>(ro), ptr<float>(rd), ptr<uint32_t>(sidx), ptr<uint32_t>(pix));
         }
-        check(rc, "drt_batch_sample_rays");
+        check(rc, "drt_batch_sample_rays_range");
     }
     void film_develop(uintptr_t L, uint64_t n_pixels, uint32_t spp, uintptr_t image)
     {
@@ -229,6 +235,7 @@ PYBIND11_MODULE(_drt_pybind, m)
         .def(py::init<const py::dict &, int>(), py::arg("props"), py::arg("device") = 0)
         .def("set_stream", &Integrator::set_stream)
         .def("synchronize", &Integrator::synchronize)
+        .def("release_scratch", &Integrator::release_scratch)
         .def("set_ray_interleave", &Integrator::set_ray_interleave)
         .def("set_medium", &Integrator::set_medium)
         .def("params_changed", &Integrator::params_changed)
@@ -239,7 +246,9 @@ PYBIND11_MODULE(_drt_pybind, m)
         .def("render_backward", &Integrator::render_backward)
         .def("nerf_render_primal", &Integrator::nerf_render_primal)
         .def("nerf_render_backward", &Integrator::nerf_render_backward)
-        .def("batch_sample_rays", &Integrator::batch_sample_rays)
+        .def("batch_sample_rays", &Integrator::batch_sample_rays, py::arg("sensors"), py::arg("n_sensors"), py::arg("batch"),
+             py::arg("spp"), py::arg("seed_px"), py::arg("seed_rays"), py::arg("ro"), py::arg("rd"), py::arg("sidx"),
+             py::arg("pix"), py::arg("batch_first") = 0)
         .def("film_develop", &Integrator::film_develop)
         .def("film_backward", &Integrator::film_backward)
         .def("debug_eval", &Integrator::debug_eval)

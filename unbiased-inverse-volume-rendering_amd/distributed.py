@@ -54,6 +54,18 @@ class ShardSpec:
         return (i // self.chunk_pixels) * (self.chunk_pixels * self.world) \
             + self.rank * self.chunk_pixels + (i % self.chunk_pixels)
 
+    def batch_range(self, batch_size: int):
+        """(first, count): this rank's contiguous share of a `batch_size` list of random (sensor, pixel)
+        entries (render_batch; SURVEY.md 8e "shard the batch_size pixel list").  The entries are i.i.d., so a
+        contiguous split is balanced; ragged sizes are allowed (counts differ by at most one)."""
+        first = (batch_size * self.rank) // self.world
+        return first, (batch_size * (self.rank + 1)) // self.world - first
+
+    @property
+    def partitioned(self) -> bool:
+        """True when the work of a render call was dealt across ranks (the gradients then need the all-reduce)."""
+        return self.world > 1
+
     @staticmethod
     def default_chunk(n_pixels: int, world: int, target: int = 2048) -> int:
         """Largest chunk <= target such that n_pixels % (chunk*world) == 0."""
@@ -74,13 +86,21 @@ def from_environment(n_pixels: Optional[int] = None) -> ShardSpec:
     return ShardSpec(rank=rank, world=world, chunk_pixels=chunk)
 
 
-def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None) -> None:
+def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, shard: Optional[ShardSpec] = None) -> None:
     """Sum the gradient grids over all ranks, in place: one collective per backward.
     The grids live in (or are flattened into) ONE buffer (sigma_t: V floats + albedo:
-    3V floats) so that a single large all-reduce crosses xGMI instead of one per parameter."""
+    3V floats) so that a single large all-reduce crosses xGMI instead of one per parameter.
+
+    Only PARTITIONED work is summed: with `shard` given, the call is a no-op unless `shard.world > 1`
+    (every rank of an unsharded render computed the full gradient already; summing those would
+    multiply it by the world size)."""
     import torch.distributed as dist
+    if shard is not None and not shard.partitioned:
+        return
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
+    if shard is not None and shard.world != dist.get_world_size(group):
+        raise ValueError(f"ShardSpec.world={shard.world} does not match the process group size {dist.get_world_size(group)}")
     if "_flat" in grads:      # render.alloc_grads: the grids are views of one buffer
         dist.all_reduce(grads["_flat"], op=dist.ReduceOp.SUM, group=group)
         return
@@ -92,6 +112,14 @@ def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None) -> None:
         n = grads[k].numel()
         grads[k].copy_(flat[off:off + n].view_as(grads[k]))
         off += n
+
+
+def local_loss_scale(n_local: int, n_global: int) -> float:
+    """Factor that turns a loss normalised by the LOCAL entry count (every loss of `losses.py` divides by
+    `img.numel()`) into this rank's additive share of the loss over the global image / batch:
+    sum_ranks scale_r * loss_r == loss(global).  Back-propagating `scale * loss_local` on every rank and
+    all-reducing (SUM) the gradient grids then yields exactly the gradient of the global loss."""
+    return float(n_local) / float(n_global)
 
 
 def allreduce_scalar(value: torch.Tensor, group=None) -> torch.Tensor:

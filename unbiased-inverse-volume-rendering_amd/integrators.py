@@ -158,17 +158,23 @@ class _DeviceIntegrator:
             h = native().Integrator(self._native_props(), idx)
             self._handles[idx] = h
         h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        # The derived device state (apron-brick sigma_t copy, majorant, supergrid, empty-space mask) is
+        # rebuilt by set_medium only.  The cache key is (address, version counter, geometry) of the bound
+        # grids, and the entry HOLDS the bound tensors: while it is cached their storage cannot be freed,
+        # so an equal address means the same storage (whose views share one version counter) - a freshly
+        # allocated grid can never alias a cached key through the caching allocator.
         al_key = (al.data_ptr(), al._version) if isinstance(al, torch.Tensor) else (0, 0)
         key = (st.data_ptr(), st._version) + al_key + (tuple(st.shape),
                tuple(m.bbox_min), tuple(m.bbox_max), float(m.scale), int(m.majorant_resolution_factor))
         self._bind_emitter(h, idx, scene.emitter, dev)
-        if self._bound.get(idx) != key:
+        bound = self._bound.get(idx)
+        if bound is None or bound[0] != key:
             z, y, x = st.shape[:3]
             h.set_medium(st.data_ptr(), al.data_ptr() if isinstance(al, torch.Tensor) else 0,
                          [int(x), int(y), int(z)],
                          [float(v) for v in m.bbox_min], [float(v) for v in m.bbox_max],
                          float(m.scale), int(m.majorant_resolution_factor))
-            self._bound[idx] = key
+            self._bound[idx] = (key, st, al)
         return h, dev
 
     def _bind_emitter(self, h, idx, emitter, dev):
@@ -183,14 +189,16 @@ class _DeviceIntegrator:
             _check(px, tuple(px.shape), dev, "envmap pixels")
             R = emitter.to_world_flat()
             ekey = ("envmap", px.data_ptr(), px._version, tuple(px.shape), float(emitter.scale), tuple(R))
-            if self._bound_emitter.get(idx) != ekey:
+            bound = self._bound_emitter.get(idx)
+            if bound is None or bound[0] != ekey:
                 h.set_emitter_envmap(px.data_ptr(), int(px.shape[1]), int(px.shape[0]), R, float(emitter.scale))
-                self._bound_emitter[idx] = ekey
+                self._bound_emitter[idx] = (ekey, px)             # holds the map: see _bind
         else:
             ekey = ("constant",) + tuple(float(v) for v in emitter.radiance)
-            if self._bound_emitter.get(idx) != ekey:
+            bound = self._bound_emitter.get(idx)
+            if bound is None or bound[0] != ekey:
                 h.set_emitter_constant([float(v) for v in emitter.radiance])
-                self._bound_emitter[idx] = ekey
+                self._bound_emitter[idx] = (ekey, None)
 
     @staticmethod
     def _set_rays(h, ray: RayBatch):

@@ -209,6 +209,7 @@ def upsample_grid(values: torch.Tensor, new_res) -> torch.Tensor:
 
 def save_params(output_dir: str, scene_config: SceneConfig, params: Dict[str, torch.Tensor], name: str, medium: GridMedium) -> None:
     """python/util.py:55-71: one `.vol` per parameter, `<name>-medium1_sigma_t.vol`."""
+    os.makedirs(output_dir, exist_ok=True)                            # util.py:57 (create_checkpoint always does)
     for key in scene_config.param_keys:
         if not key.endswith('.data'):
             raise NotImplementedError(f'Checkpointing of parameter {key}')
@@ -224,11 +225,31 @@ def _scene_with(scene: Scene, params: Dict[str, torch.Tensor], factor: int) -> S
     return Scene(medium=medium, emitter=scene.emitter, sensors=scene.sensors)
 
 
+def _resample_like(grid: torch.Tensor, res3) -> torch.Tensor:
+    """A non-optimised grid next to optimised ones at another resolution (multi-resolution schedules): the
+    integrator needs all grids on one lattice, so the fixed grid is resampled (trilinear, as `upsample_grid`)."""
+    if tuple(grid.shape[:3]) == tuple(res3):
+        return grid
+    return upsample_grid(grid, tuple(res3) + (grid.shape[-1],))
+
+
 def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, scene_config: SceneConfig,
-                     int_config, ref_images: Optional[torch.Tensor] = None, progress: Optional[Callable] = None):
+                     int_config, ref_images: Optional[torch.Tensor] = None, progress: Optional[Callable] = None,
+                     shard=None):
     """python/optimize.py:275-365.  `ref_images`: (n_sensors, H, W, 3) reference tensor; rendered from
     `scene_config.scene` at `ref_spp` with `ref_integrator` when None (optimize.py:24-87).
-    Returns (scene, params, opt, losses)."""
+    Returns (scene, params, opt, losses).
+
+    `scene_config.param_keys` may be any subset / superset of the integrator's keys (the reference's configs
+    list sigma_t, albedo AND emission whatever the integrator, scene_config.py:148): keys the integrator does
+    not read simply receive no gradient, keys it reads but that are not optimised are taken from the scene.
+
+    `shard` (a `ShardSpec` with world > 1, one process per GPU): the batch / the image pixels of every
+    iteration are dealt across the ranks, the local loss is scaled to its share of the global loss and the
+    gradient grids are summed with one all-reduce per backward; every rank then takes the identical
+    optimizer step."""
+    from .distributed import ShardSpec, allreduce_scalar, local_loss_scale
+    shard = shard or ShardSpec()
     int_config = get_int_config(int_config)
     scene0 = scene_config.scene
     dev = scene0.medium.sigma_t.device
@@ -239,6 +260,8 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
     film = (sensors[0].width, sensors[0].height)
     spp_grad = opt_config.spp
     spp_primal = spp_grad * opt_config.primal_spp_factor
+    if output_dir:
+        os.makedirs(os.path.join(output_dir, 'params'), exist_ok=True)       # util.py:55-71 always creates it
 
     if ref_images is None:                                             # reference renderings
         ref_int = get_int_config(scene_config.ref_integrator).create(max_depth=scene_config.max_depth)
@@ -254,25 +277,48 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
 
     # --- initialisation (optimize.py:134-166)
     full = {SIGMA_T_KEY: scene0.medium.sigma_t, ALBEDO_KEY: scene0.medium.albedo, EMISSION_KEY: scene0.medium.emission}
+    base_res = tuple(scene0.medium.sigma_t.shape[:3])
     n_up = len(opt_config.upsample) if opt_config.upsample else 0
     params: Dict[str, torch.Tensor] = {}
     for k in keys:
-        shape = tuple(full[k].shape)
+        if k not in full:
+            raise ValueError(f'Unknown parameter key "{k}" (known: {sorted(full)})')
+        channels = 1 if k == SIGMA_T_KEY else 3
+        shape = tuple(full[k].shape) if full[k] is not None else base_res + (channels,)
         init_res = tuple(max(1, s // (2 ** n_up)) for s in shape[:3]) + (shape[-1],)
         if n_up and 1 in init_res[:3]:
             raise ValueError(f'Initial resolution not supported: {init_res}. Maybe reduce upsample_steps?')
         v = scene_config.start_from_value[k]
         if v is None:
             assert not opt_config.upsample
+            if full[k] is None:
+                raise ValueError(f'Parameter "{k}" has neither an initial value nor a grid in the scene')
             params[k] = full[k].detach().clone()
         else:
             params[k] = torch.full(init_res, float(v), dtype=torch.float32, device=dev)
-    factor = adjusted_majorant_res_factor(scene_config.majorant_resolution_factor, params[SIGMA_T_KEY].shape)
+    for k in integrator.param_keys:
+        if k not in params and full[k] is None:
+            raise ValueError(f'The integrator reads "{k}" but it is neither optimised nor present in the scene')
+
+    def current_grids():
+        """The grids the integrator reads: optimised ones from `params`, the others from the scene, all on
+        the lattice of the current sigma_t."""
+        st = params[SIGMA_T_KEY] if SIGMA_T_KEY in params else None
+        res3 = tuple(st.shape[:3]) if st is not None else tuple(next(iter(params.values())).shape[:3])
+        out = {}
+        for k in (SIGMA_T_KEY, ALBEDO_KEY, EMISSION_KEY):
+            if k in params:
+                out[k] = params[k]
+            elif full[k] is not None:
+                out[k] = _resample_like(full[k], res3)
+        return out
+
+    grids = current_grids()
+    factor = adjusted_majorant_res_factor(scene_config.majorant_resolution_factor, grids[SIGMA_T_KEY].shape)
     opt = opt_config.optimizer(params)
-    scene = _scene_with(Scene(scene0.medium, scene0.emitter, sensors), params, factor)
+    scene = _scene_with(Scene(scene0.medium, scene0.emitter, sensors), grids, factor)
     table = sensors_to_device(sensors, dev)
     if output_dir and opt_config.checkpoint_initial:
-        os.makedirs(os.path.join(output_dir, 'params'), exist_ok=True)
         save_params(os.path.join(output_dir, 'params'), scene_config, params, 'initial', scene.medium)
 
     host_rng = torch.Generator().manual_seed(93483)                    # sensor choice (optimize.py:291,344)
@@ -287,29 +333,37 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
                 new_res = tuple(2 * r for r in old.shape[:3]) + (old.shape[-1],)
                 opt[k] = upsample_grid(old, new_res)
                 params[k] = opt[k]
-            factor = adjusted_majorant_res_factor(scene_config.majorant_resolution_factor, params[SIGMA_T_KEY].shape)
-            scene = _scene_with(scene, params, factor)
-        leaves = {k: params[k].detach().requires_grad_(True) for k in integrator.param_keys}
+            grids = current_grids()
+            factor = adjusted_majorant_res_factor(scene_config.majorant_resolution_factor, grids[SIGMA_T_KEY].shape)
+            scene = _scene_with(scene, grids, factor)
+        # leaves: what the integrator differentiates; only the optimised ones require (and receive) gradients
+        leaves = {k: (params[k].detach().requires_grad_(True) if k in params else grids[k].detach())
+                  for k in integrator.param_keys}
         if opt_config.batch_size is not None:                          # batched rendering (:332-341)
             image, _, _, sensor_idx, pixel_idx = render_batch(
                 opt_config.batch_size, scene, sensors=sensors, params=leaves, integrator=integrator,
-                spp=spp_primal, spp_grad=spp_grad, seed=seed, seed_grad=seed_grad, sensor_table=table)
+                spp=spp_primal, spp_grad=spp_grad, seed=seed, seed_grad=seed_grad, sensor_table=table, shard=shard)
             ref_values = gather_ref_values(ref_images, sensor_idx, pixel_idx)
+            n_global = opt_config.batch_size
         else:                                                          # sensor-based rendering (:342-348)
             s_i = int(torch.rand((), generator=host_rng).item() * n_sensors)
             image = render(scene, params=leaves, integrator=integrator, sensor=s_i, spp=spp_primal,
-                           spp_grad=spp_grad, seed=seed, seed_grad=seed_grad)
+                           spp_grad=spp_grad, seed=seed, seed_grad=seed_grad, shard=shard if shard.partitioned else None)
             ref_values = ref_images[s_i].reshape(-1, 3)
-        loss_value = opt_config.loss(image, ref_values)
+            n_global = ref_values.shape[0]
+            if shard.partitioned:
+                ref_values = ref_values[shard.pixel_indices(n_global, ref_values.device)]
+        # the losses normalise by the local entry count: scale to this rank's share of the global loss
+        loss_value = opt_config.loss(image, ref_values) * local_loss_scale(image.shape[0], n_global)
         loss_value.backward()                                          # dr.backward (:350)
-        opt.step({k: leaves[k].grad for k in keys if k in leaves})     # :352
+        opt.step({k: leaves[k].grad for k in keys if k in leaves and leaves[k].requires_grad})     # :352
         enforce_valid_params(scene_config, opt)                        # :353
-        history.append(float(loss_value.detach()))
+        total = allreduce_scalar(loss_value.detach()) if shard.partitioned else loss_value.detach()
+        history.append(float(total))
         if output_dir and it_i > 0 and opt_config.checkpoint_stride and it_i % opt_config.checkpoint_stride == 0:
             save_params(os.path.join(output_dir, 'params'), scene_config, params, f'{it_i:08d}', scene.medium)
         if progress:
             progress(it_i, history[-1])
     if output_dir and opt_config.checkpoint_final:
-        os.makedirs(os.path.join(output_dir, 'params'), exist_ok=True)
         save_params(os.path.join(output_dir, 'params'), scene_config, params, 'final', scene.medium)
     return scene, params, opt, history

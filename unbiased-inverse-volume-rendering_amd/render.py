@@ -30,7 +30,9 @@ def _grid(scene: Scene, key: str):
 def alloc_grads(scene: Scene, keys=(SIGMA_T_KEY, ALBEDO_KEY)) -> Dict[str, torch.Tensor]:
     """Zeroed gradient grids shaped like the parameters `keys` (an integrator's `param_keys`),
     carved out of ONE flat buffer (`_flat`) so that the multi-GPU all-reduce is a single
-    collective."""
+    collective.  (A fresh buffer per backward: autograd hands these tensors out as `.grad`, so they cannot
+    be pooled; the cost is one caching-allocator hit plus a 256 MiB memset = 0.05 ms at 256^3, and the
+    benchmark's step pays the same memset.)"""
     grids = [_grid(scene, k) for k in keys]
     flat = torch.zeros(sum(g.numel() for g in grids), dtype=torch.float32, device=grids[0].device)
     out, off = {"_flat": flat}, 0
@@ -73,7 +75,11 @@ def render_backward(scene: Scene, integrator, grad_image: torch.Tensor, sensor: 
                     grads: Optional[Dict[str, torch.Tensor]] = None,
                     allreduce: bool = True) -> Dict[str, torch.Tensor]:
     """The H1 sequence (batched.py:212-326) for the local pixels; returns the
-    gradient grids (summed over all ranks when a process group is active)."""
+    gradient grids - summed over all ranks when the pixels were dealt across a process group
+    (`shard.world > 1`); an unsharded call never communicates.  For the sum to be the gradient of
+    the GLOBAL loss, `grad_image` must be the derivative of the global loss with respect to the local
+    pixels (a mean over the local pixels only over-scales it by `world`: use
+    `distributed.local_loss_scale`)."""
     batch = _sensor_batch(scene, sensor, spp, shard)
     sampler = IndependentSampler(seed, spp)
     L, _, state_out = integrator.sample(ADMode.Primal, scene, sampler.clone(), batch)     # :255-264
@@ -83,7 +89,7 @@ def render_backward(scene: Scene, integrator, grad_image: torch.Tensor, sensor: 
     integrator.sample(ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state_out,  # :309-318
                       grads=grads)
     if allreduce:
-        allreduce_gradients(grads)
+        allreduce_gradients(grads, shard=shard or ShardSpec())
     return grads
 
 
