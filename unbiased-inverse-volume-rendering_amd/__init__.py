@@ -10,7 +10,7 @@ from .scene import (ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, ConstantEmitter, Envm
 from .integrators import (ADMode, IndependentSampler, NeRFIntegrator, RayBatch, VolpathSimpleIntegrator, load_dict,
                           register_integrator, sample_tea_32)
 from .opt_config import IntegratorConfig, add_int_config, get_int_config
-from .distributed import ShardSpec, allreduce_gradients, allreduce_scalar, from_environment
+from .distributed import ShardSpec, allreduce_gradients, allreduce_scalar, from_environment, local_loss_scale
 from .render import alloc_grads, render, render_backward, render_primal
 from .batched import gather_ref_values, render_batch, sample_batch, sensors_to_device
 from . import losses
@@ -23,7 +23,7 @@ __all__ = [
     "Scene", "cube_test_scene", "scene_to", "ADMode", "IndependentSampler", "RayBatch",
     "VolpathSimpleIntegrator", "NeRFIntegrator", "load_dict", "register_integrator", "sample_tea_32", "IntegratorConfig",
     "add_int_config", "get_int_config", "ShardSpec", "allreduce_gradients", "allreduce_scalar",
-    "from_environment", "alloc_grads", "render", "render_backward", "render_primal", "render_batch",
+    "from_environment", "local_loss_scale", "alloc_grads", "render", "render_backward", "render_primal", "render_batch",
     "gather_ref_values", "sample_batch", "sensors_to_device", "losses", "Adam", "SGD", "OptimizationConfig",
     "SceneConfig", "Schedule", "adjusted_majorant_res_factor", "enforce_valid_params", "run_optimization",
     "save_params", "upsample_grid", "read_vol", "write_vol",

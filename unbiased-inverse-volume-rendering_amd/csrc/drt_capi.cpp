@@ -732,7 +732,8 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
     {
         size_t nbx = ((size_t) res[0] + 2) / 3, nby = ((size_t) res[1] + 2) / 3;
         size_t floats = nbx * nby * (size_t) res[2] * 32;
-        if (nbx * nby * (size_t) res[2] > 0x7ffffffull || res[0] > 21000 || res[1] > 21000)
+        if (nbx * nby * (size_t) res[2] > 0x7ffffffull || res[0] > 21000 || res[1] > 21000 || nbx * nby >= (1u << 24) ||
+            res[2] >= (1 << 24))                                   // eval_sigma_t indexes with 24-bit multiplies
             return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the apron-brick copy");
         if (floats != h->sigma_b_floats) {
             DeviceGuard g(h->device);

@@ -74,7 +74,11 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
     return ((uint64_t) hi << 32) | lo;
 }
 
-template <bool COUNT, bool ENV, bool DEFER>
+// SPEC: the registered `volpathsimple-drt` estimator (use_nee, use_drt, use_drt_subsampling all on; use_drt_mis stays a
+// runtime flag) as compile-time constants: the in-loop quadratic DRT branch - a second inlined copy of the whole
+// recursive path - and the flag tests disappear from the production kernels (smaller code, fewer live registers
+// across the bounce loop).  Every other configuration runs the generic instantiation.
+template <bool COUNT, bool ENV, bool DEFER, bool SPEC = false>
 struct CoopTracer {
     const Params &P;
     float maj, inv_maj;
@@ -95,6 +99,9 @@ struct CoopTracer {
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
     __device__ __forceinline__ void count(int slot) { if (COUNT) cnt[slot]++; }
+    __device__ __forceinline__ bool use_nee() const { return SPEC ? true : P.use_nee != 0; }
+    __device__ __forceinline__ bool use_drt() const { return SPEC ? true : P.use_drt != 0; }
+    __device__ __forceinline__ bool use_sub() const { return SPEC ? true : P.use_drt_subsampling != 0; }
 
     __device__ __forceinline__ uint64_t pcg_jump(uint64_t state, uint64_t inc, int k) const
     {
@@ -348,7 +355,7 @@ struct CoopTracer {
     __device__ void sample_recursive(bool job, Pcg32 &A, V3 p, int depth, float Li[3])
     {
         Li[0] = Li[1] = Li[2] = 0.0f;
-        if (P.use_nee) {                                                        // :621-624 (wave-uniform condition)
+        if (use_nee()) {                                                        // :621-624 (wave-uniform condition)
             const float one[3] = { 1.0f, 1.0f, 1.0f };
             float nee[3];
             sample_emitter_for_nee<false>(job, p, A, one, nullptr, nee);
@@ -404,8 +411,7 @@ struct CoopTracer {
                 gs += a * alb[k];
                 ga[k] = a * sig;
             }
-            splat_sigma_t<DEFER>(P, p, gs, rec); count(C_SC);                   // :577-581
-            splat_albedo<DEFER>(P, p, ga, rec);  count(C_SC_ALB);
+            splat_scatter<DEFER>(P, p, gs, ga, rec); count(C_SC); count(C_SC_ALB);   // :577-581
         }
     }
 
@@ -493,8 +499,8 @@ struct CoopTracer {
             if (did_scatter) { eval_albedo(P, mei.p, albedo); count(C_ALB); }
 
             if constexpr (ADJ) {
-                if (P.use_drt) {                                                // :143-150
-                    if (P.use_drt_subsampling) {                                // :521-539, :745-753
+                if (use_drt()) {                                                // :143-150
+                    if (use_sub()) {                                            // :521-539, :745-753
                         if (run) {
                             float u = A.next_1d();
                             float mm = 0.0f;
@@ -506,15 +512,15 @@ struct CoopTracer {
                                 r_depth = depth; r_si_t = si.t; r_ray = ray;
                             }
                         }
-                    } else {
+                    } else if constexpr (!SPEC) {
                         float adj[3] = { 0.0f, 0.0f, 0.0f };
                         if (run) { adj[0] = dL[0] * beta[0]; adj[1] = dL[1] * beta[1]; adj[2] = dL[2] * beta[2]; }
                         drt_backprop(run, A, ray, si.t, depth, adj);
                     }
                 }
-                if ((!P.use_drt || P.use_drt_mis) && did_scatter) {             // :152-172
+                if ((!use_drt() || P.use_drt_mis) && did_scatter) {             // :152-172
                     float w = 1.0f;
-                    if (P.use_drt && P.use_drt_mis) {
+                    if (use_drt() && P.use_drt_mis) {
                         float s2 = mei.sigma_t * mei.sigma_t;
                         w = s2 / (1.0f + s2);
                     }
@@ -527,8 +533,7 @@ struct CoopTracer {
                         gs += a * albedo[k];
                         ga[k] = a * mei.sigma_t;
                     }
-                    splat_sigma_t<DEFER>(P, mei.p, gs, rec); count(C_SC);
-                    splat_albedo<DEFER>(P, mei.p, ga, rec);  count(C_SC_ALB);
+                    splat_scatter<DEFER>(P, mei.p, gs, ga, rec); count(C_SC); count(C_SC_ALB);
                 }
                 if (run) backprop_transmittance(A, ray, did_escape ? si.t : mei.t, dL, result);   // :181-189
             }
@@ -538,9 +543,9 @@ struct CoopTracer {
                 beta[0] *= albedo[0]; beta[1] *= albedo[1]; beta[2] *= albedo[2];   // :193
                 if (did_scatter) depth += 1;                                    // :199
                 active = did_scatter && (depth < P.max_depth);                  // :200
-                nee_job = P.use_nee && did_scatter && active;                   // :206-215
+                nee_job = use_nee() && did_scatter && active;                   // :206-215
             }
-            if (P.use_nee) {
+            if (use_nee()) {
                 float nee[3];
                 sample_emitter_for_nee<ADJ>(nee_job, mei.p, S, beta, dL, nee, nee_job ? cmode : 0, ce ? ce + 1 : nullptr);
                 if (nee_job) {
@@ -568,7 +573,7 @@ struct CoopTracer {
         }
 
         if constexpr (ADJ) {
-            if (P.use_drt && P.use_drt_subsampling) {                           // :249-259, :756-760
+            if (use_drt() && use_sub()) {                                       // :249-259, :756-760
                 const bool rjob = job && r_depth >= 0;
                 float adj[3] = { 0.0f, 0.0f, 0.0f };
                 if (rjob) {
@@ -582,7 +587,7 @@ struct CoopTracer {
         } else {                                                                // :263-287
             if (job && escaped && !(depth <= 0 && P.hide_emitters)) {
                 float w = 1.0f, Le[3];
-                if (P.use_nee) {
+                if (use_nee()) {
                     float epdf = 0.0f;                                          // :273-277
                     if (has_scattered) epdf = emitter_pdf<ENV>(P, ray.d);
                     w = mis_weight(last_pdf, epdf);
@@ -596,7 +601,7 @@ struct CoopTracer {
     }
 };
 
-template <bool ADJ, bool COUNT, bool ENV, bool DEFER>
+template <bool ADJ, bool COUNT, bool ENV, bool DEFER, bool SPEC = false>
 __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const Params P)
 {
     uint32_t b = blockIdx.x;                                    // XCD-aware block -> ray-chunk map (see trace_kernel)
@@ -613,7 +618,7 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
     }
 #endif
     uint64_t i = P.ray_first + (uint64_t) b * blockDim.x + threadIdx.x;
-    CoopTracer<COUNT, ENV, DEFER> tr(P);
+    CoopTracer<COUNT, ENV, DEFER, SPEC> tr(P);
     __shared__ uint32_t slot_lds[4 * 64];
     tr.slots = slot_lds + (threadIdx.x >> 6) * 64;
     __shared__ uint64_t jump_lds[2 * (kJumpMax + 1)];
@@ -768,6 +773,10 @@ hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStrea
     dim3 block(256), grid((unsigned)((P.n_rays - P.ray_first + 255) / 256));
     const bool env = P.env_pix != nullptr, defer = adjoint && P.rec_buf[0] != nullptr;
 #define DRT_COOP_LAUNCH(A, C, E, D) hipLaunchKernelGGL((trace_coop_kernel<A, C, E, D>), grid, block, 0, stream, P)
+    // the registered `volpathsimple-drt` configuration with the constant emitter: specialised kernels
+    const bool spec = P.use_nee && P.use_drt && P.use_drt_subsampling && !count && !env && !(P.debug_flags & 2097152u);
+    if (spec && !adjoint) { hipLaunchKernelGGL((trace_coop_kernel<false, false, false, false, true>), grid, block, 0, stream, P); return hipGetLastError(); }
+    if (spec && defer) { hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true>), grid, block, 0, stream, P); return hipGetLastError(); }
     if (!adjoint) {
         if (count) { if (env) DRT_COOP_LAUNCH(false, true, true, false); else DRT_COOP_LAUNCH(false, true, false, false); }
         else       { if (env) DRT_COOP_LAUNCH(false, false, true, false); else DRT_COOP_LAUNCH(false, false, false, false); }

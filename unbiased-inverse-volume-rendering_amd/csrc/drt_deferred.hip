@@ -3,28 +3,32 @@
 // The adjoint tracer emits ~14 trilinear splats per ray (volpathsimple.py:170,489,580,594,607).  As
 // global fp32 atomics they cost one L2 atomic request per splat and plane, and the chip retires only
 // ~21 G requests/s: 8.6 of the adjoint's 21.8 ms.  Here the tracer appends
-// 16-byte records {p, value} to per-plane streams instead (emit_record, drt_device.h) and this file
-// turns them into gradients with streaming passes only:
+// records to two streams instead (emit_record, drt_device.h) - stream 0: 16 bytes {p, g_sigma_t}; stream 1:
+// 32 bytes {p, g_sigma_t, g_r, g_g, g_b} for the splats that carry all four channels at one point (scatter
+// events, nerf queries) - and this file turns them into gradients with streaming passes only:
 //
 //   bin_histogram  records -> per-(workgroup, tile) counts            (LDS histogram)
 //   bin_offsets    counts  -> exclusive offsets, tile bases, reduce units
 //   bin_scatter    records -> tile-sorted copy                         (LDS cursors)
-//   tile_reduce    workgroups walk runs of <= kUnitRecords-record units of ONE tile: trilinear weights
-//                  recomputed (same axis_setup / stencil_weights as the lookup), 8 LDS adds per record
-//                  into a (32+1)x(16+1)x(16+1) tile, then one coalesced flush of the non-zero tile
-//                  entries into the caller's gradient grid (+=, fp32 atomics: ~10^7 per launch instead
-//                  of ~10^9 lane-atomics).
+//   tile_reduce    workgroups walk runs of <= kUnitRecords-record units of ONE tile and ONE gradient plane
+//                  (stream 0 -> sigma_t; stream 1 -> sigma_t, r, g, b: four passes over the sorted records, which
+//                  stay in the memory-side cache): trilinear weights recomputed (same axis_setup / stencil_weights
+//                  as the lookup), 8 LDS adds per record into a (32+1)x(16+1)x(16+1) tile, then one coalesced
+//                  flush of the non-zero tile entries into the caller's gradient grid (+=, fp32 atomics: ~10^7
+//                  per launch instead of ~10^9 lane-atomics).
 //
 // The LDS accumulators are 64-bit FIXED POINT: on gfx950 ds_add_f32 retires 0.2 T lane-atomics/s but
 // ds_add_u64 3.4 T/s (tools/ubench/lds_atomic_rate.hip; the fp32 version of this kernel took 5.3 ms,
 // 4.9 of them in ds_add_f32).  Every float product w*v is scaled by a power of two chosen from the
-// stream's max |v| (found by the histogram pass) so that |w*v| * scale < 2^40 and rounded to an
+// plane's max |v| (found by the histogram pass) so that |w*v| * scale < 2^40 and rounded to an
 // integer: quantisation 2^-41 max|v| per add, exact and order-independent sums inside a tile.
+// A non-finite value poisons its plane's maximum: the tile then takes a float path that PROPAGATES the
+// NaN / inf into the gradient exactly as the atomic path would (no silent clamping).
 //
 // A tile is addressed by the BASE corner cell of the splat, so its footprint is the tile plus a
-// one-voxel apron on the high side.  Streams: 0 = sigma_t (value already times `scale`), 1..3 = the
-// colour planes of albedo / emission.  Sum order differs from the atomic path (as it does between
-// two runs of the atomic path); the parity tolerance on gradients is unchanged.
+// one-voxel apron on the high side.  The sigma_t values already carry the medium `scale`.  Sum order differs
+// from the atomic path (as it does between two runs of the atomic path); the parity tolerance on gradients
+// is unchanged.
 #include "drt_device.h"
 #include "drt_launch.h"
 
@@ -68,43 +72,63 @@ __device__ __forceinline__ int bin_of(const Params &P, const DeferredPlan &D, fl
     return ((z0 / kTileZ) * D.nty + (y0 / kTileY)) * D.ntx + (x0 / kTileX);
 }
 
+// max |v| over finite values; a non-finite value returns +inf bits so that the plane is reduced on the
+// propagating float path (tile_reduce)
+__device__ __forceinline__ float plane_max(float vmax, float v)
+{
+    const float a = fabsf(v);
+    if (!(a <= 3.0e38f)) return kInf;                            // inf or NaN
+    return a > vmax ? a : vmax;
+}
+
+template <int S>
 __global__ void __launch_bounds__(kPartThreads) bin_histogram_kernel(const Params P, const DeferredPlan D)
 {
     extern __shared__ uint32_t h[];
-    const int s = blockIdx.y;
+    constexpr int kPlanes = S == 0 ? 1 : 4, kQuads = S == 0 ? 1 : 2;
     for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) h[b] = 0;
     __syncthreads();
-    const uint32_t used = min(D.cursor[s], D.cap_chunks[s]);
-    float vmax = 0.0f;
+    const uint32_t used = min(D.cursor[S], D.cap_chunks[S]);
+    float vmax[kPlanes];
+#pragma unroll
+    for (int c = 0; c < kPlanes; ++c) vmax[c] = 0.0f;
     static_assert(kRecChunk == 256, "one record per thread and chunk");
     // chunk -> workgroup map (shared with the scatter pass): workgroup g owns chunks g*kSub + sub (mod stride)
     constexpr uint32_t kSub = kPartThreads / 256;                  // chunks a workgroup reads side by side
     const uint32_t sub = threadIdx.x >> 8, rec = threadIdx.x & 255u;
     for (uint32_t c0 = blockIdx.x * kSub + sub; c0 < used; c0 += kPartUnroll * kSub * gridDim.x) {
-        float4 r[kPartUnroll]; bool ok[kPartUnroll];
+        float4 r[kPartUnroll], q[kPartUnroll]; bool ok[kPartUnroll];
 #pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) {                   // kPartUnroll chunks in flight per thread
             const uint32_t c = c0 + k * kSub * gridDim.x;
-            ok[k] = c < used && rec < D.chunk_count[s][c];
-            if (ok[k]) r[k] = D.in[s][(size_t) c * kRecChunk + rec];
+            ok[k] = c < used && rec < D.chunk_count[S][c];
+            if (ok[k]) {
+                const float4 *src = D.in[S] + ((size_t) c * kRecChunk + rec) * kQuads;
+                r[k] = src[0];
+                if constexpr (S == 1) q[k] = src[1];
+            }
         }
 #pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) {
             if (!ok[k]) continue;
             atomicAdd(&h[bin_of(P, D, r[k])], 1u);
-            const float a = fabsf(r[k].w);
-            if (a > vmax && a <= 3.0e38f) vmax = a;               // finite values only
+            vmax[0] = plane_max(vmax[0], r[k].w);
+            if constexpr (S == 1) { vmax[1] = plane_max(vmax[1], q[k].x); vmax[2] = plane_max(vmax[2], q[k].y); vmax[3] = plane_max(vmax[3], q[k].z); }
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-    __shared__ uint32_t wg_vmax;                                 // one global atomic per workgroup, not per wave
-    if (threadIdx.x == 0) wg_vmax = 0u;
+    __shared__ uint32_t wg_vmax[4];                              // one global atomic per workgroup and plane, not per wave
+    if (threadIdx.x < 4) wg_vmax[threadIdx.x] = 0u;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(&wg_vmax, __float_as_uint(vmax));
+#pragma unroll
+    for (int c = 0; c < kPlanes; ++c) {
+        float v = vmax[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+        if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(&wg_vmax[c], __float_as_uint(v));
+    }
     lds_atomics_barrier();
-    if (threadIdx.x == 0 && wg_vmax) atomicMax(D.vmax + s, wg_vmax);
-    uint32_t *dst = D.hist + ((size_t) s * gridDim.x + blockIdx.x) * D.n_bins;
+    if (threadIdx.x < kPlanes && wg_vmax[threadIdx.x]) atomicMax(D.vmax + (S == 0 ? 0 : 1) + threadIdx.x, wg_vmax[threadIdx.x]);
+    uint32_t *dst = D.hist + ((size_t) S * gridDim.x + blockIdx.x) * D.n_bins;
     for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) dst[b] = h[b];
 }
 
@@ -161,42 +185,56 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const DeferredPlan D)
     if (t == 1023) { base[D.n_bins] = sa[t]; ustart[D.n_bins] = sb[t]; }
 }
 
+template <int S>
 __global__ void __launch_bounds__(kPartThreads) bin_scatter_kernel(const Params P, const DeferredPlan D)
 {
     extern __shared__ uint32_t cur[];
-    const int s = blockIdx.y;
-    const uint32_t *off = D.hist + ((size_t) s * gridDim.x + blockIdx.x) * D.n_bins;
-    const uint32_t *base = D.bin_base + (size_t) s * (D.n_bins + 1);
+    constexpr int kQuads = S == 0 ? 1 : 2;
+    const uint32_t *off = D.hist + ((size_t) S * gridDim.x + blockIdx.x) * D.n_bins;
+    const uint32_t *base = D.bin_base + (size_t) S * (D.n_bins + 1);
     for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) cur[b] = base[b] + off[b];
     __syncthreads();
-    const uint32_t used = min(D.cursor[s], D.cap_chunks[s]);
-    float4 *dst = D.out[s];
+    const uint32_t used = min(D.cursor[S], D.cap_chunks[S]);
+    float4 *dst = D.out[S];
     constexpr uint32_t kSub = kPartThreads / 256;
     const uint32_t sub = threadIdx.x >> 8, rec = threadIdx.x & 255u;
     for (uint32_t c0 = blockIdx.x * kSub + sub; c0 < used; c0 += kPartUnroll * kSub * gridDim.x) {   // same map as the histogram
-        float4 r[kPartUnroll]; bool ok[kPartUnroll];
+        float4 r[kPartUnroll], q[kPartUnroll]; bool ok[kPartUnroll];
 #pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) {
             const uint32_t c = c0 + k * kSub * gridDim.x;
-            ok[k] = c < used && rec < D.chunk_count[s][c];
-            if (ok[k]) r[k] = D.in[s][(size_t) c * kRecChunk + rec];
+            ok[k] = c < used && rec < D.chunk_count[S][c];
+            if (ok[k]) {
+                const float4 *src = D.in[S] + ((size_t) c * kRecChunk + rec) * kQuads;
+                r[k] = src[0];
+                if constexpr (S == 1) q[k] = src[1];
+            }
         }
         uint32_t slot[kPartUnroll];
 #pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) if (ok[k]) slot[k] = atomicAdd(&cur[bin_of(P, D, r[k])], 1u);
 #pragma unroll
-        for (int k = 0; k < kPartUnroll; ++k) if (ok[k]) dst[slot[k]] = r[k];
+        for (int k = 0; k < kPartUnroll; ++k) if (ok[k]) {
+            float4 *o = dst + (size_t) slot[k] * kQuads;
+            o[0] = r[k];
+            if constexpr (S == 1) o[1] = q[k];
+        }
     }
 }
 
+// blockIdx.y = reduce plane: 0: stream 0 -> sigma_t; 1..4: stream 1 -> sigma_t, r, g, b
 __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const DeferredPlan D)
 {
     extern __shared__ unsigned long long tile[];                 // kLdsTile signed 64-bit fixed-point accumulators
-    const int s = blockIdx.y;
+    const int plane = blockIdx.y;
+    const int s = plane == 0 ? 0 : 1, ch = plane == 0 ? 0 : plane - 1;        // stream, channel of the record
+    const int quads = s == 0 ? 1 : 2;
     // scale = 2^(40 - e) with max|v| < 2^e: |w * v| * scale < 2^40, 2^23 such adds fit an int64
-    const float vmax = __uint_as_float(D.vmax[s]);
+    const float vmax = __uint_as_float(D.vmax[plane]);
+    if (vmax == 0.0f) return;                                    // nothing but zeros in this plane
+    const bool finite = vmax <= 3.0e38f;                         // a NaN / inf anywhere in the plane: float path below
     int e = 0;
-    (void) frexpf(vmax, &e);
+    (void) frexpf(finite ? vmax : 1.0f, &e);
     const double scale = ldexp(1.0, 40 - e), inv_scale = ldexp(1.0, e - 40);
     const uint32_t *base = D.bin_base + (size_t) s * (D.n_bins + 1);
     const uint32_t *ustart = D.unit_start + (size_t) s * (D.n_bins + 1);
@@ -205,8 +243,8 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
     // units of a heavy tile follow one another, so the LDS tile is zeroed / flushed once per run
     const uint32_t u_begin = (uint32_t) (((uint64_t) n_units * blockIdx.x) / gridDim.x);
     const uint32_t u_end = (uint32_t) (((uint64_t) n_units * (blockIdx.x + 1)) / gridDim.x);
-    float *dst = s == 0 ? P.g_sigma : P.g_albedo + (s - 1);
-    const int stride = s == 0 ? 1 : 3;
+    float *dst = ch == 0 ? P.g_sigma : P.g_albedo + (ch - 1);
+    const int stride = ch == 0 ? 1 : 3;
     const float4 *src = D.out[s];
     int b = -1, X0 = 0, Y0 = 0, Z0 = 0;
     for (uint32_t u = u_begin; u <= u_end; ++u) {
@@ -218,20 +256,15 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
         }
         if (nb == b && nb < 0) break;                             // no units at all for this workgroup
         if (nb != b) {
-            if (b >= 0 && !(P.debug_flags & 1024u)) {             // flush the finished tile (+=)
+            if (b >= 0 && finite && !(P.debug_flags & 1024u)) {   // flush the finished tile (+=)
                 lds_atomics_barrier();
                 for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) {
                     const long long q = (long long) tile[j];
                     if (q == 0) continue;
-                    if (P.debug_flags & 8192u) atomicAdd((unsigned long long *) (D.cursor + 12) + s, (unsigned long long) q);   // exact checksum of what is flushed
+                    if (P.debug_flags & 8192u) atomicAdd((unsigned long long *) (D.cursor + 12) + plane, (unsigned long long) q);   // exact checksum of what is flushed
                     const float v = (float) ((double) q * inv_scale);
                     const int lx = j % (kTileX + 1), ly = (j / (kTileX + 1)) % (kTileY + 1), lz = j / ((kTileX + 1) * (kTileY + 1));
                     const size_t vox = ((size_t) (Z0 + lz) * P.ry + (Y0 + ly)) * P.rx + (X0 + lx);
-                    if (P.debug_flags & 4096u) {                      // experiment: compare-and-swap loop instead of the hardware fp32 add
-                        unsigned int *a = (unsigned int *) (dst + (size_t) stride * vox);
-                        unsigned int old = *a, assumed;
-                        do { assumed = old; old = atomicCAS(a, assumed, __float_as_uint(__uint_as_float(assumed) + v)); } while (old != assumed);
-                    } else
                     atomicAdd(dst + (size_t) stride * vox, v);
                 }
                 __syncthreads();
@@ -239,25 +272,45 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
             if (nb < 0) break;
             b = nb;
             X0 = (b % D.ntx) * kTileX; Y0 = ((b / D.ntx) % D.nty) * kTileY; Z0 = (b / (D.ntx * D.nty)) * kTileZ;
-            for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) tile[j] = 0ull;
-            __syncthreads();
+            if (finite) {
+                for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) tile[j] = 0ull;
+                __syncthreads();
+            }
         }
         const uint32_t first = base[b] + (u - ustart[b]) * kUnitRecords;
         const uint32_t last = min(first + kUnitRecords, base[b + 1]);
         for (uint32_t i0 = first + threadIdx.x; i0 < last; i0 += 4 * blockDim.x) {
-            float4 rr[4];
+            float4 rr[4]; float vv[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (i0 + k * blockDim.x < last) rr[k] = src[i0 + k * blockDim.x];
+            for (int k = 0; k < 4; ++k) if (i0 + k * blockDim.x < last) {
+                const float4 *rp = src + (size_t) (i0 + k * blockDim.x) * quads;
+                rr[k] = rp[0];
+                vv[k] = rr[k].w;
+                if (s == 1 && ch > 0) { const float4 c4 = rp[1]; vv[k] = ch == 1 ? c4.x : (ch == 2 ? c4.y : c4.z); }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
             if (i0 + k * blockDim.x >= last) break;
             const float4 r = rr[k];
+            const float val = vv[k];
+            if (val == 0.0f) continue;                            // adding exact zeros changes nothing
             Stencil st;
             axis_setup(r.x, P.bmin[0], P.inv_ext[0], P.rx, st.x0, st.x1, st.wx0, st.wx1);
             axis_setup(r.y, P.bmin[1], P.inv_ext[1], P.ry, st.y0, st.y1, st.wy0, st.wy1);
             axis_setup(r.z, P.bmin[2], P.inv_ext[2], P.rz, st.z0, st.z1, st.wz0, st.wz1);
             float w[8];
             stencil_weights(st, w);
+            if (!finite) {
+                // a non-finite gradient value somewhere in this plane: add the float products straight to the
+                // caller's grid, as the atomic path does - NaN / inf propagate instead of being clamped away
+                const int gx[2] = { st.x0, st.x1 }, gy[2] = { st.y0, st.y1 }, gz[2] = { st.z0, st.z1 };
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const size_t vox = ((size_t) gz[c >> 2] * P.ry + gy[(c >> 1) & 1]) * P.rx + gx[c & 1];
+                    atomicAdd(dst + (size_t) stride * vox, w[c] * val);
+                }
+                continue;
+            }
             const int x0 = st.x0 - X0, x1 = st.x1 - X0;
             const int y0 = (st.y0 - Y0) * (kTileX + 1), y1 = (st.y1 - Y0) * (kTileX + 1);
             const int z0 = (st.z0 - Z0) * ((kTileX + 1) * (kTileY + 1)), z1 = (st.z1 - Z0) * ((kTileX + 1) * (kTileY + 1));
@@ -265,9 +318,8 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
                                z1 + y0 + x0, z1 + y0 + x1, z1 + y1 + x0, z1 + y1 + x1 };
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float pv = w[c] * r.w;                       // the float product the atomic path adds
-                const float pc = fminf(fmaxf(pv, -vmax), vmax);    // non-finite input cannot wrap the accumulator
-                atomicAdd(&tile[o[c]], (unsigned long long) __double2ll_rn((double) pc * scale));
+                const float pv = w[c] * val;                       // the float product the atomic path adds (|pv| <= vmax)
+                atomicAdd(&tile[o[c]], (unsigned long long) __double2ll_rn((double) pv * scale));
             }
             }
         }
@@ -281,20 +333,19 @@ hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStr
     const size_t lds = (size_t) D.n_bins * sizeof(uint32_t);
     auto mark = [&](int k) { if (ev) (void) hipEventRecord(ev[k], stream); };
     mark(0);
-    hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, 4), dim3(kPartThreads), lds, stream, P, D);
+    hipLaunchKernelGGL(bin_histogram_kernel<0>, dim3(kPartWGs), dim3(kPartThreads), lds, stream, P, D);
+    hipLaunchKernelGGL(bin_histogram_kernel<1>, dim3(kPartWGs), dim3(kPartThreads), lds, stream, P, D);
     mark(1);
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3((D.n_bins + 3) / 4, 4), dim3(256), 0, stream, D, kPartWGs);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(4), dim3(1024), 0, stream, D);
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3((D.n_bins + 3) / 4, kRecStreams), dim3(256), 0, stream, D, kPartWGs);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(kRecStreams), dim3(1024), 0, stream, D);
     mark(2);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(kPartWGs, 4), dim3(kPartThreads), lds, stream, P, D);
+    hipLaunchKernelGGL(bin_scatter_kernel<0>, dim3(kPartWGs), dim3(kPartThreads), lds, stream, P, D);
+    hipLaunchKernelGGL(bin_scatter_kernel<1>, dim3(kPartWGs), dim3(kPartThreads), lds, stream, P, D);
     mark(3);
-    static const int lds_tile = [] { const char *e = getenv("DRT_REDUCE_LDS"); int v = e ? atoi(e) : 0; return v > kLdsTile * 8 ? v : kLdsTile * 8; }();
-    static const hipError_t attr = hipFuncSetAttribute((const void *) tile_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tile);
+    static const hipError_t attr = hipFuncSetAttribute((const void *) tile_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTile * 8);
     if (attr != hipSuccess) return attr;
-    static const uint32_t wgs_env = [] { const char *e = getenv("DRT_REDUCE_WGS"); return e ? (uint32_t) atoi(e) : 0u; }();
-    const uint32_t wgs = wgs_env ? wgs_env : (D.max_units < kReduceWGs ? D.max_units : kReduceWGs);
-    hipLaunchKernelGGL(tile_reduce_kernel, dim3(wgs, 4), dim3(256),
-                       (size_t) lds_tile, stream, P, D);
+    const uint32_t wgs = D.max_units < kReduceWGs ? D.max_units : kReduceWGs;
+    hipLaunchKernelGGL(tile_reduce_kernel, dim3(wgs, 5), dim3(256), (size_t) kLdsTile * 8, stream, P, D);
     mark(4);
     return hipGetLastError();
 }

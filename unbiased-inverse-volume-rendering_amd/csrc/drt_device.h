@@ -241,14 +241,17 @@ struct Params {
     float *gt;                 // plane c at gt + c * gt_plane
     uint32_t gt_plane;         // floats per plane = nbx * ry * rz * 16
     int gt_nbx;                // lines per grid row = ceil(rx / 3)
-    // Deferred splatting (adjoint, drt_deferred.hip): instead of atomics the tracer appends 16-byte
-    // records {p.x, p.y, p.z, value} to stream 0 (sigma_t) / 1..3 (colour planes), in chunks of
-    // kRecChunk records handed out by rec_cursor[s]; the records are then partitioned by grid tile and
-    // reduced in LDS.  rec_buf[0] == nullptr: the atomic path (apron scratch) is used.
-    float4 *rec_buf[4];
-    uint32_t *rec_chunk_count[4];   // valid records per chunk (zeroed per launch)
-    uint32_t rec_cap_chunks[4];     // chunks available per stream
-    uint32_t *rec_cursor;           // [0..3] chunks handed out, [4..7] splats that overflowed (direct atomics)
+    // Deferred splatting (adjoint, drt_deferred.hip): instead of atomics the tracer appends records to two
+    // streams, in chunks of kRecChunk records handed out by rec_cursor[s]; the records are then partitioned
+    // by grid tile and reduced in LDS.  rec_buf[0] == nullptr: the atomic path (apron scratch) is used.
+    //   stream 0: 16-byte records {p.x, p.y, p.z, g_sigma_t}                     (float4)
+    //   stream 1: 32-byte records {p.x, p.y, p.z, g_sigma_t, g_r, g_g, g_b, 0}   (2 x float4): the splats that carry
+    //             all four gradient channels at one point - scatter events (sigma_t + albedo, volpathsimple.py:170,580)
+    //             and nerf queries (sigma_t + emission, nerf.py:122-129) - one append instead of four
+    float4 *rec_buf[2];
+    uint32_t *rec_chunk_count[2];   // valid records per chunk (zeroed per launch)
+    uint32_t rec_cap_chunks[2];     // chunks available per stream
+    uint32_t *rec_cursor;           // [0..1] chunks handed out, [4..5] splats that overflowed (direct atomics)
     // Path cache (drt_coop.hip): the primal pass of an H1 step records, per ray and bounce-loop iteration,
     // what its delta-tracking walk and its NEE transmittance walk returned (distance / transmittance, the
     // sampler state behind them, their step counts); the adjoint pass of the SAME job reads them instead of
@@ -505,21 +508,28 @@ __device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p, const uint3
     axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, s.x0, s.x1, s.wx0, s.wx1);
     axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, s.y0, s.y1, s.wy0, s.wy1);
     axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, s.z0, s.z1, s.wz0, s.wz1);
+    // index arithmetic with 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 issue at the full rate, v_mul_lo_u32
+    // at less than half of it - tools/ubench/valu_issue.hip); every operand below is < 2^24 (drt_set_medium checks)
     if (occ) {
-        const int c = ((s.z0 >> P.occ_shift) * P.occ_y + (s.y0 >> P.occ_shift)) * P.occ_x + (s.x0 >> P.occ_shift);
-        if (!((occ[c >> 5] >> (c & 31)) & 1u)) return 0.0f;      // all 8 corners are exactly 0
+        const uint32_t c = __umul24(__umul24((uint32_t) s.z0 >> P.occ_shift, (uint32_t) P.occ_y) + ((uint32_t) s.y0 >> P.occ_shift),
+                                    (uint32_t) P.occ_x) + ((uint32_t) s.x0 >> P.occ_shift);
+        if (!((occ[c >> 5] >> (c & 31u)) & 1u)) return 0.0f;     // all 8 corners are exactly 0
     }
     // x0 / 3 and x0 % 3 for x0 < 65536 / 3 (multiply-shift)
-    const uint32_t bx = ((uint32_t) s.x0 * 43691u) >> 17, by = ((uint32_t) s.y0 * 43691u) >> 17;
+    const uint32_t bx = __umul24((uint32_t) s.x0, 43691u) >> 17, by = __umul24((uint32_t) s.y0, 43691u) >> 17;
     const uint32_t ox = (uint32_t) s.x0 - 3u * bx, oy = (uint32_t) s.y0 - 3u * by;
-    const float *g = P.sigma_b + ((size_t) ((uint32_t) s.z0 * (uint32_t) P.sb_zstride + by * (uint32_t) P.sb_ystride + bx) << 5)
+    const float *g = P.sigma_b + ((size_t) (__umul24((uint32_t) s.z0, (uint32_t) P.sb_zstride) + __umul24(by, (uint32_t) P.sb_ystride) + bx) << 5)
                    + (oy << 2) + ox;
     // the line stores clamped neighbours itself, so +1 / +4 / +16 are always the right corners
     float d0 = g[0], d1 = g[1], d2 = g[4], d3 = g[5], d4 = g[16], d5 = g[17], d6 = g[20], d7 = g[21];
-    // lower clamp (floor(q) = -1): both corners of that axis are voxel 0 (axis_setup), not 0 and 1
-    if (s.x1 == s.x0) { d1 = d0; d3 = d2; d5 = d4; d7 = d6; }
-    if (s.y1 == s.y0) { d2 = d0; d3 = d1; d6 = d4; d7 = d5; }
-    if (s.z1 == s.z0) { d4 = d0; d5 = d1; d6 = d2; d7 = d3; }
+    // lower clamp (floor(q) = -1): both corners of that axis are voxel 0 (axis_setup), not 0 and 1.  Only lookups
+    // within half a voxel of the box surface get here: one wave-level test keeps the 15 selects out of the common path
+    const bool border = s.x1 == s.x0 || s.y1 == s.y0 || s.z1 == s.z0;
+    if (__builtin_expect(__ballot(border) != 0ull, 0)) {
+        if (s.x1 == s.x0) { d1 = d0; d3 = d2; d5 = d4; d7 = d6; }
+        if (s.y1 == s.y0) { d2 = d0; d3 = d1; d6 = d4; d7 = d5; }
+        if (s.z1 == s.z0) { d4 = d0; d5 = d1; d6 = d2; d7 = d3; }
+    }
     return trilerp8(s, d0, d1, d2, d3, d4, d5, d6, d7) * P.scale;
 }
 
@@ -608,23 +618,25 @@ __device__ __forceinline__ void coop_scatter(float *dst, uint32_t chan_stride, c
 }
 
 // ---------------------------------------------------------------------------
-// Deferred splatting: record append.  `st` = the wave's LDS state {cur[4], end[4]} (absolute record
-// slots of the stream's open chunk).  Called under divergence: the active lanes compact themselves
-// (ballot / prefix), the first one advances the cursor - taking a fresh chunk from the global counter
-// when the open one fills up, so chunks are always full except each wave's last - and every lane
-// stores its record with one 16-byte write.  Out of chunks: the splat goes straight to the caller's
-// grid with 8 atomics (slow, correct; counted in rec_cursor[4+s]).
+// Deferred splatting: record append.  `st` = the wave's LDS state {cur[2], -, -, end[2]} (absolute record
+// slots of the stream's open chunk group).  Called under divergence: the active lanes compact themselves
+// (ballot / prefix), the first one advances the cursor - taking fresh chunks from the global counter
+// when the open ones fill up, so chunks are always full except each wave's last - and every lane
+// stores its record with one (stream 0) or two (stream 1) 16-byte writes.  Out of chunks: the splat goes
+// straight to the caller's grids with atomics (slow, correct; counted in rec_cursor[4+s]).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRecChunk = 256;
-constexpr uint32_t kRecGroup0 = 4;      // sigma_t stream: chunks handed out per allocation
+constexpr uint32_t kRecStreams = 2;
+// chunks handed out per allocation (every wave fills several: fewer same-address returning atomics on the cursor)
+__host__ __device__ constexpr uint32_t rec_group(int s) { return s == 0 ? 4u : 2u; }
 
-__device__ __forceinline__ void splat_direct(const Params &P, int s, V3 p, float v)
+__device__ __forceinline__ void splat_direct(const Params &P, int plane, V3 p, float v)
 {
     Stencil st = make_stencil(P, p);
     float w[8];
     stencil_weights(st, w);
-    float *dst = s == 0 ? P.g_sigma : P.g_albedo + (s - 1);
-    const int stride = s == 0 ? 1 : 3;
+    float *dst = plane == 0 ? P.g_sigma : P.g_albedo + (plane - 1);
+    const int stride = plane == 0 ? 1 : 3;
     const int idx[8] = { st.z0 + st.y0 + st.x0, st.z0 + st.y0 + st.x1, st.z0 + st.y1 + st.x0, st.z0 + st.y1 + st.x1,
                          st.z1 + st.y0 + st.x0, st.z1 + st.y0 + st.x1, st.z1 + st.y1 + st.x0, st.z1 + st.y1 + st.x1 };
 #pragma unroll
@@ -636,7 +648,9 @@ __device__ __forceinline__ void splat_direct(const Params &P, int s, V3 p, float
 // instead of FLAT accesses (observed to lose an update now and then under the nerf kernel's emission rate).
 typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
 
-__device__ __forceinline__ void emit_record(const Params &P, int s, V3 p, float v, uint32_t *st_)
+// S = 0: {p, v0};  S = 1: {p, v0, c[0..2]} (c may be nullptr for S = 0)
+template <int S>
+__device__ __forceinline__ void emit_record(const Params &P, V3 p, float v0, const float *c, uint32_t *st_)
 {
     lds_u32 *st = (lds_u32 *) st_;
     const uint64_t mask = __ballot(1);
@@ -645,46 +659,58 @@ __device__ __forceinline__ void emit_record(const Params &P, int s, V3 p, float 
     const uint32_t n = (uint32_t) __popcll(mask);
     uint32_t base0 = 0, base1 = 0, split = 0;
     if (rank == 0) {
-        const uint32_t cur = st[s], end = st[4 + s];
+        const uint32_t cur = st[S], end = st[4 + S];
         base0 = cur;
-        if (cur + n <= end) { split = n; st[s] = cur + n; }
+        if (cur + n <= end) { split = n; st[S] = cur + n; }
         else {
             split = end - cur;
-            // chunks are handed out kRecGroup0 at a time on the busy sigma_t stream (every wave fills several:
-            // fewer same-address returning atomics), one at a time on the colour streams
-            const uint32_t G = s == 0 ? kRecGroup0 : 1u;
+            constexpr uint32_t G = rec_group(S);
             if (end) {                                                              // the open chunks are full
                 const uint32_t last = (end - 1u) / kRecChunk;
-                for (uint32_t j = 0; j < G; ++j) P.rec_chunk_count[s][last - j] = kRecChunk;
+                for (uint32_t j = 0; j < G; ++j) P.rec_chunk_count[S][last - j] = kRecChunk;
             }
-            const uint32_t c = atomicAdd(P.rec_cursor + s, G);
-            if (c + G <= P.rec_cap_chunks[s]) {
-                base1 = c * kRecChunk;
-                st[s] = base1 + (n - split); st[4 + s] = base1 + G * kRecChunk;
+            const uint32_t ch = atomicAdd(P.rec_cursor + S, G);
+            if (ch + G <= P.rec_cap_chunks[S]) {
+                base1 = ch * kRecChunk;
+                st[S] = base1 + (n - split); st[4 + S] = base1 + G * kRecChunk;
             } else {
                 base1 = 0xffffffffu;                                                // out of chunks
-                st[s] = end;
-                atomicAdd(P.rec_cursor + 4 + s, n - split);
+                st[S] = end;
+                atomicAdd(P.rec_cursor + 4 + S, n - split);
             }
         }
     }
     base0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base0);
     base1 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base1);
     split = (uint32_t) __builtin_amdgcn_readfirstlane((int) split);
-    if (rank < split) P.rec_buf[s][base0 + rank] = make_float4(p.x, p.y, p.z, v);
-    else if (base1 != 0xffffffffu) P.rec_buf[s][base1 + (rank - split)] = make_float4(p.x, p.y, p.z, v);
-    else splat_direct(P, s, p, v);
+    uint32_t slot = 0xffffffffu;
+    if (rank < split) slot = base0 + rank;
+    else if (base1 != 0xffffffffu) slot = base1 + (rank - split);
+    if (slot != 0xffffffffu) {
+        if constexpr (S == 0) P.rec_buf[0][slot] = make_float4(p.x, p.y, p.z, v0);
+        else {
+            float4 *dst = P.rec_buf[1] + 2 * (size_t) slot;
+            dst[0] = make_float4(p.x, p.y, p.z, v0);
+            dst[1] = make_float4(c[0], c[1], c[2], 0.0f);
+        }
+    } else {
+        if (v0 != 0.0f) splat_direct(P, 0, p, v0);
+        if constexpr (S == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (c[k] != 0.0f) splat_direct(P, 1 + k, p, c[k]);
+        }
+    }
 }
 
 // end of the wave: publish the fill of the chunks still open
 __device__ __forceinline__ void close_records(const Params &P, uint32_t *st_)
 {
     lds_u32 *st = (lds_u32 *) st_;
-    if (__lane_id() < 4) {
+    if (__lane_id() < kRecStreams) {
         const int s = (int) __lane_id();
         const uint32_t cur = st[s], end = st[4 + s];
         if (end) {
-            const uint32_t G = s == 0 ? kRecGroup0 : 1u, first = end / kRecChunk - G;
+            const uint32_t G = rec_group(s), first = end / kRecChunk - G;
             for (uint32_t j = 0; j < G; ++j) {
                 const uint32_t lo = (first + j) * kRecChunk;
                 P.rec_chunk_count[s][first + j] = cur <= lo ? 0u : (cur - lo < kRecChunk ? cur - lo : kRecChunk);
@@ -700,7 +726,7 @@ __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, ui
     if (g == 0.0f) return;            // adding exact zeros changes nothing: skip the requests
     if constexpr (DEFER) {
         if (P.debug_flags & 1u) return;
-        emit_record(P, 0, p, g * P.scale, rec);
+        emit_record<0>(P, p, g * P.scale, nullptr, rec);
         return;
     }
     float w[8]; int idx[8];
@@ -721,14 +747,8 @@ __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, ui
 template <bool DEFER = false>
 __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float g[3], uint32_t *rec)
 {
+    static_assert(!DEFER, "deferred colour splats travel with their sigma_t splat: splat_scatter");
     if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) return;   // e.g. nerf queries in empty space (weight 0)
-    if constexpr (DEFER) {
-        if (P.debug_flags & 1u) return;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (g[k] != 0.0f) emit_record(P, 1 + k, p, g[k], rec);
-        return;
-    }
     float w[8]; int idx[8];
     make_grad_indices(P, p, idx, w);
     if (P.debug_flags & 1u) return;
@@ -746,6 +766,23 @@ __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float 
 #pragma unroll
     for (int k = 0; k < 8; ++k) { val[0][k] = w[k] * g[0]; val[1][k] = w[k] * g[1]; val[2][k] = w[k] * g[2]; }
     coop_scatter<3>(P.gt + P.gt_plane, P.gt_plane, idx, val, rec);
+}
+
+// A sigma_t splat and a colour (albedo / emission) splat at the SAME point: scatter events
+// (volpathsimple.py:170,580) and nerf queries (nerf.py:122-129).  Deferred: ONE 32-byte record when any colour
+// channel is non-zero, the 16-byte sigma_t record otherwise (nerf queries in empty space), nothing if all are zero.
+template <bool DEFER = false>
+__device__ __forceinline__ void splat_scatter(const Params &P, V3 p, float gs, const float ga[3], uint32_t *rec)
+{
+    if constexpr (DEFER) {
+        if (P.debug_flags & 1u) return;
+        const bool colour = ga[0] != 0.0f || ga[1] != 0.0f || ga[2] != 0.0f;
+        if (colour) emit_record<1>(P, p, gs * P.scale, ga, rec);
+        else if (gs != 0.0f) emit_record<0>(P, p, gs * P.scale, nullptr, rec);
+    } else {
+        splat_sigma_t<false>(P, p, gs, rec);
+        splat_albedo<false>(P, p, ga, rec);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -275,8 +275,7 @@ struct Tracer {
             gs += a * alb[k];
             ga[k] = a * sig;
         }
-        splat_sigma_t<DEFER>(P, p, gs, rec); count(C_SC);                           // :577-581
-        splat_albedo<DEFER>(P, p, ga, rec);  count(C_SC_ALB);
+        splat_scatter<DEFER>(P, p, gs, ga, rec); count(C_SC); count(C_SC_ALB);   // :577-581
     }
 
     // backpropagate_transmittance (volpathsimple.py:584-607)
@@ -379,8 +378,7 @@ struct Tracer {
                         gs += a * albedo[k];
                         ga[k] = a * mei.sigma_t;
                     }
-                    splat_sigma_t<DEFER>(P, mei.p, gs, rec); count(C_SC);
-                    splat_albedo<DEFER>(P, mei.p, ga, rec);  count(C_SC_ALB);
+                    splat_scatter<DEFER>(P, mei.p, gs, ga, rec); count(C_SC); count(C_SC_ALB);
                 }
                 backprop_transmittance(A, ray, did_escape ? si.t : mei.t, dL, result);   // :181-189
             }
@@ -606,8 +604,7 @@ __global__ void __launch_bounds__(256) nerf_kernel(const Params P)
                         ge[k] = dL[k] * weight;
                     }
                     if (P.nerf_relu && !(raw > 0.0f)) gs = 0.0f;
-                    splat_sigma_t<DEFER>(P, p, gs, rec);
-                    splat_albedo<DEFER>(P, p, ge, rec);    // colour planes = emission gradients here
+                    splat_scatter<DEFER>(P, p, gs, ge, rec);   // colour planes = emission gradients here
                 }
                 t_a = t_b;
                 if (!last) { throughput *= safe_a; weights_sum += weight; }  // :117-120

@@ -37,14 +37,15 @@ constexpr uint32_t kUnitRecords = 16384;                 // records per reduce w
 constexpr int kPartWGs = DRT_PART_WGS;
 constexpr int kPartThreads = DRT_PART_THREADS;
 struct DeferredPlan {
-    float4 *in[4], *out[4];          // record streams as emitted / tile-sorted
-    uint32_t *chunk_count[4];        // valid records per chunk of in[s]
-    uint32_t cap_chunks[4];
-    uint32_t *cursor;                // [0..3] chunks handed out (may exceed the capacity), [4..7] overflowed splats
-    uint32_t *hist;                  // [4][kPartWGs][n_bins] counts, then exclusive offsets
-    uint32_t *bin_base;              // [4][n_bins + 1]
-    uint32_t *unit_start;            // [4][n_bins + 1] first reduce unit of every tile
-    uint32_t *vmax;                  // [4] bit pattern of max |value| per stream (zeroed per launch)
+    float4 *in[2], *out[2];          // record streams as emitted / tile-sorted (stream 0: 1 float4 per record, stream 1: 2)
+    uint32_t *chunk_count[2];        // valid records per chunk of in[s]
+    uint32_t cap_chunks[2];
+    uint32_t *cursor;                // [0..1] chunks handed out (may exceed the capacity), [4..5] overflowed splats
+    uint32_t *hist;                  // [2][kPartWGs][n_bins] counts, then exclusive offsets
+    uint32_t *bin_base;              // [2][n_bins + 1]
+    uint32_t *unit_start;            // [2][n_bins + 1] first reduce unit of every tile
+    uint32_t *vmax;                  // [5] bit pattern of max |value| per reduce plane (zeroed per launch):
+                                     //     [0] stream 0; [1..4] stream 1's sigma_t, r, g, b
     int n_bins, ntx, nty, ntz;
     uint32_t max_units;              // launch bound of the reduce kernel (any stream)
 };
