@@ -229,13 +229,16 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
  * of deferred records; bit 8 (256): two-chunk record streams (exercises the out-of-chunks fallback);
  * bits 9, 10 (512, 1024): reduction without LDS adds / without the flush (timing only); bit 11 (2048):
  * overlap the tracer of ray sub-batch b with the reduction of sub-batch b - 1 on a side stream (also
- * DRT_PIPELINE in the environment; measured slower); bit 12 (4096): compare-and-swap flush; bit 13
+ * DRT_PIPELINE in the environment; measured slower); bit 13
  * (8192): exact checksum of the flushed sums; bit 14 (16384): 8 MB record budget, i.e. many ray
  * sub-batches (test hook); bit 15 (32768): plain one-ray-per-lane adjoint kernel instead of the
  * wave-cooperative tracking loops (drt_coop.hip); bit 16 (65536): state-machine kernel for the primal
  * (default: the cooperative kernel, which also writes the path cache); bit 20 (1048576): no path
  * cache (the adjoint pass walks its primal path again); bit 18 (262144): pretend that the record
- * streams cannot be allocated (the job then takes the atomic path, as it does when hipMalloc fails). */
+ * streams cannot be allocated (the job then takes the atomic path, as it does when hipMalloc fails); bit 19
+ * (524288): pretend that they cannot be (re)allocated from the second ray sub-batch on (the remaining rays take
+ * the atomic path); bit 21 (2097152): generic tracing kernels instead of the ones specialised for the registered
+ * `volpathsimple-drt` estimator. */
 int drt_set_debug_flags(drt_handle h, uint32_t flags);
 
 const char *drt_version(void);

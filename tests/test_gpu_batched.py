@@ -78,3 +78,37 @@ def test_losses(uivr, gpu):
     assert float(L.root_mean_squared_error(a, b)) == pytest.approx(float(((a - b) ** 2).mean().sqrt()), rel=1e-6)
     assert float(L.psnr(a, b)) == pytest.approx(-10 * np.log10(float(((a - b) ** 2).mean())), rel=1e-5)
     assert float(L.mean_relative_absolute_error(a, b)) > 0 and float(L.huber(a, b)) > 0
+
+
+@pytest.mark.parametrize("factor", [0, 6])
+def test_render_batch_logical_shards_equal_unsharded(uivr, gpu, factor):
+    """Sharded render_batch without a process group (SURVEY.md 8e "G logical shards on one device"): the ranks'
+    shares, rendered one after the other, tile the unsharded batch bit for bit; gradient shares sum to the
+    unsharded gradient.  Global majorant (cooperative kernels) and supergrid (state machine + per-lane kernels)."""
+    from uivr_amd import synthetic
+    scene = synthetic.smoke_scene(res=24, film=32, device=gpu, optical_side=10.0)
+    scene.sensors = synthetic.ring_sensors(5, radius=5.0, height=0.8, fov=30.0, width=32, film_height=32)
+    scene.medium.majorant_resolution_factor = factor
+    integ = uivr.get_int_config("volpathsimple-drt").create(max_depth=32)
+    B, spp, spp_grad, seed, seed_grad = 515, 4, 2, 21, 22
+
+    def run(shard):
+        params = {k: v.clone().requires_grad_(True) for k, v in scene.params().items() if k in integ.param_keys}
+        image, _, _, sidx, pix = uivr.render_batch(B, scene, params=params, integrator=integ, seed=seed, seed_grad=seed_grad,
+                                                   spp=spp, spp_grad=spp_grad, shard=shard)
+        n_local = image.shape[0]
+        (uivr.losses.l1(image, torch.full_like(image, 0.3)) * uivr.local_loss_scale(n_local, B)).backward()
+        return image.detach(), sidx, pix, torch.cat([params[k].grad.reshape(-1) for k in integ.param_keys])
+
+    img_u, sidx_u, pix_u, g_u = run(None)
+    for world in (2, 3):
+        acc = torch.zeros_like(g_u)
+        for rank in range(world):
+            sh = uivr.ShardSpec(rank, world)
+            first, count = sh.batch_range(B)
+            img, sidx, pix, g = run(sh)
+            assert torch.equal(img, img_u[first:first + count]), (world, rank)
+            assert torch.equal(sidx, sidx_u[first:first + count]) and torch.equal(pix, pix_u[first:first + count])
+            acc += g
+        tol = 2e-4 * float(g_u.abs().max())
+        assert float((acc - g_u).abs().max()) <= tol, (world, float((acc - g_u).abs().max()), tol)

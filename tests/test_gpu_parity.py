@@ -465,7 +465,8 @@ def test_sigma_t_gradient_vs_finite_differences(uivr, gpu, variant):
                                            (2, "drt"), (16, "drt"), (128, "drt"), (128, "quadratic"), (256, "drt"),
                                            (256, "basic"), (16384, "drt"), (16384 + 2048, "drt"), (2048, "basic"),
                                            (32768, "drt"), (32768, "quadratic"), (65536, "drt"), (65536, "basic"),
-                                           (65536, "quadratic-nomis"), (262144, "drt"), (1048576, "drt")])
+                                           (65536, "quadratic-nomis"), (262144, "drt"), (1048576, "drt"),
+                                           (16384 + 524288, "drt"), (2097152, "drt"), (2097152 + 128, "drt")])
 def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     """The production path uses the wave-synchronous state machine for the primal and the
     one-ray-per-lane kernel for the adjoint (measured faster).  The other combinations
@@ -477,7 +478,9 @@ def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     of sub-batch b - 1 overlapped with the tracer of sub-batch b on a side stream, 32768 = plain per-lane
     adjoint kernel instead of the wave-cooperative tracking loops (production default for the adjoint),
     65536 = state-machine kernel for the primal (no path cache), 262144 = record streams "cannot be
-    allocated" (fallback to the atomic path), 1048576 = path cache off."""
+    allocated" (fallback to the atomic path), 1048576 = path cache off, 524288 (with 16384) = the record memory
+    "runs out" after the first ray sub-batch (the rest of the job takes the atomic path), 2097152 = generic
+    instead of the specialised `volpathsimple-drt` kernels."""
     props = props_for(variant)
     scene = uivr.cube_test_scene(32, 32, density_scale=2.0)
     spp, seed = 16, 777
@@ -499,3 +502,33 @@ def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     assert cnt == {k: ref["counters"][k] + 2 * c_primal[k] for k in ref["counters"]}
     _assert_grads_close(grads[uivr.SIGMA_T_KEY], ref["grad_sigma_t"], "grad sigma_t")
     _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], "grad albedo")
+
+
+def test_non_finite_gradients_propagate(uivr, gpu):
+    """A NaN / inf in dL must reach the gradient grids on every gradient path (the reference's scatter_reduce
+    would propagate it): the deferred reduction must not clamp it away into a finite value."""
+    scene = uivr.cube_test_scene(16, 16, density_scale=2.0)
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props_for("drt"))
+    h = integ.native_handle(sg)
+    spp, seed = 4, 3
+    n = 16 * 16 * spp
+    batch = uivr.RayBatch(n_rays=n, spp=spp, sensor=sg.sensors[0])
+    for flags in (0, 128):
+        h.set_debug_flags(flags)
+        for bad in (float("nan"), float("inf")):
+            samp = uivr.IndependentSampler(seed, spp)
+            L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+            dL = torch.full((n, 3), 1e-3, device=gpu)
+            dL[(8 * 16 + 8) * spp] = bad                          # one ray through the middle of the volume
+            grads = uivr.alloc_grads(sg)
+            integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=dL, state_in=st, grads=grads)
+            assert not torch.isfinite(grads[uivr.SIGMA_T_KEY]).all(), (flags, bad)
+            assert not torch.isfinite(grads[uivr.ALBEDO_KEY]).all(), (flags, bad)
+            # and a finite job afterwards is finite again (no state left behind)
+            dL = torch.full((n, 3), 1e-3, device=gpu)
+            grads = uivr.alloc_grads(sg)
+            L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+            integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=dL, state_in=st, grads=grads)
+            assert torch.isfinite(grads["_flat"]).all() and float(grads["_flat"].abs().max()) > 0
+    h.set_debug_flags(0)

@@ -273,22 +273,27 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
     const bool tiny = (h->debug_flags & 256u) != 0;                // test hook: force the out-of-chunks path
     if (!R.mem || n_rays > R.rays || n_bins != R.bins || tiny != R.tiny || per_ray_sigma > R.per_ray[0] ||
         per_ray_colour > R.per_ray[1]) {
-        // capacity: every wave may leave one chunk partly filled per stream, plus the expected volume;
+        // capacity: every wave may leave one chunk group partly filled per stream, plus the expected volume;
         // beyond it the tracer falls back to direct atomics (emit_record): a performance choice only
         const uint64_t waves = (n_rays + 63) / 64;
-        uint64_t chunks[4];
-        chunks[0] = tiny ? 2 * kRecGroup0 : (kRecGroup0 + 1) * waves + (n_rays * per_ray_sigma + kRecChunk - 1) / kRecChunk;   // a wave may leave a group partly used
-        for (int s = 1; s < 4; ++s) chunks[s] = tiny ? 1 : 2 * waves + (n_rays * per_ray_colour + kRecChunk - 1) / kRecChunk;
+        const uint32_t per_ray[2] = { per_ray_sigma, per_ray_colour };
+        uint64_t chunks[2];
+        for (int s = 0; s < 2; ++s)
+            chunks[s] = tiny ? 2 * rec_group(s) : (rec_group(s) + 1) * waves + (n_rays * per_ray[s] + kRecChunk - 1) / kRecChunk;
+        const size_t quads[2] = { 1, 2 };                          // float4s per record
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
-        size_t o_cursor = carve(20 * sizeof(uint32_t));          // cursors [8] + vmax [4] + debug checksums [4 x u64]
-        size_t o_count[4], o_in[4], o_out[4];
-        for (int s = 0; s < 4; ++s) o_count[s] = carve(chunks[s] * sizeof(uint32_t));
+        size_t o_cursor = carve(32 * sizeof(uint32_t));          // cursors [8] + vmax [5] (+3) + debug checksums [5 x u64]
+        size_t o_count[2], o_in[2], o_out[2];
+        for (int s = 0; s < 2; ++s) o_count[s] = carve(chunks[s] * sizeof(uint32_t));
         const size_t clear = off;
-        size_t o_hist = carve((size_t) 4 * kPartWGs * n_bins * sizeof(uint32_t));
-        size_t o_base = carve((size_t) 4 * (n_bins + 1) * sizeof(uint32_t));
-        size_t o_unit = carve((size_t) 4 * (n_bins + 1) * sizeof(uint32_t));
-        for (int s = 0; s < 4; ++s) { o_in[s] = carve(chunks[s] * kRecChunk * sizeof(float4)); o_out[s] = carve(chunks[s] * kRecChunk * sizeof(float4)); }
+        size_t o_hist = carve((size_t) 2 * kPartWGs * n_bins * sizeof(uint32_t));
+        size_t o_base = carve((size_t) 2 * (n_bins + 1) * sizeof(uint32_t));
+        size_t o_unit = carve((size_t) 2 * (n_bins + 1) * sizeof(uint32_t));
+        for (int s = 0; s < 2; ++s) {
+            o_in[s] = carve(chunks[s] * kRecChunk * quads[s] * sizeof(float4));
+            o_out[s] = carve(chunks[s] * kRecChunk * quads[s] * sizeof(float4));
+        }
         if (off > R.bytes) {
             if (R.mem) {
                 DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -306,7 +311,7 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
         D.cursor = (uint32_t *) (b + o_cursor);
         D.vmax = D.cursor + 8;
         uint64_t max_chunks = 0;
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 2; ++s) {
             D.chunk_count[s] = (uint32_t *) (b + o_count[s]);
             D.in[s] = (float4 *) (b + o_in[s]); D.out[s] = (float4 *) (b + o_out[s]);
             D.cap_chunks[s] = (uint32_t) chunks[s];
@@ -319,7 +324,7 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
         R.per_ray[0] = per_ray_sigma; R.per_ray[1] = per_ray_colour;
     }
     DRT_HIP_CHECK(h, hipMemsetAsync(R.mem, 0, R.clear_bytes, h->stream));
-    for (int s = 0; s < 4; ++s) { P.rec_buf[s] = D.in[s]; P.rec_chunk_count[s] = D.chunk_count[s]; P.rec_cap_chunks[s] = D.cap_chunks[s]; }
+    for (int s = 0; s < 2; ++s) { P.rec_buf[s] = D.in[s]; P.rec_chunk_count[s] = D.chunk_count[s]; P.rec_cap_chunks[s] = D.cap_chunks[s]; }
     P.rec_cursor = D.cursor;
     return DRT_OK;
 }
@@ -350,7 +355,7 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
         if (rc) return rc;
     } else {
         const uint64_t n_rays = P.n_rays;
-        const uint64_t bytes_per_ray = 32ull * ((uint64_t) per_ray_sigma + 3ull * per_ray_colour) + 1024ull;   // streams in + sorted, chunk slack
+        const uint64_t bytes_per_ray = 32ull * (uint64_t) per_ray_sigma + 64ull * (uint64_t) per_ray_colour + 1024ull;   // streams in + sorted, chunk slack
         // measured on the headline workload: overlapping costs more than it hides (tracer 15.0 -> 19.8 ms
         // with the reductions alongside, step 22.1 -> 24.7 ms), so the overlap is opt-in
         static const bool env_pipe = getenv("DRT_PIPELINE") != nullptr;
@@ -389,7 +394,7 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
             if (rc == kNoRecordMemory) {
                 // no memory for the record streams (now): the rays that are left, [first, n_rays), take the
                 // atomic path (splats into the apron scratch + untile) - slower, same gradients
-                for (int s2 = 0; s2 < 4; ++s2) P.rec_buf[s2] = nullptr;
+                for (int s2 = 0; s2 < 2; ++s2) P.rec_buf[s2] = nullptr;
                 P.rec_cursor = nullptr; P.ray_first = first; P.n_rays = n_rays;
                 rc = launch(P);
                 if (rc) return rc;
@@ -433,70 +438,7 @@ int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D,
         DRT_HIP_CHECK(h, hipEventCreate(&b));
         DRT_HIP_CHECK(h, hipEventRecord(a, stream));
     }
-    static const bool profile = getenv("DRT_REDUCE_PROFILE") != nullptr;   // stage timings to stderr (synchronises)
-    static const bool checksum = getenv("DRT_RECORD_CHECKSUM") != nullptr;   // debugging aid: order-independent sums of the record streams
-    if (checksum) {
-        DRT_HIP_CHECK(h, hipStreamSynchronize(stream));
-        for (int s2 = 0; s2 < 4; ++s2) {
-            uint32_t used = 0;
-            DRT_HIP_CHECK(h, hipMemcpy(&used, D.cursor + s2, 4, hipMemcpyDeviceToHost));
-            if (used > D.cap_chunks[s2]) used = D.cap_chunks[s2];
-            std::vector<uint32_t> cnt(used);
-            std::vector<float> recs((size_t) used * drt::kRecChunk * 4);
-            if (used) {
-                DRT_HIP_CHECK(h, hipMemcpy(cnt.data(), D.chunk_count[s2], used * 4, hipMemcpyDeviceToHost));
-                DRT_HIP_CHECK(h, hipMemcpy(recs.data(), D.in[s2], recs.size() * 4, hipMemcpyDeviceToHost));
-            }
-            double sv = 0, sx = 0, sa = 0; uint64_t n = 0, xr = 0;
-            for (uint32_t c = 0; c < used; ++c)
-                for (uint32_t i = 0; i < cnt[c]; ++i) {
-                    const float *r = recs.data() + ((size_t) c * drt::kRecChunk + i) * 4;
-                    sv += r[3]; sx += (double) r[0] * r[3] + 2.0 * r[1] * r[3] + 3.0 * r[2] * r[3]; sa += fabs((double) r[3]); ++n;
-                    uint32_t b[4]; memcpy(b, r, 16); xr ^= ((uint64_t) (b[0] * 2654435761u) << 32) ^ (b[1] * 40503u) ^ ((uint64_t) b[2] << 17) ^ b[3];
-                }
-            fprintf(stderr, "[drt] stream %d emitted: n %llu sum %.12e mom %.12e abs %.12e xor %016llx\n", s2, (unsigned long long) n, sv, sx, sa, (unsigned long long) xr);
-        }
-    }
-    if (profile) {
-        hipEvent_t ev[5];
-        for (auto &e : ev) DRT_HIP_CHECK(h, hipEventCreate(&e));
-        DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, D, stream, ev));
-        DRT_HIP_CHECK(h, hipStreamSynchronize(stream));
-        float ms[4];
-        for (int k = 0; k < 4; ++k) DRT_HIP_CHECK(h, hipEventElapsedTime(ms + k, ev[k], ev[k + 1]));
-        uint32_t cur[8];
-        DRT_HIP_CHECK(h, hipMemcpy(cur, D.cursor, sizeof cur, hipMemcpyDeviceToHost));
-        uint32_t tot[4], units[4];
-        for (int k = 0; k < 4; ++k) {
-            DRT_HIP_CHECK(h, hipMemcpy(tot + k, D.bin_base + (size_t) k * (D.n_bins + 1) + D.n_bins, 4, hipMemcpyDeviceToHost));
-            DRT_HIP_CHECK(h, hipMemcpy(units + k, D.unit_start + (size_t) k * (D.n_bins + 1) + D.n_bins, 4, hipMemcpyDeviceToHost));
-        }
-        fprintf(stderr, "[drt] reduce: histogram %.3f offsets %.3f scatter %.3f tiles %.3f ms; chunks %u %u %u %u (cap %u %u) overflow %u %u %u %u; records %u %u %u %u units %u %u %u %u\n",
-                ms[0], ms[1], ms[2], ms[3], cur[0], cur[1], cur[2], cur[3], D.cap_chunks[0], D.cap_chunks[1],
-                cur[4], cur[5], cur[6], cur[7], tot[0], tot[1], tot[2], tot[3], units[0], units[1], units[2], units[3]);
-        for (auto &e : ev) (void) hipEventDestroy(e);
-    } else {
-        DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, D, stream));
-    }
-    if (checksum) {
-        DRT_HIP_CHECK(h, hipStreamSynchronize(stream));
-        unsigned long long fl[4];
-        DRT_HIP_CHECK(h, hipMemcpy(fl, D.cursor + 12, sizeof fl, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[drt] flushed fixed-point sums: %lld %lld %lld %lld\n", (long long) fl[0], (long long) fl[1], (long long) fl[2], (long long) fl[3]);
-        for (int s2 = 0; s2 < 4; ++s2) {
-            uint32_t tot = 0;
-            DRT_HIP_CHECK(h, hipMemcpy(&tot, D.bin_base + (size_t) s2 * (D.n_bins + 1) + D.n_bins, 4, hipMemcpyDeviceToHost));
-            std::vector<float> recs((size_t) tot * 4);
-            if (tot) DRT_HIP_CHECK(h, hipMemcpy(recs.data(), D.out[s2], recs.size() * 4, hipMemcpyDeviceToHost));
-            double sv = 0, sx = 0, sa = 0; uint64_t xr = 0;
-            for (uint32_t i = 0; i < tot; ++i) {
-                const float *r = recs.data() + (size_t) i * 4;
-                sv += r[3]; sx += (double) r[0] * r[3] + 2.0 * r[1] * r[3] + 3.0 * r[2] * r[3]; sa += fabs((double) r[3]);
-                uint32_t b[4]; memcpy(b, r, 16); xr ^= ((uint64_t) (b[0] * 2654435761u) << 32) ^ (b[1] * 40503u) ^ ((uint64_t) b[2] << 17) ^ b[3];
-            }
-            fprintf(stderr, "[drt] stream %d sorted : n %u sum %.12e mom %.12e abs %.12e xor %016llx\n", s2, tot, sv, sx, sa, (unsigned long long) xr);
-        }
-    }
+    DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, D, stream));
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventRecord(b, stream));
         h->timed[2].emplace_back(a, b);
