@@ -131,11 +131,86 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
         res["msamples_per_s"] = round(res["value"] * 32768 * (1024 + 2 * 16) / 1e6, 1)
         return res
 
+    def cfg5_fused():
+        sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+        integ = u.get_int_config("nerf-drt-fused").create(max_depth=64)
+        sensor = sc.sensors[0]
+        n_pixels, spp = sensor.width * sensor.height, 32
+        batch = u.RayBatch(n_rays=n_pixels * spp, spp=spp, sensor=sensor)
+        grads = u.alloc_grads(sc, integ.param_keys)
+        loss_scale = 2.0 / (n_pixels * 6)
+        h = integ.native_handle(sc)
+
+        def step(i):
+            sampler = u.IndependentSampler(u.sample_tea_32(2 * i + 1, 988378)[0], spp)
+            grads["_flat"].zero_()
+            L, _, state = integ.sample(u.ADMode.Primal, sc, sampler.clone(), batch)
+            img = integ.develop(sc, L, spp)
+            dL = integ.film_backward(sc, loss_scale * (img - 0.5), spp)
+            integ.sample(u.ADMode.Backward, sc, sampler, batch, δL=dL, state_in=state, grads=grads)
+            return sampler, state, dL
+
+        step(0)
+        torch.cuda.synchronize()
+        h.enable_timing(True)
+        t0 = time.perf_counter()
+        steps = 3
+        for i in range(steps):
+            sampler, state, dL = step(1 + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        t_p, t_pass = h.read_timings(0), h.read_timings(3)
+        h.enable_timing(False)
+        # event counts of one step -> algorithmic bytes with FOUR-CHANNEL events for the nerf queries (SURVEY.md 8d:
+        # 128 B per four-channel lookup, 256 B per four-channel splat); the volpathsimple events as for the headline.
+        # n_q = the nerf half's queries = fused sigma_t lookups - those of a volpathsimple-only pass over the same rays.
+        h.enable_counters(True)
+        h.reset_counters()
+        integ.sample(u.ADMode.Primal, sc, sampler.clone(), batch)
+        cp = {k: int(v) for k, v in h.get_counters().items()}
+        h.reset_counters()
+        grads["_flat"].zero_()
+        integ.sample(u.ADMode.Backward, sc, sampler, batch, δL=dL, state_in=state, grads=grads)
+        ca = {k: int(v) for k, v in h.get_counters().items()}
+        h.enable_counters(False)
+        drt = u.get_int_config(integ_name).create(max_depth=64)
+        hd = drt.native_handle(sc)
+        hd.enable_counters(True)
+        hd.reset_counters()
+        drt.sample(u.ADMode.Primal, sc, sampler.clone(), batch)
+        n_q = cp["n_dt"] - int(hd.get_counters()["n_dt"])
+        hd.enable_counters(False)
+        n = batch.n_rays
+
+        def bytes_of(c, adj):
+            d = dict(c)
+            d["n_dt"] -= n_q; d["n_alb"] -= n_q
+            if adj:
+                d["n_sc"] -= n_q; d["n_sc_alb"] -= n_q
+            b = algorithmic_bytes(d, n, primal_io=not adj, adjoint_io=adj) - (24 * n if not adj else 0)   # rays generated on device
+            return b + 128 * n_q + (256 * n_q if adj else 0) + (12 * n if not adj else 24 * n)          # + the nerf half's L / (dL, L_in)
+
+        b_p, b_a = bytes_of(cp, False), bytes_of(ca, True)
+        avg_pass = sum(t_pass) / steps if t_pass else 0.0
+        avg_p = sum(t_p) / steps if t_p else 0.0
+        h.release_scratch(); hd.release_scratch()
+        return {"value": round(n / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "n_samples_per_step": n,
+                "nerf_queries_per_step": n_q, "t_primal_ms": round(avg_p, 3), "t_adjoint_pass_ms": round(avg_pass, 3),
+                "roofline_adjoint": {"achieved_GBs": round(b_a / (avg_pass * 1e-3) / 1e9, 1) if avg_pass else None,
+                                     "frac": round(b_a / (avg_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_pass else None,
+                                     "algorithmic_bytes": b_a},
+                "roofline_primal": {"achieved_GBs": round(b_p / (avg_p * 1e-3) / 1e9, 1) if avg_p else None,
+                                    "frac": round(b_p / (avg_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_p else None,
+                                    "algorithmic_bytes": b_p},
+                "workload": "config 5 as BASELINE states it: nerf (128 queries) FUSED with volpathsimple-drt in one pass over the "
+                            "interleaved [sigma_t,r,g,b] grid, 256^3, 512x512x32spp"}
+
     guarded("config2_smoke128_512x16", cfg2)
     guarded("headline_majorant_factor8", factor8)
     guarded("config3_optimize_loop", cfg3)
     guarded("config4_512_rank_share_1024x64", cfg4)
     guarded("config5_nerf_256_512x32", cfg5)
+    guarded("config5_fused_nerf_drt_256_512x32", cfg5_fused)
     return out
 
 

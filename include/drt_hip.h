@@ -168,6 +168,21 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
                              const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
                              const float *dL, const float *L_in, float *grad_sigma_t, float *grad_emission);
 
+/* BASELINE config 5: the `nerf` march and volpathsimple scattering FUSED in one pass over one interleaved
+ * four-channel [sigma_t, r, g, b] grid.  The reference's scenes bind ONE asset as the medium's albedo and emission
+ * grid (python/scene_config.py:109-110), so the colour grid given to drt_set_medium as `albedo` is both: the library
+ * keeps an interleaved 16-byte-voxel apron-brick copy of sigma_t + colour (rebuilt after drt_set_medium /
+ * drt_params_changed).  Per ray, the pass computes NeRFIntegrator.sample (nerf.py:47-148; `cfg`) and
+ * VolpathSimpleIntegrator.sample (volpathsimple.py:38-290; the handle's drt_config) from the same camera ray and the
+ * same PCG32 stream, each bit-identical to its stand-alone call; the backward pass accumulates BOTH integrators'
+ * gradients into grad_sigma_t (Z,Y,X,1) and grad_rgb (Z,Y,X,3) (albedo gradient + emission gradient: one parameter).
+ * Constant emitter and global majorant only.  Ray / seed conventions as for drt_render_*. */
+int drt_fused_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
+                            uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_nerf_out, float *L_drt_out);
+int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
+                              uint64_t ray_offset, uint32_t spp, uint32_t seed, const float *dL_nerf, const float *L_nerf_in,
+                              const float *dL_drt, const float *L_drt_in, float *grad_sigma_t, float *grad_rgb);
+
 /* sample_batch_pixels + sample_batch_rays of the batched (ray-centric) render op
  * (python/batched.py:397-467).  `sensors`: DEVICE array of n_sensors x 16 floats {origin[3], left[3],
  * up[3], dir[3], tan_x, tan_y, width, height}.  For every batch entry b a (sensor, pixel) pair is

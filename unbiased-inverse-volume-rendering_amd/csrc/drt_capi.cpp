@@ -34,6 +34,10 @@ struct drt_handle_s {
     uint32_t *d_occ = nullptr;     // empty-space bitmask (kOccWords words)
     float *d_mgrid = nullptr;      // majorant supergrid (refreshed by drt_params_changed)
     float *d_env = nullptr;        // envmap emitter: pixels | marginal CDF | conditional CDFs (one allocation)
+    float4 *d_grid4 = nullptr;     // interleaved four-channel apron-brick copy (fused pass), built on demand
+    size_t grid4_quads = 0;
+    uint64_t grid4_version = 0;    // medium_version the copy was built at (0: never)
+    uint64_t medium_version = 0;   // bumped whenever the parameter grids (may) have changed: drt_set_medium / drt_params_changed
     // deferred splatting (drt_deferred.hip): record streams in / tile-sorted, chunk fills, partition tables.
     // Two slots: sub-batch b traces into slot b % 2 while slot (b - 1) % 2 is reduced on the side stream.
     struct RecSlot {
@@ -535,6 +539,7 @@ int drt_destroy(drt_handle h)
     if (h->d_mgrid) (void) hipFree(h->d_mgrid);
     if (h->d_occ) (void) hipFree(h->d_occ);
     if (h->d_env) (void) hipFree(h->d_env);
+    if (h->d_grid4) (void) hipFree(h->d_grid4);
     for (auto &R : h->rec) {
         if (R.mem) (void) hipFree(R.mem);
         if (R.traced) (void) hipEventDestroy(R.traced);
@@ -589,7 +594,7 @@ int drt_synchronize(drt_handle h)
 int drt_params_changed(drt_handle h)
 {
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
-    h->scene_version++;
+    h->scene_version++; h->medium_version++;
     if (!h->have_medium) return fail(h, DRT_ERR_NOT_CONFIGURED, "no medium set");
     DeviceGuard g(h->device);
     size_t n = (size_t) h->base.rx * h->base.ry * h->base.rz;
@@ -892,6 +897,101 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_emission;
     const uint32_t q = (uint32_t) cfg->queries_per_ray;          // at most one splat per query and plane
     return run_backward(h, P, q, q, [&](drt::Params &Q) { return timed_nerf(h, 1, Q, true); });
+}
+
+// ---- fused nerf + volpathsimple pass (BASELINE config 5; drt_fused.hip) ---------------------------------------------
+static int fused_prepare(drt_handle h, drt::Params &P, const drt_nerf_config *cfg)
+{
+    if (!cfg) return fail(h, DRT_ERR_INVALID_ARGUMENT, "fused: null nerf config");
+    if (cfg->queries_per_ray < 2) return fail(h, DRT_ERR_INVALID_ARGUMENT, "queries_per_ray must be >= 2");
+    if (h->base.env_pix) return fail(h, DRT_ERR_UNSUPPORTED, "the fused pass supports the constant emitter only");
+    if (h->base.mgrid) return fail(h, DRT_ERR_UNSUPPORTED, "the fused pass needs the global majorant (majorant_resolution_factor 0)");
+    const drt::Params &B = h->base;
+    const size_t nbx = ((size_t) B.rx + 2) / 3, quads = nbx * (size_t) B.ry * (size_t) B.rz * 16;
+    if (quads > 0x7fffffffull) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the four-channel copy");
+    if (quads != h->grid4_quads) {
+        if (h->d_grid4) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_grid4); h->d_grid4 = nullptr; h->grid4_quads = 0; }
+        DRT_HIP_CHECK(h, hipMalloc(&h->d_grid4, quads * sizeof(float4)));
+        h->grid4_quads = quads; h->grid4_version = 0;
+    }
+    if (h->grid4_version != h->medium_version) {           // the parameter grids (may) have changed since the copy was made
+        DRT_HIP_CHECK(h, drt::launch_brick_grid4(B.sigma_t, B.albedo, h->d_grid4, B.rx, B.ry, B.rz, (int) nbx, h->stream));
+        h->grid4_version = h->medium_version;
+    }
+    P.grid4 = h->d_grid4; P.g4_nbx = (int) nbx;
+    P.nerf_queries = cfg->queries_per_ray; P.nerf_jitter = cfg->jittering_enabled ? 1 : 0;
+    P.nerf_relu = cfg->activation_relu ? 1 : 0; P.hide_emitters_nerf = cfg->hide_emitters ? 1 : 0;
+    return DRT_OK;
+}
+
+static int timed_fused(drt_handle h, int which, const drt::Params &P, bool adjoint)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventCreate(&a));
+        DRT_HIP_CHECK(h, hipEventCreate(&b));
+        DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
+    }
+    DRT_HIP_CHECK(h, drt::launch_fused(P, adjoint, h->counting, h->stream));
+    if (h->timing) {
+        DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
+        h->timed[which].emplace_back(a, b);
+    }
+    return DRT_OK;
+}
+
+int drt_fused_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
+                            uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_nerf_out, float *L_drt_out)
+{
+    if (h && n_rays == 0) return DRT_OK;
+    int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp);
+    if (rc) return rc;
+    if (!L_nerf_out || !L_drt_out) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_fused_render_primal: null output buffer");
+    DeviceGuard g(h->device);
+    drt::Params P;
+    fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
+    rc = fused_prepare(h, P, cfg);
+    if (rc) return rc;
+    P.L_out = L_drt_out; P.L_out2 = L_nerf_out;
+    h->pcache_sig.valid = false;
+    bind_path_cache_write(h, P);
+    P.block_cost = nullptr;                                      // (the fused kernel keeps the plain XCD block map)
+    h->order_valid = false;
+    return timed_fused(h, 0, P, false);
+}
+
+int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
+                              uint64_t ray_offset, uint32_t spp, uint32_t seed, const float *dL_nerf, const float *L_nerf_in,
+                              const float *dL_drt, const float *L_drt_in, float *grad_sigma_t, float *grad_rgb)
+{
+    if (h && n_rays == 0) return DRT_OK;
+    int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp);
+    if (rc) return rc;
+    if (!dL_nerf || !L_nerf_in || !dL_drt || !L_drt_in || !grad_sigma_t || !grad_rgb)
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_fused_render_backward: null dL / L_in / gradient buffer");
+    DeviceGuard g(h->device);
+    drt::Params P;
+    fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
+    rc = fused_prepare(h, P, cfg);
+    if (rc) return rc;
+    P.dL = dL_drt; P.L_in = L_drt_in; P.dL2 = dL_nerf; P.L_in2 = L_nerf_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_rgb;
+    {   // the fused adjoint only exists on the deferred path: grids beyond kMaxBins tiles are not supported
+        const int ntx = (P.rx + drt::kTileX - 1) / drt::kTileX, nty = (P.ry + drt::kTileY - 1) / drt::kTileY, ntz = (P.rz + drt::kTileZ - 1) / drt::kTileZ;
+        if ((int64_t) ntx * nty * ntz > drt::kMaxBins) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the fused adjoint pass");
+    }
+    const uint64_t job_rays = n_rays;
+    const uint32_t q = (uint32_t) cfg->queries_per_ray;
+    const uint32_t saved = h->debug_flags;
+    h->debug_flags &= ~(128u | 2u | 32u);                         // (the atomic-path test hooks do not apply here)
+    rc = run_backward(h, P, 48 + q, 6 + q, [&](drt::Params &Q) {
+        if (!Q.rec_buf[0]) return fail(h, DRT_ERR_HIP, "not enough device memory for the record streams of the fused adjoint pass");
+        bind_path_cache_read(h, Q, job_rays);
+        Q.block_order = nullptr;
+        return timed_fused(h, 1, Q, true);
+    });
+    h->debug_flags = saved;
+    h->pcache_sig.valid = false;
+    return rc;
 }
 
 int drt_batch_sample_rays_range(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_first,

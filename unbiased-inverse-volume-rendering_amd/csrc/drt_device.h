@@ -201,6 +201,10 @@ struct Params {
     const uint32_t *occ;
     int occ_shift, occ_x, occ_y, occ_words;
     const float *albedo;       // (Z,Y,X,3)
+    // library-owned interleaved FOUR-CHANNEL apron-brick copy [sigma_t, r, g, b] (16-byte voxels) of sigma_t and the
+    // colour grid (albedo = emission, scene_config.py:109-110) for the fused nerf + volpathsimple pass (eval4), or nullptr
+    const float4 *grid4;
+    int g4_nbx;                // lines per grid row = ceil(rx / 3)
     const float *majorant;     // device: [0] = scale*max(sigma_t), [1] = 1/[0] (0 if [0]==0)
     const float *mgrid;        // majorant supergrid, one majorant per cell (x fastest), or nullptr
     int gx, gy, gz;
@@ -217,6 +221,10 @@ struct Params {
     // nerf integrator (python/integrators/nerf.py): emission grid (Z,Y,X,3) and properties
     const float *emission;
     int nerf_queries, nerf_jitter, nerf_relu;
+    // fused nerf + volpathsimple pass (drt_fused.hip): the nerf half's own outputs / adjoint inputs and hide_emitters
+    float *L_out2;
+    const float *dL2, *L_in2;
+    int hide_emitters_nerf;
     // integrator flags
     int hide_emitters, use_nee, use_drt, use_drt_subsampling, use_drt_mis, max_depth, rr_depth;
     // sensor (mi.render flow)
@@ -531,6 +539,46 @@ __device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p, const uint3
         if (s.z1 == s.z0) { d4 = d0; d5 = d1; d6 = d2; d7 = d3; }
     }
     return trilerp8(s, d0, d1, d2, d3, d4, d5, d6, d7) * P.scale;
+}
+
+// true iff the empty-space bitmask says that every voxel a lookup at p can touch is exactly zero
+__device__ __forceinline__ bool occ_empty(const Params &P, V3 p, const uint32_t *occ)
+{
+    int x0, y0, z0, i1; float w0, w1;
+    axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, x0, i1, w0, w1);
+    axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, y0, i1, w0, w1);
+    axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, z0, i1, w0, w1);
+    const uint32_t c = __umul24(__umul24((uint32_t) z0 >> P.occ_shift, (uint32_t) P.occ_y) + ((uint32_t) y0 >> P.occ_shift),
+                                (uint32_t) P.occ_x) + ((uint32_t) x0 >> P.occ_shift);
+    return !((occ[c >> 5] >> (c & 31u)) & 1u);
+}
+
+// sigma_t AND the colour grid at p from the interleaved four-channel apron-brick copy (Params::grid4): block
+// (bx = x0 / 3, y0, z0) = 256 bytes = TWO 128-byte lines holds the voxels [3bx, 3bx+3] x {y0, y0+1} x {z0, z0+1}
+// (indices clamped) as float4 {sigma_t, r, g, b}, slot (dz*2 + dy)*4 + (x - 3bx): every trilinear footprint is eight
+// float4 loads from one block (its z0 slab in one line, its z1 slab in the next), where the separate layouts
+// need 1 line (sigma_t bricks) + 4..8 lines ((Z,Y,X,3) rows).  Storage 16/3 x the four-channel grid.  The values are
+// copies and the interpolation is trilerp8 with the same stencil: results equal eval_sigma_t / eval_rgb bit for bit.
+__device__ __forceinline__ void eval4(const Params &P, V3 p, float &sigma_t, float rgb[3])
+{
+    Stencil s;
+    axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, s.x0, s.x1, s.wx0, s.wx1);
+    axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, s.y0, s.y1, s.wy0, s.wy1);
+    axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, s.z0, s.z1, s.wz0, s.wz1);
+    const uint32_t bx = __umul24((uint32_t) s.x0, 43691u) >> 17, ox = (uint32_t) s.x0 - 3u * bx;
+    const float4 *g = P.grid4 + ((size_t) ((uint32_t) s.z0 * (uint32_t) P.ry + (uint32_t) s.y0) * (uint32_t) P.g4_nbx + bx) * 16 + ox;
+    float4 d0 = g[0], d1 = g[1], d2 = g[4], d3 = g[5], d4 = g[8], d5 = g[9], d6 = g[12], d7 = g[13];
+    // lower clamp (floor(q) = -1): both corners of that axis are voxel 0 (see eval_sigma_t)
+    const bool border = s.x1 == s.x0 || s.y1 == s.y0 || s.z1 == s.z0;
+    if (__builtin_expect(__ballot(border) != 0ull, 0)) {
+        if (s.x1 == s.x0) { d1 = d0; d3 = d2; d5 = d4; d7 = d6; }
+        if (s.y1 == s.y0) { d2 = d0; d3 = d1; d6 = d4; d7 = d5; }
+        if (s.z1 == s.z0) { d4 = d0; d5 = d1; d6 = d2; d7 = d3; }
+    }
+    sigma_t = trilerp8(s, d0.x, d1.x, d2.x, d3.x, d4.x, d5.x, d6.x, d7.x) * P.scale;
+    rgb[0] = trilerp8(s, d0.y, d1.y, d2.y, d3.y, d4.y, d5.y, d6.y, d7.y);
+    rgb[1] = trilerp8(s, d0.z, d1.z, d2.z, d3.z, d4.z, d5.z, d6.z, d7.z);
+    rgb[2] = trilerp8(s, d0.w, d1.w, d2.w, d3.w, d4.w, d5.w, d6.w, d7.w);
 }
 
 __device__ __forceinline__ void eval_rgb(const Params &P, const float *g, V3 p, float out[3])

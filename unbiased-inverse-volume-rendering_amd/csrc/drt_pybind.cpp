@@ -164,6 +164,32 @@ public:
         }
         check(rc, "drt_nerf_render_backward");
     }
+    void fused_render_primal(const py::dict &props, uintptr_t rays_o, uintptr_t rays_d, uint64_t n, uint64_t off, uint32_t spp,
+                             uint32_t seed, uintptr_t L_nerf, uintptr_t L_drt)
+    {
+        drt_nerf_config c = nerf_cfg(props);
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = drt_fused_render_primal(h_, &c, ptr<const float>(rays_o), ptr<const float>(rays_d), n, off, spp, seed,
+                                         ptr<float>(L_nerf), ptr<float>(L_drt));
+        }
+        check(rc, "drt_fused_render_primal");
+    }
+    void fused_render_backward(const py::dict &props, uintptr_t rays_o, uintptr_t rays_d, uint64_t n, uint64_t off, uint32_t spp,
+                               uint32_t seed, uintptr_t dL_nerf, uintptr_t L_nerf_in, uintptr_t dL_drt, uintptr_t L_drt_in,
+                               uintptr_t g_sigma, uintptr_t g_rgb)
+    {
+        drt_nerf_config c = nerf_cfg(props);
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = drt_fused_render_backward(h_, &c, ptr<const float>(rays_o), ptr<const float>(rays_d), n, off, spp, seed,
+                                           ptr<const float>(dL_nerf), ptr<const float>(L_nerf_in), ptr<const float>(dL_drt),
+                                           ptr<const float>(L_drt_in), ptr<float>(g_sigma), ptr<float>(g_rgb));
+        }
+        check(rc, "drt_fused_render_backward");
+    }
     void batch_sample_rays(uintptr_t sensors, int n_sensors, uint32_t batch, uint32_t spp, uint32_t seed_px, uint32_t seed_rays,
                            uintptr_t ro, uintptr_t rd, uintptr_t sidx, uintptr_t pix, uint32_t batch_first)
     {
@@ -246,6 +272,8 @@ PYBIND11_MODULE(_drt_pybind, m)
         .def("render_backward", &Integrator::render_backward)
         .def("nerf_render_primal", &Integrator::nerf_render_primal)
         .def("nerf_render_backward", &Integrator::nerf_render_backward)
+        .def("fused_render_primal", &Integrator::fused_render_primal)
+        .def("fused_render_backward", &Integrator::fused_render_backward)
         .def("batch_sample_rays", &Integrator::batch_sample_rays, py::arg("sensors"), py::arg("n_sensors"), py::arg("batch"),
              py::arg("spp"), py::arg("seed_px"), py::arg("seed_rays"), py::arg("ro"), py::arg("rd"), py::arg("sidx"),
              py::arg("pix"), py::arg("batch_first") = 0)

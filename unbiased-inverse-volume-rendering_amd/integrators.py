@@ -379,5 +379,80 @@ class NeRFIntegrator(_DeviceIntegrator):
         raise NotImplementedError("forward-mode differentiation is not supported")
 
 
+class FusedNerfDrtIntegrator(VolpathSimpleIntegrator):
+    """BASELINE config 5: the `nerf` march (python/integrators/nerf.py) and `volpathsimple` scattering
+    (python/integrators/volpathsimple.py) in ONE pass over one interleaved four-channel [sigma_t, r, g, b] grid.
+
+    The reference's scenes bind one asset as the medium's albedo AND emission grid
+    (python/scene_config.py:109-110), so the parameters are `sigma_t` and ONE colour grid (key `albedo`); the
+    radiance comes back as [n, 6] = [nerf rgb | volpathsimple rgb], each half bit-identical to its stand-alone
+    integrator, and the backward pass accumulates both integrators' gradients into the same two grids.
+    Properties: those of `volpathsimple` plus the `nerf` ones (`queries_per_ray`, `jittering_enabled`,
+    `activation`, `nerf_hide_emitters`)."""
+
+    def __init__(self, props: Optional[dict] = None):
+        props = dict(props or {})
+        self.queries_per_ray = int(props.pop("queries_per_ray", 128))
+        self.jittering_enabled = bool(props.pop("jittering_enabled", True))
+        self.activation_type = str(props.pop("activation", "identity")).lower()
+        self.nerf_hide_emitters = bool(props.pop("nerf_hide_emitters", False))
+        if self.activation_type not in ("identity", "relu"):
+            raise ValueError(f"Unsupported activation: {self.activation_type}")
+        if self.queries_per_ray < 2:
+            raise ValueError("queries_per_ray must be >= 2")
+        super().__init__(props)
+
+    def _nerf_props(self) -> dict:
+        return dict(hide_emitters=self.nerf_hide_emitters, queries_per_ray=self.queries_per_ray,
+                    jittering_enabled=self.jittering_enabled, activation_relu=self.activation_type == "relu")
+
+    def nerf_props(self) -> dict:
+        return dict(hide_emitters=self.nerf_hide_emitters, queries_per_ray=self.queries_per_ray,
+                    jittering_enabled=self.jittering_enabled, activation=self.activation_type)
+
+    def develop(self, scene: Scene, L: torch.Tensor, spp: int) -> torch.Tensor:
+        if L.shape[-1] != 6:
+            return super().develop(scene, L, spp)
+        return torch.cat([super().develop(scene, L[:, :3].contiguous(), spp), super().develop(scene, L[:, 3:].contiguous(), spp)], dim=1)
+
+    def film_backward(self, scene: Scene, grad_image: torch.Tensor, spp: int) -> torch.Tensor:
+        if grad_image.shape[-1] != 6:
+            return super().film_backward(scene, grad_image, spp)
+        return torch.cat([super().film_backward(scene, grad_image[:, :3].contiguous(), spp),
+                          super().film_backward(scene, grad_image[:, 3:].contiguous(), spp)], dim=1)
+
+    def sample(self, mode, scene: Scene, sampler: IndependentSampler, ray: RayBatch,
+               δL: Optional[torch.Tensor] = None, state_in: Optional[torch.Tensor] = None,
+               active=None, grads: Optional[Dict[str, torch.Tensor]] = None, **kwargs):
+        """-> (L [n, 6], valid, state_out); Backward: δL / state_in are [n, 6], gradients accumulate into
+        grads[sigma_t] and grads[albedo] (= the colour grid: albedo and emission are one parameter)."""
+        mode = ADMode(int(mode))
+        h, dev = self._bind(scene)
+        self._set_rays(h, ray)
+        n, ro, rd = self._ray_ptrs(ray, dev)
+        if mode == ADMode.Primal:
+            Ln = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            Ld = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            h.fused_render_primal(self._nerf_props(), ro, rd, n, int(ray.ray_offset), int(ray.spp), sampler.seed_value,
+                                  Ln.data_ptr(), Ld.data_ptr())
+            L = torch.cat([Ln, Ld], dim=1)
+            return L, True, L
+        if mode == ADMode.Backward:
+            if δL is None or state_in is None or grads is None:
+                raise ValueError("sample(Backward) needs δL, state_in and grads")
+            _check(δL, (n, 6), dev, "δL")
+            _check(state_in, (n, 6), dev, "state_in")
+            gs, ga = grads[SIGMA_T_KEY], grads[ALBEDO_KEY]
+            _check(gs, tuple(scene.medium.sigma_t.shape), dev, "grads[sigma_t]")
+            _check(ga, tuple(scene.medium.albedo.shape), dev, "grads[albedo]")
+            dLn, dLd = δL[:, :3].contiguous(), δL[:, 3:].contiguous()
+            Ln, Ld = state_in[:, :3].contiguous(), state_in[:, 3:].contiguous()
+            h.fused_render_backward(self._nerf_props(), ro, rd, n, int(ray.ray_offset), int(ray.spp), sampler.seed_value,
+                                    dLn.data_ptr(), Ln.data_ptr(), dLd.data_ptr(), Ld.data_ptr(), gs.data_ptr(), ga.data_ptr())
+            return None, True, None
+        raise NotImplementedError("forward-mode differentiation is not supported")
+
+
+register_integrator("nerf+volpathsimple", lambda props: FusedNerfDrtIntegrator(props))
 register_integrator("volpathsimple", lambda props: VolpathSimpleIntegrator(props))
 register_integrator("nerf", lambda props: NeRFIntegrator(props))

@@ -67,3 +67,8 @@ add_int_config('volpathsimple-basic', pretty_name='Free-flight based',
                params={'type': 'volpathsimple', 'use_drt': False})
 add_int_config('nerf', pretty_name='NeRF (grid-backed)',
                params={'type': 'nerf', 'queries_per_ray': 128})
+# BASELINE config 5 (no counterpart among the reference's registrations): `nerf` + `volpathsimple-drt` fused in one
+# pass over the interleaved four-channel grid (integrators.FusedNerfDrtIntegrator).
+add_int_config('nerf-drt-fused', pretty_name='NeRF + Differential Ratio Tracking (fused, 4-channel grid)',
+               params={'type': 'nerf+volpathsimple', 'queries_per_ray': 128, 'use_drt': True,
+                       'use_drt_subsampling': True, 'use_drt_mis': True})
