@@ -388,6 +388,13 @@ def sample_interaction_drt(oscene: OracleScene, o, d, seed: int, n: int, first: 
     return valid.astype(bool), t, W, float(maxt)
 
 
+def _fused_counters(cn: dict, cd: dict) -> dict:
+    """events of both halves; the rays are the same rays, counted once"""
+    out = {k: cn[k] + cd[k] for k in cd}
+    out["n_rays"] = cd["n_rays"]
+    return out
+
+
 def fused_render_primal(oscene: OracleScene, drt_props: dict, nerf_props: dict, spp: int, seed: int, **kw):
     """BASELINE config 5, the fused nerf + volpathsimple pass, restated: NeRFIntegrator.sample (nerf.py:47-148) with
     emission = the medium's colour grid (albedo and emission are one asset, scene_config.py:109-110) and
@@ -395,7 +402,7 @@ def fused_render_primal(oscene: OracleScene, drt_props: dict, nerf_props: dict, 
     -> (L [n, 6] = [nerf | volpathsimple], counters: the sum of both)."""
     Ln, cn = nerf_render(oscene, oscene.albedo, nerf_props, spp, seed, **kw)
     Ld, cd = render_primal(oscene, drt_props, spp, seed, **kw)
-    return np.concatenate([Ln, Ld], axis=1), {k: cn[k] + cd[k] for k in cd}
+    return np.concatenate([Ln, Ld], axis=1), _fused_counters(cn, cd)
 
 
 def fused_render_backward(oscene: OracleScene, drt_props: dict, nerf_props: dict, spp: int, seed: int, dL, L_in, **kw):
@@ -404,4 +411,4 @@ def fused_render_backward(oscene: OracleScene, drt_props: dict, nerf_props: dict
     gs_n, ge, cn = nerf_render(oscene, oscene.albedo, nerf_props, spp, seed, dL=np.ascontiguousarray(dL[:, :3]),
                                L_in=np.ascontiguousarray(L_in[:, :3]), **kw)
     gs_d, ga, cd = render_backward(oscene, drt_props, spp, seed, np.ascontiguousarray(dL[:, 3:]), np.ascontiguousarray(L_in[:, 3:]), **kw)
-    return gs_n + gs_d, ge + ga, {k: cn[k] + cd[k] for k in cd}
+    return gs_n + gs_d, ge + ga, _fused_counters(cn, cd)

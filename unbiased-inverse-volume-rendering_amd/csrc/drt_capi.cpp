@@ -59,6 +59,7 @@ struct drt_handle_s {
     size_t pcache_bytes = 0;
     struct JobSig { uint64_t n_rays, ray_offset, chunk, stride; uint32_t spp, seed; const void *rays_o, *rays_d; uint64_t scene_version; bool valid; } pcache_sig{};
     bool order_valid = false;          // block_order of the last primal launch is usable
+    bool perm_valid = false;           // ray_perm was written by the primal launch the path cache signature describes
     uint64_t order_rays = 0;           // ray count of the launch that produced the stored order (0: none)
     uint64_t scene_version = 0;        // bumped by every call that changes the medium / emitter / sensor / integrator state
     size_t mgrid_cells = 0;
@@ -181,7 +182,7 @@ void bind_path_cache_write(drt_handle h, drt::Params &P)
     if (P.n_rays != h->order_rays) h->order_rays = 0;           // another launch shape re-carves the buffer: the stored order dies
     if ((h->debug_flags & 1048576u) || P.n_rays > kPathCacheMaxRays) return;
     const size_t entries = (size_t) P.n_rays * kPathCacheCap * 2 * sizeof(uint4), n_blocks = (size_t) ((P.n_rays + 255) / 256);
-    const size_t need = entries + (size_t) P.n_rays * sizeof(uint32_t) + 2 * n_blocks * sizeof(uint32_t);
+    const size_t need = entries + (size_t) P.n_rays * sizeof(uint32_t) + 2 * n_blocks * sizeof(uint32_t) + n_blocks * 256;
     if (need > h->pcache_bytes) {
         if (h->d_pcache) { if (hipStreamSynchronize(h->stream) != hipSuccess) return; (void) hipFree(h->d_pcache); h->d_pcache = nullptr; h->pcache_bytes = 0; }
         h->order_rays = 0;
@@ -193,6 +194,8 @@ void bind_path_cache_write(drt_handle h, drt::Params &P)
     P.path_cache_cap = kPathCacheCap; P.path_cache_mode = 1;
     P.block_cost = P.ray_hash + P.n_rays;
     if (hipMemsetAsync(P.block_cost, 0, n_blocks * sizeof(uint32_t), h->stream) != hipSuccess) { (void) hipGetLastError(); P.block_cost = nullptr; }
+    if (!(h->debug_flags & 4194304u)) P.ray_perm = (uint8_t *) (P.ray_hash + P.n_rays + 2 * n_blocks);   // written by the cooperative primal kernel only
+    h->perm_valid = false;
     h->pcache_sig = job_sig(h, P);
 }
 
@@ -210,6 +213,7 @@ void bind_path_cache_read(drt_handle h, drt::Params &P, uint64_t job_rays)
     //  the full 512^2 the XCD-contiguous block map is worth more than the order: 9.48 vs 10.02 ms)
     if (!no_lpt && P.ray_first == 0 && P.n_rays == job_rays && h->order_valid)
         P.block_order = P.ray_hash + job_rays + (job_rays + 255) / 256;
+    if (h->perm_valid && !(h->debug_flags & 4194304u)) P.ray_perm = (uint8_t *) (P.ray_hash + job_rays + 2 * ((job_rays + 255) / 256));
 }
 
 int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
@@ -821,6 +825,7 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     }
     rc = timed_launch(h, 0, P, false);
     h->order_valid = false;
+    h->perm_valid = rc == DRT_OK && P.ray_perm && !P.mgrid && !(h->debug_flags & (8u | 65536u));   // the cooperative primal kernel wrote it
     if (rc == DRT_OK && P.block_cost && !P.mgrid && !(h->debug_flags & (8u | 65536u))) {   // cooperative primal: it filled block_cost
         const uint32_t n_blocks = (uint32_t) ((P.n_rays + 255) / 256);
         DRT_HIP_CHECK(h, drt::launch_block_order(P.block_cost, n_blocks, P.block_cost + n_blocks, n_blocks <= kHeavyFirstMaxBlocks, h->stream));

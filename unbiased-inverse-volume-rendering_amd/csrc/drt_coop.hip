@@ -24,7 +24,9 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
         }
     }
 #endif
-    uint64_t i = P.ray_first + (uint64_t) b * blockDim.x + threadIdx.x;
+    const uint64_t i_block = P.ray_first + (uint64_t) b * blockDim.x;
+    uint64_t i = i_block + threadIdx.x;
+    if constexpr (ADJ) { if (P.ray_perm) i = i_block + P.ray_perm[i_block + threadIdx.x]; }   // rays of similar length share a wave
     CoopTracer<COUNT, ENV, DEFER, SPEC> tr(P);
     __shared__ uint32_t slot_lds[4 * 64];
     tr.slots = slot_lds + (threadIdx.x >> 6) * 64;
@@ -90,6 +92,20 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
     }
     if constexpr (ADJ && DEFER) close_records(P, tr.rec);
     if constexpr (!ADJ) {
+        if (P.ray_perm) {
+            // counting sort of the block's rays by bounce-loop iterations, longest first (ties in arrival order: the
+            // permutation is a schedule, not a result)
+            __shared__ uint32_t perm_hist[32];
+            const uint32_t key = tr.iters < 31u ? tr.iters : 31u;
+            if (threadIdx.x < 32) perm_hist[threadIdx.x] = 0;
+            __syncthreads();
+            atomicAdd(&perm_hist[key], 1u);
+            __syncthreads();
+            if (threadIdx.x == 0) { uint32_t run = 0; for (int k = 31; k >= 0; --k) { const uint32_t c = perm_hist[k]; perm_hist[k] = run; run += c; } }
+            __syncthreads();
+            const uint32_t pos = atomicAdd(&perm_hist[key], 1u);
+            P.ray_perm[i_block + pos] = (uint8_t) threadIdx.x;
+        }
         if (P.block_cost) {
             uint32_t v = tr.work;
 #pragma unroll

@@ -93,12 +93,13 @@ struct CoopTracer {
     const uint32_t *occ;
     uint4 *pc;              // this ray's path-cache entries (2 x uint4 per bounce-loop iteration) or nullptr
     uint32_t work;          // tracking steps of this ray's main path (primal pass: feeds block_cost)
+    uint32_t iters;         // bounce-loop iterations of this ray's main path (primal pass: feeds ray_perm)
     uint32_t cnt[C_COUNT];
 
     __device__ __forceinline__ CoopTracer(const Params &p) : P(p)
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
-        ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr; work = 0;
+        ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr; work = 0; iters = 0;
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
@@ -603,6 +604,7 @@ struct CoopTracer {
                 for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
             }
         }
+        if (!RECURSIVE) iters = (uint32_t) it;
         out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
     }
 };

@@ -269,6 +269,11 @@ struct Params {
     // block_cost, block_order (blocks by descending cost) then tells the adjoint launch which block a workgroup takes
     uint32_t *block_cost;
     const uint32_t *block_order;
+    // ray -> lane schedule inside every 256-ray block: the primal pass sorts the block's rays by the number of
+    // bounce-loop iterations they ran (longest first) and writes the permutation; the adjoint pass of the same job
+    // hands ray ray_perm[slot] of the block to thread `slot`, so that a wave's 64 rays leave the bounce loop together
+    // (a schedule only: every ray's result is independent of the lane that traces it)
+    uint8_t *ray_perm;
     uint4 *path_cache;
     uint32_t *ray_hash;
     uint32_t path_cache_cap, path_cache_mode;

@@ -158,8 +158,13 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t xcc = xcc_id();
     const uint64_t n_runs = (P.n_rays + DRT_QUEUE_RUN - 1) / DRT_QUEUE_RUN;
-    const uint64_t my_len = (n_runs > xcc ? (n_runs - xcc + 7) / 8 : 0) * DRT_QUEUE_RUN;   // runs xcc, xcc+8, ...
-    unsigned long long *queue = P.queues + xcc;
+    // queue x serves the runs x, x + 8, ...; a wave starts on the queue of the XCD it runs on (L2 locality) and, when
+    // that one is drained, moves on to the next ones: every ray is traced whatever the placement of the workgroups
+    // (HIP promises no block -> XCD map; another process on the device can keep whole XCDs busy)
+    uint32_t qsel = 0;                         // wave-uniform: queues drained so far by this wave
+    uint32_t qx = xcc;                         // current queue
+    uint64_t my_len = (n_runs > qx ? (n_runs - qx + 7) / 8 : 0) * DRT_QUEUE_RUN;
+    unsigned long long *queue = P.queues + qx;
     uint64_t pool_next = 0, pool_end = 0;      // wave-uniform: this wave's reserved queue positions
     uint32_t cnt[C_COUNT];
 #pragma unroll
@@ -203,21 +208,29 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
         {
             const uint64_t wmask = __ballot(ph == PH_IDLE);
             if (wmask && (__popcll(wmask) >= DRT_WF_REGEN_MIN || !__ballot(ph < PH_IDLE))) {
-                if (pool_next >= pool_end) {                                     // refill (wave-uniform)
+                while (pool_next >= pool_end && qsel < 8) {                      // refill (wave-uniform)
                     const int leader = __ffsll((long long) wmask) - 1;
                     unsigned long long base = 0;
                     if ((int) lane == leader) base = atomicAdd(queue, (unsigned long long) DRT_WF_CHUNK);
                     base = ((unsigned long long)(unsigned int) __shfl((int)(base >> 32), leader, 64) << 32)
                          | (unsigned int) __shfl((int) base, leader, 64);
-                    pool_next = base; pool_end = base + DRT_WF_CHUNK;
+                    if (base < my_len) { pool_next = base; pool_end = base + DRT_WF_CHUNK; }
+                    else {                                                       // this queue is drained: next one
+                        ++qsel;
+                        qx = (xcc + qsel) & 7u;
+                        my_len = (n_runs > qx ? (n_runs - qx + 7) / 8 : 0) * DRT_QUEUE_RUN;
+                        queue = P.queues + qx;
+                    }
                 }
+                const bool drained = qsel >= 8;
                 const uint64_t q = pool_next + (uint64_t) __popcll(wmask & ((1ull << lane) - 1ull));
-                const bool take = (ph == PH_IDLE) && q < pool_end;
+                const bool take = (ph == PH_IDLE) && !drained && q < pool_end;
+                if (drained && ph == PH_IDLE) ph = PH_DEAD;                      // all eight queues are empty
                 pool_next += (uint64_t) __popcll(wmask);
                 if (pool_next > pool_end) pool_next = pool_end;
                 if (take) {
-                    const uint64_t i = ((q / DRT_QUEUE_RUN) * 8 + xcc) * DRT_QUEUE_RUN + (q % DRT_QUEUE_RUN);
-                    if (q >= my_len) ph = PH_DEAD;
+                    const uint64_t i = ((q / DRT_QUEUE_RUN) * 8 + qx) * DRT_QUEUE_RUN + (q % DRT_QUEUE_RUN);
+                    if (q >= my_len) { /* tail of the reserved chunk beyond the queue: stay idle and draw again */ }
                     else if (i < P.n_rays) {
                         // ---- sample() prologue (:51-108) + reach_medium (:292-319) ----
                         li = i;
