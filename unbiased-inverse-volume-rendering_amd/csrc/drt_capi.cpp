@@ -175,6 +175,13 @@ drt_handle_s::JobSig job_sig(drt_handle h, const drt::Params &P)
     return drt_handle_s::JobSig{ P.n_rays, P.ray_offset, P.chunk, P.stride, P.spp, P.seed, P.rays_o, P.rays_d, h->scene_version, true };
 }
 
+// layout behind the path-cache entries: [rays] hash words | [blocks] cost | [blocks] order | [perm slots] u16 schedule | [perm slots] u8 keys
+uint16_t *perm_base(uint32_t *ray_hash, uint64_t n_rays)
+{
+    const uint64_t n_blocks = (n_rays + 255) / 256;
+    return (uint16_t *) (((uintptr_t) (ray_hash + n_rays + 2 * n_blocks) + 7) & ~(uintptr_t) 7);
+}
+
 // primal launch of the cooperative kernel: bind the cache for writing (best effort)
 void bind_path_cache_write(drt_handle h, drt::Params &P)
 {
@@ -182,7 +189,8 @@ void bind_path_cache_write(drt_handle h, drt::Params &P)
     if (P.n_rays != h->order_rays) h->order_rays = 0;           // another launch shape re-carves the buffer: the stored order dies
     if ((h->debug_flags & 1048576u) || P.n_rays > kPathCacheMaxRays) return;
     const size_t entries = (size_t) P.n_rays * kPathCacheCap * 2 * sizeof(uint4), n_blocks = (size_t) ((P.n_rays + 255) / 256);
-    const size_t need = entries + (size_t) P.n_rays * sizeof(uint32_t) + 2 * n_blocks * sizeof(uint32_t) + n_blocks * 256;
+    const size_t perm_slots = ((size_t) P.n_rays + drt::kPermGroup - 1) / drt::kPermGroup * drt::kPermGroup;
+    const size_t need = entries + (size_t) P.n_rays * sizeof(uint32_t) + 2 * n_blocks * sizeof(uint32_t) + perm_slots * 3 + 16;
     if (need > h->pcache_bytes) {
         if (h->d_pcache) { if (hipStreamSynchronize(h->stream) != hipSuccess) return; (void) hipFree(h->d_pcache); h->d_pcache = nullptr; h->pcache_bytes = 0; }
         h->order_rays = 0;
@@ -194,7 +202,7 @@ void bind_path_cache_write(drt_handle h, drt::Params &P)
     P.path_cache_cap = kPathCacheCap; P.path_cache_mode = 1;
     P.block_cost = P.ray_hash + P.n_rays;
     if (hipMemsetAsync(P.block_cost, 0, n_blocks * sizeof(uint32_t), h->stream) != hipSuccess) { (void) hipGetLastError(); P.block_cost = nullptr; }
-    if (!(h->debug_flags & 4194304u)) P.ray_perm = (uint8_t *) (P.ray_hash + P.n_rays + 2 * n_blocks);   // written by the cooperative primal kernel only
+    if (!(h->debug_flags & 4194304u)) P.ray_iters = (uint8_t *) (perm_base(P.ray_hash, P.n_rays) + perm_slots);   // written by the cooperative primal kernel only
     h->perm_valid = false;
     h->pcache_sig = job_sig(h, P);
 }
@@ -213,7 +221,7 @@ void bind_path_cache_read(drt_handle h, drt::Params &P, uint64_t job_rays)
     //  the full 512^2 the XCD-contiguous block map is worth more than the order: 9.48 vs 10.02 ms)
     if (!no_lpt && P.ray_first == 0 && P.n_rays == job_rays && h->order_valid)
         P.block_order = P.ray_hash + job_rays + (job_rays + 255) / 256;
-    if (h->perm_valid && !(h->debug_flags & 4194304u)) P.ray_perm = (uint8_t *) (P.ray_hash + job_rays + 2 * ((job_rays + 255) / 256));
+    if (h->perm_valid && !(h->debug_flags & 4194304u)) P.ray_perm = perm_base(P.ray_hash, job_rays);
 }
 
 int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
@@ -385,7 +393,8 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
         uint64_t batch = (budget / want_pipe_slots) / bytes_per_ray;
         const bool pipe = want_pipe && (forced || n_rays >= kPipeMinRays);
         if (pipe && batch > (n_rays + kPipeBatches - 1) / kPipeBatches) batch = (n_rays + kPipeBatches - 1) / kPipeBatches;
-        batch = (h->debug_flags & 16384u) ? (batch + 255) / 256 * 256 : (batch + 65535) / 65536 * 65536;   // whole workgroups (and XCD runs) per sub-batch
+        // whole ray-schedule groups (kPermGroup rays = 4 workgroups) and XCD runs per sub-batch
+        batch = (h->debug_flags & 16384u) ? (batch + drt::kPermGroup - 1) / drt::kPermGroup * drt::kPermGroup : (batch + 65535) / 65536 * 65536;
         const bool overlap = pipe;
         if (overlap && !h->side) {
             int lo = 0, hi = 0;
@@ -825,7 +834,11 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     }
     rc = timed_launch(h, 0, P, false);
     h->order_valid = false;
-    h->perm_valid = rc == DRT_OK && P.ray_perm && !P.mgrid && !(h->debug_flags & (8u | 65536u));   // the cooperative primal kernel wrote it
+    h->perm_valid = false;
+    if (rc == DRT_OK && P.ray_iters && !P.mgrid && !(h->debug_flags & (8u | 65536u))) {    // the cooperative primal kernel wrote the keys
+        DRT_HIP_CHECK(h, drt::launch_ray_perm(P.ray_iters, P.n_rays, perm_base(P.ray_hash, P.n_rays), h->stream));
+        h->perm_valid = true;
+    }
     if (rc == DRT_OK && P.block_cost && !P.mgrid && !(h->debug_flags & (8u | 65536u))) {   // cooperative primal: it filled block_cost
         const uint32_t n_blocks = (uint32_t) ((P.n_rays + 255) / 256);
         DRT_HIP_CHECK(h, drt::launch_block_order(P.block_cost, n_blocks, P.block_cost + n_blocks, n_blocks <= kHeavyFirstMaxBlocks, h->stream));

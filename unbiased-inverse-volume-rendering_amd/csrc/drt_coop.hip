@@ -26,7 +26,9 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
 #endif
     const uint64_t i_block = P.ray_first + (uint64_t) b * blockDim.x;
     uint64_t i = i_block + threadIdx.x;
-    if constexpr (ADJ) { if (P.ray_perm) i = i_block + P.ray_perm[i_block + threadIdx.x]; }   // rays of similar length share a wave
+    if constexpr (ADJ) {                                        // rays of similar length share a wave (ray_perm_kernel)
+        if (P.ray_perm) i = (i_block & ~(uint64_t) (kPermGroup - 1)) + P.ray_perm[i_block + threadIdx.x];
+    }
     CoopTracer<COUNT, ENV, DEFER, SPEC> tr(P);
     __shared__ uint32_t slot_lds[4 * 64];
     tr.slots = slot_lds + (threadIdx.x >> 6) * 64;
@@ -92,20 +94,7 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
     }
     if constexpr (ADJ && DEFER) close_records(P, tr.rec);
     if constexpr (!ADJ) {
-        if (P.ray_perm) {
-            // counting sort of the block's rays by bounce-loop iterations, longest first (ties in arrival order: the
-            // permutation is a schedule, not a result)
-            __shared__ uint32_t perm_hist[32];
-            const uint32_t key = tr.iters < 31u ? tr.iters : 31u;
-            if (threadIdx.x < 32) perm_hist[threadIdx.x] = 0;
-            __syncthreads();
-            atomicAdd(&perm_hist[key], 1u);
-            __syncthreads();
-            if (threadIdx.x == 0) { uint32_t run = 0; for (int k = 31; k >= 0; --k) { const uint32_t c = perm_hist[k]; perm_hist[k] = run; run += c; } }
-            __syncthreads();
-            const uint32_t pos = atomicAdd(&perm_hist[key], 1u);
-            P.ray_perm[i_block + pos] = (uint8_t) threadIdx.x;
-        }
+        if (P.ray_iters && job) P.ray_iters[i] = (uint8_t) (tr.iters < 255u ? tr.iters : 255u);   // sort key of ray_perm_kernel
         if (P.block_cost) {
             uint32_t v = tr.work;
 #pragma unroll
@@ -181,6 +170,39 @@ __global__ void __launch_bounds__(1024) block_light_last_kernel(const uint32_t *
     }
 }
 }  // namespace
+
+namespace {
+// Ray -> lane schedule of the adjoint pass: every group of kPermGroup consecutive rays (4 workgroups) is sorted by the
+// number of bounce-loop iterations the primal pass counted (longest first), so that the 64 rays
+// of a wave leave the adjoint's bounce loop together.  One workgroup per group; rays beyond n_rays sort last.
+__global__ void __launch_bounds__(kPermGroup) ray_perm_kernel(const uint8_t *iters, uint64_t n_rays, uint16_t *perm)
+{
+    __shared__ uint32_t hist[64];
+    const uint64_t i = (uint64_t) blockIdx.x * kPermGroup + threadIdx.x;
+    const uint32_t key = i < n_rays ? (iters[i] < 63u ? 63u - iters[i] : 0u) : 63u;      // bucket 0 = longest
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    atomicAdd(&hist[key], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {                                      // exclusive scan of the 64 buckets by one wave
+        const uint32_t c = hist[threadIdx.x];
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off, 64); if ((int) threadIdx.x >= off) incl += t; }
+        hist[threadIdx.x] = incl - c;
+    }
+    __syncthreads();
+    const uint32_t pos = atomicAdd(&hist[key], 1u);              // ties in arrival order: a schedule, not a result
+    perm[(uint64_t) blockIdx.x * kPermGroup + pos] = (uint16_t) threadIdx.x;
+}
+}  // namespace
+
+hipError_t launch_ray_perm(const uint8_t *iters, uint64_t n_rays, uint16_t *perm, hipStream_t stream)
+{
+    if (n_rays == 0) return hipSuccess;
+    hipLaunchKernelGGL(ray_perm_kernel, dim3((unsigned) ((n_rays + kPermGroup - 1) / kPermGroup)), dim3(kPermGroup), 0, stream, iters, n_rays, perm);
+    return hipGetLastError();
+}
 
 hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t *order, bool heavy_first, hipStream_t stream)
 {

@@ -222,15 +222,18 @@ __global__ void __launch_bounds__(kPartThreads) bin_scatter_kernel(const Params 
     }
 }
 
-// blockIdx.y = reduce plane: 0: stream 0 -> sigma_t; 1..4: stream 1 -> sigma_t, r, g, b
+// blockIdx.y = reduce plane: 0: sigma_t of stream 0 AND of stream 1 (for every tile that has stream-0 records: the
+// workgroup that starts such a tile's first unit also adds stream 1's sigma_t values of that tile - one zero / flush
+// of the LDS tile instead of two); 1: sigma_t of stream 1 for the tiles WITHOUT stream-0 records; 2..4: r, g, b of stream 1
 __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const DeferredPlan D)
 {
     extern __shared__ unsigned long long tile[];                 // kLdsTile signed 64-bit fixed-point accumulators
     const int plane = blockIdx.y;
     const int s = plane == 0 ? 0 : 1, ch = plane == 0 ? 0 : plane - 1;        // stream, channel of the record
     const int quads = s == 0 ? 1 : 2;
-    // scale = 2^(40 - e) with max|v| < 2^e: |w * v| * scale < 2^40, 2^23 such adds fit an int64
-    const float vmax = __uint_as_float(D.vmax[plane]);
+    // scale = 2^(40 - e) with max|v| < 2^e: |w * v| * scale < 2^40, 2^23 such adds fit an int64; the two sigma_t
+    // planes share one scale (plane 0 adds values of both streams)
+    const float vmax = plane <= 1 ? fmaxf(__uint_as_float(D.vmax[0]), __uint_as_float(D.vmax[1])) : __uint_as_float(D.vmax[plane]);
     if (vmax == 0.0f) return;                                    // nothing but zeros in this plane
     const bool finite = vmax <= 3.0e38f;                         // a NaN / inf anywhere in the plane: float path below
     int e = 0;
@@ -238,6 +241,7 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
     const double scale = ldexp(1.0, 40 - e), inv_scale = ldexp(1.0, e - 40);
     const uint32_t *base = D.bin_base + (size_t) s * (D.n_bins + 1);
     const uint32_t *ustart = D.unit_start + (size_t) s * (D.n_bins + 1);
+    const uint32_t *base0 = D.bin_base, *base1 = D.bin_base + (D.n_bins + 1);
     const uint32_t n_units = ustart[D.n_bins];
     // persistent workgroups (empty ones are not free to dispatch), each a CONTIGUOUS run of units: the
     // units of a heavy tile follow one another, so the LDS tile is zeroed / flushed once per run
@@ -247,6 +251,40 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
     const int stride = ch == 0 ? 1 : 3;
     const float4 *src = D.out[s];
     int b = -1, X0 = 0, Y0 = 0, Z0 = 0;
+    bool live = false;                                            // the LDS tile holds sums of tile b that must be flushed
+
+    // one record {position r.xyz, value}: 8 LDS adds (or, on the non-finite path, 8 float atomics into the grid)
+    auto add_record = [&](const float4 r, const float val) {
+        if (val == 0.0f) return;                                  // adding exact zeros changes nothing
+        Stencil st;
+        axis_setup(r.x, P.bmin[0], P.inv_ext[0], P.rx, st.x0, st.x1, st.wx0, st.wx1);
+        axis_setup(r.y, P.bmin[1], P.inv_ext[1], P.ry, st.y0, st.y1, st.wy0, st.wy1);
+        axis_setup(r.z, P.bmin[2], P.inv_ext[2], P.rz, st.z0, st.z1, st.wz0, st.wz1);
+        float w[8];
+        stencil_weights(st, w);
+        if (!finite) {
+            // a non-finite gradient value somewhere in this plane: add the float products straight to the
+            // caller's grid, as the atomic path does - NaN / inf propagate instead of being clamped away
+            const int gx[2] = { st.x0, st.x1 }, gy[2] = { st.y0, st.y1 }, gz[2] = { st.z0, st.z1 };
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const size_t vox = ((size_t) gz[c >> 2] * P.ry + gy[(c >> 1) & 1]) * P.rx + gx[c & 1];
+                atomicAdd(dst + (size_t) stride * vox, w[c] * val);
+            }
+            return;
+        }
+        const int x0 = st.x0 - X0, x1 = st.x1 - X0;
+        const int y0 = (st.y0 - Y0) * (kTileX + 1), y1 = (st.y1 - Y0) * (kTileX + 1);
+        const int z0 = (st.z0 - Z0) * ((kTileX + 1) * (kTileY + 1)), z1 = (st.z1 - Z0) * ((kTileX + 1) * (kTileY + 1));
+        const int o[8] = { z0 + y0 + x0, z0 + y0 + x1, z0 + y1 + x0, z0 + y1 + x1,
+                           z1 + y0 + x0, z1 + y0 + x1, z1 + y1 + x0, z1 + y1 + x1 };
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float pv = w[c] * val;                           // the float product the atomic path adds (|pv| <= vmax)
+            atomicAdd(&tile[o[c]], (unsigned long long) __double2ll_rn((double) pv * scale));
+        }
+    };
+
     for (uint32_t u = u_begin; u <= u_end; ++u) {
         int nb = -1;
         if (u < u_end) {
@@ -256,12 +294,11 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
         }
         if (nb == b && nb < 0) break;                             // no units at all for this workgroup
         if (nb != b) {
-            if (b >= 0 && finite && !(P.debug_flags & 1024u)) {   // flush the finished tile (+=)
+            if (b >= 0 && live && finite && !(P.debug_flags & 1024u)) {   // flush the finished tile (+=)
                 lds_atomics_barrier();
                 for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) {
                     const long long q = (long long) tile[j];
                     if (q == 0) continue;
-                    if (P.debug_flags & 8192u) atomicAdd((unsigned long long *) (D.cursor + 12) + plane, (unsigned long long) q);   // exact checksum of what is flushed
                     const float v = (float) ((double) q * inv_scale);
                     const int lx = j % (kTileX + 1), ly = (j / (kTileX + 1)) % (kTileY + 1), lz = j / ((kTileX + 1) * (kTileY + 1));
                     const size_t vox = ((size_t) (Z0 + lz) * P.ry + (Y0 + ly)) * P.rx + (X0 + lx);
@@ -272,11 +309,20 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
             if (nb < 0) break;
             b = nb;
             X0 = (b % D.ntx) * kTileX; Y0 = ((b / D.ntx) % D.nty) * kTileY; Z0 = (b / (D.ntx * D.nty)) * kTileZ;
-            if (finite) {
+            live = !(plane == 1 && base0[b + 1] > base0[b]);      // plane 1 leaves tiles with stream-0 records to plane 0
+            if (live && finite) {
                 for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) tile[j] = 0ull;
                 __syncthreads();
             }
+            if (plane == 0 && u == ustart[b]) {                   // first unit of this tile: stream 1's sigma_t values come along
+                const float4 *src1 = D.out[1];
+                for (uint32_t i1 = base1[b] + threadIdx.x; i1 < base1[b + 1]; i1 += blockDim.x) {
+                    const float4 r = src1[2 * (size_t) i1];
+                    add_record(r, r.w);
+                }
+            }
         }
+        if (!live) continue;
         const uint32_t first = base[b] + (u - ustart[b]) * kUnitRecords;
         const uint32_t last = min(first + kUnitRecords, base[b + 1]);
         for (uint32_t i0 = first + threadIdx.x; i0 < last; i0 += 4 * blockDim.x) {
@@ -290,37 +336,8 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-            if (i0 + k * blockDim.x >= last) break;
-            const float4 r = rr[k];
-            const float val = vv[k];
-            if (val == 0.0f) continue;                            // adding exact zeros changes nothing
-            Stencil st;
-            axis_setup(r.x, P.bmin[0], P.inv_ext[0], P.rx, st.x0, st.x1, st.wx0, st.wx1);
-            axis_setup(r.y, P.bmin[1], P.inv_ext[1], P.ry, st.y0, st.y1, st.wy0, st.wy1);
-            axis_setup(r.z, P.bmin[2], P.inv_ext[2], P.rz, st.z0, st.z1, st.wz0, st.wz1);
-            float w[8];
-            stencil_weights(st, w);
-            if (!finite) {
-                // a non-finite gradient value somewhere in this plane: add the float products straight to the
-                // caller's grid, as the atomic path does - NaN / inf propagate instead of being clamped away
-                const int gx[2] = { st.x0, st.x1 }, gy[2] = { st.y0, st.y1 }, gz[2] = { st.z0, st.z1 };
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const size_t vox = ((size_t) gz[c >> 2] * P.ry + gy[(c >> 1) & 1]) * P.rx + gx[c & 1];
-                    atomicAdd(dst + (size_t) stride * vox, w[c] * val);
-                }
-                continue;
-            }
-            const int x0 = st.x0 - X0, x1 = st.x1 - X0;
-            const int y0 = (st.y0 - Y0) * (kTileX + 1), y1 = (st.y1 - Y0) * (kTileX + 1);
-            const int z0 = (st.z0 - Z0) * ((kTileX + 1) * (kTileY + 1)), z1 = (st.z1 - Z0) * ((kTileX + 1) * (kTileY + 1));
-            const int o[8] = { z0 + y0 + x0, z0 + y0 + x1, z0 + y1 + x0, z0 + y1 + x1,
-                               z1 + y0 + x0, z1 + y0 + x1, z1 + y1 + x0, z1 + y1 + x1 };
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float pv = w[c] * val;                       // the float product the atomic path adds (|pv| <= vmax)
-                atomicAdd(&tile[o[c]], (unsigned long long) __double2ll_rn((double) pv * scale));
-            }
+                if (i0 + k * blockDim.x >= last) break;
+                add_record(rr[k], vv[k]);
             }
         }
     }

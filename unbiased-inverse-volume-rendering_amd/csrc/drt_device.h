@@ -269,11 +269,12 @@ struct Params {
     // block_cost, block_order (blocks by descending cost) then tells the adjoint launch which block a workgroup takes
     uint32_t *block_cost;
     const uint32_t *block_order;
-    // ray -> lane schedule inside every 256-ray block: the primal pass sorts the block's rays by the number of
-    // bounce-loop iterations they ran (longest first) and writes the permutation; the adjoint pass of the same job
-    // hands ray ray_perm[slot] of the block to thread `slot`, so that a wave's 64 rays leave the bounce loop together
-    // (a schedule only: every ray's result is independent of the lane that traces it)
-    uint8_t *ray_perm;
+    // ray -> lane schedule inside every group of kPermGroup rays: the primal pass records how many bounce-loop
+    // iterations each ray ran, ray_perm_kernel sorts every group by it (longest first), and the adjoint pass of the
+    // same job hands ray ray_perm[slot] of the group to thread `slot`, so that a wave's 64 rays leave the bounce
+    // loop together (a schedule only: every ray's result is independent of the lane that traces it)
+    uint8_t *ray_iters;            // [rays] written by the cooperative primal kernel
+    const uint16_t *ray_perm;      // [rays rounded up to kPermGroup] read by the cooperative adjoint kernel
     uint4 *path_cache;
     uint32_t *ray_hash;
     uint32_t path_cache_cap, path_cache_mode;
@@ -628,6 +629,7 @@ __device__ __forceinline__ void stencil_indices(const Stencil &s, int idx[8])
 // lanes stage (index, value) records in a wave-private LDS area and then, in groups
 // of up to 8 lanes, walk the group's records: lane j of the group adds corner j.
 constexpr int kCoopDwords = 32;   // per lane: 8 indices + 3 x 8 values
+constexpr int kPermGroup = 1024;  // rays per sort group of the adjoint's ray -> lane schedule (a multiple of the workgroup size)
 constexpr int kOccWords = 1024;   // empty-space bitmask: at most 32768 cells = 4 KiB of LDS per workgroup
 
 // Lanes of ONE wavefront exchange records through LDS.  The hardware executes a wave's DS
