@@ -52,6 +52,7 @@ __device__ __forceinline__ void lds_atomics_barrier()
     __syncthreads();
 }
 constexpr int kPartUnroll = DRT_PART_UNROLL;   // chunks a partition thread keeps in flight
+constexpr uint32_t kRideRecords = 4096;  // stream-1 records per tile that plane 0 takes along (a quarter of a reduce unit)
 constexpr uint32_t kReduceWGs = 1024;   // per stream: 4 workgroups per CU, looping over the reduce units
 
 struct Cell { int x0, x1, y0, y1, z0, z1; float w[8]; };
@@ -309,12 +310,15 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
             if (nb < 0) break;
             b = nb;
             X0 = (b % D.ntx) * kTileX; Y0 = ((b / D.ntx) % D.nty) * kTileY; Z0 = (b / (D.ntx * D.nty)) * kTileZ;
-            live = !(plane == 1 && base0[b + 1] > base0[b]);      // plane 1 leaves tiles with stream-0 records to plane 0
+            // stream 1's sigma_t values of tile b ride along with stream 0's when they are few (scatter events next to
+            // the transmittance splats); when they are many (nerf queries) they keep their own plane and units
+            const bool ride = base0[b + 1] > base0[b] && base1[b + 1] - base1[b] <= kRideRecords;
+            live = !(plane == 1 && ride);
             if (live && finite) {
                 for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) tile[j] = 0ull;
                 __syncthreads();
             }
-            if (plane == 0 && u == ustart[b]) {                   // first unit of this tile: stream 1's sigma_t values come along
+            if (plane == 0 && ride && u == ustart[b]) {           // first unit of this tile: stream 1's sigma_t values come along
                 const float4 *src1 = D.out[1];
                 for (uint32_t i1 = base1[b] + threadIdx.x; i1 < base1[b + 1]; i1 += blockDim.x) {
                     const float4 r = src1[2 * (size_t) i1];

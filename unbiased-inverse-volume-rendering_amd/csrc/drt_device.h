@@ -207,6 +207,8 @@ struct Params {
     int g4_nbx;                // lines per grid row = ceil(rx / 3)
     const float *majorant;     // device: [0] = scale*max(sigma_t), [1] = 1/[0] (0 if [0]==0)
     const float *mgrid;        // majorant supergrid, one majorant per cell (x fastest), or nullptr
+    const uint32_t *mocc;      // bit c = supergrid cell c has a non-zero majorant (the DDA skips the others without a load)
+    int mocc_words;
     int gx, gy, gz;
     int rx, ry, rz;
     float bmin[3], bmax[3], inv_ext[3];
@@ -432,6 +434,57 @@ __device__ __forceinline__ void emitter_eval(const Params &P, V3 d, float Le[3])
 {
     if constexpr (ENV) envmap_eval(P, d, Le);
     else { Le[0] = P.Le[0]; Le[1] = P.Le[1]; Le[2] = P.Le[2]; }
+}
+
+// Medium::sample_interaction with a majorant supergrid (scene_config.py:36, optimize.py:182-199) [M3-ext]: 3-D DDA
+// through the cells the ray crosses, accumulating majorant * length until tau = -log(1-u) is reached.  Returns the
+// distance (inf if the ray leaves [0, tmax] first) and the local majorant / reciprocal at the collision.
+// `mocc`: bitmask of the cells with a non-zero majorant as this wave reads it (LDS copy inside the tracing kernels,
+// nullptr: every cell is loaded): empty cells contribute nothing to the optical depth, so the walk through empty
+// space - most of a sparse volume - runs on LDS bit tests instead of a chain of dependent L2 loads.
+__device__ __forceinline__ float dda_collision(const Params &P, const float *mg, const uint32_t *mocc, V3 o, V3 d, float tmax,
+                                               float u, float &m_out, float &im_out)
+{
+    const float tau = -drt_logf(1.0f - u);
+    float gxf = ((o.x - P.bmin[0]) * P.inv_ext[0]) * (float) P.gx, dgx = (d.x * P.inv_ext[0]) * (float) P.gx;
+    float gyf = ((o.y - P.bmin[1]) * P.inv_ext[1]) * (float) P.gy, dgy = (d.y * P.inv_ext[1]) * (float) P.gy;
+    float gzf = ((o.z - P.bmin[2]) * P.inv_ext[2]) * (float) P.gz, dgz = (d.z * P.inv_ext[2]) * (float) P.gz;
+    float flx = fminf(fmaxf(floorf(gxf), 0.0f), (float)(P.gx - 1));
+    float fly = fminf(fmaxf(floorf(gyf), 0.0f), (float)(P.gy - 1));
+    float flz = fminf(fmaxf(floorf(gzf), 0.0f), (float)(P.gz - 1));
+    int cx = (int) flx, cy = (int) fly, cz = (int) flz;
+    float tnx, tny, tnz, tdx, tdy, tdz; int sx, sy, sz;
+    if (dgx > 0.0f) { tnx = ((flx + 1.0f) - gxf) / dgx; tdx = 1.0f / dgx; sx = 1; }
+    else if (dgx < 0.0f) { tnx = (flx - gxf) / dgx; tdx = -1.0f / dgx; sx = -1; }
+    else { tnx = kInf; tdx = kInf; sx = 0; }
+    if (dgy > 0.0f) { tny = ((fly + 1.0f) - gyf) / dgy; tdy = 1.0f / dgy; sy = 1; }
+    else if (dgy < 0.0f) { tny = (fly - gyf) / dgy; tdy = -1.0f / dgy; sy = -1; }
+    else { tny = kInf; tdy = kInf; sy = 0; }
+    if (dgz > 0.0f) { tnz = ((flz + 1.0f) - gzf) / dgz; tdz = 1.0f / dgz; sz = 1; }
+    else if (dgz < 0.0f) { tnz = (flz - gzf) / dgz; tdz = -1.0f / dgz; sz = -1; }
+    else { tnz = kInf; tdz = kInf; sz = 0; }
+    float t = 0.0f, acc = 0.0f;
+    for (;;) {
+        int a = (tny < tnx) ? 1 : 0;
+        float tmin = (tny < tnx) ? tny : tnx;
+        if (tnz < tmin) { a = 2; tmin = tnz; }
+        float texit = fminf(tmin, tmax);
+        const int cell = (cz * P.gy + cy) * P.gx + cx;
+        float mc = 0.0f;
+        if (!mocc || ((mocc[cell >> 5] >> (cell & 31)) & 1u)) mc = mg[cell];
+        if (mc > 0.0f) {
+            float dtau = mc * (texit - t);
+            if (acc + dtau >= tau) { float im = 1.0f / mc; m_out = mc; im_out = im; return fmaf(tau - acc, im, t); }
+            acc += dtau;
+        }
+        t = texit;
+        if (!(texit < tmax)) break;
+        if (a == 0) { cx += sx; if (cx < 0 || cx >= P.gx) break; tnx += tdx; }
+        else if (a == 1) { cy += sy; if (cy < 0 || cy >= P.gy) break; tny += tdy; }
+        else { cz += sz; if (cz < 0 || cz >= P.gz) break; tnz += tdz; }
+    }
+    m_out = 0.0f; im_out = 0.0f;
+    return kInf;
 }
 
 enum CounterSlot { C_RAYS = 0, C_DT, C_RT, C_DRT, C_ALB, C_TR, C_RT_ADJ, C_SC, C_SC_ALB, C_COUNT };

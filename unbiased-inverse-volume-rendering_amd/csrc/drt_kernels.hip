@@ -29,12 +29,13 @@ struct Tracer {
     const float *mg;        // majorant supergrid as the DDA reads it (global memory, L2-resident; an LDS copy
                             // was measured slower: it costs a wave per SIMD of occupancy)
     uint4 *pc;              // this ray's path-cache entries (drt_device.h: Params::path_cache) or nullptr
+    const uint32_t *mocc;   // non-empty supergrid cells (LDS copy) or nullptr
     uint32_t cnt[C_COUNT];
 
     __device__ __forceinline__ Tracer(const Params &p) : P(p)
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
-        ray_index = 0; rec = nullptr; mg = p.mgrid; occ = nullptr; pc = nullptr;
+        ray_index = 0; rec = nullptr; mg = p.mgrid; occ = nullptr; pc = nullptr; mocc = nullptr;
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
@@ -48,52 +49,12 @@ struct Tracer {
         return -drt_logf(1.0f - u) * inv_maj;
     }
 
-    // Medium::sample_interaction with a majorant supergrid (scene_config.py:36,
-    // optimize.py:182-199): 3-D DDA through the cells the ray crosses, accumulating
-    // majorant * length until tau = -log(1-u) is reached.  Returns the distance (inf if the
-    // ray leaves [0,tmax] first) and the local majorant / reciprocal at the collision.
-    // Without a supergrid: the global majorant (bit-identical to sample_distance).
+    // Medium::sample_interaction with a majorant supergrid (dda_collision, drt_device.h); without a supergrid:
+    // the global majorant (bit-identical to sample_distance).
     __device__ __forceinline__ float sample_collision(V3 o, V3 d, float tmax, float u, float &m_out, float &im_out) const
     {
         if (!P.mgrid) { m_out = maj; im_out = inv_maj; return sample_distance(u); }
-        const float tau = -drt_logf(1.0f - u);
-        float gxf = ((o.x - P.bmin[0]) * P.inv_ext[0]) * (float) P.gx, dgx = (d.x * P.inv_ext[0]) * (float) P.gx;
-        float gyf = ((o.y - P.bmin[1]) * P.inv_ext[1]) * (float) P.gy, dgy = (d.y * P.inv_ext[1]) * (float) P.gy;
-        float gzf = ((o.z - P.bmin[2]) * P.inv_ext[2]) * (float) P.gz, dgz = (d.z * P.inv_ext[2]) * (float) P.gz;
-        float flx = fminf(fmaxf(floorf(gxf), 0.0f), (float)(P.gx - 1));
-        float fly = fminf(fmaxf(floorf(gyf), 0.0f), (float)(P.gy - 1));
-        float flz = fminf(fmaxf(floorf(gzf), 0.0f), (float)(P.gz - 1));
-        int cx = (int) flx, cy = (int) fly, cz = (int) flz;
-        float tnx, tny, tnz, tdx, tdy, tdz; int sx, sy, sz;
-        if (dgx > 0.0f) { tnx = ((flx + 1.0f) - gxf) / dgx; tdx = 1.0f / dgx; sx = 1; }
-        else if (dgx < 0.0f) { tnx = (flx - gxf) / dgx; tdx = -1.0f / dgx; sx = -1; }
-        else { tnx = kInf; tdx = kInf; sx = 0; }
-        if (dgy > 0.0f) { tny = ((fly + 1.0f) - gyf) / dgy; tdy = 1.0f / dgy; sy = 1; }
-        else if (dgy < 0.0f) { tny = (fly - gyf) / dgy; tdy = -1.0f / dgy; sy = -1; }
-        else { tny = kInf; tdy = kInf; sy = 0; }
-        if (dgz > 0.0f) { tnz = ((flz + 1.0f) - gzf) / dgz; tdz = 1.0f / dgz; sz = 1; }
-        else if (dgz < 0.0f) { tnz = (flz - gzf) / dgz; tdz = -1.0f / dgz; sz = -1; }
-        else { tnz = kInf; tdz = kInf; sz = 0; }
-        float t = 0.0f, acc = 0.0f;
-        for (;;) {
-            int a = (tny < tnx) ? 1 : 0;
-            float tmin = (tny < tnx) ? tny : tnx;
-            if (tnz < tmin) { a = 2; tmin = tnz; }
-            float texit = fminf(tmin, tmax);
-            float mc = mg[(cz * P.gy + cy) * P.gx + cx];
-            if (mc > 0.0f) {
-                float dtau = mc * (texit - t);
-                if (acc + dtau >= tau) { float im = 1.0f / mc; m_out = mc; im_out = im; return fmaf(tau - acc, im, t); }
-                acc += dtau;
-            }
-            t = texit;
-            if (!(texit < tmax)) break;
-            if (a == 0) { cx += sx; if (cx < 0 || cx >= P.gx) break; tnx += tdx; }
-            else if (a == 1) { cy += sy; if (cy < 0 || cy >= P.gy) break; tny += tdy; }
-            else { cz += sz; if (cz < 0 || cz >= P.gz) break; tnz += tdz; }
-        }
-        m_out = 0.0f; im_out = 0.0f;
-        return kInf;
+        return dda_collision(P, mg, mocc, o, d, tmax, u, m_out, im_out);
     }
 
     // estimate_transmittance: ratio tracking (volpathsimple.py:436-504)
@@ -453,7 +414,11 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
         }
     }
 #endif
-    uint64_t i = P.ray_first + (uint64_t) b * blockDim.x + threadIdx.x;
+    const uint64_t i_block = P.ray_first + (uint64_t) b * blockDim.x;
+    uint64_t i = i_block + threadIdx.x;
+    if constexpr (ADJ) {                                        // rays of similar length share a wave (ray_perm_kernel, drt_coop.hip)
+        if (P.ray_perm) i = (i_block & ~(uint64_t) (kPermGroup - 1)) + P.ray_perm[i_block + threadIdx.x];
+    }
     Tracer<COUNT, ENV, DEFER> tr(P);
     if constexpr (ADJ && DEFER) {
         __shared__ uint32_t rec_state[4 * 8];                   // per wave: cur[4], end[4]
@@ -470,6 +435,12 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
         for (int w = threadIdx.x; w < P.occ_words; w += blockDim.x) occ_lds[w] = P.occ[w];
         __syncthreads();
         tr.occ = occ_lds;
+    }
+    __shared__ uint32_t mocc_lds[kOccWords];
+    if (P.mgrid && P.mocc && P.mocc_words <= kOccWords && !(P.debug_flags & 8388608u)) {
+        for (int w = threadIdx.x; w < P.mocc_words; w += blockDim.x) mocc_lds[w] = P.mocc[w];
+        __syncthreads();
+        tr.mocc = mocc_lds;
     }
     if (i < P.n_rays) {
         uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
@@ -657,7 +628,7 @@ __global__ void majorant_finalize_kernel(const uint32_t *max_bits, float scale, 
 // cell can touch, padded by one voxel: [floor(I*res/G) - 1, ceil((I+1)*res/G)] per axis, clamped.
 // One wavefront per cell.
 __global__ void __launch_bounds__(256) majorant_grid_kernel(const float *sigma_t, int rx, int ry, int rz,
-                                                            int gx, int gy, int gz, float scale, float *out)
+                                                            int gx, int gy, int gz, float scale, float *out, uint32_t *mask)
 {
     uint32_t cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (cell >= (uint32_t) gx * gy * gz) return;
@@ -673,7 +644,10 @@ __global__ void __launch_bounds__(256) majorant_grid_kernel(const float *sigma_t
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-    if (lane == 0) out[cell] = m * scale;
+    if (lane == 0) {
+        out[cell] = m * scale;
+        if (mask && m * scale > 0.0f) atomicOr(mask + (cell >> 5), 1u << (cell & 31u));   // (mask zeroed by the launcher)
+    }
 }
 
 // Empty-space bitmask (Params::occ): one thread per cell ORs the voxels [c*S, (c+1)*S] per axis
@@ -983,10 +957,14 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
 }
 
 hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
-                                float *out, hipStream_t stream)
+                                float *out, uint32_t *mask, hipStream_t stream)
 {
     uint32_t cells = (uint32_t) gx * gy * gz;
-    hipLaunchKernelGGL(majorant_grid_kernel, dim3((cells * 64 + 255) / 256), dim3(256), 0, stream, sigma_t, rx, ry, rz, gx, gy, gz, scale, out);
+    if (mask) {
+        hipError_t e = hipMemsetAsync(mask, 0, (size_t) ((cells + 31) / 32) * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(majorant_grid_kernel, dim3((cells * 64 + 255) / 256), dim3(256), 0, stream, sigma_t, rx, ry, rz, gx, gy, gz, scale, out, mask);
     return hipGetLastError();
 }
 

@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t xcc_id()
 
 // Medium::sample_interaction free-flight distance (global majorant or supergrid DDA); identical to
 // Tracer::sample_collision in drt_kernels.hip.
-__device__ __forceinline__ float collide(const Params &P, float maj, float inv_maj, V3 o, V3 d, float tmax, float u,
+__device__ __forceinline__ float collide(const Params &P, const uint32_t *mocc, float maj, float inv_maj, V3 o, V3 d, float tmax, float u,
                                          float &m_out, float &im_out)
 {
     if (!P.mgrid) {
@@ -68,44 +68,7 @@ __device__ __forceinline__ float collide(const Params &P, float maj, float inv_m
         if (maj == 0.0f) return kInf;
         return -drt_logf(1.0f - u) * inv_maj;
     }
-    const float tau = -drt_logf(1.0f - u);
-    float gxf = ((o.x - P.bmin[0]) * P.inv_ext[0]) * (float) P.gx, dgx = (d.x * P.inv_ext[0]) * (float) P.gx;
-    float gyf = ((o.y - P.bmin[1]) * P.inv_ext[1]) * (float) P.gy, dgy = (d.y * P.inv_ext[1]) * (float) P.gy;
-    float gzf = ((o.z - P.bmin[2]) * P.inv_ext[2]) * (float) P.gz, dgz = (d.z * P.inv_ext[2]) * (float) P.gz;
-    float flx = fminf(fmaxf(floorf(gxf), 0.0f), (float)(P.gx - 1));
-    float fly = fminf(fmaxf(floorf(gyf), 0.0f), (float)(P.gy - 1));
-    float flz = fminf(fmaxf(floorf(gzf), 0.0f), (float)(P.gz - 1));
-    int cx = (int) flx, cy = (int) fly, cz = (int) flz;
-    float tnx, tny, tnz, tdx, tdy, tdz; int sx, sy, sz;
-    if (dgx > 0.0f) { tnx = ((flx + 1.0f) - gxf) / dgx; tdx = 1.0f / dgx; sx = 1; }
-    else if (dgx < 0.0f) { tnx = (flx - gxf) / dgx; tdx = -1.0f / dgx; sx = -1; }
-    else { tnx = kInf; tdx = kInf; sx = 0; }
-    if (dgy > 0.0f) { tny = ((fly + 1.0f) - gyf) / dgy; tdy = 1.0f / dgy; sy = 1; }
-    else if (dgy < 0.0f) { tny = (fly - gyf) / dgy; tdy = -1.0f / dgy; sy = -1; }
-    else { tny = kInf; tdy = kInf; sy = 0; }
-    if (dgz > 0.0f) { tnz = ((flz + 1.0f) - gzf) / dgz; tdz = 1.0f / dgz; sz = 1; }
-    else if (dgz < 0.0f) { tnz = (flz - gzf) / dgz; tdz = -1.0f / dgz; sz = -1; }
-    else { tnz = kInf; tdz = kInf; sz = 0; }
-    float t = 0.0f, acc = 0.0f;
-    for (;;) {
-        int a = (tny < tnx) ? 1 : 0;
-        float tmin = (tny < tnx) ? tny : tnx;
-        if (tnz < tmin) { a = 2; tmin = tnz; }
-        float texit = fminf(tmin, tmax);
-        float mc = P.mgrid[(cz * P.gy + cy) * P.gx + cx];
-        if (mc > 0.0f) {
-            float dtau = mc * (texit - t);
-            if (acc + dtau >= tau) { float im = 1.0f / mc; m_out = mc; im_out = im; return fmaf(tau - acc, im, t); }
-            acc += dtau;
-        }
-        t = texit;
-        if (!(texit < tmax)) break;
-        if (a == 0) { cx += sx; if (cx < 0 || cx >= P.gx) break; tnx += tdx; }
-        else if (a == 1) { cy += sy; if (cy < 0 || cy >= P.gy) break; tny += tdy; }
-        else { cz += sz; if (cz < 0 || cz >= P.gz) break; tnz += tdz; }
-    }
-    m_out = 0.0f; im_out = 0.0f;
-    return kInf;
+    return dda_collision(P, P.mgrid, mocc, o, d, tmax, u, m_out, im_out);
 }
 
 // Whole-wave cooperative sigma_t splat: lanes with `pending` own one splat each (8 scratch indices
@@ -148,6 +111,13 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
         for (int w = threadIdx.x; w < P.occ_words; w += blockDim.x) occ_lds[w] = P.occ[w];
         __syncthreads();
         occ = occ_lds;
+    }
+    const uint32_t *mocc = nullptr;
+    __shared__ uint32_t mocc_lds[kOccWords];
+    if (P.mgrid && P.mocc && P.mocc_words <= kOccWords && !(P.debug_flags & 8388608u)) {
+        for (int w = threadIdx.x; w < P.mocc_words; w += blockDim.x) mocc_lds[w] = P.mocc[w];
+        __syncthreads();
+        mocc = mocc_lds;
     }
     uint32_t *rec = nullptr;
     if constexpr (ADJ) {
@@ -308,6 +278,7 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                     }
                     if constexpr (!ADJ) {
                         P.L_out[3 * li] = result[0]; P.L_out[3 * li + 1] = result[1]; P.L_out[3 * li + 2] = result[2];
+                        if (P.ray_iters) P.ray_iters[li] = (uint8_t) (pc_it < 255 ? pc_it : 255);   // sort key of the adjoint's ray schedule
                         ph = PH_IDLE;
                     } else {
                         if (rec_mode) {
@@ -551,7 +522,7 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                         const V3 d = drt ? r_d : (ph == PH_DT ? rd : nd);
                         const float tmax = drt ? wmax - wt : wmax;
                         if (drt && !P.mgrid) dt = (maj == 0.0f) ? kInf : -drt_logf(1.0f - u) * inv_maj;
-                        else dt = collide(P, maj, inv_maj, o, d, tmax, u, lm, lim);
+                        else dt = collide(P, mocc, maj, inv_maj, o, d, tmax, u, lm, lim);
                         if (drt) { wt += dt; inside = wt <= wmax; p = ray_at(r_o, r_d, wt); }
                         else { inside = dt <= tmax; p = ray_at(o, d, dt); }
                         if (inside) sig = eval_sigma_t(P, p, occ);
