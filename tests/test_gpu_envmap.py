@@ -73,7 +73,7 @@ def test_envmap_render_matches_oracle(uivr, oracle, gpu, flags, variant):
     ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
     _, c_primal = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)
     sg = uivr.scene_to(scene, gpu)
-    integ = uivr.load_dict(dict(type="volpathsimple", **props))
+    integ = uivr.load_dict(dict(type="volpathsimple", test_hooks=flags != 0, **props))
     h = integ.native_handle(sg)
     h.set_debug_flags(flags)
     h.enable_counters(True)

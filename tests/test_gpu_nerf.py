@@ -43,7 +43,7 @@ def test_nerf_matches_oracle(uivr, oracle, gpu, props, flags):
     gs, ge, _ = oracle.nerf_render(osc, scene.medium.emission, props, spp, seed, dL=dL, L_in=Lr)
 
     sg = uivr.scene_to(scene, gpu)
-    integ = uivr.load_dict(dict(type="nerf", **props))
+    integ = uivr.load_dict(dict(type="nerf", test_hooks=flags != 0, **props))      # flags: the flavour with test hooks
     assert isinstance(integ, uivr.NeRFIntegrator)
     batch = uivr.RayBatch(n_rays=32 * 32 * spp, spp=spp, sensor=sg.sensors[0])
     samp = uivr.IndependentSampler(seed, spp)

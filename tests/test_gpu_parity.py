@@ -17,9 +17,12 @@ pytestmark = pytest.mark.gpu
 GRAD_RTOL = 2e-4
 
 
-def _integrator(uivr, props):
+def _integrator(uivr, props, hooks=False):
+    """`hooks`: bind the library flavour with test hooks (kernel-variant selection through set_debug_flags)."""
     d = {"type": "volpathsimple"}
     d.update(props)
+    if hooks:
+        d["test_hooks"] = True
     return uivr.load_dict(d)
 
 
@@ -139,7 +142,7 @@ def test_multi_tile_grid_gradients_match_oracle(uivr, oracle, gpu):
     gs, ga, cr = oracle.render_backward(osc, props, spp, seed, dL, Lr, rays_o=o, rays_d=d)
 
     sg = uivr.scene_to(scene, gpu)
-    integ = _integrator(uivr, props)
+    integ = _integrator(uivr, props, hooks=True)
     batch = uivr.RayBatch(n_rays=n, spp=spp, o=torch.from_numpy(o).to(gpu), d=torch.from_numpy(d).to(gpu))
     samp = uivr.IndependentSampler(seed, spp)
     h = integ.native_handle(sg)
@@ -183,7 +186,7 @@ def test_path_cache_is_tied_to_the_rays(uivr, oracle, gpu):
     gs, ga, cb = oracle.render_backward(osc, props, spp, seed, dL, Lb, rays_o=ob, rays_d=db)
 
     sg = uivr.scene_to(scene, gpu)
-    integ = _integrator(uivr, props)
+    integ = _integrator(uivr, props, hooks=True)
     to, td = torch.from_numpy(oa).to(gpu), torch.from_numpy(da).to(gpu)
     batch = uivr.RayBatch(n_rays=n, spp=spp, o=to, d=td)
     samp = uivr.IndependentSampler(seed, spp)
@@ -487,7 +490,7 @@ def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
     _, c_primal = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)
     sg = uivr.scene_to(scene, gpu)
-    integ = _integrator(uivr, props)
+    integ = _integrator(uivr, props, hooks=True)
     h = integ.native_handle(sg)
     h.set_debug_flags(flags)
     h.enable_counters(True)
@@ -509,7 +512,7 @@ def test_non_finite_gradients_propagate(uivr, gpu):
     would propagate it): the deferred reduction must not clamp it away into a finite value."""
     scene = uivr.cube_test_scene(16, 16, density_scale=2.0)
     sg = uivr.scene_to(scene, gpu)
-    integ = _integrator(uivr, props_for("drt"))
+    integ = _integrator(uivr, props_for("drt"), hooks=True)
     h = integ.native_handle(sg)
     spp, seed = 4, 3
     n = 16 * 16 * spp
@@ -532,3 +535,17 @@ def test_non_finite_gradients_propagate(uivr, gpu):
             integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=dL, state_in=st, grads=grads)
             assert torch.isfinite(grads["_flat"]).all() and float(grads["_flat"].abs().max()) > 0
     h.set_debug_flags(0)
+
+
+def test_production_library_has_no_test_hooks(uivr, gpu):
+    """The production flavour rejects debug flags (they are compiled out); the hooks flavour accepts them."""
+    sg = uivr.scene_to(uivr.cube_test_scene(8, 8), gpu)
+    h = _integrator(uivr, props_for("drt")).native_handle(sg)
+    h.set_debug_flags(0)
+    with pytest.raises(RuntimeError, match="test hooks"):
+        h.set_debug_flags(128)
+    hh = _integrator(uivr, props_for("drt"), hooks=True).native_handle(sg)
+    hh.set_debug_flags(128)
+    hh.set_debug_flags(0)
+    from uivr_amd._native import native
+    assert "test hooks" in native(hooks=True).version() and "test hooks" not in native().version()

@@ -120,12 +120,13 @@ def test_c_abi_library_exports_every_declared_symbol(uivr):
     assert {"drt_create", "drt_destroy", "drt_last_error", "drt_set_medium", "drt_render_primal",
             "drt_render_backward", "drt_film_develop", "drt_film_backward", "drt_get_counters",
             "drt_set_ray_interleave", "drt_params_changed"} <= set(names)
-    lib = ctypes.CDLL(library_path())
-    for n in names:
-        assert hasattr(lib, n), f"libdrt_hip.so does not export {n}"
-    lib.drt_version.restype = ctypes.c_char_p
-    assert b"gfx950" in lib.drt_version()
-    assert "gfx950" in native().version()            # the pybind11 shim loads too
+    for hooks in (False, True):                        # the production library and the flavour with test hooks
+        lib = ctypes.CDLL(library_path(hooks))
+        for n in names:
+            assert hasattr(lib, n), f"{library_path(hooks)} does not export {n}"
+        lib.drt_version.restype = ctypes.c_char_p
+        assert b"gfx950" in lib.drt_version() and (b"test hooks" in lib.drt_version()) == hooks
+        assert "gfx950" in native(hooks).version()   # the pybind11 shims load too
 
 
 def test_c_abi_argument_errors_without_gpu(uivr):

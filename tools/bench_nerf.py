@@ -34,7 +34,7 @@ def main():
     if args.dense:
         scene.medium.sigma_t.add_(0.05 * float(scene.medium.sigma_t.max()))
     scene.medium.emission = (scene.medium.albedo * 0.8 + 0.1).contiguous()
-    integ = u.load_dict({"type": "nerf", "queries_per_ray": args.queries})
+    integ = u.load_dict({"type": "nerf", "queries_per_ray": args.queries, "test_hooks": bool(args.debug_flags)})
     h = integ.native_handle(scene)
     if args.debug_flags:
         h.set_debug_flags(args.debug_flags)

@@ -11,9 +11,9 @@ flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 scene = u.cube_test_scene(32, 32, density_scale=1.5)
 sg = u.scene_to(scene, dev)
 if which == "nerf":
-    integ = u.load_dict(dict(type="nerf", queries_per_ray=64, activation="relu"))
+    integ = u.load_dict(dict(type="nerf", queries_per_ray=64, activation="relu", test_hooks=True))
 else:
-    integ = u.get_int_config("volpathsimple-drt").create(max_depth=64)
+    integ = u.get_int_config("volpathsimple-drt").create(max_depth=64, test_hooks=True)
 spp, seed = 4, 1234
 integ.native_handle(sg).set_debug_flags(flags)
 n = 32 * 32

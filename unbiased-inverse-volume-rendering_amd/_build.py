@@ -1,7 +1,9 @@
 """In-tree build of the native pieces (gfx950 only):
 
-  csrc/libdrt_hip.so                  hipcc: kernels + C ABI (include/drt_hip.h)
+  csrc/libdrt_hip.so                  hipcc: kernels + C ABI (include/drt_hip.h) - the production library
   _drt_pybind.<abi>.so                g++:   pybind11 shim linked against it
+  csrc/libdrt_hip_hooks.so            the same sources with -DDRT_TEST_HOOKS: kernel-variant selection, ablations,
+  _drt_pybind_hooks.<abi>.so          simulated out-of-memory (drt_set_debug_flags) for the tests / profiling
 
 The arithmetic specification requires -ffp-contract=off; hardware fp32
 atomics need -munsafe-fp-atomics.
@@ -23,8 +25,11 @@ HIP_HEADERS = ["drt_device.h", "drt_launch.h", "drt_coop_tracer.h", os.path.join
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
              "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall"]
 
-LIB_PATH = os.path.join(_CSRC, "libdrt_hip.so")
-PYBIND_PATH = os.path.join(_PKG, "_drt_pybind" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+_EXT = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+LIB_PATH = os.path.join(_CSRC, "libdrt_hip.so")                 # production library: no test hooks
+PYBIND_PATH = os.path.join(_PKG, "_drt_pybind" + _EXT)
+HOOKS_LIB_PATH = os.path.join(_CSRC, "libdrt_hip_hooks.so")     # the same sources with -DDRT_TEST_HOOKS (variant tests, ablations)
+HOOKS_PYBIND_PATH = os.path.join(_PKG, "_drt_pybind_hooks" + _EXT)
 
 
 def _newer(target, deps):
@@ -41,62 +46,74 @@ def _hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libdrt_hip.so)")
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
-    """Every translation unit is compiled on its own (in parallel: the tracing kernels take about a minute
-    each) into csrc/_obj/, then linked; only units whose sources changed are recompiled."""
+def _flavours(hooks):
+    """(library path, object directory, extra -D flags) of the flavours to build."""
+    out = [(LIB_PATH, os.path.join(_CSRC, "_obj"), [])]
+    if hooks:
+        out.append((HOOKS_LIB_PATH, os.path.join(_CSRC, "_obj_hooks"), ["-DDRT_TEST_HOOKS=1"]))
+    return out
+
+
+def build_hip(force: bool = False, verbose: bool = False, hooks: bool = True):
+    """Every translation unit of every flavour is compiled on its own (in parallel: the tracing kernels take about a
+    minute each) into csrc/_obj*/, then linked; only units whose sources changed are recompiled."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(_CSRC, s) for s in HIP_SOURCES]
     hdrs = [h if os.path.isabs(h) else os.path.join(_CSRC, h) for h in HIP_HEADERS]
-    extra = [f"-D{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("DRT_") and v.lstrip("-").isdigit()]
-    objdir = os.path.join(_CSRC, "_obj")
-    os.makedirs(objdir, exist_ok=True)
-    stamp = os.path.join(objdir, "flags.txt")
-    flags_now = " ".join(HIP_FLAGS + extra)
-    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
-        force = True
+    env_defs = [f"-D{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("DRT_") and v.lstrip("-").isdigit()]
     compile_flags = [f for f in HIP_FLAGS if f != "-shared"]
+    jobs, links = [], []
+    for lib, objdir, defs in _flavours(hooks):
+        os.makedirs(objdir, exist_ok=True)
+        stamp = os.path.join(objdir, "flags.txt")
+        flags_now = " ".join(HIP_FLAGS + env_defs + defs)
+        stale = force or not os.path.exists(stamp) or open(stamp).read() != flags_now
+        objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in srcs]
+        todo = [(s, o) for s, o in zip(srcs, objs) if stale or _newer(o, [s] + hdrs)]
+        jobs += [(s, o, defs) for s, o in todo]
+        links.append((lib, objs, bool(todo), stamp, flags_now))
 
-    def obj_of(src):
-        return os.path.join(objdir, os.path.basename(src) + ".o")
-
-    def compile_one(src):
-        cmd = [_hipcc()] + compile_flags + extra + ["-c", src, "-o", obj_of(src)]
+    def compile_one(job):
+        src, obj, defs = job
+        cmd = [_hipcc()] + compile_flags + env_defs + defs + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=_CSRC)
 
-    todo = [s for s in srcs if force or _newer(obj_of(s), [s] + hdrs)]
-    if todo:
-        with ThreadPoolExecutor(max_workers=min(len(todo), max(1, (os.cpu_count() or 2) - 1))) as ex:
-            list(ex.map(compile_one, todo))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as ex:
+            list(ex.map(compile_one, jobs))
+    for lib, objs, changed, stamp, flags_now in links:
+        if changed or _newer(lib, objs):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=_CSRC)
         with open(stamp, "w") as f:
             f.write(flags_now)
-    objs = [obj_of(s) for s in srcs]
-    if todo or _newer(LIB_PATH, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True, cwd=_CSRC)
-    return LIB_PATH
+    return [l[0] for l in links]
 
 
-def build_pybind(force: bool = False, verbose: bool = False) -> str:
+def build_pybind(force: bool = False, verbose: bool = False, hooks: bool = True):
     import pybind11
     src = os.path.join(_CSRC, "drt_pybind.cpp")
-    deps = [src, os.path.join(_ROOT, "include", "drt_hip.h"), LIB_PATH]
-    if force or _newer(PYBIND_PATH, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-               "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
-               src, "-o", PYBIND_PATH,
-               "-L" + _CSRC, "-ldrt_hip", "-Wl,-rpath,$ORIGIN/csrc"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True, cwd=_CSRC)
-    return PYBIND_PATH
+    out = []
+    for lib, target, name in [(LIB_PATH, PYBIND_PATH, "_drt_pybind")] + ([(HOOKS_LIB_PATH, HOOKS_PYBIND_PATH, "_drt_pybind_hooks")] if hooks else []):
+        deps = [src, os.path.join(_ROOT, "include", "drt_hip.h"), lib]
+        if force or _newer(target, deps):
+            libname = os.path.basename(lib)[3:-3]
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", f"-DDRT_PYBIND_NAME={name}",
+                   "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+                   src, "-o", target, "-L" + _CSRC, "-l" + libname, "-Wl,-rpath,$ORIGIN/csrc"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, cwd=_CSRC)
+        out.append(target)
+    return out
 
 
-def build_all(force: bool = False, verbose: bool = False):
-    return build_hip(force, verbose), build_pybind(force, verbose)
+def build_all(force: bool = False, verbose: bool = False, hooks: bool = True):
+    return build_hip(force, verbose, hooks), build_pybind(force, verbose, hooks)
 
 
 if __name__ == "__main__":

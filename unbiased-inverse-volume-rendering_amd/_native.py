@@ -6,26 +6,27 @@ import importlib
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_mod = None
+_mods = {}
 
 
 class NativeExtensionMissing(ImportError):
     pass
 
 
-def native():
-    """The pybind11 module `_drt_pybind` (thin shim over include/drt_hip.h)."""
-    global _mod
-    if _mod is None:
+def native(hooks: bool = False):
+    """The pybind11 module over include/drt_hip.h: `_drt_pybind` (production library) or, with `hooks`,
+    `_drt_pybind_hooks` (the build with test hooks: drt_set_debug_flags accepts non-zero flags)."""
+    name = "._drt_pybind_hooks" if hooks else "._drt_pybind"
+    if name not in _mods:
         try:
-            _mod = importlib.import_module(__package__ + "._drt_pybind")
+            _mods[name] = importlib.import_module(__package__ + name)
         except ImportError as e:  # pragma: no cover - exercised only on broken installs
             raise NativeExtensionMissing(
                 "the HIP extension of the DRT integrator is not built: run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, gfx950). "
                 f"Original error: {e}") from e
-    return _mod
+    return _mods[name]
 
 
-def library_path() -> str:
-    return os.path.join(_PKG, "csrc", "libdrt_hip.so")
+def library_path(hooks: bool = False) -> str:
+    return os.path.join(_PKG, "csrc", "libdrt_hip_hooks.so" if hooks else "libdrt_hip.so")

@@ -75,6 +75,8 @@ struct drt_handle_s {
     std::string error;
 };
 
+using drt::dbg;
+
 namespace {
 
 thread_local std::string g_error;
@@ -187,7 +189,7 @@ void bind_path_cache_write(drt_handle h, drt::Params &P)
 {
     h->pcache_sig.valid = false;
     if (P.n_rays != h->order_rays) h->order_rays = 0;           // another launch shape re-carves the buffer: the stored order dies
-    if ((h->debug_flags & 1048576u) || P.n_rays > kPathCacheMaxRays) return;
+    if (dbg(h->debug_flags, 1048576u) || P.n_rays > kPathCacheMaxRays) return;
     const size_t entries = (size_t) P.n_rays * kPathCacheCap * 2 * sizeof(uint4), n_blocks = (size_t) ((P.n_rays + 255) / 256);
     const size_t perm_slots = ((size_t) P.n_rays + drt::kPermGroup - 1) / drt::kPermGroup * drt::kPermGroup;
     const size_t need = entries + (size_t) P.n_rays * sizeof(uint32_t) + 2 * n_blocks * sizeof(uint32_t) + perm_slots * 3 + 16;
@@ -202,7 +204,7 @@ void bind_path_cache_write(drt_handle h, drt::Params &P)
     P.path_cache_cap = kPathCacheCap; P.path_cache_mode = 1;
     P.block_cost = P.ray_hash + P.n_rays;
     if (hipMemsetAsync(P.block_cost, 0, n_blocks * sizeof(uint32_t), h->stream) != hipSuccess) { (void) hipGetLastError(); P.block_cost = nullptr; }
-    if (!(h->debug_flags & 4194304u)) P.ray_iters = (uint8_t *) (perm_base(P.ray_hash, P.n_rays) + perm_slots);   // written by the cooperative primal kernel only
+    if (!dbg(h->debug_flags, 4194304u)) P.ray_iters = (uint8_t *) (perm_base(P.ray_hash, P.n_rays) + perm_slots);   // written by the cooperative primal kernel only
     h->perm_valid = false;
     h->pcache_sig = job_sig(h, P);
 }
@@ -211,17 +213,17 @@ void bind_path_cache_write(drt_handle h, drt::Params &P)
 void bind_path_cache_read(drt_handle h, drt::Params &P, uint64_t job_rays)
 {
     drt::Params J = P; J.n_rays = job_rays;
-    if (!h->pcache_sig.valid || (h->debug_flags & 1048576u) || !same_job(h->pcache_sig, job_sig(h, J))) return;
+    if (!h->pcache_sig.valid || dbg(h->debug_flags, 1048576u) || !same_job(h->pcache_sig, job_sig(h, J))) return;
     const size_t entries = (size_t) job_rays * kPathCacheCap * 2 * sizeof(uint4);
     P.path_cache = (uint4 *) h->d_pcache;
     P.ray_hash = (uint32_t *) ((char *) h->d_pcache + entries);
     P.path_cache_cap = kPathCacheCap; P.path_cache_mode = 2;
-    static const bool no_lpt = getenv("DRT_NO_HEAVY_FIRST") != nullptr;
+    const bool no_lpt = dbg(h->debug_flags, 16777216u);   // test hook: plain XCD block map
     // (measured: film 184^2 x 32 spp, the per-rank share at 8 GPUs: adjoint 2.22 -> 1.70 ms; 256^2: 3.11 -> 2.85 ms; at
     //  the full 512^2 the XCD-contiguous block map is worth more than the order: 9.48 vs 10.02 ms)
     if (!no_lpt && P.ray_first == 0 && P.n_rays == job_rays && h->order_valid)
         P.block_order = P.ray_hash + job_rays + (job_rays + 255) / 256;
-    if (h->perm_valid && !(h->debug_flags & 4194304u)) P.ray_perm = perm_base(P.ray_hash, job_rays);
+    if (h->perm_valid && !dbg(h->debug_flags, 4194304u)) P.ray_perm = perm_base(P.ray_hash, job_rays);
 }
 
 int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
@@ -242,10 +244,10 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     //                    bits 8 / 32768) for the adjoint, path cache included: the free-flight distance depends
     //                    on the position, the cooperative loops do not apply.
     const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
-    const bool sm_primal = !adjoint && (P.mgrid != nullptr || (h->debug_flags & 65536u)) && !(h->debug_flags & 8u);
-    const bool sm_adjoint = adjoint && (h->debug_flags & 32u) && !quadratic && !(h->debug_flags & 8u);
+    const bool sm_primal = !adjoint && (P.mgrid != nullptr || dbg(h->debug_flags, 65536u)) && !dbg(h->debug_flags, 8u);
+    const bool sm_adjoint = adjoint && dbg(h->debug_flags, 32u) && !quadratic && !dbg(h->debug_flags, 8u);
     const bool wavefront = sm_primal || sm_adjoint;
-    const bool coop = !wavefront && !P.mgrid && !(h->debug_flags & (adjoint ? 32768u : 8u));
+    const bool coop = !wavefront && !P.mgrid && !dbg(h->debug_flags, (adjoint ? 32768u : 8u));
     const bool coop_primal = false;
     if (coop || coop_primal) {
         DRT_HIP_CHECK(h, drt::launch_trace_coop(P, adjoint, h->counting, h->stream));
@@ -276,7 +278,7 @@ constexpr uint64_t kRecBudgetBytes = 48ull << 30;               // record stream
 
 bool want_deferred(drt_handle h, const drt::Params &P)
 {
-    if (h->debug_flags & (128u | 2u | 32u)) return false;          // 128: atomic path; 2: per-lane atomics; 32: state machine
+    if (dbg(h->debug_flags, (128u | 2u | 32u))) return false;          // 128: atomic path; 2: per-lane atomics; 32: state machine
     const int ntx = (P.rx + drt::kTileX - 1) / drt::kTileX, nty = (P.ry + drt::kTileY - 1) / drt::kTileY,
               ntz = (P.rz + drt::kTileZ - 1) / drt::kTileZ;
     return (int64_t) ntx * nty * ntz <= drt::kMaxBins;
@@ -290,7 +292,7 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
     DeferredPlan &D = R.plan;
     const int ntx = (P.rx + kTileX - 1) / kTileX, nty = (P.ry + kTileY - 1) / kTileY, ntz = (P.rz + kTileZ - 1) / kTileZ;
     const int n_bins = ntx * nty * ntz;
-    const bool tiny = (h->debug_flags & 256u) != 0;                // test hook: force the out-of-chunks path
+    const bool tiny = dbg(h->debug_flags, 256u) != 0;                // test hook: force the out-of-chunks path
     if (!R.mem || n_rays > R.rays || n_bins != R.bins || tiny != R.tiny || per_ray_sigma > R.per_ray[0] ||
         per_ray_colour > R.per_ray[1]) {
         // capacity: every wave may leave one chunk group partly filled per stream, plus the expected volume;
@@ -320,7 +322,7 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
                 if (h->side) DRT_HIP_CHECK(h, hipStreamSynchronize(h->side));
                 (void) hipFree(R.mem); R.mem = nullptr; R.bytes = 0;
             }
-            if ((h->debug_flags & 262144u) || hipMalloc(&R.mem, off) != hipSuccess) {   // not enough memory for the record streams (bit 262144: simulate):
+            if (dbg(h->debug_flags, 262144u) || hipMalloc(&R.mem, off) != hipSuccess) {   // not enough memory for the record streams (bit 262144: simulate):
                 (void) hipGetLastError();                         // this job uses the atomic path instead
                 R.mem = nullptr; R.rays = 0;
                 return kNoRecordMemory;
@@ -378,11 +380,10 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
         const uint64_t bytes_per_ray = 32ull * (uint64_t) per_ray_sigma + 64ull * (uint64_t) per_ray_colour + 1024ull;   // streams in + sorted, chunk slack
         // measured on the headline workload: overlapping costs more than it hides (tracer 15.0 -> 19.8 ms
         // with the reductions alongside, step 22.1 -> 24.7 ms), so the overlap is opt-in
-        static const bool env_pipe = getenv("DRT_PIPELINE") != nullptr;
-        const bool forced = (h->debug_flags & 2048u) != 0;         // test hook: overlap whatever the job size
-        const bool want_pipe = env_pipe || forced;
+        const bool forced = dbg(h->debug_flags, 2048u);         // test hook: overlap the reductions with the next sub-batch's tracer
+        const bool want_pipe = forced;
         const uint64_t want_pipe_slots = want_pipe ? 2 : 1;
-        uint64_t budget = (h->debug_flags & 16384u) ? (8ull << 20) : kRecBudgetBytes;   // test hook: 8 MB -> many sub-batches
+        uint64_t budget = dbg(h->debug_flags, 16384u) ? (8ull << 20) : kRecBudgetBytes;   // test hook: 8 MB -> many sub-batches
         {   // never ask for more than the device can give next to the caller's (torch's) allocations: what the slots
             // hold already plus 80 % of what is free now; smaller budgets only mean more ray sub-batches
             size_t free_b = 0, total_b = 0;
@@ -398,7 +399,7 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
         const bool pipe = want_pipe && (forced || n_rays >= kPipeMinRays);
         if (pipe && batch > (n_rays + kPipeBatches - 1) / kPipeBatches) batch = (n_rays + kPipeBatches - 1) / kPipeBatches;
         // whole ray-schedule groups (kPermGroup rays = 4 workgroups) and XCD runs per sub-batch
-        batch = (h->debug_flags & 16384u) ? (batch + drt::kPermGroup - 1) / drt::kPermGroup * drt::kPermGroup : (batch + 65535) / 65536 * 65536;
+        batch = dbg(h->debug_flags, 16384u) ? (batch + drt::kPermGroup - 1) / drt::kPermGroup * drt::kPermGroup : (batch + 65535) / 65536 * 65536;
         const bool overlap = pipe;
         if (overlap && !h->side) {
             int lo = 0, hi = 0;
@@ -411,7 +412,7 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
             const uint64_t count = n_rays - first < batch ? n_rays - first : batch;
             if (R.busy) { DRT_HIP_CHECK(h, hipStreamWaitEvent(h->stream, R.reduced, 0)); R.busy = false; }
             int rc = ensure_deferred(h, R, P, count, per_ray_sigma, per_ray_colour,
-                                     (h->debug_flags & 524288u) && first > 0);   // test hook: memory runs out after the first sub-batch
+                                     dbg(h->debug_flags, 524288u) && first > 0);   // test hook: memory runs out after the first sub-batch
             if (rc == kNoRecordMemory) {
                 // no memory for the record streams (now): the rays that are left, [first, n_rays), take the
                 // atomic path (splats into the apron scratch + untile) - slower, same gradients
@@ -503,7 +504,7 @@ int timed_untile(drt_handle h, const drt::Params &P)
 
 extern "C" {
 
-const char *drt_version(void) { return "drt-hip 0.1 (gfx950)"; }
+const char *drt_version(void) { return drt::kTestHooks ? "drt-hip 0.2 (gfx950, test hooks)" : "drt-hip 0.2 (gfx950)"; }
 
 const char *drt_last_error(drt_handle h)
 {
@@ -830,22 +831,22 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     bind_path_cache_write(h, P);                                 // every primal kernel records its walks
     {   // the block order left by the previous primal launch of the same shape predicts this one's heavy blocks
         // (same sensor, next step); an order is only ever a schedule, never a result
-        static const bool no_lpt = getenv("DRT_NO_HEAVY_FIRST") != nullptr;
+        const bool no_lpt = dbg(h->debug_flags, 16777216u);   // test hook: plain XCD block map
         const uint64_t n_blocks = (n_rays + 255) / 256;
         (void) n_blocks;
         if (!no_lpt && P.block_cost && h->order_rays == n_rays && !P.mgrid &&
-            !(h->debug_flags & (8u | 65536u)))
+            !dbg(h->debug_flags, (8u | 65536u)))
             P.block_order = P.block_cost + n_blocks;
     }
     rc = timed_launch(h, 0, P, false);
     h->order_valid = false;
     h->perm_valid = false;
     // the cooperative primal kernel (global majorant) and the state machine (supergrid) write the sort keys
-    if (rc == DRT_OK && P.ray_iters && !(h->debug_flags & 8u)) {   // (the plain per-lane primal kernel, bit 8, does not)
+    if (rc == DRT_OK && P.ray_iters && !dbg(h->debug_flags, 8u)) {   // (the plain per-lane primal kernel, bit 8, does not)
         DRT_HIP_CHECK(h, drt::launch_ray_perm(P.ray_iters, P.n_rays, perm_base(P.ray_hash, P.n_rays), h->stream));
         h->perm_valid = true;
     }
-    if (rc == DRT_OK && P.block_cost && !P.mgrid && !(h->debug_flags & (8u | 65536u))) {   // cooperative primal: it filled block_cost
+    if (rc == DRT_OK && P.block_cost && !P.mgrid && !dbg(h->debug_flags, (8u | 65536u))) {   // cooperative primal: it filled block_cost
         const uint32_t n_blocks = (uint32_t) ((P.n_rays + 255) / 256);
         DRT_HIP_CHECK(h, drt::launch_block_order(P.block_cost, n_blocks, P.block_cost + n_blocks, n_blocks <= kHeavyFirstMaxBlocks, h->stream));
         h->order_valid = true; h->order_rays = n_rays;
@@ -870,7 +871,7 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     // tracer falls back to direct atomics (emit_record), so this is a performance choice only
     const uint64_t job_rays = n_rays;
     rc = run_backward(h, P, 48, 6, [&](drt::Params &Q) {
-        if (!(h->debug_flags & 32u) || (h->debug_flags & 8u)) bind_path_cache_read(h, Q, job_rays);      // ... and every adjoint kernel but it
+        if (!dbg(h->debug_flags, 32u) || dbg(h->debug_flags, 8u)) bind_path_cache_read(h, Q, job_rays);      // ... and every adjoint kernel but it
         return timed_launch(h, 1, Q, true);
     });
     h->pcache_sig.valid = false;
@@ -1075,6 +1076,8 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
 int drt_set_debug_flags(drt_handle h, uint32_t flags)
 {
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!drt::kTestHooks && flags)
+        return fail(h, DRT_ERR_UNSUPPORTED, "this is the production library: test hooks are compiled out (use libdrt_hip_hooks.so)");
     h->debug_flags = flags; h->scene_version++;
     return DRT_OK;
 }

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
         tr.rec = coop_rec + (threadIdx.x >> 6) * (64 * kCoopDwords);
     }
     __shared__ uint32_t occ_lds[kOccWords];
-    if (P.occ && !(P.debug_flags & 16u)) {
+    if (P.occ && !dbg(P.debug_flags, 16u)) {
         for (int w = threadIdx.x; w < P.occ_words; w += blockDim.x) occ_lds[w] = P.occ[w];
         __syncthreads();
         tr.occ = occ_lds;
@@ -219,7 +219,7 @@ hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStrea
     const bool env = P.env_pix != nullptr, defer = adjoint && P.rec_buf[0] != nullptr;
 #define DRT_COOP_LAUNCH(A, C, E, D) hipLaunchKernelGGL((trace_coop_kernel<A, C, E, D>), grid, block, 0, stream, P)
     // the registered `volpathsimple-drt` configuration with the constant emitter: specialised kernels
-    const bool spec = P.use_nee && P.use_drt && P.use_drt_subsampling && !count && !env && !(P.debug_flags & 2097152u);
+    const bool spec = P.use_nee && P.use_drt && P.use_drt_subsampling && !count && !env && !dbg(P.debug_flags, 2097152u);
     if (spec && !adjoint) { hipLaunchKernelGGL((trace_coop_kernel<false, false, false, false, true>), grid, block, 0, stream, P); return hipGetLastError(); }
     if (spec && defer) { hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true>), grid, block, 0, stream, P); return hipGetLastError(); }
     if (!adjoint) {

@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
         }
         if (nb == b && nb < 0) break;                             // no units at all for this workgroup
         if (nb != b) {
-            if (b >= 0 && live && finite && !(P.debug_flags & 1024u)) {   // flush the finished tile (+=)
+            if (b >= 0 && live && finite && !dbg(P.debug_flags, 1024u)) {   // flush the finished tile (+=)
                 lds_atomics_barrier();
                 for (int j = threadIdx.x; j < kLdsTile; j += blockDim.x) {
                     const long long q = (long long) tile[j];

@@ -24,6 +24,16 @@ __device__ __forceinline__ V3 ray_at(V3 o, V3 d, float t)
     return V3{ fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z) };
 }
 
+// Test hooks (kernel-variant selection, ablations, simulated out-of-memory; include/drt_hip.h: drt_set_debug_flags)
+// exist only in the build with -DDRT_TEST_HOOKS (libdrt_hip_hooks.so, used by the variant tests and profiling
+// ablations); in the production library every test compiles to `false` and drt_set_debug_flags rejects non-zero flags.
+#ifdef DRT_TEST_HOOKS
+constexpr bool kTestHooks = true;
+#else
+constexpr bool kTestHooks = false;
+#endif
+__host__ __device__ __forceinline__ constexpr bool dbg(uint32_t flags, uint32_t bits) { return kTestHooks && (flags & bits) != 0u; }
+
 constexpr float kInvFourPi = 0.07957747154594767f;
 constexpr float kFourPi    = 12.566370614359172f;
 constexpr float kHalfPi    = 1.5707963267948966f;
@@ -833,15 +843,15 @@ __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, ui
 {
     if (g == 0.0f) return;            // adding exact zeros changes nothing: skip the requests
     if constexpr (DEFER) {
-        if (P.debug_flags & 1u) return;
+        if (dbg(P.debug_flags, 1u)) return;
         emit_record<0>(P, p, g * P.scale, nullptr, rec);
         return;
     }
     float w[8]; int idx[8];
     make_grad_indices(P, p, idx, w);
     float gs = g * P.scale;
-    if (P.debug_flags & 1u) return;   // ablation: no gradient atomics
-    if (P.debug_flags & 2u) {         // ablation: one lane, eight instructions (round-1 v1 behaviour)
+    if (dbg(P.debug_flags, 1u)) return;   // ablation: no gradient atomics
+    if (dbg(P.debug_flags, 2u)) {         // ablation: one lane, eight instructions (round-1 v1 behaviour)
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicAdd(P.gt + idx[k], w[k] * gs);
         return;
@@ -859,8 +869,8 @@ __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float 
     if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) return;   // e.g. nerf queries in empty space (weight 0)
     float w[8]; int idx[8];
     make_grad_indices(P, p, idx, w);
-    if (P.debug_flags & 1u) return;
-    if (P.debug_flags & 2u) {
+    if (dbg(P.debug_flags, 1u)) return;
+    if (dbg(P.debug_flags, 2u)) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float *dst = P.gt + P.gt_plane + idx[k];
@@ -883,7 +893,7 @@ template <bool DEFER = false>
 __device__ __forceinline__ void splat_scatter(const Params &P, V3 p, float gs, const float ga[3], uint32_t *rec)
 {
     if constexpr (DEFER) {
-        if (P.debug_flags & 1u) return;
+        if (dbg(P.debug_flags, 1u)) return;
         const bool colour = ga[0] != 0.0f || ga[1] != 0.0f || ga[2] != 0.0f;
         if (colour) emit_record<1>(P, p, gs * P.scale, ga, rec);
         else if (gs != 0.0f) emit_record<0>(P, p, gs * P.scale, nullptr, rec);

@@ -217,7 +217,7 @@ hipError_t launch_fused(const Params &P, bool adjoint, bool count, hipStream_t s
 {
     if (P.n_rays <= P.ray_first) return hipSuccess;
     dim3 block(256), grid((unsigned) ((P.n_rays - P.ray_first + 255) / 256));
-    const bool spec = P.use_nee && P.use_drt && P.use_drt_subsampling && !count && !(P.debug_flags & 2097152u);
+    const bool spec = P.use_nee && P.use_drt && P.use_drt_subsampling && !count && !dbg(P.debug_flags, 2097152u);
 #define DRT_FUSED_LAUNCH(A, C, S) hipLaunchKernelGGL((fused_kernel<A, C, S>), grid, block, 0, stream, P)
     if (!adjoint) {
         if (count) DRT_FUSED_LAUNCH(false, true, false); else if (spec) DRT_FUSED_LAUNCH(false, false, true); else DRT_FUSED_LAUNCH(false, false, false);

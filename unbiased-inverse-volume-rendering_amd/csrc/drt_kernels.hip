@@ -431,13 +431,13 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
     }
     // empty-space bitmask -> LDS (4 KiB): most lookups of a sparse volume never leave the CU
     __shared__ uint32_t occ_lds[kOccWords];
-    if (P.occ && !(P.debug_flags & 16u)) {
+    if (P.occ && !dbg(P.debug_flags, 16u)) {
         for (int w = threadIdx.x; w < P.occ_words; w += blockDim.x) occ_lds[w] = P.occ[w];
         __syncthreads();
         tr.occ = occ_lds;
     }
     __shared__ uint32_t mocc_lds[kOccWords];
-    if (P.mgrid && P.mocc && P.mocc_words <= kOccWords && !(P.debug_flags & 8388608u)) {
+    if (P.mgrid && P.mocc && P.mocc_words <= kOccWords && !dbg(P.debug_flags, 8388608u)) {
         for (int w = threadIdx.x; w < P.mocc_words; w += blockDim.x) mocc_lds[w] = P.mocc[w];
         __syncthreads();
         tr.mocc = mocc_lds;
@@ -738,7 +738,7 @@ __device__ __forceinline__ void untile_march(const Params &P, int plane0, int bx
     const bool have_prev = bx > 0;
     const bool keep3 = last_lane && bx + 1 < P.gt_nbx;      // slot 3 is read by another wave's first lane
     const bool has_z = Z > 0;
-    const bool wr = !(P.debug_flags & 64u);
+    const bool wr = !dbg(P.debug_flags, 64u);
     const size_t row = (size_t) P.gt_nbx << 4;              // floats per line-row
     const int X = 3 * bx, nvx = min(3, P.rx - X);           // voxels of this line that exist
     Quad c1[NPL], c3[NPL];                                  // dy = 1 quads of the previous step
@@ -1006,7 +1006,7 @@ hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t st
 
 hipError_t launch_untile(const Params &P, hipStream_t stream)
 {
-    static const int chunk = [] { const char *e = getenv("DRT_UNTILE_CHUNK"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
+    constexpr int chunk = 8;                                     // y rows per thread march
     const int nc = (P.ry + chunk - 1) / chunk;
     hipLaunchKernelGGL(untile_gradients_kernel,
                        dim3((P.gt_nbx + kUntileLanes - 1) / kUntileLanes, (P.rz + kUntileRows - 1) / kUntileRows, nc * 2),

@@ -253,11 +253,14 @@ private:
 
 }  // namespace
 
-PYBIND11_MODULE(_drt_pybind, m)
+#ifndef DRT_PYBIND_NAME
+#define DRT_PYBIND_NAME _drt_pybind
+#endif
+PYBIND11_MODULE(DRT_PYBIND_NAME, m)
 {
     m.doc() = "pybind11 shim over libdrt_hip.so (C ABI in include/drt_hip.h)";
     m.def("version", []() { return std::string(drt_version()); });
-    py::class_<Integrator>(m, "Integrator")
+    py::class_<Integrator>(m, "Integrator", py::module_local())   // (two flavours of this module can live in one process)
         .def(py::init<const py::dict &, int>(), py::arg("props"), py::arg("device") = 0)
         .def("set_stream", &Integrator::set_stream)
         .def("synchronize", &Integrator::synchronize)

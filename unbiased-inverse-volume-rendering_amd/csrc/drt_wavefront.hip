@@ -90,7 +90,7 @@ __device__ __forceinline__ void wave_splat_sigma(const Params &P, bool pending, 
         for (int c = 0; c < 8; ++c) { mine[c] = (uint32_t) idx[c]; mine[8 + c] = __float_as_uint(w[c] * gs); }
     }
     coop_stage_sync();
-    if (!(P.debug_flags & 1u)) {
+    if (!dbg(P.debug_flags, 1u)) {
         const uint32_t k = (uint32_t) __popcll(mask), c = lane & 7u;
         for (uint32_t s = lane >> 3; s < k; s += 8u) {
             const uint32_t *src = rec + s * 16u;
@@ -107,14 +107,14 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
 {
     __shared__ uint32_t occ_lds[kOccWords];
     const uint32_t *occ = nullptr;
-    if (P.occ && !(P.debug_flags & 16u)) {
+    if (P.occ && !dbg(P.debug_flags, 16u)) {
         for (int w = threadIdx.x; w < P.occ_words; w += blockDim.x) occ_lds[w] = P.occ[w];
         __syncthreads();
         occ = occ_lds;
     }
     const uint32_t *mocc = nullptr;
     __shared__ uint32_t mocc_lds[kOccWords];
-    if (P.mgrid && P.mocc && P.mocc_words <= kOccWords && !(P.debug_flags & 8388608u)) {
+    if (P.mgrid && P.mocc && P.mocc_words <= kOccWords && !dbg(P.debug_flags, 8388608u)) {
         for (int w = threadIdx.x; w < P.mocc_words; w += blockDim.x) mocc_lds[w] = P.mocc[w];
         __syncthreads();
         mocc = mocc_lds;

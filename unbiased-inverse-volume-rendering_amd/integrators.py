@@ -155,7 +155,7 @@ class _DeviceIntegrator:
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         h = self._handles.get(idx)
         if h is None:
-            h = native().Integrator(self._native_props(), idx)
+            h = native(getattr(self, "test_hooks", False)).Integrator(self._native_props(), idx)
             self._handles[idx] = h
         h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         # The derived device state (apron-brick sigma_t copy, majorant, supergrid, empty-space mask) is
@@ -239,6 +239,8 @@ class VolpathSimpleIntegrator(_DeviceIntegrator):
         self.use_drt = bool(props.get("use_drt", True))
         self.use_drt_subsampling = bool(props.get("use_drt_subsampling", True))
         self.use_drt_mis = bool(props.get("use_drt_mis", True))
+        # not a reference property: bind the library flavour with test hooks (kernel-variant selection, ablations)
+        self.test_hooks = bool(props.get("test_hooks", False))
         # RBIntegrator base properties (defaults of mi.ad.integrators.common)
         self.max_depth = int(props.get("max_depth", 6))
         self.rr_depth = int(props.get("rr_depth", 5))
@@ -319,6 +321,7 @@ class NeRFIntegrator(_DeviceIntegrator):
         self.density_noise_std = float(props.get("density_noise_std", 0.0))
         self.jittering_enabled = bool(props.get("jittering_enabled", True))
         self.activation_type = str(props.get("activation", "identity")).lower()
+        self.test_hooks = bool(props.get("test_hooks", False))
         self.max_depth = int(props.get("max_depth", 6))          # RBIntegrator base; unused (nerf.py)
         self.rr_depth = int(props.get("rr_depth", 5))
         if self.activation_type not in ("identity", "relu"):
