@@ -547,5 +547,4 @@ def test_production_library_has_no_test_hooks(uivr, gpu):
     hh = _integrator(uivr, props_for("drt"), hooks=True).native_handle(sg)
     hh.set_debug_flags(128)
     hh.set_debug_flags(0)
-    from uivr_amd._native import native
-    assert "test hooks" in native(hooks=True).version() and "test hooks" not in native().version()
+    assert type(h).__module__.endswith("_drt_pybind") and type(hh).__module__.endswith("_drt_pybind_hooks")

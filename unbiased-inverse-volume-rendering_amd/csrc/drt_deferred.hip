@@ -20,8 +20,8 @@
 // The LDS accumulators are 64-bit FIXED POINT: on gfx950 ds_add_f32 retires 0.2 T lane-atomics/s but
 // ds_add_u64 3.4 T/s (tools/ubench/lds_atomic_rate.hip; the fp32 version of this kernel took 5.3 ms,
 // 4.9 of them in ds_add_f32).  Every float product w*v is scaled by a power of two chosen from the
-// plane's max |v| (found by the histogram pass) so that |w*v| * scale < 2^40 and rounded to an
-// integer: quantisation 2^-41 max|v| per add, exact and order-independent sums inside a tile.
+// plane's max |v| (found by the histogram pass) so that |w*v| * scale < 2^30 and rounded to an
+// integer: quantisation 2^-31 max|v| per add, exact and order-independent sums inside a tile.
 // A non-finite value poisons its plane's maximum: the tile then takes a float path that PROPAGATES the
 // NaN / inf into the gradient exactly as the atomic path would (no silent clamping).
 //
@@ -83,9 +83,8 @@ __device__ __forceinline__ float plane_max(float vmax, float v)
 }
 
 template <int S>
-__global__ void __launch_bounds__(kPartThreads) bin_histogram_kernel(const Params P, const DeferredPlan D)
+__device__ __forceinline__ void bin_histogram_stream(const Params &P, const DeferredPlan &D, uint32_t *h)
 {
-    extern __shared__ uint32_t h[];
     constexpr int kPlanes = S == 0 ? 1 : 4, kQuads = S == 0 ? 1 : 2;
     for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) h[b] = 0;
     __syncthreads();
@@ -186,10 +185,16 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const DeferredPlan D)
     if (t == 1023) { base[D.n_bins] = sa[t]; ustart[D.n_bins] = sb[t]; }
 }
 
-template <int S>
-__global__ void __launch_bounds__(kPartThreads) bin_scatter_kernel(const Params P, const DeferredPlan D)
+// both streams in one launch (blockIdx.y): the small stream's workgroups fill the tail of the large one's
+__global__ void __launch_bounds__(kPartThreads) bin_histogram_kernel(const Params P, const DeferredPlan D)
 {
-    extern __shared__ uint32_t cur[];
+    extern __shared__ uint32_t h[];
+    if (blockIdx.y == 0) bin_histogram_stream<0>(P, D, h); else bin_histogram_stream<1>(P, D, h);
+}
+
+template <int S>
+__device__ __forceinline__ void bin_scatter_stream(const Params &P, const DeferredPlan &D, uint32_t *cur)
+{
     constexpr int kQuads = S == 0 ? 1 : 2;
     const uint32_t *off = D.hist + ((size_t) S * gridDim.x + blockIdx.x) * D.n_bins;
     const uint32_t *base = D.bin_base + (size_t) S * (D.n_bins + 1);
@@ -223,6 +228,12 @@ __global__ void __launch_bounds__(kPartThreads) bin_scatter_kernel(const Params 
     }
 }
 
+__global__ void __launch_bounds__(kPartThreads) bin_scatter_kernel(const Params P, const DeferredPlan D)
+{
+    extern __shared__ uint32_t cur[];
+    if (blockIdx.y == 0) bin_scatter_stream<0>(P, D, cur); else bin_scatter_stream<1>(P, D, cur);
+}
+
 // blockIdx.y = reduce plane: 0: sigma_t of stream 0 AND of stream 1 (for every tile that has stream-0 records: the
 // workgroup that starts such a tile's first unit also adds stream 1's sigma_t values of that tile - one zero / flush
 // of the LDS tile instead of two); 1: sigma_t of stream 1 for the tiles WITHOUT stream-0 records; 2..4: r, g, b of stream 1
@@ -232,14 +243,18 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
     const int plane = blockIdx.y;
     const int s = plane == 0 ? 0 : 1, ch = plane == 0 ? 0 : plane - 1;        // stream, channel of the record
     const int quads = s == 0 ? 1 : 2;
-    // scale = 2^(40 - e) with max|v| < 2^e: |w * v| * scale < 2^40, 2^23 such adds fit an int64; the two sigma_t
-    // planes share one scale (plane 0 adds values of both streams)
+    // scale = 2^(30 - e) with max|v| < 2^e: every product |w * v| * scale < 2^30 is rounded to a 32-bit integer (one
+    // multiply + one conversion; the 64-bit route through double cost ~12 instructions per corner, i.e. most of this
+    // kernel's VALU time) and sign-extended into the 64-bit accumulator, which holds 2^33 such adds.  Quantisation
+    // 2^-31 max|v| per add (an fp32 atomic add rounds at 2^-24 of the running sum).  The two sigma_t planes share one
+    // scale (plane 0 adds values of both streams)
     const float vmax = plane <= 1 ? fmaxf(__uint_as_float(D.vmax[0]), __uint_as_float(D.vmax[1])) : __uint_as_float(D.vmax[plane]);
     if (vmax == 0.0f) return;                                    // nothing but zeros in this plane
     const bool finite = vmax <= 3.0e38f;                         // a NaN / inf anywhere in the plane: float path below
     int e = 0;
     (void) frexpf(finite ? vmax : 1.0f, &e);
-    const double scale = ldexp(1.0, 40 - e), inv_scale = ldexp(1.0, e - 40);
+    const float scale = ldexpf(1.0f, 30 - e);
+    const double inv_scale = ldexp(1.0, e - 30);
     const uint32_t *base = D.bin_base + (size_t) s * (D.n_bins + 1);
     const uint32_t *ustart = D.unit_start + (size_t) s * (D.n_bins + 1);
     const uint32_t *base0 = D.bin_base, *base1 = D.bin_base + (D.n_bins + 1);
@@ -282,7 +297,7 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float pv = w[c] * val;                           // the float product the atomic path adds (|pv| <= vmax)
-            atomicAdd(&tile[o[c]], (unsigned long long) __double2ll_rn((double) pv * scale));
+            atomicAdd(&tile[o[c]], (unsigned long long) (long long) __float2int_rn(pv * scale));
         }
     };
 
@@ -354,14 +369,12 @@ hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStr
     const size_t lds = (size_t) D.n_bins * sizeof(uint32_t);
     auto mark = [&](int k) { if (ev) (void) hipEventRecord(ev[k], stream); };
     mark(0);
-    hipLaunchKernelGGL(bin_histogram_kernel<0>, dim3(kPartWGs), dim3(kPartThreads), lds, stream, P, D);
-    hipLaunchKernelGGL(bin_histogram_kernel<1>, dim3(kPartWGs), dim3(kPartThreads), lds, stream, P, D);
+    hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D);
     mark(1);
     hipLaunchKernelGGL(bin_offsets_kernel, dim3((D.n_bins + 3) / 4, kRecStreams), dim3(256), 0, stream, D, kPartWGs);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(kRecStreams), dim3(1024), 0, stream, D);
     mark(2);
-    hipLaunchKernelGGL(bin_scatter_kernel<0>, dim3(kPartWGs), dim3(kPartThreads), lds, stream, P, D);
-    hipLaunchKernelGGL(bin_scatter_kernel<1>, dim3(kPartWGs), dim3(kPartThreads), lds, stream, P, D);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D);
     mark(3);
     static const hipError_t attr = hipFuncSetAttribute((const void *) tile_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTile * 8);
     if (attr != hipSuccess) return attr;
