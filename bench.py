@@ -362,7 +362,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": "adjoint pass (sample(Backward)): trace_kernel<adjoint> + gradient splat reduction",
+        "bound": "hbm", "kernel": "adjoint pass (sample(Backward)): trace_coop_kernel<adjoint> (dominant, sum_tracer_ms) + record partition + tile_reduce",
         "achieved": round(ach_a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(ach_a / HBM_PEAK_GBS, 5), "traffic": traffic,
         "algorithmic_bytes_per_launch": bytes_a, "avg_launch_ms": round(avg_pass, 4),

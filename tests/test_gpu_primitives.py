@@ -132,3 +132,29 @@ def test_ieee_div_sqrt(uivr, gpu):
     np.testing.assert_array_equal(_bits(got[:, 2]), _bits(np.sqrt(a[:, 0])))
     a2, b2 = a[:, 0] * a[:, 0], a[:, 1] * a[:, 1]
     np.testing.assert_array_equal(_bits(got[:, 0]), _bits(a2 / (a2 + b2)))
+
+
+@pytest.mark.parametrize("factor", [0, 4])
+def test_e2_sample_interaction_drt_matches_oracle(uivr, oracle, gpu, factor):
+    """E2 (Medium::sample_interaction_drt, volpathsimple.py:549-551) on the device == the oracle's restatement, walk
+    for walk (debug op 14 / drto_sample_interaction_drt: same ray, stream PCG32(tea32(0x5eed, i))): valid flag, selected
+    distance t', weight W and maxt bit for bit.  The restatement itself is pinned by tests/test_oracle_e2.py."""
+    rng = np.random.default_rng(5)
+    st = (rng.random((16, 16, 16, 1), dtype=np.float32) ** 3 * 6.0).astype(np.float32)
+    st[:, :, 5:9] = 0.0
+    medium = uivr.GridMedium(sigma_t=st, albedo=np.full((16, 16, 16, 3), 0.5, np.float32), bbox_min=(-1, -1, -1),
+                             bbox_max=(1, 1, 1), scale=1.2, majorant_resolution_factor=factor)
+    scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter(), sensors=[])
+    osc = oracle.OracleScene(scene, sensor_index=None)
+    n = 4096
+    o = (rng.random((n, 3), dtype=np.float32) * 1.8 - 0.9).astype(np.float32)          # inside the box
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    got = _eval(uivr, gpu, scene, 14, np.concatenate([o, d], axis=1))
+    n_valid = 0
+    for i in range(n):
+        valid, t, W, maxt = oracle.sample_interaction_drt(osc, o[i], d[i], 0x5eed, 1, first=i)
+        assert bool(got[i, 0]) == bool(valid[0]), i
+        np.testing.assert_array_equal(_bits(got[i, 1:4]), _bits(np.float32([t[0], W[0], maxt])), err_msg=str(i))
+        n_valid += int(valid[0])
+    assert n_valid > n // 2
