@@ -202,6 +202,9 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
                 "roofline_primal": {"achieved_GBs": round(b_p / (avg_p * 1e-3) / 1e9, 1) if avg_p else None,
                                     "frac": round(b_p / (avg_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_p else None,
                                     "algorithmic_bytes": b_p},
+                "roofline_note": "SURVEY 8d convention (every lookup / splat priced as an independent 8-corner access); "
+                                 "consecutive march steps of one ray share cache lines, so this is a lookup rate served "
+                                 "mostly by L2 and `frac` can exceed 1 - it is not HBM traffic",
                 "workload": "config 5 as BASELINE states it: nerf (128 queries) FUSED with volpathsimple-drt in one pass over the "
                             "interleaved [sigma_t,r,g,b] grid, 256^3, 512x512x32spp"}
 
