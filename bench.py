@@ -285,6 +285,8 @@ def main():
     loss_scale = 2.0 / (n_pixels * 3)
     seed_base = 988378   # opt_config.py:24
 
+    ar_stats = {}
+
     def step(i):
         seed = u.sample_tea_32(2 * i + 1, seed_base)[0]           # seed_grad of iteration i (optimize.py:328)
         sampler = u.IndependentSampler(seed, spp)
@@ -294,7 +296,7 @@ def main():
         grad_img = loss_scale * (img - 0.5)                                               # d mean((img-.5)^2)
         dL = integ.film_backward(scene, grad_img, spp)                                    # :298-306
         integ.sample(u.ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state, grads=grads)   # :309-318
-        u.allreduce_gradients(grads)                                                      # one RCCL all-reduce
+        u.allreduce_gradients(grads, stats=ar_stats)                                      # one RCCL all-reduce (non-zero blocks only)
         return img
 
     def sync():
@@ -440,6 +442,9 @@ def main():
             "t_primal_ms": round(avg_p, 3), "t_adjoint_ms": round(avg_a, 3),
             "t_grad_reduce_ms": round(avg_r, 3),
             "counters_primal": cnt_p, "counters_adjoint": cnt_a,
+            "allreduce": ({"mode": ar_stats.get("mode"), "MiB": round(ar_stats.get("floats", 0) * 4 / 2 ** 20, 1),
+                           "of_MiB": round(grads["_flat"].numel() * 4 / 2 ** 20, 1) if grads else None,
+                           "active_fraction": round(ar_stats.get("active_fraction", 1.0), 4)} if world > 1 else None),
             "other_configs": other,
         }
         if args.debug_flags:

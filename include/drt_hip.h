@@ -209,6 +209,12 @@ int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t s
 int drt_film_backward(drt_handle h, const float *grad_image, uint64_t n_pixels, uint32_t spp,
                       float *dL);
 
+/* Multi-GPU gradient exchange (no handle: works on any gradient buffer of the current device, on `hip_stream`).
+ * mask[b] = 1 if block b (block_floats = 64 | 128 | 256 consecutive floats, buf 16-byte aligned) holds anything but
+ * zeros (NaN / inf count), else 0.  The host side (distributed.py) all-reduces the masks (MAX) and then only the
+ * blocks that are non-zero on some rank - the reference is single-GPU, this replaces nothing in it. */
+int drt_grad_block_mask(void *hip_stream, const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask);
+
 /* Event counting (off by default; enabling selects a counting build of the kernels). */
 int drt_enable_counters(drt_handle h, int enable);
 int drt_reset_counters(drt_handle h);

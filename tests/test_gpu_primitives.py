@@ -158,3 +158,26 @@ def test_e2_sample_interaction_drt_matches_oracle(uivr, oracle, gpu, factor):
         np.testing.assert_array_equal(_bits(got[i, 1:4]), _bits(np.float32([t[0], W[0], maxt])), err_msg=str(i))
         n_valid += int(valid[0])
     assert n_valid > n // 2
+
+
+@pytest.mark.parametrize("block", [64, 128, 256])
+def test_grad_block_mask_matches_definition(uivr, gpu, block):
+    """drt_grad_block_mask (the compacted gradient all-reduce, distributed.py): 1 for every block that holds anything
+    but zeros - NaN, inf, denormals and a lone last element included; -0.0 is zero."""
+    native = uivr._native.native          # (attribute access: importing `uivr_amd._native` by name would load it twice)
+    gen = torch.Generator().manual_seed(block)
+    for n_blocks in (1, 3, 257, 4099):
+        body = torch.randn(n_blocks, block, generator=gen) * (torch.rand(n_blocks, 1, generator=gen) < 0.3)
+        if n_blocks > 3:
+            body[1] = 0; body[1, block - 1] = 1e-42          # denormal in the last lane
+            body[2] = 0; body[2, 0] = -0.0
+            body[5] = 0; body[5, 17] = float("nan")
+            body[6] = 0; body[6, block // 2] = float("-inf")
+        want = (body != 0).any(dim=1).to(torch.uint8)
+        dev_body = body.to(gpu)
+        mask = torch.full((n_blocks + 8,), 7, dtype=torch.uint8, device=gpu)     # guard bytes after the mask
+        native().grad_block_mask(torch.cuda.current_stream().cuda_stream, dev_body.data_ptr(), n_blocks, block, mask.data_ptr())
+        assert torch.equal(mask[:n_blocks].cpu(), want)
+        assert bool((mask[n_blocks:] == 7).all())
+    with pytest.raises(RuntimeError):
+        native().grad_block_mask(0, dev_body.data_ptr(), 1, 96, mask.data_ptr())

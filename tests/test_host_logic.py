@@ -218,3 +218,75 @@ def test_sharded_allreduce_equals_unsharded_gloo(oracle, uivr):
     np.testing.assert_allclose(ga, ref["grad_albedo"], rtol=2e-5, atol=1e-12)
     assert loss == pytest.approx(ref["loss"], rel=1e-6)
     np.testing.assert_array_equal(flat, np.full(8, 3.0))
+
+
+def _compact_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import uivr_amd as u
+    from uivr_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B = D.COMPACT_BLOCK_FLOATS
+        n = 200 * B + 37                                  # ragged tail
+        g = torch.Generator().manual_seed(1234 + rank)
+        out = {}
+        for name, active in (("sparse", 0.1), ("dense", 0.9)):
+            flat = torch.zeros(n)
+            blocks = torch.rand(200, generator=g) < active   # a different block set on every rank
+            vals = torch.randn(200, B, generator=g) * blocks[:, None]
+            flat[:200 * B] = vals.reshape(-1)
+            flat[200 * B:] = float(rank + 1)
+            if name == "sparse" and rank == 1:
+                flat[5 * B + 3] = float("nan")               # non-finite values must survive the packing
+                flat[7 * B] = -0.0                           # a block holding only -0.0 is a zero block
+            ref = flat.clone()
+            dist.all_reduce(ref)
+            for mode in ("auto", "always", "never"):
+                f = flat.clone()
+                stats = {}
+                u.allreduce_gradients({"_flat": f}, compact=mode, stats=stats)
+                out[(name, mode)] = (bool(torch.equal(torch.nan_to_num(f, nan=7.0), torch.nan_to_num(ref, nan=7.0))),
+                                     bool(torch.isnan(f[5 * B + 3])) if name == "sparse" else None, dict(stats))
+        # small buffers (the 3^3 fixtures) never pay for a mask
+        small = torch.full((100,), 1.0)
+        st = {}
+        u.allreduce_gradients({"_flat": small}, stats=st)
+        out["small"] = (bool((small == world).all()), st["mode"])
+        try:
+            u.allreduce_gradients({"_flat": small}, compact="sometimes")
+            out["bad"] = False
+        except ValueError:
+            out["bad"] = True
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_compacted_allreduce_equals_dense_gloo(uivr):
+    """SURVEY.md 8e / VERDICT r1 item 5c: the all-reduce of a sparse gradient buffer only moves the blocks that are
+    non-zero on some rank - and gives the same sums as the dense collective."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_compact_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from uivr_amd.distributed import COMPACT_BLOCK_FLOATS as B
+    for (name, mode), (equal, nan_kept, stats) in ((k, v) for k, v in out.items() if isinstance(k, tuple)):
+        assert equal, (name, mode, stats)
+        if name == "sparse":
+            assert nan_kept
+        want = {"never": "dense", "always": "compact", "auto": "compact" if name == "sparse" else "dense"}[mode]
+        assert stats["mode"] == want, (name, mode, stats)
+        if stats["mode"] == "compact":
+            assert stats["floats"] < 200 * B * (0.35 if name == "sparse" else 1.01) + 37
+    assert out["small"] == (True, "dense")
+    assert out["bad"]

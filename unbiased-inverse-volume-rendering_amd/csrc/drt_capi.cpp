@@ -1051,6 +1051,14 @@ int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t s
     return DRT_OK;
 }
 
+int drt_grad_block_mask(void *hip_stream, const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask)
+{
+    if (n_blocks && (!buf || !mask)) return DRT_ERR_INVALID_ARGUMENT;
+    if (block_floats != 64 && block_floats != 128 && block_floats != 256) return DRT_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t) buf % 16) return DRT_ERR_INVALID_ARGUMENT;
+    return drt::launch_block_mask(buf, n_blocks, block_floats, mask, (hipStream_t) hip_stream) == hipSuccess ? DRT_OK : DRT_ERR_HIP;
+}
+
 int drt_film_backward(drt_handle h, const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL)
 {
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");

@@ -1046,6 +1046,43 @@ hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, 
     return hipGetLastError();
 }
 
+// Which blocks of a gradient buffer hold anything but zeros (distributed.py: the compacted all-reduce).
+// One float4 per lane: a wave-wide load covers 256 floats = 256 / BLOCK blocks; NaN / inf count as non-zero.
+template <int BLOCK>
+__global__ __launch_bounds__(256) void block_mask_kernel(const float4 *buf, uint64_t n_vec, uint8_t *mask)
+{
+    constexpr int kLanes = BLOCK / 4;                       // lanes per block
+    const uint64_t stride = (uint64_t) gridDim.x * 256;
+    for (uint64_t v = (uint64_t) blockIdx.x * 256 + threadIdx.x; v < (n_vec + 63) / 64 * 64; v += stride) {
+        bool nz = false;
+        if (v < n_vec) {
+            const float4 f = buf[v];
+            nz = !(f.x == 0.f && f.y == 0.f && f.z == 0.f && f.w == 0.f);
+        }
+        const uint64_t b = __ballot(nz);
+        const unsigned lane = threadIdx.x & 63u;
+        if (lane % kLanes == 0 && v < n_vec) {
+            const uint64_t field = (b >> lane) & (kLanes == 64 ? ~0ull : ((1ull << (kLanes & 63)) - 1ull));
+            mask[v / kLanes] = field ? 1 : 0;
+        }
+    }
+}
+
+hipError_t launch_block_mask(const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const uint64_t n_vec = n_blocks * (block_floats / 4);
+    unsigned blocks = (unsigned) ((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
+    const float4 *b4 = reinterpret_cast<const float4 *>(buf);
+    switch (block_floats) {
+    case 64:  hipLaunchKernelGGL(block_mask_kernel<64>, dim3(blocks), dim3(256), 0, stream, b4, n_vec, mask); break;
+    case 128: hipLaunchKernelGGL(block_mask_kernel<128>, dim3(blocks), dim3(256), 0, stream, b4, n_vec, mask); break;
+    case 256: hipLaunchKernelGGL(block_mask_kernel<256>, dim3(blocks), dim3(256), 0, stream, b4, n_vec, mask); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_film_backward(const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL, hipStream_t stream)
 {
     uint64_t n = n_pixels * spp * 3;

@@ -260,6 +260,11 @@ PYBIND11_MODULE(DRT_PYBIND_NAME, m)
 {
     m.doc() = "pybind11 shim over libdrt_hip.so (C ABI in include/drt_hip.h)";
     m.def("version", []() { return std::string(drt_version()); });
+    m.def("grad_block_mask", [](uintptr_t stream, uintptr_t buf, uint64_t n_blocks, uint32_t block_floats, uintptr_t mask) {
+        const int rc = drt_grad_block_mask(reinterpret_cast<void *>(stream), reinterpret_cast<const float *>(buf), n_blocks,
+                                           block_floats, reinterpret_cast<uint8_t *>(mask));
+        if (rc != DRT_OK) throw std::runtime_error("drt_grad_block_mask failed (code " + std::to_string(rc) + ")");
+    });
     py::class_<Integrator>(m, "Integrator", py::module_local())   // (two flavours of this module can live in one process)
         .def(py::init<const py::dict &, int>(), py::arg("props"), py::arg("device") = 0)
         .def("set_stream", &Integrator::set_stream)

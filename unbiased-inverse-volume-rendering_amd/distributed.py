@@ -86,15 +86,74 @@ def from_environment(n_pixels: Optional[int] = None) -> ShardSpec:
     return ShardSpec(rank=rank, world=world, chunk_pixels=chunk)
 
 
-def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, shard: Optional[ShardSpec] = None) -> None:
-    """Sum the gradient grids over all ranks, in place: one collective per backward.
-    The grids live in (or are flattened into) ONE buffer (sigma_t: V floats + albedo:
-    3V floats) so that a single large all-reduce crosses xGMI instead of one per parameter.
+COMPACT_BLOCK_FLOATS = 64           # 256 B of the flat gradient buffer per block (64 | 128 | 256)
+COMPACT_MAX_ACTIVE = 0.7            # above this fraction of non-zero blocks the dense all-reduce is cheaper
+
+
+def _block_mask(body: torch.Tensor) -> torch.Tensor:
+    """uint8 [n_blocks]: 1 where a row of `body` holds anything but zeros (NaN / inf count as non-zero).
+    Device buffers: drt_grad_block_mask (one streaming pass at HBM rate; torch's row reductions take 3x longer)."""
+    if body.is_cuda:
+        from ._native import native
+        mask = torch.empty(body.shape[0], dtype=torch.uint8, device=body.device)
+        with torch.cuda.device(body.device):
+            native().grad_block_mask(torch.cuda.current_stream().cuda_stream, body.data_ptr(), body.shape[0], body.shape[1],
+                                     mask.data_ptr())
+        return mask
+    return (body != 0).any(dim=1).to(torch.uint8)
+
+
+def _allreduce_flat(flat: torch.Tensor, group, compact, stats: Optional[dict]) -> None:
+    """Sum `flat` over the group in place.  `compact`: "auto" (default) | "never" | "always".
+
+    The gradient of a sparse volume is mostly exact zeros: the albedo planes (3/4 of the buffer) only receive
+    splats where real scattering happens, i.e. next to voxels with sigma_t > 0, and with a majorant supergrid
+    (majorant_resolution_factor > 0) the sigma_t plane only where the local majorant is positive.  So the ranks first
+    agree on the set of 256-B blocks that are non-zero on ANY rank (an all-reduce(MAX) of one byte per block:
+    1 MiB for a 256^3 medium), and, when that set is small enough to pay for the packing, all-reduce only those
+    blocks.  Blocks outside the set are zero on every rank, so the sum is the same as the dense one (up to the
+    summation order inside the collective); non-finite values count as non-zero and propagate."""
+    import torch.distributed as dist
+    n = flat.numel()
+    B = COMPACT_BLOCK_FLOATS
+    if compact == "never" or n < 64 * B:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if stats is not None:
+            stats.update(mode="dense", floats=n, active_fraction=1.0)
+        return
+    n_full = (n // B) * B
+    body = flat[:n_full].view(-1, B)
+    mask = _block_mask(body)
+    dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
+    idx = mask.nonzero(as_tuple=False).squeeze(1)          # host sync: the collective below needs its size
+    frac = idx.numel() / mask.numel()
+    if compact != "always" and frac > COMPACT_MAX_ACTIVE:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if stats is not None:
+            stats.update(mode="dense", floats=n, active_fraction=frac)
+        return
+    tail = flat[n_full:]
+    packed = torch.cat([body.index_select(0, idx).reshape(-1), tail])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    body.index_copy_(0, idx, packed[:idx.numel() * B].view(-1, B))
+    if tail.numel():
+        tail.copy_(packed[idx.numel() * B:])
+    if stats is not None:
+        stats.update(mode="compact", floats=packed.numel(), active_fraction=frac)
+
+
+def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, shard: Optional[ShardSpec] = None,
+                        compact: str = "auto", stats: Optional[dict] = None) -> None:
+    """Sum the gradient grids over all ranks, in place: one collective per backward (plus a one-byte-per-block
+    mask, see `_allreduce_flat`).  The grids live in (or are flattened into) ONE buffer (sigma_t: V floats +
+    albedo: 3V floats) so that a single large all-reduce crosses xGMI instead of one per parameter.
 
     Only PARTITIONED work is summed: with `shard` given, the call is a no-op unless `shard.world > 1`
     (every rank of an unsharded render computed the full gradient already; summing those would
-    multiply it by the world size)."""
+    multiply it by the world size).  `stats`, if given, receives {"mode", "floats", "active_fraction"}."""
     import torch.distributed as dist
+    if compact not in ("auto", "never", "always"):
+        raise ValueError(f"compact must be 'auto', 'never' or 'always', not {compact!r}")
     if shard is not None and not shard.partitioned:
         return
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -102,11 +161,11 @@ def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, shard: Optio
     if shard is not None and shard.world != dist.get_world_size(group):
         raise ValueError(f"ShardSpec.world={shard.world} does not match the process group size {dist.get_world_size(group)}")
     if "_flat" in grads:      # render.alloc_grads: the grids are views of one buffer
-        dist.all_reduce(grads["_flat"], op=dist.ReduceOp.SUM, group=group)
+        _allreduce_flat(grads["_flat"], group, compact, stats)
         return
     keys = sorted(grads)
     flat = torch.cat([grads[k].reshape(-1) for k in keys])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    _allreduce_flat(flat, group, compact, stats)
     off = 0
     for k in keys:
         n = grads[k].numel()
