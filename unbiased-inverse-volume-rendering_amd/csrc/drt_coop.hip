@@ -220,6 +220,13 @@ hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStrea
 #define DRT_COOP_LAUNCH(A, C, E, D) hipLaunchKernelGGL((trace_coop_kernel<A, C, E, D>), grid, block, 0, stream, P)
     // the registered `volpathsimple-drt` configuration with the constant emitter: specialised kernels
     const bool spec = P.use_nee && P.use_drt && P.use_drt_subsampling && !count && !env && !dbg(P.debug_flags, 2097152u);
+#if DRT_PHASE_PROFILE
+    // experiment build: the counting launches run the specialised kernels too (their counters then hold phase cycles)
+    if (P.use_nee && P.use_drt && P.use_drt_subsampling && count && !env) {
+        if (!adjoint) { hipLaunchKernelGGL((trace_coop_kernel<false, true, false, false, true>), grid, block, 0, stream, P); return hipGetLastError(); }
+        if (defer) { hipLaunchKernelGGL((trace_coop_kernel<true, true, false, true, true>), grid, block, 0, stream, P); return hipGetLastError(); }
+    }
+#endif
     if (spec && !adjoint) { hipLaunchKernelGGL((trace_coop_kernel<false, false, false, false, true>), grid, block, 0, stream, P); return hipGetLastError(); }
     if (spec && defer) { hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true>), grid, block, 0, stream, P); return hipGetLastError(); }
     if (!adjoint) {

@@ -61,6 +61,14 @@ static __device__ const JumpTable kJump = make_jump_table();
 
 constexpr uint64_t kPcgMul = 0x5851f42d4c957f2dull;
 
+// walks pending in a wave from which a tracking round is taken on the walks' own lanes (33: exactly the m = 1 rounds)
+#ifndef DRT_PHASE_PROFILE
+#define DRT_PHASE_PROFILE 0
+#endif
+#ifndef DRT_COOP_SOLO_MIN
+#define DRT_COOP_SOLO_MIN 33
+#endif
+
 // output function of the draw whose pre-advance state is `old` (Pcg32::next_u32 / next_1d)
 __device__ __forceinline__ float pcg_float(uint64_t old)
 {
@@ -100,10 +108,35 @@ struct CoopTracer {
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
         ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr; work = 0; iters = 0;
+#if DRT_PHASE_PROFILE
+        ph_t = __builtin_readcyclecounter();
+#endif
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
     }
+#if DRT_PHASE_PROFILE
+    // experiment build (tools/phase_profile.py): the counter slots hold shader cycles per phase of the tracer instead of
+    // event counts (the clock is wave-uniform, every lane adds the same value: the flushed sum / 64 = cycles per wave)
+    uint64_t ph_t;
+    __device__ __forceinline__ void count(int) {}
+    __device__ __forceinline__ void stamp(int slot)
+    {
+        if (COUNT) { const uint64_t t = __builtin_readcyclecounter(); cnt[slot] += (uint32_t) ((t - ph_t) >> 4); ph_t = t; }
+    }
+    __device__ __forceinline__ void phase(int slot) { if (DRT_PHASE_PROFILE == 1) stamp(slot); }
+    // modes 2 / 3: cycles of the coop_rt / coop_dt rounds by the number of pending walks (everything else: n_tr)
+    __device__ __forceinline__ void round_begin(int which) { if (DRT_PHASE_PROFILE == which) stamp(C_TR); }
+    __device__ __forceinline__ void round_end(int which, int J)
+    {
+        if (DRT_PHASE_PROFILE == which)
+            stamp(J >= 33 ? C_DT : J >= 17 ? C_RT : J >= 9 ? C_DRT : J >= 5 ? C_ALB : J >= 3 ? C_RT_ADJ : J == 2 ? C_SC : C_SC_ALB);
+    }
+#else
+    __device__ __forceinline__ void round_begin(int) {}
+    __device__ __forceinline__ void round_end(int, int) {}
     __device__ __forceinline__ void count(int slot) { if (COUNT) cnt[slot]++; }
+    __device__ __forceinline__ void phase(int) {}
+#endif
     __device__ __forceinline__ bool use_nee() const { return SPEC ? true : P.use_nee != 0; }
     __device__ __forceinline__ bool use_drt() const { return SPEC ? true : P.use_drt != 0; }
     __device__ __forceinline__ bool use_sub() const { return SPEC ? true : P.use_drt_subsampling != 0; }
@@ -149,6 +182,35 @@ struct CoopTracer {
         uint32_t steps = 0;
         uint64_t pending = __ballot(job);
         while (pending) {
+            const int Jprof = __popcll(pending); (void) Jprof;
+            round_begin(2);
+            if (__popcll(pending) >= DRT_COOP_SOLO_MIN) {
+                // more than half of the lanes carry a walk: a round would give every walk ONE lane (m = 1) - take that
+                // step on the walk's own lane, without the slot table, the gathers and the jump-ahead (same arithmetic)
+                if (job) {
+                    const uint64_t sc = S.state;
+                    const float dt = sample_distance(pcg_float(sc));
+                    const bool inside = dt <= tmax;                             // :480-481
+                    const V3 p = v3(fmaf(d.x, dt, o.x), fmaf(d.y, dt, o.y), fmaf(d.z, dt, o.z));
+                    const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
+                    const float tr = (maj - sig) * inv_maj;                     // :473-476
+                    const float Tout = inside ? T * tr : T;
+                    if (inside) {
+                        count(C_RT);
+                        if constexpr (ADJ) if (tr > 0.0f) {                     // :487-492
+                            splat_sigma_t<DEFER>(P, p, -(a_sum * inv_maj) / tr, rec);
+                            count(C_RT_ADJ);
+                        }
+                        ++steps;
+                    }
+                    S.state = sc * kPcgMul + S.inc;
+                    T = Tout; o = p; tmax = tmax - dt;
+                    if (!inside || Tout == 0.0f) job = false;                   // :495, :502
+                }
+                pending = __ballot(job);
+                round_end(2, Jprof);
+                continue;
+            }
             int m, lg, js, c, owner, my_rank; bool serve;
             round_setup(job, pending, m, lg, js, c, serve, owner, my_rank);
             // the walk this lane serves
@@ -213,6 +275,7 @@ struct CoopTracer {
                 if (rend) job = false;
             }
             pending = __ballot(job);
+            round_end(2, Jprof);
         }
         if (steps_out) *steps_out = steps;
         return T;
@@ -228,6 +291,30 @@ struct CoopTracer {
         V3 ro = ray.o; float rmaxt = ray.maxt, running_t = 0.0f;
         uint64_t pending = __ballot(job);
         while (pending) {
+            const int Jprof = __popcll(pending); (void) Jprof;
+            round_begin(3);
+            if (__popcll(pending) >= DRT_COOP_SOLO_MIN) {                        // m = 1 rounds on the walks' own lanes (see coop_rt)
+                if (job) {
+                    const uint64_t s0 = S.state, s1 = s0 * kPcgMul + S.inc;
+                    const float dt = sample_distance(pcg_float(s0));            // :348
+                    const float u2 = pcg_float(s1);                             // :359
+                    const bool inside = dt <= rmaxt;                            // :358
+                    const V3 p = v3(fmaf(ray.d.x, dt, ro.x), fmaf(ray.d.y, dt, ro.y), fmaf(ray.d.z, dt, ro.z));
+                    const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
+                    const float r = sig * inv_maj;                              // :354
+                    const bool accepted = inside && !(u2 >= r);                 // :351
+                    if (inside) count(C_DT);
+                    S.state = inside ? s1 * kPcgMul + S.inc : s1;
+                    const float rtm = running_t + dt;
+                    if (!inside || accepted) {
+                        job = false;
+                        if (accepted) { mei.valid = true; mei.t = rtm; steps += 1u; }
+                    } else { ro = p; rmaxt = rmaxt - dt; running_t = rtm; steps += 1u; }
+                }
+                pending = __ballot(job);
+                round_end(3, Jprof);
+                continue;
+            }
             int m, lg, js, c, owner, my_rank; bool serve;
             round_setup(job, pending, m, lg, js, c, serve, owner, my_rank);
             float cx = __shfl(ro.x, owner), cy = __shfl(ro.y, owner), cz = __shfl(ro.z, owner);
@@ -278,6 +365,7 @@ struct CoopTracer {
                 } else { ro = v3(rx, ry, rz); rmaxt = rt; running_t = rtm; steps += (uint32_t) m; }
             }
             pending = __ballot(job);
+            round_end(3, Jprof);
         }
         return mei;                                                             // mei.p / attached sigma_t: the caller (:371-375)
     }
@@ -363,7 +451,9 @@ struct CoopTracer {
         if (use_nee()) {                                                        // :621-624 (wave-uniform condition)
             const float one[3] = { 1.0f, 1.0f, 1.0f };
             float nee[3];
+            phase(C_SC);
             sample_emitter_for_nee<false>(job, p, A, one, nullptr, nee);
+            phase(C_RT_ADJ);
 #pragma unroll
             for (int k = 0; k < 3; ++k) Li[k] += nee[k];
         }
@@ -393,7 +483,9 @@ struct CoopTracer {
         sub.maxt = isfinite(si_t) ? si_t : kLargest;                            // :544-545
         float tp = kInf, W = 0.0f;
         bool found = false;
+        phase(C_TR);
         if (job) found = sample_interaction_drt(sub, A, tp, W);                 // :550,558
+        phase(C_DRT);
         V3 p = v3(0, 0, 0);
         float sig = 0.0f;
         float alb[3] = { 0.0f, 0.0f, 0.0f };
@@ -484,7 +576,9 @@ struct CoopTracer {
             const int cmode = (!RECURSIVE && pc && run && it < (int) P.path_cache_cap) ? (int) P.path_cache_mode : 0;
             uint4 *ce = cmode ? pc + 2 * it : nullptr;
             uint32_t dt_steps = 0;
+            phase(RECURSIVE ? C_SC : C_TR);
             Mei mei = coop_dt(run && cmode != 2, ray, S, dt_steps);             // :126
+            phase(RECURSIVE ? C_ALB : C_DT);
             work += dt_steps + 4u;
             if (cmode == 2) {
                 const uint4 e = ce[0];
@@ -554,7 +648,9 @@ struct CoopTracer {
             }
             if (use_nee()) {
                 float nee[3];
+                phase(RECURSIVE ? C_SC : C_TR);
                 sample_emitter_for_nee<ADJ>(nee_job, mei.p, S, beta, dL, nee, nee_job ? cmode : 0, ce ? ce + 1 : nullptr);
+                phase(RECURSIVE ? C_RT_ADJ : C_RT);
                 if (nee_job) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) result[k] = ADJ ? result[k] - nee[k] : result[k] + nee[k];
@@ -604,6 +700,7 @@ struct CoopTracer {
                 for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
             }
         }
+        phase(RECURSIVE ? C_SC : C_TR);
         if (!RECURSIVE) iters = (uint32_t) it;
         out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
     }
