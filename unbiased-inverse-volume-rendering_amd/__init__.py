@@ -15,8 +15,10 @@ from .render import alloc_grads, render, render_backward, render_primal
 from .batched import gather_ref_values, render_batch, sample_batch, sensors_to_device
 from . import losses
 from .optimize import (Adam, OptimizationConfig, SGD, SceneConfig, Schedule, adjusted_majorant_res_factor,
-                       enforce_valid_params, run_optimization, save_params, upsample_grid)
+                       enforce_valid_params, get_reference_image_paths, load_reference_images, render_previews,
+                       render_reference_image, run_optimization, save_params, upsample_grid)
 from .volume_io import read_vol, write_vol
+from .image_io import read_image, write_image
 
 __all__ = [
     "ALBEDO_KEY", "EMISSION_KEY", "SIGMA_T_KEY", "ConstantEmitter", "EnvmapEmitter", "GridMedium", "PerspectiveSensor",
@@ -26,5 +28,6 @@ __all__ = [
     "from_environment", "local_loss_scale", "alloc_grads", "render", "render_backward", "render_primal", "render_batch",
     "gather_ref_values", "sample_batch", "sensors_to_device", "losses", "Adam", "SGD", "OptimizationConfig",
     "SceneConfig", "Schedule", "adjusted_majorant_res_factor", "enforce_valid_params", "run_optimization",
-    "save_params", "upsample_grid", "read_vol", "write_vol",
+    "save_params", "upsample_grid", "read_vol", "write_vol", "read_image", "write_image", "get_reference_image_paths",
+    "load_reference_images", "render_previews", "render_reference_image",
 ]

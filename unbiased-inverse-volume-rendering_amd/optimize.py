@@ -2,7 +2,8 @@
 python/opt_config.py:11-75): Adam with per-parameter learning rates and the `Last25` schedule,
 projection of the parameters onto their legal range, x2 trilinear grid upsampling, majorant
 supergrid adjustment, `.vol` checkpoints - all on the device (the reference round-trips the grids
-through scipy on the host for upsampling, optimize.py:217-223).
+through scipy on the host for upsampling, optimize.py:217-223); reference renderings cached on disk and
+preview renderings (N3; PFM instead of EXR, image_io.py).
 """
 from __future__ import annotations
 
@@ -20,6 +21,7 @@ from .integrators import sample_tea_32
 from .opt_config import get_int_config
 from .render import render, render_primal
 from .scene import ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, GridMedium, Scene
+from .image_io import read_image, write_image
 from .volume_io import write_vol
 
 
@@ -101,6 +103,7 @@ class SceneConfig:
     # sparse volumes and the estimators agree in expectation: pass 0 for speed.
     majorant_resolution_factor: int = 8
     param_lr_factors: Optional[Dict[str, float]] = None
+    references: Optional[str] = None       # scene_config.py:47-50: directory of the cached reference renderings
 
     def __post_init__(self):
         for k in self.param_keys:
@@ -217,6 +220,86 @@ def save_params(output_dir: str, scene_config: SceneConfig, params: Dict[str, to
         write_vol(os.path.join(output_dir, f'{name}-{var_name}.vol'), params[key], medium.bbox_min, medium.bbox_max)
 
 
+IMAGE_EXT = '.pfm'      # the reference writes .exr (optimize.py:50,131); OpenEXR does not exist here (image_io.py)
+
+
+def render_reference_image(scene_config: SceneConfig, to_render: Dict[int, Optional[str]], seed: int = 1234,
+                           max_rays_per_pass: int = 720 * 720 * 2048) -> Dict[int, torch.Tensor]:
+    """python/optimize.py:24-50: render the sensors `to_render` ({sensor id: file name or None}) of the reference
+    scene at `ref_spp` with `ref_integrator`, in passes of at most `max_rays_per_pass` rays (pass i uses seed + i,
+    the result is the mean of the passes), and write each to its file.  Returns {sensor id: (H, W, 3) tensor}."""
+    scene = scene_config.scene
+    integrator = get_int_config(scene_config.ref_integrator).create(max_depth=scene_config.max_depth)
+    ref_spp = scene_config.ref_spp
+    out = {}
+    for s, fname in to_render.items():
+        sensor = scene.sensors[s]
+        total_rays = sensor.width * sensor.height * ref_spp
+        pass_count = -(-total_rays // max_rays_per_pass)
+        spp_per_pass = -(-ref_spp // pass_count)
+        assert spp_per_pass * pass_count >= ref_spp
+        result = None
+        for pass_i in range(pass_count):
+            image = render_primal(scene, integrator, s, spp_per_pass, seed + pass_i) / pass_count
+            result = image if result is None else result + image
+        result = result.view(sensor.height, sensor.width, 3)
+        if fname:
+            write_image(fname, result)
+        out[s] = result
+    return out
+
+
+def get_reference_image_paths(scene_config: SceneConfig, overwrite: bool = False) -> Dict[int, str]:
+    """python/optimize.py:53-68: `<references>/ref_<sensor id>` for every sensor of the configuration; the
+    missing ones (all with `overwrite`) are rendered first."""
+    if not scene_config.references:
+        raise ValueError('SceneConfig.references (the directory of the reference renderings) is not set')
+    os.makedirs(scene_config.references, exist_ok=True)
+    paths = {s: os.path.join(scene_config.references, f'ref_{s:06d}{IMAGE_EXT}') for s in scene_config.sensors}
+    missing = dict(paths) if overwrite else {s: f for s, f in paths.items() if not os.path.isfile(f)}
+    if missing:
+        render_reference_image(scene_config, missing)
+    return paths
+
+
+def load_reference_images(paths: Dict[int, str], batchify: bool = False, device=None):
+    """python/optimize.py:71-85: one (n_sensors, H, W, 3) tensor in the order of `paths` (batched rendering gathers
+    from it) or {sensor id: (H, W, 3) tensor}."""
+    imgs = {s: torch.from_numpy(read_image(f)).to(device) for s, f in paths.items()}
+    if batchify:
+        return torch.stack(list(imgs.values()))
+    return imgs
+
+
+def render_previews(output_dir: str, opt_config: OptimizationConfig, scene_config: SceneConfig, scene: Scene,
+                    integrator, it_i) -> List[str]:
+    """python/optimize.py:108-131: `opt<suffix>_<sensor>` for every preview sensor, seed 1234, `preview_spp`.
+    `scene.sensors` is the configuration's sensor list; `scene_config.preview_sensors` holds ids of the full scene."""
+    if it_i == 'initial':
+        if not opt_config.render_initial:
+            return []
+        suffix = '_init'
+    elif it_i == 'final':
+        if not opt_config.render_final:
+            return []
+        suffix = '_final'
+    elif isinstance(it_i, int):
+        suffix = f'_{it_i:08d}'
+    else:
+        assert isinstance(it_i, str)
+        suffix = it_i
+    preview_spp = opt_config.preview_spp or opt_config.spp
+    full = Scene(medium=scene.medium, emitter=scene.emitter, sensors=scene_config.scene.sensors)
+    written = []
+    for s in scene_config.preview_sensors:
+        sensor = full.sensors[s]
+        fname = os.path.join(output_dir, f'opt{suffix}_{s:04d}{IMAGE_EXT}')
+        image = render_primal(full, integrator, s, preview_spp, 1234)
+        write_image(fname, image.view(sensor.height, sensor.width, 3))
+        written.append(fname)
+    return written
+
+
 def _scene_with(scene: Scene, params: Dict[str, torch.Tensor], factor: int) -> Scene:
     m = scene.medium
     medium = GridMedium(sigma_t=params.get(SIGMA_T_KEY, m.sigma_t), albedo=params.get(ALBEDO_KEY, m.albedo),
@@ -263,17 +346,17 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
     if output_dir:
         os.makedirs(os.path.join(output_dir, 'params'), exist_ok=True)       # util.py:55-71 always creates it
 
-    if ref_images is None:                                             # reference renderings
-        ref_int = get_int_config(scene_config.ref_integrator).create(max_depth=scene_config.max_depth)
-        ref_scene = Scene(medium=scene0.medium, emitter=scene0.emitter, sensors=sensors)
-        imgs = []
-        for s in range(n_sensors):
-            passes = max(1, scene_config.ref_spp // 2048)
-            acc = 0
-            for p in range(passes):                                    # multi-pass (optimize.py:24-50)
-                acc = acc + render_primal(ref_scene, ref_int, s, scene_config.ref_spp // passes, 1234 + p) / passes
-            imgs.append(acc.view(film[1], film[0], 3))
-        ref_images = torch.stack(imgs)
+    if ref_images is None:                                             # reference renderings (optimize.py:284-285)
+        if scene_config.references:                                    # cached on disk; rank 0 renders what is missing
+            if shard.partitioned:
+                import torch.distributed as dist
+                if shard.rank == 0:
+                    get_reference_image_paths(scene_config)
+                dist.barrier()
+            ref_images = load_reference_images(get_reference_image_paths(scene_config), batchify=True, device=dev)
+        else:
+            rendered = render_reference_image(scene_config, {s: None for s in scene_config.sensors})
+            ref_images = torch.stack([rendered[s] for s in scene_config.sensors])
 
     # --- initialisation (optimize.py:134-166)
     full = {SIGMA_T_KEY: scene0.medium.sigma_t, ALBEDO_KEY: scene0.medium.albedo, EMISSION_KEY: scene0.medium.emission}
@@ -318,8 +401,14 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
     opt = opt_config.optimizer(params)
     scene = _scene_with(Scene(scene0.medium, scene0.emitter, sensors), grids, factor)
     table = sensors_to_device(sensors, dev)
-    if output_dir and opt_config.checkpoint_initial:
+    writer = bool(output_dir) and shard.rank == 0                      # one rank writes checkpoints and previews
+    if writer and opt_config.checkpoint_initial:
         save_params(os.path.join(output_dir, 'params'), scene_config, params, 'initial', scene.medium)
+    if writer:
+        render_previews(output_dir, opt_config, scene_config, scene, integrator, 'initial')   # optimize.py:320
+        for s in scene_config.preview_sensors:                         # the matching references, for comparison (:321-324)
+            if s in scene_config.sensors:
+                write_image(os.path.join(output_dir, f'ref_{s:04d}{IMAGE_EXT}'), ref_images[scene_config.sensors.index(s)])
 
     host_rng = torch.Generator().manual_seed(93483)                    # sensor choice (optimize.py:291,344)
     history = []
@@ -360,10 +449,14 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
         enforce_valid_params(scene_config, opt)                        # :353
         total = allreduce_scalar(loss_value.detach()) if shard.partitioned else loss_value.detach()
         history.append(float(total))
-        if output_dir and it_i > 0 and opt_config.checkpoint_stride and it_i % opt_config.checkpoint_stride == 0:
+        if writer and it_i > 0 and opt_config.checkpoint_stride and it_i % opt_config.checkpoint_stride == 0:
             save_params(os.path.join(output_dir, 'params'), scene_config, params, f'{it_i:08d}', scene.medium)
+        if writer and it_i > 0 and opt_config.preview_stride and it_i % opt_config.preview_stride == 0:   # :357-358
+            render_previews(output_dir, opt_config, scene_config, scene, integrator, it_i)
         if progress:
             progress(it_i, history[-1])
-    if output_dir and opt_config.checkpoint_final:
+    if writer and opt_config.checkpoint_final:
         save_params(os.path.join(output_dir, 'params'), scene_config, params, 'final', scene.medium)
+    if writer:
+        render_previews(output_dir, opt_config, scene_config, scene, integrator, 'final')     # :362
     return scene, params, opt, history
