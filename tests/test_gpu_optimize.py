@@ -98,3 +98,44 @@ def test_reference_cache_previews_and_checkpoints(uivr, gpu, tmp_path):
     out2 = str(tmp_path / "out2")
     uivr.run_optimization(out2, oc2, sc, "volpathsimple-drt")
     assert sorted(os.listdir(out2)) == ["params", "ref_0002.pfm"] and os.listdir(os.path.join(out2, "params")) == []
+
+
+def test_warm_start_from_nerf_checkpoint(uivr, gpu, tmp_path):
+    """The reference's `*-from-nerf` flow (python/scene_config.py:123-141, python/reproduce.py:66-77): optimise with the
+    `nerf` integrator, write `.vol` checkpoints, build the next scene's medium from those files, keep its sigma_t
+    (`start_from_value` None) and restart the albedo from a constant, optimise with `volpathsimple-drt`."""
+    scene = _target_scene(uivr, gpu, n_sensors=3)
+    scene.medium.emission = (scene.medium.albedo * 0.5).contiguous()
+    refs = torch.stack([uivr.render_primal(scene, uivr.get_int_config("volpathsimple-drt").create(max_depth=16), s, 256, 1234).view(32, 32, 3)
+                        for s in range(3)])
+    keys3 = [uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY, uivr.EMISSION_KEY]
+    sc1 = uivr.SceneConfig(name="stage1", scene=scene, param_keys=keys3, sensors=[0, 1, 2],
+                           start_from_value={uivr.SIGMA_T_KEY: 0.4, uivr.ALBEDO_KEY: 0.6, uivr.EMISSION_KEY: 0.1}, max_depth=16,
+                           max_density=20.0)
+    oc1 = uivr.OptimizationConfig("nerf", spp=4, n_iter=6, lr=1e-2, primal_spp_factor=1, batch_size=512, render_initial=False,
+                                  render_final=False)
+    out1 = str(tmp_path / "stage1" / "nerf")
+    _, p1, _, _ = uivr.run_optimization(out1, oc1, sc1, "nerf", ref_images=refs)
+    pdir = os.path.join(out1, "params")
+    medium = uivr.medium_from_vol(os.path.join(pdir, "final-medium1_sigma_t.vol"), os.path.join(pdir, "final-medium1_albedo.vol"),
+                                  os.path.join(pdir, "final-medium1_emission.vol"), scale=scene.medium.scale,
+                                  majorant_resolution_factor=8, device=gpu)
+    assert torch.equal(medium.sigma_t, p1[uivr.SIGMA_T_KEY]) and torch.equal(medium.emission, p1[uivr.EMISSION_KEY])
+    assert tuple(medium.bbox_min) == tuple(scene.medium.bbox_min)
+    scene2 = uivr.Scene(medium=medium, emitter=scene.emitter, sensors=scene.sensors)
+    sc2 = uivr.SceneConfig(name="stage2", scene=scene2, param_keys=keys3, sensors=[0, 1, 2],
+                           start_from_value={uivr.SIGMA_T_KEY: None, uivr.ALBEDO_KEY: 0.6, uivr.EMISSION_KEY: None}, max_depth=16,
+                           max_density=20.0)
+    seen = {}
+    oc2 = uivr.OptimizationConfig("drt", spp=4, n_iter=3, lr=1e-3, primal_spp_factor=2, batch_size=512, render_initial=False,
+                                  render_final=False)
+    out2 = str(tmp_path / "stage2")
+    _, p2, _, hist = uivr.run_optimization(out2, oc2, sc2, "volpathsimple-drt", ref_images=refs)
+    assert len(hist) == 3 and np.isfinite(hist).all()
+    start, _, _ = uivr.read_vol(os.path.join(out2, "params", "initial-medium1_sigma_t.vol"))
+    np.testing.assert_array_equal(start, p1[uivr.SIGMA_T_KEY].cpu().numpy())           # kept from the checkpoint
+    a0, _, _ = uivr.read_vol(os.path.join(out2, "params", "initial-medium1_albedo.vol"))
+    assert float(a0.min()) == float(a0.max()) == np.float32(0.6)                        # restarted from the constant
+    # the emission is carried along untouched (volpathsimple does not read it: no gradient), sigma_t moved
+    assert torch.equal(p2[uivr.EMISSION_KEY], p1[uivr.EMISSION_KEY])
+    assert not torch.equal(p2[uivr.SIGMA_T_KEY], p1[uivr.SIGMA_T_KEY])

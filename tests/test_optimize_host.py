@@ -97,3 +97,34 @@ def test_vol_roundtrip(uivr, tmp_path):
     with pytest.raises(ValueError):
         open(tmp_path / "bad.vol", "wb").write(b"NOPE" + b"\0" * 60)
         uivr.read_vol(str(tmp_path / "bad.vol"))
+
+
+def test_medium_from_vol(uivr, tmp_path):
+    """Warm starts / assets (python/scene_config.py:84-141): a medium assembled from `.vol` files; an albedo file on
+    another lattice is resampled onto sigma_t's, cell-centred (== scipy.ndimage.zoom(order=1, grid_mode=True))."""
+    import scipy.ndimage
+    rng = np.random.default_rng(5)
+    sig = rng.random((6, 4, 8, 1), dtype=np.float32)
+    alb = rng.random((6, 4, 8, 3), dtype=np.float32)
+    alb_lo = rng.random((3, 2, 4, 3), dtype=np.float32)
+    emi = rng.random((6, 4, 8, 1), dtype=np.float32)
+    uivr.write_vol(str(tmp_path / "s.vol"), sig, (-1, -0.5, -2), (1, 0.5, 2))
+    uivr.write_vol(str(tmp_path / "a.vol"), alb)
+    uivr.write_vol(str(tmp_path / "alo.vol"), alb_lo)
+    uivr.write_vol(str(tmp_path / "e.vol"), emi)
+    m = uivr.medium_from_vol(str(tmp_path / "s.vol"), str(tmp_path / "a.vol"), str(tmp_path / "e.vol"), scale=20.0,
+                             majorant_resolution_factor=8)
+    np.testing.assert_array_equal(m.sigma_t.numpy(), sig)
+    np.testing.assert_array_equal(m.albedo.numpy(), alb)
+    np.testing.assert_array_equal(m.emission.numpy(), np.repeat(emi, 3, axis=3))      # 1-channel file -> grey RGB
+    assert m.bbox_min == (-1, -0.5, -2) and m.bbox_max == (1, 0.5, 2) and m.scale == 20.0 and m.majorant_resolution_factor == 8
+    assert m.resolution == (8, 4, 6)
+    m2 = uivr.medium_from_vol(str(tmp_path / "s.vol"), str(tmp_path / "alo.vol"))
+    want = np.stack([scipy.ndimage.zoom(alb_lo[..., c], 2, order=1, mode="nearest", prefilter=False, grid_mode=True)
+                     for c in range(3)], axis=-1)
+    np.testing.assert_allclose(m2.albedo.numpy(), want, atol=1e-6)
+    assert m2.emission is None
+    m3 = uivr.medium_from_vol(str(tmp_path / "s.vol"), albedo_value=0.6)                # scene_config.py:137
+    assert tuple(m3.albedo.shape) == (6, 4, 8, 3) and float(m3.albedo.min()) == float(m3.albedo.max()) == np.float32(0.6)
+    with pytest.raises(ValueError):
+        uivr.medium_from_vol(str(tmp_path / "a.vol"))                                   # density must have one channel

@@ -17,7 +17,7 @@ from . import losses
 from .optimize import (Adam, OptimizationConfig, SGD, SceneConfig, Schedule, adjusted_majorant_res_factor,
                        enforce_valid_params, get_reference_image_paths, load_reference_images, render_previews,
                        render_reference_image, run_optimization, save_params, upsample_grid)
-from .volume_io import read_vol, write_vol
+from .volume_io import medium_from_vol, read_vol, write_vol
 from .image_io import read_image, write_image
 
 __all__ = [
@@ -28,6 +28,6 @@ __all__ = [
     "from_environment", "local_loss_scale", "alloc_grads", "render", "render_backward", "render_primal", "render_batch",
     "gather_ref_values", "sample_batch", "sensors_to_device", "losses", "Adam", "SGD", "OptimizationConfig",
     "SceneConfig", "Schedule", "adjusted_majorant_res_factor", "enforce_valid_params", "run_optimization",
-    "save_params", "upsample_grid", "read_vol", "write_vol", "read_image", "write_image", "get_reference_image_paths",
+    "save_params", "upsample_grid", "read_vol", "write_vol", "medium_from_vol", "read_image", "write_image", "get_reference_image_paths",
     "load_reference_images", "render_previews", "render_reference_image",
 ]

@@ -48,3 +48,46 @@ def read_vol(path: str):
             raise ValueError(f"{path}: expected {4 * n} data bytes, found {len(raw)}")
     data = np.frombuffer(raw, dtype="<f4").reshape(z, y, x, c).astype(np.float32)
     return data, tuple(bbox[:3]), tuple(bbox[3:])
+
+
+def medium_from_vol(medium_filename: str, albedo_filename=None, emission_filename=None, albedo_value: float = 0.6,
+                    scale: float = 1.0, majorant_resolution_factor: int = 0, device=None):
+    """A `GridMedium` from `.vol` files - the `medium_filename` / `albedo_filename` / `emission_filename` variables of
+    the reference's scene descriptions (python/scene_config.py:84-141), e.g. the checkpoints of a previous run for a
+    warm start (`janga-smoke-from-nerf`: `<output>/<run>/nerf/params/final-medium1_sigma_t.vol`, :123-141).
+
+    The bounding box is the one stored in the sigma_t file.  Without an albedo file the albedo is the constant
+    `albedo_value`.  The kernels read all grids on ONE lattice, sigma_t's: an albedo / emission file of a different
+    resolution (the reference pairs a 264x136x136 density with a 256x128x128 albedo, :108-109) is resampled to it
+    trilinearly (cell-centred, edge-replicated) - Mitsuba interpolates every grid on its own lattice, so that case is
+    an approximation, stated here."""
+    import torch
+    import torch.nn.functional as F
+    from .scene import GridMedium
+    sig, bmin, bmax = read_vol(medium_filename)
+    if sig.shape[3] != 1:
+        raise ValueError(f"{medium_filename}: expected a 1-channel density grid, found {sig.shape[3]} channels")
+    res3 = sig.shape[:3]
+
+    def load(path, what):
+        if path is None:
+            return None
+        g, _, _ = read_vol(path)
+        if g.shape[3] not in (1, 3):
+            raise ValueError(f"{path}: expected a 1- or 3-channel {what} grid, found {g.shape[3]} channels")
+        t = torch.from_numpy(g)
+        if t.shape[3] == 1:
+            t = t.expand(-1, -1, -1, 3)
+        if tuple(t.shape[:3]) != tuple(res3):
+            t = F.interpolate(t.permute(3, 0, 1, 2).unsqueeze(0), size=tuple(res3), mode="trilinear",
+                              align_corners=False)[0].permute(1, 2, 3, 0)
+        return t.contiguous()
+
+    albedo = load(albedo_filename, "albedo")
+    if albedo is None:
+        albedo = torch.full(tuple(res3) + (3,), float(albedo_value), dtype=torch.float32)
+    emission = load(emission_filename, "emission")
+    to = (lambda t: t.to(device)) if device is not None else (lambda t: t)
+    return GridMedium(sigma_t=to(torch.from_numpy(sig.copy())), albedo=to(albedo), bbox_min=bmin, bbox_max=bmax, scale=scale,
+                      majorant_resolution_factor=majorant_resolution_factor,
+                      emission=to(emission) if emission is not None else None)
