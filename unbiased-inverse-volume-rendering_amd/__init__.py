@@ -19,6 +19,7 @@ from .optimize import (Adam, OptimizationConfig, SGD, SceneConfig, Schedule, adj
                        render_reference_image, run_optimization, save_params, upsample_grid)
 from .volume_io import medium_from_vol, read_vol, write_vol
 from .image_io import read_image, write_image
+from .fd import fd_gradients
 
 __all__ = [
     "ALBEDO_KEY", "EMISSION_KEY", "SIGMA_T_KEY", "ConstantEmitter", "EnvmapEmitter", "GridMedium", "PerspectiveSensor",
@@ -29,5 +30,5 @@ __all__ = [
     "gather_ref_values", "sample_batch", "sensors_to_device", "losses", "Adam", "SGD", "OptimizationConfig",
     "SceneConfig", "Schedule", "adjusted_majorant_res_factor", "enforce_valid_params", "run_optimization",
     "save_params", "upsample_grid", "read_vol", "write_vol", "medium_from_vol", "read_image", "write_image", "get_reference_image_paths",
-    "load_reference_images", "render_previews", "render_reference_image",
+    "load_reference_images", "render_previews", "render_reference_image", "fd_gradients",
 ]
