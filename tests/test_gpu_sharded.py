@@ -43,3 +43,5 @@ def test_bench_two_ranks_on_one_device(gpu):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["frac"] > 0
+    ar = out["allreduce"]                                   # the moved size of the (compacted) gradient all-reduce
+    assert ar["mode"] in ("dense", "compact") and 0 < ar["MiB"] <= ar["of_MiB"] and 0 < ar["active_fraction"] <= 1
