@@ -235,29 +235,36 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
     }
     // Kernel choice (measured on MI355X, headline workload):
-    //   global majorant: one ray per lane with wave-cooperative tracking loops (drt_coop.hip) for both passes;
-    //                    the primal pass writes the path cache that the adjoint pass of the same job reads.
-    //                    The wave-synchronous state machine (drt_wavefront.hip) is as fast for the primal
-    //                    (debug bit 65536 selects it); for the adjoint (bit 32) it is slower (its transition
-    //                    blocks run with ~3 lanes).
-    //   supergrid      : state machine for the primal, plain one-ray-per-lane kernel (drt_kernels.hip; also debug
-    //                    bits 8 / 32768) for the adjoint, path cache included: the free-flight distance depends
-    //                    on the position, the cooperative loops do not apply.
+    //   the one-ray-per-lane kernels of drt_coop*.hip (CoopTracer) - wave-cooperative tracking rounds with the global
+    //   majorant, own-lane tracking steps with a majorant supergrid - for every pass but one: the PRIMAL pass over a
+    //   supergrid, which the wave-synchronous state machine (drt_wavefront.hip) runs 1.6x faster (5.9 vs 9.6 ms: it
+    //   refills lanes whose paths ended).  Every primal kernel writes the path cache the adjoint pass of the job reads.
+    //   The plain per-lane Tracer (drt_kernels.hip; bits 8 / 32768) exists only in the library flavour with test
+    //   hooks, where the variant tests keep it (and the state machine's adjoint, bit 32) in lock-step with the rest.
     const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
     const bool sm_primal = !adjoint && (P.mgrid != nullptr || dbg(h->debug_flags, 65536u)) && !dbg(h->debug_flags, 8u);
     const bool sm_adjoint = adjoint && dbg(h->debug_flags, 32u) && !quadratic && !dbg(h->debug_flags, 8u);
     const bool wavefront = sm_primal || sm_adjoint;
-    const bool coop = !wavefront && !P.mgrid && !dbg(h->debug_flags, (adjoint ? 32768u : 8u));
-    const bool coop_primal = false;
-    if (coop || coop_primal) {
-        DRT_HIP_CHECK(h, drt::launch_trace_coop(P, adjoint, h->counting, h->stream));
-    } else if (!wavefront) {
-        // the plain per-lane kernels keep rays in image order: neighbouring pixels walk the same supergrid cells, and
-        // sorting them by path length costs more (24.6 vs 18.8 ms at majorant_resolution_factor 8) than it saves
+    const bool coop = !wavefront && !dbg(h->debug_flags, (adjoint ? 32768u : 8u));
+    if (coop) {
+        if (P.mgrid) {
+            // supergrid: rays stay in image order - neighbouring pixels walk the same supergrid cells, and sorting them
+            // by path length costs more than it saves (24.6 vs 18.8 ms at majorant_resolution_factor 8)
+            drt::Params Q = P;
+            Q.ray_perm = nullptr;
+            DRT_HIP_CHECK(h, drt::launch_trace_coop(Q, adjoint, h->counting, h->stream));
+        } else {
+            DRT_HIP_CHECK(h, drt::launch_trace_coop(P, adjoint, h->counting, h->stream));
+        }
+    }
+#ifdef DRT_TEST_HOOKS
+    else if (!wavefront) {
         drt::Params Q = P;
         Q.ray_perm = nullptr;
         DRT_HIP_CHECK(h, drt::launch_trace(Q, adjoint, h->counting, h->stream));
-    } else {
+    }
+#endif
+    else {
         drt::Params Q = P;
         Q.queues = h->d_queues;
         DRT_HIP_CHECK(h, hipMemsetAsync(h->d_queues, 0, 8 * sizeof(unsigned long long), h->stream));

@@ -18,7 +18,7 @@
 // walk returns bit for bit what the per-lane loop (and the oracle) returns; only the grid lookups, the
 // logarithms and the random numbers, i.e. the expensive part, run in parallel.  Speculative steps behind a
 // walk's end are discarded (and not counted).  Supergrid scenes (majorant_resolution_factor > 0: the
-// distance depends on the position) keep the per-lane kernels.
+// distance depends on the position) take every step on the walk's own lane (template flag SUPER).
 //
 // Headline workload, adjoint tracer: 44.7 M wave-level loop iterations -> 16.4 M rounds, VALU lane
 // utilisation 15 % -> 64 %, 8.4 G -> 6.1 G wave instructions (still VALU-issue-bound: the replay and the
@@ -90,10 +90,15 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 // across the bounce loop).  Every other configuration runs the generic instantiation.
 // G4: sigma_t and albedo at scatter points come from ONE lookup into the interleaved four-channel apron-brick copy
 // (Params::grid4, eval4) instead of two lookups into two layouts - same voxel values, same interpolation arithmetic.
-template <bool COUNT, bool ENV, bool DEFER, bool SPEC = false, bool G4 = false>
+// SUPER: majorant supergrid (majorant_resolution_factor > 0).  The free-flight distance then depends on the position
+// (Medium::sample_interaction walks the supergrid cells, dda_collision in drt_device.h), the steps of a walk are no
+// longer independent, and every tracking step is taken on the walk's own lane - the same loops, path cache, record
+// streams and estimator specialisation otherwise, so that ONE tracer serves every configuration.
+template <bool COUNT, bool ENV, bool DEFER, bool SPEC = false, bool G4 = false, bool SUPER = false>
 struct CoopTracer {
     const Params &P;
     float maj, inv_maj;
+    const uint32_t *mocc;   // SUPER: non-empty supergrid cells (LDS copy) or nullptr
     uint32_t ray_index;
     uint32_t *rec;          // wave-private LDS: cooperative-scatter staging area or (DEFER) record-stream state
     uint32_t *slots;        // wave-private LDS, 64 words: walk slot -> owner lane
@@ -108,6 +113,7 @@ struct CoopTracer {
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
         ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr; work = 0; iters = 0;
+        mocc = nullptr;
 #if DRT_PHASE_PROFILE
         ph_t = __builtin_readcyclecounter();
 #endif
@@ -154,6 +160,14 @@ struct CoopTracer {
         return -drt_logf(1.0f - u) * inv_maj;
     }
 
+    // one free flight from o along d: distance to the tentative collision and the majorant it was sampled with
+    // (global majorant: bit-identical to sample_distance; supergrid: Tracer::sample_collision)
+    __device__ __forceinline__ float flight(V3 o, V3 d, float tmax, float u, float &lm, float &lim) const
+    {
+        if constexpr (SUPER) return dda_collision(P, P.mgrid, mocc, o, d, tmax, u, lm, lim);
+        else { lm = maj; lim = inv_maj; return sample_distance(u); }
+    }
+
     // round geometry shared by the cooperative loops: J pending walks -> m steps each, owner lane of my slot
     __device__ __forceinline__ void round_setup(bool job, uint64_t pending, int &m, int &lg, int &js, int &c, bool &serve, int &owner, int &my_rank)
     {
@@ -184,21 +198,23 @@ struct CoopTracer {
         while (pending) {
             const int Jprof = __popcll(pending); (void) Jprof;
             round_begin(2);
-            if (__popcll(pending) >= DRT_COOP_SOLO_MIN) {
+            if (SUPER || __popcll(pending) >= DRT_COOP_SOLO_MIN) {
                 // more than half of the lanes carry a walk: a round would give every walk ONE lane (m = 1) - take that
-                // step on the walk's own lane, without the slot table, the gathers and the jump-ahead (same arithmetic)
+                // step on the walk's own lane, without the slot table, the gathers and the jump-ahead (same arithmetic).
+                // With a supergrid every step is taken this way.
                 if (job) {
                     const uint64_t sc = S.state;
-                    const float dt = sample_distance(pcg_float(sc));
+                    float lm, lim;
+                    const float dt = flight(o, d, tmax, pcg_float(sc), lm, lim);
                     const bool inside = dt <= tmax;                             // :480-481
                     const V3 p = v3(fmaf(d.x, dt, o.x), fmaf(d.y, dt, o.y), fmaf(d.z, dt, o.z));
                     const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
-                    const float tr = (maj - sig) * inv_maj;                     // :473-476
+                    const float tr = (lm - sig) * lim;                          // :473-476
                     const float Tout = inside ? T * tr : T;
                     if (inside) {
                         count(C_RT);
                         if constexpr (ADJ) if (tr > 0.0f) {                     // :487-492
-                            splat_sigma_t<DEFER>(P, p, -(a_sum * inv_maj) / tr, rec);
+                            splat_sigma_t<DEFER>(P, p, -(a_sum * lim) / tr, rec);
                             count(C_RT_ADJ);
                         }
                         ++steps;
@@ -211,71 +227,73 @@ struct CoopTracer {
                 round_end(2, Jprof);
                 continue;
             }
-            int m, lg, js, c, owner, my_rank; bool serve;
-            round_setup(job, pending, m, lg, js, c, serve, owner, my_rank);
-            // the walk this lane serves
-            float cx = __shfl(o.x, owner), cy = __shfl(o.y, owner), cz = __shfl(o.z, owner);
-            const float dx = __shfl(d.x, owner), dy = __shfl(d.y, owner), dz = __shfl(d.z, owner);
-            float ct = __shfl(tmax, owner);
-            float Tin = __shfl(T, owner);
-            const float asum = ADJ ? __shfl(a_sum, owner) : 0.0f;
-            const uint64_t st = shfl64(S.state, owner), inc = shfl64(S.inc, owner);
-            // step c of this round: its own draw and free-flight distance
-            const uint64_t sc = pcg_jump(st, inc, c);
-            const float dt = sample_distance(pcg_float(sc));
-            // chain 1 (sequential semantics): origin and remaining length before step c; reached = every
-            // earlier step of the round found its tentative collision inside the segment
-            // (every lane replays the earlier steps of its walk itself, in order, with their distances
-            // gathered from the lanes that drew them: independent ds_bpermutes instead of a dependent chain)
-            bool reached = serve;
-            const int gb = (int) __lane_id() - c;                               // first lane of my group
-            for (int k = 0; k + 1 < m; ++k) {
-                const float dk = __shfl(dt, gb + k);
-                if (k < c) {
-                    reached = reached && dk <= ct;
-                    cx = fmaf(dx, dk, cx); cy = fmaf(dy, dk, cy); cz = fmaf(dz, dk, cz); ct = ct - dk;
+            if constexpr (!SUPER) {
+                int m, lg, js, c, owner, my_rank; bool serve;
+                round_setup(job, pending, m, lg, js, c, serve, owner, my_rank);
+                // the walk this lane serves
+                float cx = __shfl(o.x, owner), cy = __shfl(o.y, owner), cz = __shfl(o.z, owner);
+                const float dx = __shfl(d.x, owner), dy = __shfl(d.y, owner), dz = __shfl(d.z, owner);
+                float ct = __shfl(tmax, owner);
+                float Tin = __shfl(T, owner);
+                const float asum = ADJ ? __shfl(a_sum, owner) : 0.0f;
+                const uint64_t st = shfl64(S.state, owner), inc = shfl64(S.inc, owner);
+                // step c of this round: its own draw and free-flight distance
+                const uint64_t sc = pcg_jump(st, inc, c);
+                const float dt = sample_distance(pcg_float(sc));
+                // chain 1 (sequential semantics): origin and remaining length before step c; reached = every
+                // earlier step of the round found its tentative collision inside the segment
+                // (every lane replays the earlier steps of its walk itself, in order, with their distances
+                // gathered from the lanes that drew them: independent ds_bpermutes instead of a dependent chain)
+                bool reached = serve;
+                const int gb = (int) __lane_id() - c;                               // first lane of my group
+                for (int k = 0; k + 1 < m; ++k) {
+                    const float dk = __shfl(dt, gb + k);
+                    if (k < c) {
+                        reached = reached && dk <= ct;
+                        cx = fmaf(dx, dk, cx); cy = fmaf(dy, dk, cy); cz = fmaf(dz, dk, cz); ct = ct - dk;
+                    }
                 }
-            }
-            const bool inside = reached && dt <= ct;                            // :480-481
-            const V3 p = v3(fmaf(dx, dt, cx), fmaf(dy, dt, cy), fmaf(dz, dt, cz));
-            const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
-            const float tr = (maj - sig) * inv_maj;                             // :473-476
-            // chain 2: running product before step c; a step is executed iff the product is still non-zero
-            bool live = reached;                                                // step c is started (its draw is consumed)
-            for (int k = 0; k + 1 < m; ++k) {
-                const float trk = __shfl(tr, gb + k);
-                if (k < c) { Tin = Tin * trk; live = live && Tin != 0.0f; }       // :495, :502
-            }
-            const bool exec = live && inside;
-            const float Tout = exec ? Tin * tr : Tin;
-            if (exec) {
-                count(C_RT);
-                if constexpr (ADJ) if (tr > 0.0f) {                             // :487-492
-                    splat_sigma_t<DEFER>(P, p, -(asum * inv_maj) / tr, rec);
-                    count(C_RT_ADJ);
+                const bool inside = reached && dt <= ct;                            // :480-481
+                const V3 p = v3(fmaf(dx, dt, cx), fmaf(dy, dt, cy), fmaf(dz, dt, cz));
+                const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
+                const float tr = (maj - sig) * inv_maj;                             // :473-476
+                // chain 2: running product before step c; a step is executed iff the product is still non-zero
+                bool live = reached;                                                // step c is started (its draw is consumed)
+                for (int k = 0; k + 1 < m; ++k) {
+                    const float trk = __shfl(tr, gb + k);
+                    if (k < c) { Tin = Tin * trk; live = live && Tin != 0.0f; }       // :495, :502
                 }
+                const bool exec = live && inside;
+                const float Tout = exec ? Tin * tr : Tin;
+                if (exec) {
+                    count(C_RT);
+                    if constexpr (ADJ) if (tr > 0.0f) {                             // :487-492
+                        splat_sigma_t<DEFER>(P, p, -(asum * inv_maj) / tr, rec);
+                        count(C_RT_ADJ);
+                    }
+                }
+                // the last started step of every walk reports: draws consumed = its index + 1
+                const bool ends = live && (!inside || Tout == 0.0f);
+                const int nxt = __shfl_down(live ? 1 : 0, 1);
+                const bool last = live && (ends || c == m - 1 || nxt == 0);
+                const uint64_t last_mask = __ballot(last);
+                // (shuffles only in wave-uniform control flow: a lane that is switched off cannot be read)
+                const int base = my_rank << lg;
+                const int src = job ? base + __ffsll((long long) ((last_mask >> base) & ((1ull << m) - 1ull))) - 1 : (int) __lane_id();
+                const float rT = __shfl(Tout, src), rx = __shfl(p.x, src), ry = __shfl(p.y, src), rz = __shfl(p.z, src);
+                const float rt = __shfl(ct - dt, src);
+                const int rend = __shfl(ends ? 1 : 0, src);
+                const int rout = __shfl((live && !inside) ? 1 : 0, src);
+                const uint64_t rs = shfl64(sc * kPcgMul + inc, src);               // stream after the last started step's draw
+                if (job) {
+                    T = rT; o = v3(rx, ry, rz); tmax = rt;
+                    S.state = rs;
+                    steps += (uint32_t) (src - base + 1 - rout);                    // executed steps of my walk in this round
+                    if (rend) job = false;
+                }
+                pending = __ballot(job);
+                round_end(2, Jprof);
             }
-            // the last started step of every walk reports: draws consumed = its index + 1
-            const bool ends = live && (!inside || Tout == 0.0f);
-            const int nxt = __shfl_down(live ? 1 : 0, 1);
-            const bool last = live && (ends || c == m - 1 || nxt == 0);
-            const uint64_t last_mask = __ballot(last);
-            // (shuffles only in wave-uniform control flow: a lane that is switched off cannot be read)
-            const int base = my_rank << lg;
-            const int src = job ? base + __ffsll((long long) ((last_mask >> base) & ((1ull << m) - 1ull))) - 1 : (int) __lane_id();
-            const float rT = __shfl(Tout, src), rx = __shfl(p.x, src), ry = __shfl(p.y, src), rz = __shfl(p.z, src);
-            const float rt = __shfl(ct - dt, src);
-            const int rend = __shfl(ends ? 1 : 0, src);
-            const int rout = __shfl((live && !inside) ? 1 : 0, src);
-            const uint64_t rs = shfl64(sc * kPcgMul + inc, src);               // stream after the last started step's draw
-            if (job) {
-                T = rT; o = v3(rx, ry, rz); tmax = rt;
-                S.state = rs;
-                steps += (uint32_t) (src - base + 1 - rout);                    // executed steps of my walk in this round
-                if (rend) job = false;
-            }
-            pending = __ballot(job);
-            round_end(2, Jprof);
         }
         if (steps_out) *steps_out = steps;
         return T;
@@ -293,15 +311,16 @@ struct CoopTracer {
         while (pending) {
             const int Jprof = __popcll(pending); (void) Jprof;
             round_begin(3);
-            if (__popcll(pending) >= DRT_COOP_SOLO_MIN) {                        // m = 1 rounds on the walks' own lanes (see coop_rt)
+            if (SUPER || __popcll(pending) >= DRT_COOP_SOLO_MIN) {               // m = 1 rounds on the walks' own lanes (see coop_rt)
                 if (job) {
                     const uint64_t s0 = S.state, s1 = s0 * kPcgMul + S.inc;
-                    const float dt = sample_distance(pcg_float(s0));            // :348
+                    float lm, lim;
+                    const float dt = flight(ro, ray.d, rmaxt, pcg_float(s0), lm, lim);   // :348
                     const float u2 = pcg_float(s1);                             // :359
                     const bool inside = dt <= rmaxt;                            // :358
                     const V3 p = v3(fmaf(ray.d.x, dt, ro.x), fmaf(ray.d.y, dt, ro.y), fmaf(ray.d.z, dt, ro.z));
                     const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
-                    const float r = sig * inv_maj;                              // :354
+                    const float r = sig * lim;                                  // :354
                     const bool accepted = inside && !(u2 >= r);                 // :351
                     if (inside) count(C_DT);
                     S.state = inside ? s1 * kPcgMul + S.inc : s1;
@@ -315,57 +334,59 @@ struct CoopTracer {
                 round_end(3, Jprof);
                 continue;
             }
-            int m, lg, js, c, owner, my_rank; bool serve;
-            round_setup(job, pending, m, lg, js, c, serve, owner, my_rank);
-            float cx = __shfl(ro.x, owner), cy = __shfl(ro.y, owner), cz = __shfl(ro.z, owner);
-            const float dx = __shfl(ray.d.x, owner), dy = __shfl(ray.d.y, owner), dz = __shfl(ray.d.z, owner);
-            float ct = __shfl(rmaxt, owner), crun = __shfl(running_t, owner);
-            const uint64_t st = shfl64(S.state, owner), inc = shfl64(S.inc, owner);
-            // step c: draws 2c (distance) and 2c + 1 (acceptance)
-            const uint64_t s0 = pcg_jump(st, inc, 2 * c), s1 = s0 * kPcgMul + inc;
-            const float dt = sample_distance(pcg_float(s0));                    // :348
-            const float u2 = pcg_float(s1);                                     // :359
-            bool reached = serve;
-            const int gb = (int) __lane_id() - c;                               // first lane of my group
-            for (int k = 0; k + 1 < m; ++k) {
-                const float dk = __shfl(dt, gb + k);
-                if (k < c) {                                                    // :364-367
-                    reached = reached && dk <= ct;
-                    cx = fmaf(dx, dk, cx); cy = fmaf(dy, dk, cy); cz = fmaf(dz, dk, cz); ct = ct - dk; crun = crun + dk;
+            if constexpr (!SUPER) {
+                int m, lg, js, c, owner, my_rank; bool serve;
+                round_setup(job, pending, m, lg, js, c, serve, owner, my_rank);
+                float cx = __shfl(ro.x, owner), cy = __shfl(ro.y, owner), cz = __shfl(ro.z, owner);
+                const float dx = __shfl(ray.d.x, owner), dy = __shfl(ray.d.y, owner), dz = __shfl(ray.d.z, owner);
+                float ct = __shfl(rmaxt, owner), crun = __shfl(running_t, owner);
+                const uint64_t st = shfl64(S.state, owner), inc = shfl64(S.inc, owner);
+                // step c: draws 2c (distance) and 2c + 1 (acceptance)
+                const uint64_t s0 = pcg_jump(st, inc, 2 * c), s1 = s0 * kPcgMul + inc;
+                const float dt = sample_distance(pcg_float(s0));                    // :348
+                const float u2 = pcg_float(s1);                                     // :359
+                bool reached = serve;
+                const int gb = (int) __lane_id() - c;                               // first lane of my group
+                for (int k = 0; k + 1 < m; ++k) {
+                    const float dk = __shfl(dt, gb + k);
+                    if (k < c) {                                                    // :364-367
+                        reached = reached && dk <= ct;
+                        cx = fmaf(dx, dk, cx); cy = fmaf(dy, dk, cy); cz = fmaf(dz, dk, cz); ct = ct - dk; crun = crun + dk;
+                    }
                 }
+                const bool inside = reached && dt <= ct;                            // :358
+                const V3 p = v3(fmaf(dx, dt, cx), fmaf(dy, dt, cy), fmaf(dz, dt, cz));
+                const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
+                const float r = sig * inv_maj;                                      // :354
+                const bool accepted = inside && !(u2 >= r);                         // :351
+                const bool term = reached && (!inside || accepted);
+                const uint64_t term_mask = __ballot(term);
+                const int gbase = js << lg;                                         // first lane of the group I serve
+                const uint64_t gmask = ((1ull << m) - 1ull);
+                const uint64_t gterm = serve ? ((term_mask >> gbase) & gmask) : 0ull;
+                const int e = gterm ? __ffsll((long long) gterm) - 1 : m - 1;      // last started step of my walk in this round
+                if (inside && c <= e) count(C_DT);
+                // owner side
+                const int base = my_rank << lg;
+                const uint64_t oterm = job ? ((term_mask >> base) & gmask) : 0ull;
+                const int oe = oterm ? __ffsll((long long) oterm) - 1 : m - 1;
+                const int src = job ? base + oe : (int) __lane_id();
+                const int racc = __shfl(accepted ? 1 : 0, src);
+                const float rtm = __shfl(crun + dt, src);                           // running_t + dt: mei.t or the new running_t
+                const float rx = __shfl(p.x, src), ry = __shfl(p.y, src), rz = __shfl(p.z, src), rt = __shfl(ct - dt, src);
+                // stream after the last started step: one draw if it fell outside the segment, two otherwise
+                const uint64_t rs = shfl64((reached && !inside) ? s1 : s1 * kPcgMul + inc, src);
+                if (job) {
+                    S.state = rs;
+                    if (oterm) {
+                        job = false;
+                        if (racc) { mei.valid = true; mei.t = rtm; }
+                        steps += (uint32_t) (racc ? oe + 1 : oe);
+                    } else { ro = v3(rx, ry, rz); rmaxt = rt; running_t = rtm; steps += (uint32_t) m; }
+                }
+                pending = __ballot(job);
+                round_end(3, Jprof);
             }
-            const bool inside = reached && dt <= ct;                            // :358
-            const V3 p = v3(fmaf(dx, dt, cx), fmaf(dy, dt, cy), fmaf(dz, dt, cz));
-            const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
-            const float r = sig * inv_maj;                                      // :354
-            const bool accepted = inside && !(u2 >= r);                         // :351
-            const bool term = reached && (!inside || accepted);
-            const uint64_t term_mask = __ballot(term);
-            const int gbase = js << lg;                                         // first lane of the group I serve
-            const uint64_t gmask = ((1ull << m) - 1ull);
-            const uint64_t gterm = serve ? ((term_mask >> gbase) & gmask) : 0ull;
-            const int e = gterm ? __ffsll((long long) gterm) - 1 : m - 1;      // last started step of my walk in this round
-            if (inside && c <= e) count(C_DT);
-            // owner side
-            const int base = my_rank << lg;
-            const uint64_t oterm = job ? ((term_mask >> base) & gmask) : 0ull;
-            const int oe = oterm ? __ffsll((long long) oterm) - 1 : m - 1;
-            const int src = job ? base + oe : (int) __lane_id();
-            const int racc = __shfl(accepted ? 1 : 0, src);
-            const float rtm = __shfl(crun + dt, src);                           // running_t + dt: mei.t or the new running_t
-            const float rx = __shfl(p.x, src), ry = __shfl(p.y, src), rz = __shfl(p.z, src), rt = __shfl(ct - dt, src);
-            // stream after the last started step: one draw if it fell outside the segment, two otherwise
-            const uint64_t rs = shfl64((reached && !inside) ? s1 : s1 * kPcgMul + inc, src);
-            if (job) {
-                S.state = rs;
-                if (oterm) {
-                    job = false;
-                    if (racc) { mei.valid = true; mei.t = rtm; }
-                    steps += (uint32_t) (racc ? oe + 1 : oe);
-                } else { ro = v3(rx, ry, rz); rmaxt = rt; running_t = rtm; steps += (uint32_t) m; }
-            }
-            pending = __ballot(job);
-            round_end(3, Jprof);
         }
         return mei;                                                             // mei.p / attached sigma_t: the caller (:371-375)
     }
@@ -429,15 +450,17 @@ struct CoopTracer {
         float t = 0.0f, T = 1.0f, wsum = 0.0f, tsel = kInf;
         bool valid = false;
         for (;;) {
-            t += sample_distance(A.next_1d());
+            float lm, lim;
+            if constexpr (SUPER) t += flight(ray_at(ray.o, ray.d, t), ray.d, ray.maxt - t, A.next_1d(), lm, lim);
+            else t += flight(ray.o, ray.d, ray.maxt, A.next_1d(), lm, lim);
             if (!(t <= ray.maxt)) break;
             float sig = eval_sigma_t(P, ray_at(ray.o, ray.d, t), occ);
             count(C_DRT);
-            float w = T * inv_maj;
+            float w = T * lim;
             wsum += w;
             float u = A.next_1d();
             if (w > 0.0f && u * wsum <= w) { tsel = t; valid = true; }
-            T *= (maj - sig) * inv_maj;
+            T *= (lm - sig) * lim;
             if (T == 0.0f) break;
         }
         t_out = tsel; W_out = wsum;

@@ -1,11 +1,11 @@
-// drt_kernels.hip -- gfx950 kernels of the DRT integrator (v1: one ray per lane).
-//
-// Implements VolpathSimpleIntegrator.sample (python/integrators/volpathsimple.py:38-290)
-// in both AD modes for a batch of rays, plus the box film and the majorant
-// reduction.  Gradients are scattered with hardware fp32 atomics into the dense
-// (Z,Y,X,C) buffers the caller owns.
+// drt_kernels.hip -- gfx950 kernels around the tracer: the nerf integrator, box film, majorant / supergrid / empty-space
+// reductions, brick layouts, batch ray generation, gradient untiling, the primitive-evaluation kernel of the parity
+// tests - and, ONLY in the library flavour with test hooks (-DDRT_TEST_HOOKS), the plain one-ray-per-lane tracer `Tracer`
+// (v1 of VolpathSimpleIntegrator.sample, python/integrators/volpathsimple.py:38-290): the variant tests keep it in
+// lock-step with the production tracer (CoopTracer, drt_coop_tracer.h), the production library does not contain it.
 #include "drt_device.h"
 #include "drt_launch.h"
+#include "drt_coop_tracer.h"
 
 #ifndef DRT_TRACE_WAVES
 #define DRT_TRACE_WAVES 4      // waves per SIMD the tracing kernels are compiled for (VGPR <= 128)
@@ -19,6 +19,7 @@ struct Ray { V3 o, d; float maxt; };
 struct Mei { bool valid; float t; V3 p; float sigma_t; };
 struct PathState { int depth; Hit si; float last_pdf; bool escaped; bool active; };
 
+#ifdef DRT_TEST_HOOKS
 template <bool COUNT, bool ENV, bool DEFER = false>
 struct Tracer {
     const Params &P;
@@ -491,6 +492,8 @@ __global__ void __launch_bounds__(256, DRT_TRACE_WAVES) trace_kernel(const Param
     }
 }
 
+#endif  // DRT_TEST_HOOKS (Tracer, trace_kernel)
+
 // ---------------------------------------------------------------------------
 // NeRFIntegrator.sample (python/integrators/nerf.py:47-148): emission-absorption ray marching,
 // queries_per_ray jittered queries per ray, PRB-style backward.  One ray per lane; the loop is
@@ -903,14 +906,14 @@ __global__ void __launch_bounds__(256) debug_eval_kernel(const Params P, int op,
             o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = envmap_pdf(P, d);
         } break;
         case 14: {                                      // E2: sample_interaction_drt from o along d to the box exit
-            Tracer<false, false, false> tr(P);
-            tr.occ = P.occ;
-            Ray r; r.o = v3(a[0], a[1], a[2]); r.d = v3(a[3], a[4], a[5]);
+            coop::Ray r; r.o = v3(a[0], a[1], a[2]); r.d = v3(a[3], a[4], a[5]);
             Hit h = box_hit(P, r.o, r.d);
             r.maxt = h.valid ? h.t : 0.0f;
             Pcg32 A; A.seed(0x5eedu, (uint32_t) i);
             float t = kInf, W = 0.0f;
-            bool ok = tr.sample_interaction_drt(r, A, t, W);
+            bool ok;
+            if (P.mgrid) { coop::CoopTracer<false, false, false, false, false, true> tr(P); tr.occ = P.occ; tr.mocc = P.mocc; ok = tr.sample_interaction_drt(r, A, t, W); }
+            else { coop::CoopTracer<false, false, false> tr(P); tr.occ = P.occ; ok = tr.sample_interaction_drt(r, A, t, W); }
             o[0] = ok ? 1.0f : 0.0f; o[1] = t; o[2] = W; o[3] = r.maxt;
         } break;
         case 9: if (P.mgrid) { o[0] = P.mgrid[__float_as_uint(a[0])]; } break;
@@ -929,6 +932,7 @@ hipError_t launch_debug_eval(const Params &P, int op, const float *in, uint64_t 
 // ---------------------------------------------------------------------------
 // launch wrappers (host)
 // ---------------------------------------------------------------------------
+#ifdef DRT_TEST_HOOKS
 hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t stream)
 {
     if (P.n_rays <= P.ray_first) return hipSuccess;
@@ -955,6 +959,7 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
     }
     return hipGetLastError();
 }
+#endif  // DRT_TEST_HOOKS
 
 hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
                                 float *out, uint32_t *mask, hipStream_t stream)

@@ -17,6 +17,7 @@ hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int 
 hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
 // one ray per lane with wave-cooperative tracking loops (drt_coop.hip); global majorant only (P.mgrid == nullptr)
+hipError_t launch_trace_coop_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_ray_perm(const uint8_t *iters, uint64_t n_rays, uint16_t *perm, hipStream_t stream);
 hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t *order, bool heavy_first, hipStream_t stream);
