@@ -97,6 +97,15 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
         r["workload"] = "headline scene with the reference's default majorant_resolution_factor 8 (scene_config.py:36)"
         return r
 
+    def envmap():
+        sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+        g = torch.Generator().manual_seed(5)
+        pix = (torch.rand(256, 512, 3, generator=g) ** 4 * 3.0 + 0.2).to(dev)      # a few bright texels: the importance sampler matters
+        sc.emitter = u.EnvmapEmitter(pixels=pix, scale=1.0)
+        r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 32)
+        r["workload"] = "headline scene lit by a 512x256 environment map (N4: importance-sampled lat-long map, MIS with phase sampling)"
+        return r
+
     def cfg4():
         sc = synthetic.dust_devil_scene(res=512, film=1024, device=dev)
         r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 64, steps=3, warmup=1,
@@ -210,6 +219,7 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
 
     guarded("config2_smoke128_512x16", cfg2)
     guarded("headline_majorant_factor8", factor8)
+    guarded("headline_envmap", envmap)
     guarded("config3_optimize_loop", cfg3)
     guarded("config4_512_rank_share_1024x64", cfg4)
     guarded("config5_nerf_256_512x32", cfg5)

@@ -133,8 +133,8 @@ hipError_t launch_trace_coop_t(const Params &P, bool adjoint, bool count, hipStr
     dim3 block(256), grid((unsigned)((P.n_rays - P.ray_first + 255) / 256));
     const bool env = P.env_pix != nullptr, defer = adjoint && P.rec_buf[0] != nullptr;
 #define DRT_COOP_LAUNCH(A, C, E, D) hipLaunchKernelGGL((trace_coop_kernel<A, C, E, D, false, SUPER>), grid, block, 0, stream, P)
-    // the registered `volpathsimple-drt` configuration with the constant emitter: specialised kernels
-    const bool spec = P.use_nee && P.use_drt && P.use_drt_subsampling && !count && !env && !dbg(P.debug_flags, 2097152u);
+    // the registered `volpathsimple-drt` configuration (either emitter): specialised kernels
+    const bool spec = P.use_nee && P.use_drt && P.use_drt_subsampling && !count && !dbg(P.debug_flags, 2097152u);
 #if DRT_PHASE_PROFILE
     // experiment build: the counting launches run the specialised kernels too (their counters then hold phase cycles)
     if (P.use_nee && P.use_drt && P.use_drt_subsampling && count && !env) {
@@ -142,8 +142,16 @@ hipError_t launch_trace_coop_t(const Params &P, bool adjoint, bool count, hipStr
         if (defer) { hipLaunchKernelGGL((trace_coop_kernel<true, true, false, true, true, SUPER>), grid, block, 0, stream, P); return hipGetLastError(); }
     }
 #endif
-    if (spec && !adjoint) { hipLaunchKernelGGL((trace_coop_kernel<false, false, false, false, true, SUPER>), grid, block, 0, stream, P); return hipGetLastError(); }
-    if (spec && defer) { hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true, SUPER>), grid, block, 0, stream, P); return hipGetLastError(); }
+    if (spec && !adjoint) {
+        if (env) hipLaunchKernelGGL((trace_coop_kernel<false, false, true, false, true, SUPER>), grid, block, 0, stream, P);
+        else hipLaunchKernelGGL((trace_coop_kernel<false, false, false, false, true, SUPER>), grid, block, 0, stream, P);
+        return hipGetLastError();
+    }
+    if (spec && defer) {
+        if (env) hipLaunchKernelGGL((trace_coop_kernel<true, false, true, true, true, SUPER>), grid, block, 0, stream, P);
+        else hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true, SUPER>), grid, block, 0, stream, P);
+        return hipGetLastError();
+    }
     if (!adjoint) {
         if (count) { if (env) DRT_COOP_LAUNCH(false, true, true, false); else DRT_COOP_LAUNCH(false, true, false, false); }
         else       { if (env) DRT_COOP_LAUNCH(false, false, true, false); else DRT_COOP_LAUNCH(false, false, false, false); }

@@ -160,6 +160,10 @@ struct CoopTracer {
         return -drt_logf(1.0f - u) * inv_maj;
     }
 
+    // own-lane steps for crowded rounds only in the specialised kernels: in the generic ones (two inlined copies of the
+    // recursive path) the extra code spills (scratch 324 -> 944 B per lane, adjoint 8.0 -> 17.9 ms)
+    static constexpr bool kSolo = SPEC;
+
     // one free flight from o along d: distance to the tentative collision and the majorant it was sampled with
     // (global majorant: bit-identical to sample_distance; supergrid: Tracer::sample_collision)
     __device__ __forceinline__ float flight(V3 o, V3 d, float tmax, float u, float &lm, float &lim) const
@@ -198,7 +202,7 @@ struct CoopTracer {
         while (pending) {
             const int Jprof = __popcll(pending); (void) Jprof;
             round_begin(2);
-            if (SUPER || __popcll(pending) >= DRT_COOP_SOLO_MIN) {
+            if (SUPER || (kSolo && __popcll(pending) >= DRT_COOP_SOLO_MIN)) {
                 // more than half of the lanes carry a walk: a round would give every walk ONE lane (m = 1) - take that
                 // step on the walk's own lane, without the slot table, the gathers and the jump-ahead (same arithmetic).
                 // With a supergrid every step is taken this way.
@@ -311,7 +315,7 @@ struct CoopTracer {
         while (pending) {
             const int Jprof = __popcll(pending); (void) Jprof;
             round_begin(3);
-            if (SUPER || __popcll(pending) >= DRT_COOP_SOLO_MIN) {               // m = 1 rounds on the walks' own lanes (see coop_rt)
+            if (SUPER || (kSolo && __popcll(pending) >= DRT_COOP_SOLO_MIN)) {               // m = 1 rounds on the walks' own lanes (see coop_rt)
                 if (job) {
                     const uint64_t s0 = S.state, s1 = s0 * kPcgMul + S.inc;
                     float lm, lim;
