@@ -548,3 +548,34 @@ def test_production_library_has_no_test_hooks(uivr, gpu):
     hh.set_debug_flags(128)
     hh.set_debug_flags(0)
     assert type(h).__module__.endswith("_drt_pybind") and type(hh).__module__.endswith("_drt_pybind_hooks")
+
+
+@pytest.mark.parametrize("factor", [0, 4])
+def test_workgroup_handoff_of_recursive_paths(uivr, oracle, gpu, factor):
+    """The specialised adjoint kernels hand the last live recursive DRT paths of waves 1..3 to wave 0 through LDS
+    (CoopTracer::wg_handoff) - a schedule, not a result: with the hand-off (production) and without it (debug bit
+    33554432, test-hooks flavour) the gradients are the oracle's.  A sparse medium, so that waves do run dry early."""
+    rng = np.random.default_rng(21)
+    st = rng.random((24, 24, 24, 1), dtype=np.float32) * 6.0
+    st[rng.random(st.shape) < 0.5] = 0.0
+    al = (rng.random((24, 24, 24, 3), dtype=np.float32) * 0.8 + 0.15).astype(np.float32)
+    medium = uivr.GridMedium(sigma_t=st, albedo=al, bbox_min=(-1, -1, -1), bbox_max=(1, 1, 1), scale=1.5,
+                             majorant_resolution_factor=factor)
+    sensor = uivr.PerspectiveSensor(origin=(3.0, 2.0, 4.0), target=(0, 0, 0), fov=30.0, width=48, height=48)
+    scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter((1.0, 0.9, 0.7)), sensors=[sensor])
+    props = props_for("drt")
+    spp, seed = 8, 4321
+    ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
+    sg = uivr.scene_to(scene, gpu)
+    got = {}
+    for name, hooks, flags in (("production", False, 0), ("hand-off", True, 0), ("no hand-off", True, 33554432)):
+        integ = _integrator(uivr, props, hooks=hooks)
+        if hooks:
+            integ.native_handle(sg).set_debug_flags(flags)
+        img, grads = _h1_gpu(uivr, sg, integ, spp, seed)
+        np.testing.assert_allclose(img.cpu().numpy(), ref["image"], rtol=0, atol=1e-6)
+        _assert_grads_close(grads[uivr.SIGMA_T_KEY], ref["grad_sigma_t"], f"{name}: grad sigma_t")
+        _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], f"{name}: grad albedo")
+        got[name] = torch.cat([grads[uivr.SIGMA_T_KEY].reshape(-1), grads[uivr.ALBEDO_KEY].reshape(-1)])
+    scale = float(got["production"].abs().max())
+    assert float((got["hand-off"] - got["no hand-off"]).abs().max()) <= 2e-5 * scale      # summation order only

@@ -37,6 +37,10 @@ names = {"n_dt": "main path: delta tracking (adjoint: path-cache read)", "n_rt":
          "n_drt": "E2 walk (sample_interaction_drt)", "n_alb": "recursive path: delta tracking",
          "n_rt_adj": "recursive path: NEE", "n_sc": "recursive path: everything else"}
 mode = int(os.environ.get("DRT_PHASE_PROFILE", "1"))
+if mode in (4, 5):
+    names = {"n_dt": ">= 33 lanes active", "n_rt": "17..32", "n_drt": "9..16", "n_alb": "5..8", "n_rt_adj": "3..4", "n_sc": "2", "n_sc_alb": "1",
+             "n_tr": "everything outside the bounce loop of the " + ("recursive" if mode == 4 else "main") + " path"}
+    print("bounce-loop iterations of the", "recursive" if mode == 4 else "main", "path by lanes active at the start of the iteration")
 if mode in (2, 3):
     names = {"n_dt": "rounds with >= 33 pending walks (own-lane steps)", "n_rt": "17..32 (m = 2)", "n_drt": "9..16 (m = 4)",
              "n_alb": "5..8 (m = 8)", "n_rt_adj": "3..4 (m = 8)", "n_sc": "2 (m = 8)", "n_sc_alb": "1 (m = 8)",

@@ -35,6 +35,12 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
     CoopTracer<COUNT, ENV, DEFER, SPEC, false, SUPER> tr(P);
     __shared__ uint32_t slot_lds[4 * 64];
     tr.slots = slot_lds + (threadIdx.x >> 6) * 64;
+    if constexpr (ADJ && SPEC) {                                // sparse waves hand their last recursive paths to wave 0 (wg_handoff)
+        __shared__ uint32_t wgc_lds[kWgcWords];
+        static_assert(DRT_COOP_WAVES >= 1, "");
+        if (threadIdx.x < 4) wgc_lds[threadIdx.x] = 0xffffffffu; // nothing published yet (made visible by the barrier below)
+        if (!dbg(P.debug_flags, 33554432u)) tr.wgc = wgc_lds;
+    }
     __shared__ uint64_t jump_lds[2 * (kJumpMax + 1)];
     if (threadIdx.x <= kJumpMax) { jump_lds[2 * threadIdx.x] = kJump.A[threadIdx.x]; jump_lds[2 * threadIdx.x + 1] = kJump.G[threadIdx.x]; }
     tr.jump = jump_lds;

@@ -35,6 +35,9 @@
 #ifndef DRT_XCD_RUN
 #define DRT_XCD_RUN 256
 #endif
+#ifndef DRT_WGC_DONATE
+#define DRT_WGC_DONATE 16          // live recursive paths at or below which a wave hands them to wave 0 (wg_handoff; swept 8 / 16 / 21 / 32 / 48: 6.36 / 6.17 / 6.17 / 6.18 / 6.44 ms)
+#endif
 #ifndef DRT_COOP_MAXM
 #define DRT_COOP_MAXM 8        // candidate steps per walk and round = chain length (swept 4 / 8 / 16: 11.7 / 11.0 / 11.5 ms)
 #endif
@@ -45,7 +48,14 @@ namespace coop {
 
 struct Ray { V3 o, d; float maxt; };
 struct Mei { bool valid; float t; V3 p; float sigma_t; };
-struct PathState { int depth; Hit si; float last_pdf; bool escaped; bool active; };
+// what the end of a recursive DRT path needs for its gradient splat (backpropagate_scattering_drt, volpathsimple.py:565-581):
+// the reservoir vertex, sigma_t / albedo there, w * W * adjoint, and the NEE term of Li - it travels with the path when
+// the path moves to another wave (CoopTracer::wg_handoff)
+struct Tail { V3 p; float sig, alb[3], wadj[3], nee[3]; };
+struct PathState { int depth; Hit si; float last_pdf; bool escaped; bool active; const Tail *tail; };
+// workgroup hand-off of sparse recursive paths: waves 1..3 give their last <= kWgcDonate live paths to wave 0 through LDS
+constexpr int kWgcDonate = DRT_WGC_DONATE, kWgcFields = 32;
+constexpr int kWgcWords = 4 + 3 * kWgcFields * kWgcDonate;     // flags[3] (+1 pad) + three donor regions
 
 // PCG32 jump-ahead: s_{n+k} = A_k s_n + G_k inc,  A_k = a^k,  G_k = 1 + a + ... + a^(k-1)  (mod 2^64)
 constexpr int kJumpMax = 2 * DRT_COOP_MAXM + 2;
@@ -99,6 +109,7 @@ struct CoopTracer {
     const Params &P;
     float maj, inv_maj;
     const uint32_t *mocc;   // SUPER: non-empty supergrid cells (LDS copy) or nullptr
+    uint32_t *wgc;          // LDS area of the workgroup hand-off (wg_handoff; kWgcWords words, flags preset to ~0) or nullptr
     uint32_t ray_index;
     uint32_t *rec;          // wave-private LDS: cooperative-scatter staging area or (DEFER) record-stream state
     uint32_t *slots;        // wave-private LDS, 64 words: walk slot -> owner lane
@@ -113,7 +124,7 @@ struct CoopTracer {
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
         ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr; work = 0; iters = 0;
-        mocc = nullptr;
+        mocc = nullptr; wgc = nullptr;
 #if DRT_PHASE_PROFILE
         ph_t = __builtin_readcyclecounter();
 #endif
@@ -472,7 +483,8 @@ struct CoopTracer {
     }
 
     // sample_recursive (volpathsimple.py:610-655)
-    __device__ void sample_recursive(bool job, Pcg32 &A, V3 p, int depth, float Li[3])
+    // `tail`: hand-off mode - the path's end (Li, gradient splat) happens inside sample(), on whichever lane it ends
+    __device__ void sample_recursive(bool job, Pcg32 &A, V3 p, int depth, float Li[3], Tail *tail = nullptr)
     {
         Li[0] = Li[1] = Li[2] = 0.0f;
         if (use_nee()) {                                                        // :621-624 (wave-uniform condition)
@@ -486,6 +498,8 @@ struct CoopTracer {
         }
         Ray rr; rr.o = p; rr.d = v3(0, 0, 1); rr.maxt = kLargest;
         PathState ps;
+        ps.tail = tail;
+        if (tail) { tail->nee[0] = Li[0]; tail->nee[1] = Li[1]; tail->nee[2] = Li[2]; }
         ps.depth = depth + 1; ps.last_pdf = kInvFourPi; ps.escaped = false; ps.active = false;
         ps.si.valid = false; ps.si.t = kInf; ps.si.p = v3(0, 0, 0); ps.si.n = v3(0, 0, 0);
         if (job) {
@@ -523,6 +537,20 @@ struct CoopTracer {
             count(C_DRT);
         }
         float Li[3];
+        if constexpr (SPEC) {
+            if (wgc) {                                                          // (workgroup-uniform: set by the kernel)
+                // hand-off mode: everything the final splat needs is computed now and travels with the recursive path
+                Tail tl;
+                tl.p = p; tl.sig = sig;
+                if (found) { if constexpr (!G4) eval_albedo(P, p, alb); count(C_ALB); }
+                const float w = P.use_drt_mis ? 1.0f / (1.0f + sig * sig) : 1.0f;   // :571-575
+                const float ww = w * W;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { tl.alb[k] = alb[k]; tl.wadj[k] = ww * adj[k]; tl.nee[k] = 0.0f; }
+                sample_recursive(found, A, p, depth, Li, &tl);                  // :565-581 (splat included)
+                return;
+            }
+        }
         sample_recursive(found, A, p, depth, Li);                               // :565-568
         if (found) {
             float w = P.use_drt_mis ? 1.0f / (1.0f + sig * sig) : 1.0f;         // :571-575
@@ -549,6 +577,113 @@ struct CoopTracer {
             float t = A.next_1d() * interval;                                   // :595
             splat_sigma_t<DEFER>(P, ray_at(ray.o, ray.d, t), g, rec);
             count(C_TR);
+        }
+    }
+
+    // emitter seen by a path that left the medium (volpathsimple.py:263-287), primal mode
+    __device__ __forceinline__ void add_escaped_emission(bool escaped, int depth, bool has_scattered, float last_pdf, V3 d,
+                                                         const float beta[3], float result[3])
+    {
+        if (escaped && !(depth <= 0 && P.hide_emitters)) {
+            float w = 1.0f, Le[3];
+            if (use_nee()) {
+                float epdf = 0.0f;                                              // :273-277
+                if (has_scattered) epdf = emitter_pdf<ENV>(P, d);
+                w = mis_weight(last_pdf, epdf);
+            }
+            emitter_eval<ENV>(P, d, Le);                                        // :284
+#pragma unroll
+            for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
+        }
+    }
+
+    // Workgroup hand-off of the recursive DRT paths, called by every wave after each bounce-loop iteration.
+    // Measured: iterations with <= 8 live lanes are half of the recursive paths' time - the
+    // tracking rounds of a sparse wave serve few walks.  So: a path that ended is finished HERE (its radiance, the
+    // gradient splat of its reservoir vertex: `tl`) and leaves its lane; waves 1..3, once they have at most kWgcDonate
+    // live paths, write them - complete state + tail - to their LDS region, publish the count and are done (they run
+    // to the end of the kernel and free their slot); wave 0 picks the donated paths up into its free lanes as they
+    // appear and runs them to the end.  No workgroup barrier: donors never wait; wave 0 only waits when it has nothing
+    // to do while another wave is still dense.  A path computes the same numbers on any lane.
+    // Returns false when this wave has no path left and expects none.
+    __device__ bool wg_handoff(bool &job, bool &active, uint32_t &taken, Ray &ray, float beta[3], float result[3], Pcg32 &S,
+                               int &depth, bool &escaped, bool &has_scattered, float last_pdf, Tail &tl)
+    {
+        lds_u32 *flags = (lds_u32 *) wgc, *pool = flags + 4;
+        const int wave = (int) (threadIdx.x >> 6), lane = (int) __lane_id();
+        if (job && !active) {                                                   // the path ended: Li, gradient splat (:565-581)
+            add_escaped_emission(escaped, depth, has_scattered, last_pdf, ray.d, beta, result);
+            float gs = 0.0f, ga[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float Li = tl.nee[k] + result[k];
+                const float a = tl.wadj[k] * Li;
+                gs += a * tl.alb[k];
+                ga[k] = a * tl.sig;
+            }
+            splat_scatter<DEFER>(P, tl.p, gs, ga, rec); count(C_SC); count(C_SC_ALB);
+            job = false;
+        }
+        uint64_t am = __ballot(active);
+        int n = __popcll(am);
+        if (wave != 0) {
+            if (n > kWgcDonate) return true;                                    // dense: carry on
+            if (active) {
+                lds_u32 *q = pool + (wave - 1) * (kWgcFields * kWgcDonate) + __popcll(am & ((1ull << lane) - 1ull));
+                const uint32_t w[kWgcFields] = {
+                    __float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z),
+                    __float_as_uint(ray.d.x), __float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(ray.maxt),
+                    __float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]),
+                    __float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]),
+                    (uint32_t) S.state, (uint32_t) (S.state >> 32), (uint32_t) S.inc, (uint32_t) (S.inc >> 32),
+                    (uint32_t) depth, (escaped ? 1u : 0u) | (has_scattered ? 2u : 0u),
+                    __float_as_uint(tl.p.x), __float_as_uint(tl.p.y), __float_as_uint(tl.p.z), __float_as_uint(tl.sig),
+                    __float_as_uint(tl.alb[0]), __float_as_uint(tl.alb[1]), __float_as_uint(tl.alb[2]),
+                    __float_as_uint(tl.wadj[0]), __float_as_uint(tl.wadj[1]), __float_as_uint(tl.wadj[2]),
+                    __float_as_uint(tl.nee[0]), __float_as_uint(tl.nee[1]), __float_as_uint(tl.nee[2]) };
+#pragma unroll
+                for (int f = 0; f < kWgcFields; ++f) q[f * kWgcDonate] = w[f];
+            }
+            coop_stage_sync();                                                  // the states are in LDS ...
+            if (lane == 0) flags[wave - 1] = (uint32_t) n;                      // ... before the count is published
+            job = active = false;
+            return false;
+        }
+        for (;;) {                                                              // wave 0: collect what the others have published
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                if (taken & (1u << w)) continue;
+                const uint32_t f = (uint32_t) __builtin_amdgcn_readfirstlane((int) flags[w]);
+                if (f == 0xffffffffu || (int) f > 64 - n) continue;
+                const int slot = __popcll(~am & ((1ull << lane) - 1ull));       // my rank among the free lanes
+                if (!active && slot < (int) f) {
+                    lds_u32 *q = pool + w * (kWgcFields * kWgcDonate) + slot;
+                    uint32_t v[kWgcFields];
+#pragma unroll
+                    for (int k = 0; k < kWgcFields; ++k) v[k] = q[k * kWgcDonate];
+                    ray.o = v3(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]));
+                    ray.d = v3(__uint_as_float(v[3]), __uint_as_float(v[4]), __uint_as_float(v[5]));
+                    ray.maxt = __uint_as_float(v[6]);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        beta[k] = __uint_as_float(v[7 + k]); result[k] = __uint_as_float(v[10 + k]);
+                        tl.alb[k] = __uint_as_float(v[23 + k]); tl.wadj[k] = __uint_as_float(v[26 + k]); tl.nee[k] = __uint_as_float(v[29 + k]);
+                    }
+                    S.state = ((uint64_t) v[14] << 32) | v[13];
+                    S.inc = ((uint64_t) v[16] << 32) | v[15];
+                    depth = (int) v[17];
+                    escaped = (v[18] & 1u) != 0u; has_scattered = (v[18] & 2u) != 0u;
+                    tl.p = v3(__uint_as_float(v[19]), __uint_as_float(v[20]), __uint_as_float(v[21]));
+                    tl.sig = __uint_as_float(v[22]);
+                    job = active = true;
+                }
+                taken |= 1u << w;
+                am = __ballot(active);
+                n = __popcll(am);
+            }
+            if (n > 0) return true;
+            if (taken == 7u) return false;
+            __builtin_amdgcn_s_sleep(16);                                       // nothing to do until another wave publishes
         }
     }
 
@@ -588,7 +723,16 @@ struct CoopTracer {
         if constexpr (ADJ) { if (job) A.seed(P.alt_seed, ray_index); }          // :100-107
 
         int it = 0;                                                             // bounce-loop iterations this ray has run
-        while (__ballot(active)) {                                              // :114, wave-uniform
+        // recursive paths of the specialised adjoint kernels: sparse waves hand their last paths to wave 0 (wg_handoff)
+        constexpr bool kWgc = !ADJ && RECURSIVE && SPEC;
+        bool wgc_on = false;
+        Tail tl;
+        uint32_t taken = 0;
+        if constexpr (kWgc) { if (wgc && ps->tail) { wgc_on = true; tl = *ps->tail; } }
+        for (;;) {                                                              // :114, wave-uniform
+            const uint64_t any_active = __ballot(active);
+            if (!wgc_on && !any_active) break;
+            if (any_active) {
             bool run = active;
             if (run) {
                 float q = fminf(fmaxf(beta[0], fmaxf(beta[1], beta[2])), 0.99f);    // :117-121
@@ -700,6 +844,10 @@ struct CoopTracer {
                 }
                 ++it;
             }
+            }
+            if constexpr (kWgc) {
+                if (wgc_on && !wg_handoff(job, active, taken, ray, beta, result, S, depth, escaped, has_scattered, last_pdf, tl)) break;
+            }
         }
 
         if constexpr (ADJ) {
@@ -715,17 +863,7 @@ struct CoopTracer {
                 drt_backprop(rjob, A, r_ray, r_si_t, r_depth, adj);
             }
         } else {                                                                // :263-287
-            if (job && escaped && !(depth <= 0 && P.hide_emitters)) {
-                float w = 1.0f, Le[3];
-                if (use_nee()) {
-                    float epdf = 0.0f;                                          // :273-277
-                    if (has_scattered) epdf = emitter_pdf<ENV>(P, ray.d);
-                    w = mis_weight(last_pdf, epdf);
-                }
-                emitter_eval<ENV>(P, ray.d, Le);                                // :284
-#pragma unroll
-                for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
-            }
+            if (job && !wgc_on) add_escaped_emission(escaped, depth, has_scattered, last_pdf, ray.d, beta, result);   // (hand-off mode: done in wg_handoff)
         }
         phase(RECURSIVE ? C_SC : C_TR);
         if (!RECURSIVE) iters = (uint32_t) it;
