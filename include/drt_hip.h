@@ -259,8 +259,8 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
  * streams cannot be allocated (the job then takes the atomic path, as it does when hipMalloc fails); bit 19
  * (524288): pretend that they cannot be (re)allocated from the second ray sub-batch on (the remaining rays take
  * the atomic path); bit 21 (2097152): generic tracing kernels instead of the ones specialised for the registered
- * `volpathsimple-drt` estimator; bit 25 (33554432): no workgroup hand-off of the recursive DRT paths (every wave runs
- * its own paths to the end). */
+ * `volpathsimple-drt` estimator; bit 25 (33554432): no workgroup hand-off of sparse waves' paths (every wave runs
+ * its own paths to the end); bit 26 (67108864): none in the primal pass only. */
 int drt_set_debug_flags(drt_handle h, uint32_t flags);
 
 const char *drt_version(void);

@@ -552,9 +552,10 @@ def test_production_library_has_no_test_hooks(uivr, gpu):
 
 @pytest.mark.parametrize("factor", [0, 4])
 def test_workgroup_handoff_of_recursive_paths(uivr, oracle, gpu, factor):
-    """The specialised adjoint kernels hand the last live recursive DRT paths of waves 1..3 to wave 0 through LDS
-    (CoopTracer::wg_handoff) - a schedule, not a result: with the hand-off (production) and without it (debug bit
-    33554432, test-hooks flavour) the gradients are the oracle's.  A sparse medium, so that waves do run dry early."""
+    """The specialised kernels hand the last live paths of waves 1..3 (primal: main paths; adjoint: recursive DRT paths)
+    to wave 0 through LDS (CoopTracer::wg_handoff) - a schedule, not a result: with the hand-off (production) and
+    without it (debug bits 33554432 / 67108864, test-hooks flavour) radiance is bit-exact and the gradients are the
+    oracle's.  A sparse medium, so that waves do run dry early."""
     rng = np.random.default_rng(21)
     st = rng.random((24, 24, 24, 1), dtype=np.float32) * 6.0
     st[rng.random(st.shape) < 0.5] = 0.0
@@ -568,10 +569,15 @@ def test_workgroup_handoff_of_recursive_paths(uivr, oracle, gpu, factor):
     ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
     sg = uivr.scene_to(scene, gpu)
     got = {}
-    for name, hooks, flags in (("production", False, 0), ("hand-off", True, 0), ("no hand-off", True, 33554432)):
+    for name, hooks, flags in (("production", False, 0), ("hand-off", True, 0), ("no hand-off", True, 33554432),
+                               ("adjoint hand-off only", True, 67108864)):
         integ = _integrator(uivr, props, hooks=hooks)
         if hooks:
             integ.native_handle(sg).set_debug_flags(flags)
+        # the primal pass hands main paths over too: radiance per ray stays bit-exact
+        batch = uivr.RayBatch(n_rays=48 * 48 * spp, spp=spp, sensor=sg.sensors[0])
+        L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(seed, spp), batch)
+        np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), ref["L"].view(np.uint32))
         img, grads = _h1_gpu(uivr, sg, integ, spp, seed)
         np.testing.assert_allclose(img.cpu().numpy(), ref["image"], rtol=0, atol=1e-6)
         _assert_grads_close(grads[uivr.SIGMA_T_KEY], ref["grad_sigma_t"], f"{name}: grad sigma_t")

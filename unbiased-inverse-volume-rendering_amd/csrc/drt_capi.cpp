@@ -850,7 +850,8 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     h->perm_valid = false;
     // the cooperative primal kernel (global majorant) and the state machine (supergrid) write the sort keys
     if (rc == DRT_OK && P.ray_iters && !dbg(h->debug_flags, 8u)) {   // (the plain per-lane primal kernel, bit 8, does not)
-        DRT_HIP_CHECK(h, drt::launch_ray_perm(P.ray_iters, P.n_rays, perm_base(P.ray_hash, P.n_rays), h->stream));
+        const bool coop_costs = P.block_cost && !P.mgrid && !dbg(h->debug_flags, 65536u);        // the cooperative primal filled block_cost
+        DRT_HIP_CHECK(h, drt::launch_ray_perm(P.ray_iters, P.n_rays, perm_base(P.ray_hash, P.n_rays), coop_costs ? P.block_cost : nullptr, h->stream));
         h->perm_valid = true;
     }
     if (rc == DRT_OK && P.block_cost && !P.mgrid && !dbg(h->debug_flags, (8u | 65536u))) {   // cooperative primal: it filled block_cost

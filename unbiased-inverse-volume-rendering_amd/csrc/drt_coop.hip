@@ -64,11 +64,22 @@ namespace {
 // Ray -> lane schedule of the adjoint pass: every group of kPermGroup consecutive rays (4 workgroups) is sorted by the
 // number of bounce-loop iterations the primal pass counted (longest first), so that the 64 rays
 // of a wave leave the adjoint's bounce loop together.  One workgroup per group; rays beyond n_rays sort last.
-__global__ void __launch_bounds__(kPermGroup) ray_perm_kernel(const uint8_t *iters, uint64_t n_rays, uint16_t *perm)
+// It also completes the primal pass's block costs (the adjoint's dispatch order, block_light_last_kernel): a wave of the
+// adjoint runs its bounce loop as long as its longest ray, so every wave adds 4 units per lane and iteration of the
+// longest of its 64 rays - counted HERE from the per-ray iteration counts and not by the primal tracer, whose waves no
+// longer hold the rays they started with (CoopTracer::wg_handoff).
+__global__ void __launch_bounds__(kPermGroup) ray_perm_kernel(const uint8_t *iters, uint64_t n_rays, uint16_t *perm, uint32_t *block_cost)
 {
     __shared__ uint32_t hist[64];
     const uint64_t i = (uint64_t) blockIdx.x * kPermGroup + threadIdx.x;
-    const uint32_t key = i < n_rays ? (iters[i] < 63u ? 63u - iters[i] : 0u) : 63u;      // bucket 0 = longest
+    const uint32_t it = i < n_rays ? iters[i] : 0u;
+    if (block_cost) {
+        uint32_t mx = it;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t) __shfl_down((int) mx, off, 64));
+        if ((threadIdx.x & 63) == 0 && mx) atomicAdd(block_cost + i / 256, 256u * mx);
+    }
+    const uint32_t key = i < n_rays ? (it < 63u ? 63u - it : 0u) : 63u;      // bucket 0 = longest
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
     atomicAdd(&hist[key], 1u);
@@ -86,10 +97,10 @@ __global__ void __launch_bounds__(kPermGroup) ray_perm_kernel(const uint8_t *ite
 }
 }  // namespace
 
-hipError_t launch_ray_perm(const uint8_t *iters, uint64_t n_rays, uint16_t *perm, hipStream_t stream)
+hipError_t launch_ray_perm(const uint8_t *iters, uint64_t n_rays, uint16_t *perm, uint32_t *block_cost, hipStream_t stream)
 {
     if (n_rays == 0) return hipSuccess;
-    hipLaunchKernelGGL(ray_perm_kernel, dim3((unsigned) ((n_rays + kPermGroup - 1) / kPermGroup)), dim3(kPermGroup), 0, stream, iters, n_rays, perm);
+    hipLaunchKernelGGL(ray_perm_kernel, dim3((unsigned) ((n_rays + kPermGroup - 1) / kPermGroup)), dim3(kPermGroup), 0, stream, iters, n_rays, perm, block_cost);
     return hipGetLastError();
 }
 

@@ -35,11 +35,12 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
     CoopTracer<COUNT, ENV, DEFER, SPEC, false, SUPER> tr(P);
     __shared__ uint32_t slot_lds[4 * 64];
     tr.slots = slot_lds + (threadIdx.x >> 6) * 64;
-    if constexpr (ADJ && SPEC) {                                // sparse waves hand their last recursive paths to wave 0 (wg_handoff)
+    tr.i_block = i_block;
+    if constexpr (SPEC) {                                       // sparse waves hand their last (adjoint: recursive, primal: main) paths to wave 0 (wg_handoff)
         __shared__ uint32_t wgc_lds[kWgcWords];
         static_assert(DRT_COOP_WAVES >= 1, "");
         if (threadIdx.x < 4) wgc_lds[threadIdx.x] = 0xffffffffu; // nothing published yet (made visible by the barrier below)
-        if (!dbg(P.debug_flags, 33554432u)) tr.wgc = wgc_lds;
+        if (!dbg(P.debug_flags, 33554432u) && !(!ADJ && dbg(P.debug_flags, 67108864u)) && P.max_depth < 32768) tr.wgc = wgc_lds;   // (the path-cache cursor travels in 16 bits)
     }
     __shared__ uint64_t jump_lds[2 * (kJumpMax + 1)];
     if (threadIdx.x <= kJumpMax) { jump_lds[2 * threadIdx.x] = kJump.A[threadIdx.x]; jump_lds[2 * threadIdx.x + 1] = kJump.G[threadIdx.x]; }
@@ -107,11 +108,11 @@ __global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const P
     if (ADJ) tr.template sample<true, false>(job, S, ray, dL, Lin, nullptr, L);
     else {
         tr.template sample<false, false>(job, S, ray, nullptr, nullptr, nullptr, L);
-        if (job) { P.L_out[3 * i] = L[0]; P.L_out[3 * i + 1] = L[1]; P.L_out[3 * i + 2] = L[2]; }
+        if (job && !(SPEC && tr.wgc)) { P.L_out[3 * i] = L[0]; P.L_out[3 * i + 1] = L[1]; P.L_out[3 * i + 2] = L[2]; }   // (hand-off: written by wg_handoff)
     }
     if constexpr (ADJ && DEFER) close_records(P, tr.rec);
     if constexpr (!ADJ) {
-        if (P.ray_iters && job) P.ray_iters[i] = (uint8_t) (tr.iters < 255u ? tr.iters : 255u);   // sort key of ray_perm_kernel
+        if (P.ray_iters && job && !(SPEC && tr.wgc)) P.ray_iters[i] = (uint8_t) (tr.iters < 255u ? tr.iters : 255u);   // sort key of ray_perm_kernel
         if (P.block_cost) {
             uint32_t v = tr.work;
 #pragma unroll

@@ -109,6 +109,7 @@ struct CoopTracer {
     const Params &P;
     float maj, inv_maj;
     const uint32_t *mocc;   // SUPER: non-empty supergrid cells (LDS copy) or nullptr
+    uint64_t i_block;       // first ray of this workgroup (hand-off of main paths: home ray = i_block + home)
     uint32_t *wgc;          // LDS area of the workgroup hand-off (wg_handoff; kWgcWords words, flags preset to ~0) or nullptr
     uint32_t ray_index;
     uint32_t *rec;          // wave-private LDS: cooperative-scatter staging area or (DEFER) record-stream state
@@ -124,7 +125,7 @@ struct CoopTracer {
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
         ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr; work = 0; iters = 0;
-        mocc = nullptr; wgc = nullptr;
+        mocc = nullptr; wgc = nullptr; i_block = 0;
 #if DRT_PHASE_PROFILE
         ph_t = __builtin_readcyclecounter();
 #endif
@@ -606,12 +607,22 @@ struct CoopTracer {
     // appear and runs them to the end.  No workgroup barrier: donors never wait; wave 0 only waits when it has nothing
     // to do while another wave is still dense.  A path computes the same numbers on any lane.
     // Returns false when this wave has no path left and expects none.
+    // MAIN: the main path of the primal pass instead (same protocol): a path that ended writes its radiance and its
+    // ray-schedule key for its home ray `i_block + home`; `it` (its path-cache cursor) travels along.
+    template <bool MAIN>
     __device__ bool wg_handoff(bool &job, bool &active, uint32_t &taken, Ray &ray, float beta[3], float result[3], Pcg32 &S,
-                               int &depth, bool &escaped, bool &has_scattered, float last_pdf, Tail &tl)
+                               int &depth, bool &escaped, bool &has_scattered, float &last_pdf, Tail &tl, int &home, int &it)
     {
         lds_u32 *flags = (lds_u32 *) wgc, *pool = flags + 4;
         const int wave = (int) (threadIdx.x >> 6), lane = (int) __lane_id();
-        if (job && !active) {                                                   // the path ended: Li, gradient splat (:565-581)
+        if (MAIN && job && !active) {                                           // the path ended: radiance, schedule key
+            add_escaped_emission(escaped, depth, has_scattered, last_pdf, ray.d, beta, result);
+            const uint64_t i = i_block + (uint64_t) home;
+            P.L_out[3 * i] = result[0]; P.L_out[3 * i + 1] = result[1]; P.L_out[3 * i + 2] = result[2];
+            if (P.ray_iters) P.ray_iters[i] = (uint8_t) (it < 255 ? it : 255);
+            job = false;
+        }
+        if (!MAIN && job && !active) {                                          // the path ended: Li, gradient splat (:565-581)
             add_escaped_emission(escaped, depth, has_scattered, last_pdf, ray.d, beta, result);
             float gs = 0.0f, ga[3];
 #pragma unroll
@@ -636,13 +647,13 @@ struct CoopTracer {
                     __float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]),
                     __float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]),
                     (uint32_t) S.state, (uint32_t) (S.state >> 32), (uint32_t) S.inc, (uint32_t) (S.inc >> 32),
-                    (uint32_t) depth, (escaped ? 1u : 0u) | (has_scattered ? 2u : 0u),
+                    (uint32_t) depth, (escaped ? 1u : 0u) | (has_scattered ? 2u : 0u) | (MAIN ? ((uint32_t) home << 8) | ((uint32_t) it << 16) : 0u),
                     __float_as_uint(tl.p.x), __float_as_uint(tl.p.y), __float_as_uint(tl.p.z), __float_as_uint(tl.sig),
                     __float_as_uint(tl.alb[0]), __float_as_uint(tl.alb[1]), __float_as_uint(tl.alb[2]),
                     __float_as_uint(tl.wadj[0]), __float_as_uint(tl.wadj[1]), __float_as_uint(tl.wadj[2]),
                     __float_as_uint(tl.nee[0]), __float_as_uint(tl.nee[1]), __float_as_uint(tl.nee[2]) };
 #pragma unroll
-                for (int f = 0; f < kWgcFields; ++f) q[f * kWgcDonate] = w[f];
+                for (int f = 0; f < (MAIN ? 19 : kWgcFields); ++f) q[f * kWgcDonate] = w[f];
             }
             coop_stage_sync();                                                  // the states are in LDS ...
             if (lane == 0) flags[wave - 1] = (uint32_t) n;                      // ... before the count is published
@@ -660,7 +671,7 @@ struct CoopTracer {
                     lds_u32 *q = pool + w * (kWgcFields * kWgcDonate) + slot;
                     uint32_t v[kWgcFields];
 #pragma unroll
-                    for (int k = 0; k < kWgcFields; ++k) v[k] = q[k * kWgcDonate];
+                    for (int k = 0; k < kWgcFields; ++k) v[k] = (MAIN && k >= 19) ? 0u : q[k * kWgcDonate];
                     ray.o = v3(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]));
                     ray.d = v3(__uint_as_float(v[3]), __uint_as_float(v[4]), __uint_as_float(v[5]));
                     ray.maxt = __uint_as_float(v[6]);
@@ -673,6 +684,11 @@ struct CoopTracer {
                     S.inc = ((uint64_t) v[16] << 32) | v[15];
                     depth = (int) v[17];
                     escaped = (v[18] & 1u) != 0u; has_scattered = (v[18] & 2u) != 0u;
+                    if constexpr (MAIN) {
+                        home = (int) ((v[18] >> 8) & 255u); it = (int) (v[18] >> 16);
+                        last_pdf = has_scattered ? kInvFourPi : 1.0f;
+                        pc = P.path_cache_mode == 1 ? P.path_cache + (size_t) (i_block + (uint64_t) home) * P.path_cache_cap * 2 : nullptr;
+                    }
                     tl.p = v3(__uint_as_float(v[19]), __uint_as_float(v[20]), __uint_as_float(v[21]));
                     tl.sig = __uint_as_float(v[22]);
                     job = active = true;
@@ -724,11 +740,19 @@ struct CoopTracer {
 
         int it = 0;                                                             // bounce-loop iterations this ray has run
         // recursive paths of the specialised adjoint kernels: sparse waves hand their last paths to wave 0 (wg_handoff)
-        constexpr bool kWgc = !ADJ && RECURSIVE && SPEC;
+        // ... and so do the main paths of the specialised primal kernels (their radiance is then written by wg_handoff)
+        constexpr bool kWgc = !ADJ && SPEC;
         bool wgc_on = false;
         Tail tl;
         uint32_t taken = 0;
-        if constexpr (kWgc) { if (wgc && ps->tail) { wgc_on = true; tl = *ps->tail; } }
+        int home = (int) threadIdx.x;
+        if constexpr (kWgc && RECURSIVE) { if (wgc && ps->tail) { wgc_on = true; tl = *ps->tail; } }
+        if constexpr (kWgc && !RECURSIVE) {
+            wgc_on = wgc != nullptr;
+            tl.p = v3(0, 0, 0); tl.sig = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { tl.alb[k] = 0.0f; tl.wadj[k] = 0.0f; tl.nee[k] = 0.0f; }
+        }
         for (;;) {                                                              // :114, wave-uniform
             const uint64_t any_active = __ballot(active);
             if (!wgc_on && !any_active) break;
@@ -750,7 +774,7 @@ struct CoopTracer {
             phase(RECURSIVE ? C_SC : C_TR);
             Mei mei = coop_dt(run && cmode != 2, ray, S, dt_steps);             // :126
             phase(RECURSIVE ? C_ALB : C_DT);
-            work += dt_steps + 4u;
+            work += dt_steps;                 // (+ 256 per bounce-loop iteration of the wave's longest path: ray_perm_kernel)
             if (cmode == 2) {
                 const uint4 e = ce[0];
                 mei.t = __uint_as_float(e.x); mei.valid = mei.t < kInf;
@@ -846,7 +870,7 @@ struct CoopTracer {
             }
             }
             if constexpr (kWgc) {
-                if (wgc_on && !wg_handoff(job, active, taken, ray, beta, result, S, depth, escaped, has_scattered, last_pdf, tl)) break;
+                if (wgc_on && !wg_handoff<!RECURSIVE>(job, active, taken, ray, beta, result, S, depth, escaped, has_scattered, last_pdf, tl, home, it)) break;
             }
         }
 
@@ -866,7 +890,7 @@ struct CoopTracer {
             if (job && !wgc_on) add_escaped_emission(escaped, depth, has_scattered, last_pdf, ray.d, beta, result);   // (hand-off mode: done in wg_handoff)
         }
         phase(RECURSIVE ? C_SC : C_TR);
-        if (!RECURSIVE) iters = (uint32_t) it;
+        if (!RECURSIVE) iters = (uint32_t) it;                                  // (hand-off mode: written per ray by wg_handoff)
         out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
     }
 };

@@ -19,7 +19,7 @@ hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int
 // one ray per lane with wave-cooperative tracking loops (drt_coop.hip); global majorant only (P.mgrid == nullptr)
 hipError_t launch_trace_coop_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStream_t stream);
-hipError_t launch_ray_perm(const uint8_t *iters, uint64_t n_rays, uint16_t *perm, hipStream_t stream);
+hipError_t launch_ray_perm(const uint8_t *iters, uint64_t n_rays, uint16_t *perm, uint32_t *block_cost, hipStream_t stream);
 hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t *order, bool heavy_first, hipStream_t stream);
 hipError_t launch_untile(const Params &P, hipStream_t stream);
 // fused nerf + volpathsimple pass over the interleaved four-channel grid (drt_fused.hip)
