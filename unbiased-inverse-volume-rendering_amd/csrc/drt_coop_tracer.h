@@ -756,6 +756,8 @@ struct CoopTracer {
         for (;;) {                                                              // :114, wave-uniform
             const uint64_t any_active = __ballot(active);
             if (!wgc_on && !any_active) break;
+            const int Jit = __popcll(any_active); (void) Jit;
+            round_begin(RECURSIVE ? 4 : 5);          // phase-profile modes 4 / 5: bounce-loop iterations by live lanes
             if (any_active) {
             bool run = active;
             if (run) {
@@ -869,6 +871,7 @@ struct CoopTracer {
                 ++it;
             }
             }
+            if (any_active) round_end(RECURSIVE ? 4 : 5, Jit);
             if constexpr (kWgc) {
                 if (wgc_on && !wg_handoff<!RECURSIVE>(job, active, taken, ray, beta, result, S, depth, escaped, has_scattered, last_pdf, tl, home, it)) break;
             }
