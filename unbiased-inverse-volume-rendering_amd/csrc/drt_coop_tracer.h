@@ -206,7 +206,7 @@ struct CoopTracer {
     // estimate_transmittance: ratio tracking (volpathsimple.py:436-504), all lanes of the wave call it
     // ---------------------------------------------------------------------------------------------
     template <bool ADJ>
-    __device__ float coop_rt(bool job, V3 o, V3 d, float tmax, Pcg32 &S, float a_sum, uint32_t *steps_out = nullptr)
+    __device__ __forceinline__ float coop_rt(bool job, V3 o, V3 d, float tmax, Pcg32 &S, float a_sum, uint32_t *steps_out = nullptr)
     {
         float T = 1.0f;
         uint32_t steps = 0;
@@ -318,7 +318,7 @@ struct CoopTracer {
     // ---------------------------------------------------------------------------------------------
     // sample_real_interaction: delta tracking (volpathsimple.py:323-377), all lanes of the wave call it
     // ---------------------------------------------------------------------------------------------
-    __device__ Mei coop_dt(bool job, const Ray &ray, Pcg32 &S, uint32_t &steps)
+    __device__ __forceinline__ Mei coop_dt(bool job, const Ray &ray, Pcg32 &S, uint32_t &steps)
     {
         Mei mei; mei.valid = false; mei.t = kInf; mei.p = v3(0, 0, 0); mei.sigma_t = 0.0f;
         steps = 0;
@@ -411,7 +411,7 @@ struct CoopTracer {
     // cache (value walk only): mode 1 stores {T, sampler state behind the walk, steps} into *ce, mode 2 takes
     // them from it instead of walking.
     template <bool ADJ>
-    __device__ float sample_emitter(bool job, V3 p, Pcg32 &S, const float *adj, float out[3], int cmode = 0, uint4 *ce = nullptr)
+    __device__ __forceinline__ float sample_emitter(bool job, V3 p, Pcg32 &S, const float *adj, float out[3], int cmode = 0, uint4 *ce = nullptr)
     {
         float val[3] = { 0.0f, 0.0f, 0.0f }, pdf = 0.0f, tmax = 0.0f;
         V3 wd = v3(0, 0, 1);
@@ -442,7 +442,7 @@ struct CoopTracer {
 
     // sample_emitter_for_nee (volpathsimple.py:380-403)
     template <bool ADJ>
-    __device__ void sample_emitter_for_nee(bool job, V3 p, Pcg32 &S, const float beta[3], const float *dL, float contrib[3],
+    __device__ __forceinline__ void sample_emitter_for_nee(bool job, V3 p, Pcg32 &S, const float beta[3], const float *dL, float contrib[3],
                                            int cmode = 0, uint4 *ce = nullptr)
     {
         Pcg32 clone = S;                                                        // :383
@@ -461,7 +461,7 @@ struct CoopTracer {
 
     // Medium::sample_interaction_drt (call site volpathsimple.py:549-551); one lane per walk (54 % lane
     // utilisation on the headline workload: the reservoir vertex of every ray is walked at the same time)
-    __device__ bool sample_interaction_drt(const Ray &ray, Pcg32 &A, float &t_out, float &W_out)
+    __device__ __forceinline__ bool sample_interaction_drt(const Ray &ray, Pcg32 &A, float &t_out, float &W_out)
     {
         float t = 0.0f, T = 1.0f, wsum = 0.0f, tsel = kInf;
         bool valid = false;
@@ -485,7 +485,7 @@ struct CoopTracer {
 
     // sample_recursive (volpathsimple.py:610-655)
     // `tail`: hand-off mode - the path's end (Li, gradient splat) happens inside sample(), on whichever lane it ends
-    __device__ void sample_recursive(bool job, Pcg32 &A, V3 p, int depth, float Li[3], Tail *tail = nullptr)
+    __device__ __forceinline__ void sample_recursive(bool job, Pcg32 &A, V3 p, int depth, float Li[3], Tail *tail = nullptr)
     {
         Li[0] = Li[1] = Li[2] = 0.0f;
         if (use_nee()) {                                                        // :621-624 (wave-uniform condition)
@@ -519,7 +519,7 @@ struct CoopTracer {
     }
 
     // backpropagate_scattering_drt, final / quadratic branch (volpathsimple.py:543-581)
-    __device__ void drt_backprop(bool job, Pcg32 &A, const Ray &ray, float si_t, int depth, const float adj[3])
+    __device__ __forceinline__ void drt_backprop(bool job, Pcg32 &A, const Ray &ray, float si_t, int depth, const float adj[3])
     {
         Ray sub = ray;
         sub.maxt = isfinite(si_t) ? si_t : kLargest;                            // :544-545
@@ -570,7 +570,7 @@ struct CoopTracer {
     }
 
     // backpropagate_transmittance (volpathsimple.py:584-607)
-    __device__ void backprop_transmittance(Pcg32 &A, const Ray &ray, float interval, const float dL[3], const float result[3])
+    __device__ __forceinline__ void backprop_transmittance(Pcg32 &A, const Ray &ray, float interval, const float dL[3], const float result[3])
     {
         float adjw = (dL[0] * result[0] + dL[1] * result[1]) + dL[2] * result[2];
         float g = -(adjw * (interval / 4.0f));
@@ -610,7 +610,7 @@ struct CoopTracer {
     // MAIN: the main path of the primal pass instead (same protocol): a path that ended writes its radiance and its
     // ray-schedule key for its home ray `i_block + home`; `it` (its path-cache cursor) travels along.
     template <bool MAIN>
-    __device__ bool wg_handoff(bool &job, bool &active, uint32_t &taken, Ray &ray, float beta[3], float result[3], Pcg32 &S,
+    __device__ __forceinline__ bool wg_handoff(bool &job, bool &active, uint32_t &taken, Ray &ray, float beta[3], float result[3], Pcg32 &S,
                                int &depth, bool &escaped, bool &has_scattered, float &last_pdf, Tail &tl, int &home, int &it)
     {
         lds_u32 *flags = (lds_u32 *) wgc, *pool = flags + 4;
@@ -705,7 +705,7 @@ struct CoopTracer {
 
     // VolpathSimpleIntegrator.sample (volpathsimple.py:38-290); `job`: this lane carries a ray
     template <bool ADJ, bool RECURSIVE>
-    __device__ void sample(bool job, Pcg32 &S, Ray ray, const float *dL, const float *state_in, const PathState *ps, float out[3])
+    __device__ __forceinline__ void sample(bool job, Pcg32 &S, Ray ray, const float *dL, const float *state_in, const PathState *ps, float out[3])
     {
         float result[3] = { 0.0f, 0.0f, 0.0f };
         float beta[3] = { 1.0f, 1.0f, 1.0f };
