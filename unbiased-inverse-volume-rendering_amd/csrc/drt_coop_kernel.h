@@ -12,7 +12,7 @@ namespace {
 using namespace coop;
 
 template <bool ADJ, bool COUNT, bool ENV, bool DEFER, bool SPEC = false, bool SUPER = false>
-__global__ void __launch_bounds__(256, DRT_COOP_WAVES) trace_coop_kernel(const Params P)
+__global__ void __launch_bounds__(256, ADJ ? DRT_COOP_WAVES : DRT_COOP_WAVES_PRIMAL) trace_coop_kernel(const Params P)
 {
     uint32_t b = blockIdx.x;                                    // XCD-aware block -> ray-chunk map (see trace_kernel)
     if (P.block_order) b = P.block_order[blockIdx.x];            // heavy blocks first (adjoint: this job's primal costs; primal: the previous launch's)
