@@ -207,6 +207,8 @@ __device__ __forceinline__ void bin_scatter_stream(const Params &P, const Deferr
     for (uint32_t c0 = blockIdx.x * kSub + sub; c0 < used; c0 += kPartUnroll * kSub * gridDim.x) {   // same map as the histogram
         float4 r[kPartUnroll], q[kPartUnroll]; bool ok[kPartUnroll];
 #pragma unroll
+        for (int k = 0; k < kPartUnroll; ++k) { r[k] = make_float4(0.f, 0.f, 0.f, 0.f); q[k] = r[k]; }
+#pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) {
             const uint32_t c = c0 + k * kSub * gridDim.x;
             ok[k] = c < used && rec < D.chunk_count[S][c];
@@ -218,7 +220,7 @@ __device__ __forceinline__ void bin_scatter_stream(const Params &P, const Deferr
         }
         uint32_t slot[kPartUnroll];
 #pragma unroll
-        for (int k = 0; k < kPartUnroll; ++k) if (ok[k]) slot[k] = atomicAdd(&cur[bin_of(P, D, r[k])], 1u);
+        for (int k = 0; k < kPartUnroll; ++k) slot[k] = ok[k] ? atomicAdd(&cur[bin_of(P, D, r[k])], 1u) : 0u;
 #pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) if (ok[k]) {
             float4 *o = dst + (size_t) slot[k] * kQuads;
