@@ -242,7 +242,10 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     //   The plain per-lane Tracer (drt_kernels.hip; bits 8 / 32768) exists only in the library flavour with test
     //   hooks, where the variant tests keep it (and the state machine's adjoint, bit 32) in lock-step with the rest.
     const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
-    const bool sm_primal = !adjoint && (P.mgrid != nullptr || dbg(h->debug_flags, 65536u)) && !dbg(h->debug_flags, 8u);
+#ifndef DRT_SUPER_COOP_PRIMAL
+#define DRT_SUPER_COOP_PRIMAL 0     // experiment: 1 = the supergrid primal runs in CoopTracer<SUPER> too (measured slower)
+#endif
+    const bool sm_primal = !adjoint && ((P.mgrid != nullptr && !DRT_SUPER_COOP_PRIMAL) || dbg(h->debug_flags, 65536u)) && !dbg(h->debug_flags, 8u);
     const bool sm_adjoint = adjoint && dbg(h->debug_flags, 32u) && !quadratic && !dbg(h->debug_flags, 8u);
     const bool wavefront = sm_primal || sm_adjoint;
     const bool coop = !wavefront && !dbg(h->debug_flags, (adjoint ? 32768u : 8u));
