@@ -29,6 +29,8 @@ struct drt_handle_s {
     unsigned long long *d_counters = nullptr;   // [C_COUNT]
     float *d_gt = nullptr;         // gradient scratch, 4 planes (always zero between launches)
     unsigned long long *d_queues = nullptr;   // 8 per-XCD ray queue heads (wavefront kernel)
+    void *d_tail = nullptr;                   // tail pool of the cooperative kernels: [counter, pad to 256 B][entries x 128 B]
+    size_t tail_entries = 0;
     int n_cus = 256;
     float *d_sigma_b = nullptr;    // bricked copy of sigma_t (refreshed by drt_params_changed)
     uint32_t *d_occ = nullptr;     // empty-space bitmask (kOccWords words)
@@ -250,14 +252,28 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     const bool wavefront = sm_primal || sm_adjoint;
     const bool coop = !wavefront && !dbg(h->debug_flags, (adjoint ? 32768u : 8u));
     if (coop) {
+        // tail pool: room for 1/16 of the launch's rays (a workgroup sends at most 16 of its 256), kept while it is big enough;
+        // without it (allocation failed) the kernels simply finish every path where it is
+        drt::Params PT = P;
+        PT.tail_pool = nullptr; PT.tail_count = nullptr; PT.tail_cap = 0; PT.tail_mode = 0;
+        if (adjoint && !P.mgrid && P.n_rays > P.ray_first) {
+            const size_t want = (((size_t) (P.n_rays - P.ray_first) / 16 + 255) / 256) * 256;
+            if (want > h->tail_entries) {
+                if (h->d_tail) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_tail); h->d_tail = nullptr; h->tail_entries = 0; }
+                if (hipMalloc(&h->d_tail, 256 + want * 128) == hipSuccess) h->tail_entries = want; else { (void) hipGetLastError(); h->d_tail = nullptr; }
+            }
+            if (h->d_tail && want >= 256) {
+                PT.tail_count = (uint32_t *) h->d_tail; PT.tail_pool = (uint4 *) ((char *) h->d_tail + 256); PT.tail_cap = (uint32_t) want;
+            }
+        }
         if (P.mgrid) {
             // supergrid: rays stay in image order - neighbouring pixels walk the same supergrid cells, and sorting them
             // by path length costs more than it saves (24.6 vs 18.8 ms at majorant_resolution_factor 8)
-            drt::Params Q = P;
+            drt::Params Q = PT;
             Q.ray_perm = nullptr;
             DRT_HIP_CHECK(h, drt::launch_trace_coop(Q, adjoint, h->counting, h->stream));
         } else {
-            DRT_HIP_CHECK(h, drt::launch_trace_coop(P, adjoint, h->counting, h->stream));
+            DRT_HIP_CHECK(h, drt::launch_trace_coop(PT, adjoint, h->counting, h->stream));
         }
     }
 #ifdef DRT_TEST_HOOKS
@@ -563,6 +579,7 @@ int drt_destroy(drt_handle h)
     if (h->d_counters) (void) hipFree(h->d_counters);
     if (h->d_gt) (void) hipFree(h->d_gt);
     if (h->d_queues) (void) hipFree(h->d_queues);
+    if (h->d_tail) (void) hipFree(h->d_tail);
     if (h->d_sigma_b) (void) hipFree(h->d_sigma_b);
     if (h->d_mgrid) (void) hipFree(h->d_mgrid);
     if (h->d_occ) (void) hipFree(h->d_occ);
@@ -592,6 +609,8 @@ int drt_release_scratch(drt_handle h)
     }
     if (h->d_pcache) (void) hipFree(h->d_pcache);
     h->d_pcache = nullptr; h->pcache_bytes = 0; h->pcache_sig.valid = false; h->order_valid = false; h->order_rays = 0;
+    if (h->d_tail) (void) hipFree(h->d_tail);
+    h->d_tail = nullptr; h->tail_entries = 0;
     return DRT_OK;
 }
 

@@ -11,9 +11,12 @@ namespace {
 
 using namespace coop;
 
-template <bool ADJ, bool COUNT, bool ENV, bool DEFER, bool SPEC = false, bool SUPER = false>
+// TAIL: the second launch of a specialised kernel - its workgroups start from 256 paths of the tail pool each
+// (CoopTracer::wg_handoff) instead of from rays, and finish them
+template <bool ADJ, bool COUNT, bool ENV, bool DEFER, bool SPEC = false, bool SUPER = false, bool TAIL = false>
 __global__ void __launch_bounds__(256, ADJ ? DRT_COOP_WAVES : DRT_COOP_WAVES_PRIMAL) trace_coop_kernel(const Params P)
 {
+    if constexpr (TAIL) { if (blockIdx.x * 256u >= *P.tail_count) return; }   // (workgroup-uniform) nothing for this workgroup
     uint32_t b = blockIdx.x;                                    // XCD-aware block -> ray-chunk map (see trace_kernel)
     if (P.block_order) b = P.block_order[blockIdx.x];            // heavy blocks first (adjoint: this job's primal costs; primal: the previous launch's)
     else
@@ -35,7 +38,8 @@ __global__ void __launch_bounds__(256, ADJ ? DRT_COOP_WAVES : DRT_COOP_WAVES_PRI
     CoopTracer<COUNT, ENV, DEFER, SPEC, false, SUPER> tr(P);
     __shared__ uint32_t slot_lds[4 * 64];
     tr.slots = slot_lds + (threadIdx.x >> 6) * 64;
-    tr.i_block = i_block;
+    tr.i_block = TAIL ? 0 : i_block;
+    tr.tail_load = TAIL;
     if constexpr (SPEC) {                                       // sparse waves hand their last (adjoint: recursive, primal: main) paths to wave 0 (wg_handoff)
         __shared__ uint32_t wgc_lds[kWgcWords];
         static_assert(DRT_COOP_WAVES >= 1, "");
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(256, ADJ ? DRT_COOP_WAVES : DRT_COOP_WAVES_PRI
             tr.mocc = mocc_lds;
         }
     }
-    const bool job = i < P.n_rays;
+    const bool job = !TAIL && i < P.n_rays;
     Pcg32 S; S.state = 0; S.inc = 1;
     Ray ray; ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.maxt = kLargest;
     float dL[3] = { 0, 0, 0 }, Lin[3] = { 0, 0, 0 };
@@ -105,7 +109,16 @@ __global__ void __launch_bounds__(256, ADJ ? DRT_COOP_WAVES : DRT_COOP_WAVES_PRI
         }
     }
     float L[3];
-    if (ADJ) tr.template sample<true, false>(job, S, ray, dL, Lin, nullptr, L);
+    if constexpr (TAIL && ADJ) {                                // recursive DRT paths of the pool, their gradient splats included
+        Tail tl;
+        tl.p = v3(0, 0, 0); tl.sig = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { tl.alb[q] = 0.0f; tl.wadj[q] = 0.0f; tl.nee[q] = 0.0f; }
+        PathState ps;
+        ps.depth = 0; ps.last_pdf = kInvFourPi; ps.escaped = false; ps.active = false; ps.tail = &tl;
+        ps.si.valid = false; ps.si.t = kInf; ps.si.p = v3(0, 0, 0); ps.si.n = v3(0, 0, 0);
+        tr.template sample<false, true>(false, S, ray, nullptr, nullptr, &ps, L);
+    } else if (ADJ) tr.template sample<true, false>(job, S, ray, dL, Lin, nullptr, L);
     else {
         tr.template sample<false, false>(job, S, ray, nullptr, nullptr, nullptr, L);
         if (job && !(SPEC && tr.wgc)) { P.L_out[3 * i] = L[0]; P.L_out[3 * i + 1] = L[1]; P.L_out[3 * i + 2] = L[2]; }   // (hand-off: written by wg_handoff)
@@ -113,7 +126,7 @@ __global__ void __launch_bounds__(256, ADJ ? DRT_COOP_WAVES : DRT_COOP_WAVES_PRI
     if constexpr (ADJ && DEFER) close_records(P, tr.rec);
     if constexpr (!ADJ) {
         if (P.ray_iters && job && !(SPEC && tr.wgc)) P.ray_iters[i] = (uint8_t) (tr.iters < 255u ? tr.iters : 255u);   // sort key of ray_perm_kernel
-        if (P.block_cost) {
+        if (P.block_cost && !TAIL) {
             uint32_t v = tr.work;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -149,14 +162,35 @@ hipError_t launch_trace_coop_t(const Params &P, bool adjoint, bool count, hipStr
         if (defer) { hipLaunchKernelGGL((trace_coop_kernel<true, true, false, true, true, SUPER>), grid, block, 0, stream, P); return hipGetLastError(); }
     }
 #endif
+    // ... each followed by its tail launch (the workgroups' last few paths, pooled: wg_handoff) when the caller gave a pool
+    // (adjoint only: a tail launch exposes the longest path of the job - ~0.5 ms - which the primal pass has nothing to
+    // hide behind: primal 2.58 -> 2.85 ms with it, adjoint tracer 6.19 -> 5.99 ms)
+    const bool tail = !SUPER && adjoint && P.tail_pool && P.tail_count && P.tail_cap >= 256u && !dbg(P.debug_flags, 33554432u);
+    Params T = P;
+    if (spec && (!adjoint || defer)) {
+        if (tail) {
+            hipError_t e = hipMemsetAsync(P.tail_count, 0, sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
+            T.tail_mode = 1; T.block_order = nullptr; T.ray_perm = nullptr;
+        } else T.tail_pool = nullptr;
+    }
+    Params M = P;
+    if (!tail) M.tail_pool = nullptr;
+    M.tail_mode = 0;
+    const dim3 tgrid(tail ? P.tail_cap / 256u : 1u);
+    // (pool capacity = 1/16 of the launch's rays; the tail kernel's surplus workgroups return at once)
     if (spec && !adjoint) {
-        if (env) hipLaunchKernelGGL((trace_coop_kernel<false, false, true, false, true, SUPER>), grid, block, 0, stream, P);
-        else hipLaunchKernelGGL((trace_coop_kernel<false, false, false, false, true, SUPER>), grid, block, 0, stream, P);
+        if (env) hipLaunchKernelGGL((trace_coop_kernel<false, false, true, false, true, SUPER>), grid, block, 0, stream, M);
+        else hipLaunchKernelGGL((trace_coop_kernel<false, false, false, false, true, SUPER>), grid, block, 0, stream, M);
         return hipGetLastError();
     }
     if (spec && defer) {
-        if (env) hipLaunchKernelGGL((trace_coop_kernel<true, false, true, true, true, SUPER>), grid, block, 0, stream, P);
-        else hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true, SUPER>), grid, block, 0, stream, P);
+        if (env) hipLaunchKernelGGL((trace_coop_kernel<true, false, true, true, true, SUPER>), grid, block, 0, stream, M);
+        else hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true, SUPER>), grid, block, 0, stream, M);
+        if constexpr (!SUPER) if (tail) {
+            if (env) hipLaunchKernelGGL((trace_coop_kernel<true, false, true, true, true, false, true>), tgrid, block, 0, stream, T);
+            else hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true, false, true>), tgrid, block, 0, stream, T);
+        }
         return hipGetLastError();
     }
     if (!adjoint) {

@@ -41,6 +41,9 @@
 #ifndef DRT_WGC_DONATE
 #define DRT_WGC_DONATE 16          // live recursive paths at or below which a wave hands them to wave 0 (wg_handoff; swept 8 / 16 / 21 / 32 / 48: 6.36 / 6.17 / 6.17 / 6.18 / 6.44 ms)
 #endif
+#ifndef DRT_TAIL_PUSH
+#define DRT_TAIL_PUSH 16           // live recursive paths at or below which a workgroup's last wave sends them to the tail pool (4 / 8 / 16 / 32: 6.13 / 5.96 / 5.85 / 6.25 ms)
+#endif
 #ifndef DRT_COOP_MAXM
 #define DRT_COOP_MAXM 8        // candidate steps per walk and round = chain length (swept 4 / 8 / 16: 11.7 / 11.0 / 11.5 ms)
 #endif
@@ -113,6 +116,7 @@ struct CoopTracer {
     float maj, inv_maj;
     const uint32_t *mocc;   // SUPER: non-empty supergrid cells (LDS copy) or nullptr
     uint64_t i_block;       // first ray of this workgroup (hand-off of main paths: home ray = i_block + home)
+    bool tail_load;         // tail-mode launch: this lane still has to fetch its path from the tail pool
     uint32_t *wgc;          // LDS area of the workgroup hand-off (wg_handoff; kWgcWords words, flags preset to ~0) or nullptr
     uint32_t ray_index;
     uint32_t *rec;          // wave-private LDS: cooperative-scatter staging area or (DEFER) record-stream state
@@ -128,7 +132,7 @@ struct CoopTracer {
     {
         maj = p.majorant[0]; inv_maj = p.majorant[1];
         ray_index = 0; rec = nullptr; slots = nullptr; occ = nullptr; jump = nullptr; pc = nullptr; work = 0; iters = 0;
-        mocc = nullptr; wgc = nullptr; i_block = 0;
+        mocc = nullptr; wgc = nullptr; i_block = 0; tail_load = false;
 #if DRT_PHASE_PROFILE
         ph_t = __builtin_readcyclecounter();
 #endif
@@ -612,15 +616,70 @@ struct CoopTracer {
     // Returns false when this wave has no path left and expects none.
     // MAIN: the main path of the primal pass instead (same protocol): a path that ended writes its radiance and its
     // ray-schedule key for its home ray `i_block + home`; `it` (its path-cache cursor) travels along.
+    // Tail pool (adjoint pass): when wave 0 has taken every donation and is itself down to DRT_TAIL_PUSH live paths, it
+    // writes them to a global pool and ends as well; a second launch of the same kernel in tail mode
+    // (Params::tail_mode) starts with 256 of those paths per workgroup - the longest recursive paths of the job, densely
+    // packed again.  (Dropping them, as a timing experiment, took 0.8 ms off the adjoint tracer: what they cost at
+    // <= 8 lanes per wave.  The tail launch gives back 0.35 of it: its own duration is the job's longest path.  The
+    // primal pass has nothing to hide that behind and keeps its paths.)
     template <bool MAIN>
     __device__ __forceinline__ bool wg_handoff(bool &job, bool &active, uint32_t &taken, Ray &ray, float beta[3], float result[3], Pcg32 &S,
                                int &depth, bool &escaped, bool &has_scattered, float &last_pdf, Tail &tl, int &home, int &it)
     {
         lds_u32 *flags = (lds_u32 *) wgc, *pool = flags + 4;
         const int wave = (int) (threadIdx.x >> 6), lane = (int) __lane_id();
+        constexpr int kUsed = MAIN ? 20 : kWgcFields;                           // words of an entry in use
+// the complete state of a path as kWgcFields words (MAIN: word 19 = home ray, relative to i_block) and back
+#define DRT_PACK_PATH(w)                                                                                                   \
+        const uint32_t w[kWgcFields] = {                                                                                   \
+            __float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z),                                  \
+            __float_as_uint(ray.d.x), __float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(ray.maxt),       \
+            __float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]),                                  \
+            __float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]),                            \
+            (uint32_t) S.state, (uint32_t) (S.state >> 32), (uint32_t) S.inc, (uint32_t) (S.inc >> 32),                    \
+            (uint32_t) depth, (escaped ? 1u : 0u) | (has_scattered ? 2u : 0u) | (MAIN ? ((uint32_t) it << 16) : 0u),       \
+            MAIN ? (uint32_t) home : __float_as_uint(tl.p.x), __float_as_uint(tl.p.y), __float_as_uint(tl.p.z),            \
+            __float_as_uint(tl.sig), __float_as_uint(tl.alb[0]), __float_as_uint(tl.alb[1]), __float_as_uint(tl.alb[2]),   \
+            __float_as_uint(tl.wadj[0]), __float_as_uint(tl.wadj[1]), __float_as_uint(tl.wadj[2]),                         \
+            __float_as_uint(tl.nee[0]), __float_as_uint(tl.nee[1]), __float_as_uint(tl.nee[2]) }
+#define DRT_UNPACK_PATH(v)                                                                                                 \
+        do {                                                                                                               \
+            ray.o = v3(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]));                               \
+            ray.d = v3(__uint_as_float(v[3]), __uint_as_float(v[4]), __uint_as_float(v[5]));                               \
+            ray.maxt = __uint_as_float(v[6]);                                                                              \
+            _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                                             \
+                beta[k_] = __uint_as_float(v[7 + k_]); result[k_] = __uint_as_float(v[10 + k_]);                           \
+                tl.alb[k_] = __uint_as_float(v[23 + k_]); tl.wadj[k_] = __uint_as_float(v[26 + k_]);                       \
+                tl.nee[k_] = __uint_as_float(v[29 + k_]);                                                                  \
+            }                                                                                                              \
+            S.state = ((uint64_t) v[14] << 32) | v[13];                                                                    \
+            S.inc = ((uint64_t) v[16] << 32) | v[15];                                                                      \
+            depth = (int) v[17];                                                                                           \
+            escaped = (v[18] & 1u) != 0u; has_scattered = (v[18] & 2u) != 0u;                                              \
+            if constexpr (MAIN) {                                                                                          \
+                home = (int) v[19]; it = (int) (v[18] >> 16);                                                              \
+                last_pdf = has_scattered ? kInvFourPi : 1.0f;                                                              \
+                pc = P.path_cache_mode == 1 ? P.path_cache + (size_t) (i_block + (uint64_t) (uint32_t) home) * P.path_cache_cap * 2 : nullptr; \
+            }                                                                                                              \
+            tl.p = v3(__uint_as_float(v[19]), __uint_as_float(v[20]), __uint_as_float(v[21]));                             \
+            tl.sig = __uint_as_float(v[22]);                                                                               \
+            job = active = true;                                                                                           \
+        } while (0)
+
+        if (!MAIN && tail_load) {                                               // tail-mode launch: fetch this lane's path from the pool
+            tail_load = false;
+            const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+            if (idx < min(*P.tail_count, P.tail_cap)) {
+                const uint4 *src = P.tail_pool + (size_t) idx * 8;
+                uint32_t v[kWgcFields];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const uint4 u = (4 * q < kUsed) ? src[q] : make_uint4(0, 0, 0, 0); v[4 * q] = u.x; v[4 * q + 1] = u.y; v[4 * q + 2] = u.z; v[4 * q + 3] = u.w; }
+                DRT_UNPACK_PATH(v);
+            }
+        }
         if (MAIN && job && !active) {                                           // the path ended: radiance, schedule key
             add_escaped_emission(escaped, depth, has_scattered, last_pdf, ray.d, beta, result);
-            const uint64_t i = i_block + (uint64_t) home;
+            const uint64_t i = i_block + (uint64_t) (uint32_t) home;
             P.L_out[3 * i] = result[0]; P.L_out[3 * i + 1] = result[1]; P.L_out[3 * i + 2] = result[2];
             if (P.ray_iters) P.ray_iters[i] = (uint8_t) (it < 255 ? it : 255);
             job = false;
@@ -644,19 +703,9 @@ struct CoopTracer {
             if (n > kWgcDonate) return true;                                    // dense: carry on
             if (active) {
                 lds_u32 *q = pool + (wave - 1) * (kWgcFields * kWgcDonate) + __popcll(am & ((1ull << lane) - 1ull));
-                const uint32_t w[kWgcFields] = {
-                    __float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z),
-                    __float_as_uint(ray.d.x), __float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(ray.maxt),
-                    __float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]),
-                    __float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]),
-                    (uint32_t) S.state, (uint32_t) (S.state >> 32), (uint32_t) S.inc, (uint32_t) (S.inc >> 32),
-                    (uint32_t) depth, (escaped ? 1u : 0u) | (has_scattered ? 2u : 0u) | (MAIN ? ((uint32_t) home << 8) | ((uint32_t) it << 16) : 0u),
-                    __float_as_uint(tl.p.x), __float_as_uint(tl.p.y), __float_as_uint(tl.p.z), __float_as_uint(tl.sig),
-                    __float_as_uint(tl.alb[0]), __float_as_uint(tl.alb[1]), __float_as_uint(tl.alb[2]),
-                    __float_as_uint(tl.wadj[0]), __float_as_uint(tl.wadj[1]), __float_as_uint(tl.wadj[2]),
-                    __float_as_uint(tl.nee[0]), __float_as_uint(tl.nee[1]), __float_as_uint(tl.nee[2]) };
+                DRT_PACK_PATH(w);
 #pragma unroll
-                for (int f = 0; f < (MAIN ? 19 : kWgcFields); ++f) q[f * kWgcDonate] = w[f];
+                for (int f = 0; f < kUsed; ++f) q[f * kWgcDonate] = w[f];
             }
             coop_stage_sync();                                                  // the states are in LDS ...
             if (lane == 0) flags[wave - 1] = (uint32_t) n;                      // ... before the count is published
@@ -674,36 +723,42 @@ struct CoopTracer {
                     lds_u32 *q = pool + w * (kWgcFields * kWgcDonate) + slot;
                     uint32_t v[kWgcFields];
 #pragma unroll
-                    for (int k = 0; k < kWgcFields; ++k) v[k] = (MAIN && k >= 19) ? 0u : q[k * kWgcDonate];
-                    ray.o = v3(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]));
-                    ray.d = v3(__uint_as_float(v[3]), __uint_as_float(v[4]), __uint_as_float(v[5]));
-                    ray.maxt = __uint_as_float(v[6]);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        beta[k] = __uint_as_float(v[7 + k]); result[k] = __uint_as_float(v[10 + k]);
-                        tl.alb[k] = __uint_as_float(v[23 + k]); tl.wadj[k] = __uint_as_float(v[26 + k]); tl.nee[k] = __uint_as_float(v[29 + k]);
-                    }
-                    S.state = ((uint64_t) v[14] << 32) | v[13];
-                    S.inc = ((uint64_t) v[16] << 32) | v[15];
-                    depth = (int) v[17];
-                    escaped = (v[18] & 1u) != 0u; has_scattered = (v[18] & 2u) != 0u;
-                    if constexpr (MAIN) {
-                        home = (int) ((v[18] >> 8) & 255u); it = (int) (v[18] >> 16);
-                        last_pdf = has_scattered ? kInvFourPi : 1.0f;
-                        pc = P.path_cache_mode == 1 ? P.path_cache + (size_t) (i_block + (uint64_t) home) * P.path_cache_cap * 2 : nullptr;
-                    }
-                    tl.p = v3(__uint_as_float(v[19]), __uint_as_float(v[20]), __uint_as_float(v[21]));
-                    tl.sig = __uint_as_float(v[22]);
-                    job = active = true;
+                    for (int k = 0; k < kWgcFields; ++k) v[k] = k < kUsed ? q[k * kWgcDonate] : 0u;
+                    DRT_UNPACK_PATH(v);
                 }
                 taken |= 1u << w;
                 am = __ballot(active);
                 n = __popcll(am);
             }
+            if (!MAIN && taken == 7u && n > 0 && n <= DRT_TAIL_PUSH && P.tail_pool && !P.tail_mode) {
+                // the workgroup's last few paths: to the tail pool, if it has room
+                uint32_t base = 0xffffffffu;
+                if (lane == 0) {
+                    base = atomicAdd(P.tail_count, (uint32_t) n);
+                    if (base + (uint32_t) n > P.tail_cap) { atomicSub(P.tail_count, (uint32_t) n); base = 0xffffffffu; }
+                }
+                base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                if (base != 0xffffffffu) {
+                    if (active) {
+                        DRT_PACK_PATH(w);
+                        uint32_t ww[kWgcFields];
+#pragma unroll
+                        for (int f = 0; f < kWgcFields; ++f) ww[f] = w[f];
+                        if constexpr (MAIN) ww[19] = (uint32_t) (i_block + (uint64_t) (uint32_t) home);   // the tail launch has i_block = 0
+                        uint4 *dst = P.tail_pool + (size_t) (base + (uint32_t) __popcll(am & ((1ull << lane) - 1ull))) * 8;
+#pragma unroll
+                        for (int q = 0; 4 * q < kUsed; ++q) dst[q] = make_uint4(ww[4 * q], ww[4 * q + 1], ww[4 * q + 2], ww[4 * q + 3]);
+                    }
+                    job = active = false;
+                    return false;
+                }
+            }
             if (n > 0) return true;
             if (taken == 7u) return false;
             __builtin_amdgcn_s_sleep(16);                                       // nothing to do until another wave publishes
         }
+#undef DRT_PACK_PATH
+#undef DRT_UNPACK_PATH
     }
 
     // VolpathSimpleIntegrator.sample (volpathsimple.py:38-290); `job`: this lane carries a ray

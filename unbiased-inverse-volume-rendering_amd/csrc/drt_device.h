@@ -290,6 +290,11 @@ struct Params {
     uint4 *path_cache;
     uint32_t *ray_hash;
     uint32_t path_cache_cap, path_cache_mode;
+    // tail pool of the specialised cooperative kernels (CoopTracer::wg_handoff): the last <= kTailPush live paths of a
+    // workgroup are written here (32 words each) and finished by a second, dense launch of the same kernel in tail mode
+    uint4 *tail_pool;              // [tail_cap][8] uint4 or nullptr
+    uint32_t *tail_count;          // entries written (zeroed before the main launch)
+    uint32_t tail_cap, tail_mode;  // capacity in entries; 1 = this launch finishes the pool's paths
     unsigned long long *queues;     // 8 per-XCD ray queue heads (wavefront kernel), zeroed per launch
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
