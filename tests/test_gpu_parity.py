@@ -553,7 +553,8 @@ def test_production_library_has_no_test_hooks(uivr, gpu):
 @pytest.mark.parametrize("factor", [0, 4])
 def test_workgroup_handoff_of_recursive_paths(uivr, oracle, gpu, factor):
     """The specialised kernels hand the last live paths of waves 1..3 (primal: main paths; adjoint: recursive DRT paths)
-    to wave 0 through LDS (CoopTracer::wg_handoff) - a schedule, not a result: with the hand-off (production) and
+    to wave 0 through LDS (CoopTracer::wg_handoff), and the adjoint sends each workgroup's last recursive paths to a
+    global pool that a second launch finishes - schedules, not results: with the hand-off (production) and
     without it (debug bits 33554432 / 67108864, test-hooks flavour) radiance is bit-exact and the gradients are the
     oracle's.  A sparse medium, so that waves do run dry early."""
     rng = np.random.default_rng(21)
@@ -570,7 +571,7 @@ def test_workgroup_handoff_of_recursive_paths(uivr, oracle, gpu, factor):
     sg = uivr.scene_to(scene, gpu)
     got = {}
     for name, hooks, flags in (("production", False, 0), ("hand-off", True, 0), ("no hand-off", True, 33554432),
-                               ("adjoint hand-off only", True, 67108864)):
+                               ("adjoint hand-off only", True, 67108864), ("hand-off, 8 MB record budget: many sub-batches", True, 16384)):
         integ = _integrator(uivr, props, hooks=hooks)
         if hooks:
             integ.native_handle(sg).set_debug_flags(flags)
