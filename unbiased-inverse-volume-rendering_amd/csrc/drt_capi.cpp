@@ -252,12 +252,12 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     const bool wavefront = sm_primal || sm_adjoint;
     const bool coop = !wavefront && !dbg(h->debug_flags, (adjoint ? 32768u : 8u));
     if (coop) {
-        // tail pool: room for 1/16 of the launch's rays (a workgroup sends at most 16 of its 256), kept while it is big enough;
+        // tail pool: room for 1/8 of the launch's rays (a workgroup sends at most DRT_TAIL_PUSH = 24 of its 256; a full pool only means that the rest stays where it is), kept while it is big enough;
         // without it (allocation failed) the kernels simply finish every path where it is
         drt::Params PT = P;
         PT.tail_pool = nullptr; PT.tail_count = nullptr; PT.tail_cap = 0; PT.tail_mode = 0;
         if (adjoint && !P.mgrid && P.n_rays > P.ray_first) {
-            const size_t want = (((size_t) (P.n_rays - P.ray_first) / 16 + 255) / 256) * 256;
+            const size_t want = (((size_t) (P.n_rays - P.ray_first) / 8 + 255) / 256) * 256;
             if (want > h->tail_entries) {
                 if (h->d_tail) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_tail); h->d_tail = nullptr; h->tail_entries = 0; }
                 if (hipMalloc(&h->d_tail, 256 + want * 128) == hipSuccess) h->tail_entries = want; else { (void) hipGetLastError(); h->d_tail = nullptr; }

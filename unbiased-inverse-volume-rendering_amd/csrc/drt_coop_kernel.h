@@ -178,7 +178,7 @@ hipError_t launch_trace_coop_t(const Params &P, bool adjoint, bool count, hipStr
     if (!tail) M.tail_pool = nullptr;
     M.tail_mode = 0;
     const dim3 tgrid(tail ? P.tail_cap / 256u : 1u);
-    // (pool capacity = 1/16 of the launch's rays; the tail kernel's surplus workgroups return at once)
+    // (pool capacity = 1/8 of the launch's rays; the tail kernel's surplus workgroups return at once)
     if (spec && !adjoint) {
         if (env) hipLaunchKernelGGL((trace_coop_kernel<false, false, true, false, true, SUPER>), grid, block, 0, stream, M);
         else hipLaunchKernelGGL((trace_coop_kernel<false, false, false, false, true, SUPER>), grid, block, 0, stream, M);

@@ -42,7 +42,7 @@
 #define DRT_WGC_DONATE 16          // live recursive paths at or below which a wave hands them to wave 0 (wg_handoff; swept 8 / 16 / 21 / 32 / 48: 6.36 / 6.17 / 6.17 / 6.18 / 6.44 ms)
 #endif
 #ifndef DRT_TAIL_PUSH
-#define DRT_TAIL_PUSH 16           // live recursive paths at or below which a workgroup's last wave sends them to the tail pool (4 / 8 / 16 / 32: 6.13 / 5.96 / 5.85 / 6.25 ms)
+#define DRT_TAIL_PUSH 24           // live recursive paths at or below which a workgroup's last wave sends them to the tail pool (4 / 8 / 16 / 24 / 32 / 64: 6.13 / 5.96 / 5.85 / 5.75 / 5.76 / 5.73 ms)
 #endif
 #ifndef DRT_COOP_MAXM
 #define DRT_COOP_MAXM 8        // candidate steps per walk and round = chain length (swept 4 / 8 / 16: 11.7 / 11.0 / 11.5 ms)
