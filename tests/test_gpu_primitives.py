@@ -181,3 +181,19 @@ def test_grad_block_mask_matches_definition(uivr, gpu, block):
         assert bool((mask[n_blocks:] == 7).all())
     with pytest.raises(RuntimeError):
         native().grad_block_mask(0, dev_body.data_ptr(), 1, 96, mask.data_ptr())
+
+
+@pytest.mark.parametrize("spp", [1, 7, 32, 128, 200, 1024])
+def test_film_develop_is_the_sample_mean(uivr, gpu, spp):
+    """Box film (python/batched.py:176-197): image = mean over the pixel's samples - the thread-per-channel kernel
+    (few samples) and the wave-per-pixel kernel (>= 128 samples: the optimisation loop's 1024) against float64."""
+    scene = uivr.scene_to(uivr.cube_test_scene(8, 8), gpu)
+    integ = uivr.load_dict({"type": "volpathsimple"})
+    n_pix = 37
+    gen = torch.Generator().manual_seed(spp)
+    L = (torch.rand(n_pix * spp, 3, generator=gen) * 3.0).to(gpu)
+    img = integ.develop(scene, L, spp)
+    want = L.view(n_pix, spp, 3).double().mean(dim=1)
+    assert tuple(img.shape) == (n_pix, 3)
+    assert float((img.double() - want).abs().max()) <= 2e-6 * 3.0
+    torch.testing.assert_close(img, integ.develop(scene, L, spp), rtol=0, atol=0)        # deterministic

