@@ -215,6 +215,12 @@ int drt_film_backward(drt_handle h, const float *grad_image, uint64_t n_pixels, 
  * blocks that are non-zero on some rank - the reference is single-GPU, this replaces nothing in it. */
 int drt_grad_block_mask(void *hip_stream, const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask);
 
+/* One Adam step on a parameter grid in a single pass (no handle; N2: mi.ad.Adam as python/optimize.py:329,352-354 uses it):
+ * m = beta_1 m + (1 - beta_1) g;  v = beta_2 v + (1 - beta_2) g^2;  p -= lr_t m / (sqrt(v) + epsilon), where the caller folds the
+ * bias corrections into lr_t = lr sqrt(1 - beta_2^t) / (1 - beta_1^t).  All four buffers: n floats, 16-byte aligned. */
+int drt_adam_step(void *hip_stream, float *p, const float *g, float *m, float *v, uint64_t n, double beta_1, double beta_2,
+                  double epsilon, double lr_t);
+
 /* Event counting (off by default; enabling selects a counting build of the kernels). */
 int drt_enable_counters(drt_handle h, int enable);
 int drt_reset_counters(drt_handle h);

@@ -148,3 +148,27 @@ def test_run_optimization_parameter_key_subsets(uivr, gpu, keys, int_name, tmp_p
     # the stride checkpoint is written although checkpoint_initial is off (util.py:57 always creates the directory)
     import os
     assert any(f.startswith("00000002-") for f in os.listdir(tmp_path / "out" / "params"))
+
+
+def test_fused_adam_step_equals_elementwise_sequence(uivr, gpu):
+    """drt_adam_step (one pass over p, g, m, v) against the same update written as torch elementwise ops - the
+    sequence the CPU path of `Adam.step` runs - for sizes that are and are not multiples of four; unaligned buffers
+    are refused."""
+    native = uivr._native.native
+    gen = torch.Generator().manual_seed(3)
+    for n in (1, 3, 4, 1023, 4099):
+        p = torch.rand(n, generator=gen).to(gpu); g = torch.randn(n, generator=gen).to(gpu)
+        m = (torch.randn(n, generator=gen) * 0.1).to(gpu); v = (torch.rand(n, generator=gen) * 0.01).to(gpu)
+        b1, b2, eps, lr_t = 0.9, 0.999, 1e-8, 3.1e-3
+        pe, me, ve = p.clone(), m.clone(), v.clone()
+        me.mul_(b1).add_(g, alpha=1 - b1)
+        ve.mul_(b2).addcmul_(g, g, value=1 - b2)
+        pe.addcdiv_(me, ve.sqrt().add_(eps), value=-lr_t)
+        native().adam_step(torch.cuda.current_stream().cuda_stream, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, b1, b2, eps, lr_t)
+        # (torch may contract m * b1 + a * g into an fma: the two agree to an ulp or two)
+        torch.testing.assert_close(m, me, rtol=1e-6, atol=2e-8)
+        torch.testing.assert_close(v, ve, rtol=1e-6, atol=2e-9)
+        torch.testing.assert_close(p, pe, rtol=0, atol=2e-7)
+    big = torch.zeros(64, device=gpu)
+    with pytest.raises(RuntimeError):
+        native().adam_step(0, big.data_ptr() + 4, big.data_ptr(), big.data_ptr(), big.data_ptr(), 8, 0.9, 0.999, 1e-8, 1e-3)

@@ -1081,6 +1081,14 @@ int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t s
     return DRT_OK;
 }
 
+int drt_adam_step(void *hip_stream, float *p, const float *g, float *m, float *v, uint64_t n, double beta_1, double beta_2,
+                  double epsilon, double lr_t)
+{
+    if (n && (!p || !g || !m || !v)) return DRT_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t) p | (uintptr_t) g | (uintptr_t) m | (uintptr_t) v) % 16) return DRT_ERR_INVALID_ARGUMENT;
+    return drt::launch_adam_step(p, g, m, v, n, beta_1, beta_2, epsilon, lr_t, (hipStream_t) hip_stream) == hipSuccess ? DRT_OK : DRT_ERR_HIP;
+}
+
 int drt_grad_block_mask(void *hip_stream, const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask)
 {
     if (n_blocks && (!buf || !mask)) return DRT_ERR_INVALID_ARGUMENT;

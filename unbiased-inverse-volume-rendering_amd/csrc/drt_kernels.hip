@@ -1070,6 +1070,42 @@ hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, 
     return hipGetLastError();
 }
 
+// One Adam step in one pass over (p, g, m, v) (N2; mi.ad.Adam as optimize.py:329,352 uses it):
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr_t m / (sqrt(v) + eps)      (lr_t carries the bias corrections)
+// instead of seven elementwise passes: 0.55 -> 0.2 ms per step for the 256^3 x (1 + 3) parameters.
+__global__ void __launch_bounds__(256) adam_step_kernel(float *p, const float *g, float *m, float *v, uint64_t n,
+                                                        float b1, float a1, float b2, float a2, float eps, float lr_t)
+{
+    const uint64_t stride = (uint64_t) gridDim.x * 256;
+    const uint64_t n4 = n / 4;
+    float4 *p4 = reinterpret_cast<float4 *>(p), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    auto upd = [&](float &pp, float gg, float &mm, float &vv) {
+        mm = mm * b1 + a1 * gg;
+        vv = vv * b2 + a2 * (gg * gg);
+        pp = pp - lr_t * (mm / (sqrtf(vv) + eps));
+    };
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 P = p4[i], M = m4[i], V = v4[i]; const float4 G = g4[i];
+        upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
+        p4[i] = P; m4[i] = M; v4[i] = V;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const uint64_t i = n4 * 4 + threadIdx.x; upd(p[i], g[i], m[i], v[i]); }
+}
+
+hipError_t launch_adam_step(float *p, const float *g, float *m, float *v, uint64_t n, double b1, double b2, double eps, double lr_t,
+                            hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t n4 = n / 4;
+    unsigned blocks = (unsigned) ((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    if (blocks == 0) blocks = 1;
+    // (1 - beta in double, THEN to float: 1.0f - 0.999f is off by 1.3e-5 relative)
+    hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, (float) b1, (float) (1.0 - b1), (float) b2,
+                       (float) (1.0 - b2), (float) eps, (float) lr_t);
+    return hipGetLastError();
+}
+
 // Which blocks of a gradient buffer hold anything but zeros (distributed.py: the compacted all-reduce).
 // One float4 per lane: a wave-wide load covers 256 floats = 256 / BLOCK blocks; NaN / inf count as non-zero.
 template <int BLOCK>

@@ -61,6 +61,8 @@ hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t
 hipError_t launch_batch_raygen(const float *sensors, int n_sensors, uint32_t batch_first, uint32_t batch_size, uint32_t spp,
                                uint32_t seed_pixels, uint32_t seed_rays, float *rays_o, float *rays_d, uint32_t *sensor_idx,
                                uint32_t *pixels, hipStream_t stream);
+hipError_t launch_adam_step(float *p, const float *g, float *m, float *v, uint64_t n, double b1, double b2, double eps, double lr_t,
+                            hipStream_t stream);
 hipError_t launch_block_mask(const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask, hipStream_t stream);
 hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, float *image,
                                hipStream_t stream);
