@@ -15,6 +15,7 @@ from uivr_amd import synthetic
 
 dev = torch.device("cuda", 0)
 scene = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+scene.medium.majorant_resolution_factor = int(os.environ.get("DRT_PROFILE_FACTOR", "0"))     # 8: the supergrid kernels
 spp = 32
 sensor = scene.sensors[0]
 integ = u.get_int_config("volpathsimple-drt").create(max_depth=64)
