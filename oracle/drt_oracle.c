@@ -614,8 +614,11 @@ static float sample_collision(const scene_t *sc, v3 o, v3 d, float tmax, float u
         float dg = (dd[a] * ie[a]) * (float) G[a];
         float fl = fminf(fmaxf(floorf(g), 0.0f), (float)(G[a] - 1));
         cell[a] = (int) fl;
-        if (dg > 0.0f) { tnext[a] = ((fl + 1.0f) - g) / dg; tdelta[a] = 1.0f / dg; step[a] = 1; }
-        else if (dg < 0.0f) { tnext[a] = (fl - g) / dg; tdelta[a] = -1.0f / dg; step[a] = -1; }
+        /* crossing times: tdelta = 1/|dg| (one division per axis: d is the same for every flight of a walk), first
+         * crossing = distance to the next plane in cells * tdelta.  |dg| < 1e-20: the ray cannot cross a plane of this
+         * axis inside the box - parallel (keeps every crossing time finite or +inf, never NaN) */
+        if (dg >= 1e-20f) { tdelta[a] = 1.0f / dg; tnext[a] = ((fl + 1.0f) - g) * tdelta[a]; step[a] = 1; }
+        else if (dg <= -1e-20f) { tdelta[a] = 1.0f / -dg; tnext[a] = (g - fl) * tdelta[a]; step[a] = -1; }
         else { tnext[a] = INFINITY; tdelta[a] = INFINITY; step[a] = 0; }
     }
     float t = 0.0f, acc = 0.0f;

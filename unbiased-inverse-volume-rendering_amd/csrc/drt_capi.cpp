@@ -247,6 +247,22 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
 #ifndef DRT_SUPER_COOP_PRIMAL
 #define DRT_SUPER_COOP_PRIMAL 0     // experiment: 1 = the supergrid primal runs in CoopTracer<SUPER> too (measured slower)
 #endif
+    // supergrid scenes: the cell-stepping state machine (drt_super.hip) for both passes; bit 134217728 keeps the older
+    // kernels (state machine of whole flights for the primal, one ray per lane for the adjoint) for the variant tests
+    const bool super = P.mgrid && !quadratic && !dbg(h->debug_flags, (134217728u | 8u | 32u | 32768u | 65536u)) &&
+                       (!adjoint || P.rec_buf[0] != nullptr) && drt::super_supported(P);
+    if (super) {
+        drt::Params Q = P;
+        Q.queues = h->d_queues;
+        Q.ray_perm = nullptr; Q.block_order = nullptr;
+        DRT_HIP_CHECK(h, hipMemsetAsync(h->d_queues, 0, 8 * sizeof(unsigned long long), h->stream));
+        DRT_HIP_CHECK(h, drt::launch_trace_super(Q, adjoint, h->counting, h->n_cus, h->stream));
+        if (h->timing) {
+            DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
+            h->timed[which].emplace_back(a, b);
+        }
+        return DRT_OK;
+    }
     const bool sm_primal = !adjoint && ((P.mgrid != nullptr && !DRT_SUPER_COOP_PRIMAL) || dbg(h->debug_flags, 65536u)) && !dbg(h->debug_flags, 8u);
     const bool sm_adjoint = adjoint && dbg(h->debug_flags, 32u) && !quadratic && !dbg(h->debug_flags, 8u);
     const bool wavefront = sm_primal || sm_adjoint;

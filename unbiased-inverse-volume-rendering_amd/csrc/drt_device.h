@@ -468,15 +468,17 @@ __device__ __forceinline__ float dda_collision(const Params &P, const float *mg,
     float fly = fminf(fmaxf(floorf(gyf), 0.0f), (float)(P.gy - 1));
     float flz = fminf(fmaxf(floorf(gzf), 0.0f), (float)(P.gz - 1));
     int cx = (int) flx, cy = (int) fly, cz = (int) flz;
+    // crossing times: td = 1 / |dg| (the same for every flight of a walk), first crossing = cells to the next plane * td;
+    // |dg| < 1e-20: parallel (every crossing time stays finite or +inf) - as oracle/drt_oracle.c sample_collision
     float tnx, tny, tnz, tdx, tdy, tdz; int sx, sy, sz;
-    if (dgx > 0.0f) { tnx = ((flx + 1.0f) - gxf) / dgx; tdx = 1.0f / dgx; sx = 1; }
-    else if (dgx < 0.0f) { tnx = (flx - gxf) / dgx; tdx = -1.0f / dgx; sx = -1; }
+    if (dgx >= 1e-20f) { tdx = 1.0f / dgx; tnx = ((flx + 1.0f) - gxf) * tdx; sx = 1; }
+    else if (dgx <= -1e-20f) { tdx = 1.0f / -dgx; tnx = (gxf - flx) * tdx; sx = -1; }
     else { tnx = kInf; tdx = kInf; sx = 0; }
-    if (dgy > 0.0f) { tny = ((fly + 1.0f) - gyf) / dgy; tdy = 1.0f / dgy; sy = 1; }
-    else if (dgy < 0.0f) { tny = (fly - gyf) / dgy; tdy = -1.0f / dgy; sy = -1; }
+    if (dgy >= 1e-20f) { tdy = 1.0f / dgy; tny = ((fly + 1.0f) - gyf) * tdy; sy = 1; }
+    else if (dgy <= -1e-20f) { tdy = 1.0f / -dgy; tny = (gyf - fly) * tdy; sy = -1; }
     else { tny = kInf; tdy = kInf; sy = 0; }
-    if (dgz > 0.0f) { tnz = ((flz + 1.0f) - gzf) / dgz; tdz = 1.0f / dgz; sz = 1; }
-    else if (dgz < 0.0f) { tnz = (flz - gzf) / dgz; tdz = -1.0f / dgz; sz = -1; }
+    if (dgz >= 1e-20f) { tdz = 1.0f / dgz; tnz = ((flz + 1.0f) - gzf) * tdz; sz = 1; }
+    else if (dgz <= -1e-20f) { tdz = 1.0f / -dgz; tnz = (gzf - flz) * tdz; sz = -1; }
     else { tnz = kInf; tdz = kInf; sz = 0; }
     float t = 0.0f, acc = 0.0f;
     for (;;) {
@@ -822,6 +824,54 @@ __device__ __forceinline__ void emit_record(const Params &P, V3 p, float v0, con
 #pragma unroll
             for (int k = 0; k < 3; ++k) if (c[k] != 0.0f) splat_direct(P, 1 + k, p, c[k]);
         }
+    }
+}
+
+// N records of stream 0 per active lane with ONE reservation (the four resampled points of
+// backpropagate_transmittance, volpathsimple.py:584-607: one cursor transaction instead of four; a lane's records are
+// consecutive slots, 64 contiguous bytes, unless the reservation straddles two chunk groups)
+template <int N>
+__device__ __forceinline__ void emit_records0(const Params &P, const V3 (&p)[N], float v0, uint32_t *st_)
+{
+    lds_u32 *st = (lds_u32 *) st_;
+    const uint64_t mask = __ballot(1);
+    const uint32_t lane = __lane_id();
+    const uint32_t rank = (uint32_t) __popcll(mask & ((1ull << lane) - 1ull)) * N;
+    const uint32_t n = (uint32_t) __popcll(mask) * N;
+    uint32_t base0 = 0, base1 = 0, split = 0;
+    if (rank == 0) {
+        const uint32_t cur = st[0], end = st[4];
+        base0 = cur;
+        if (cur + n <= end) { split = n; st[0] = cur + n; }
+        else {
+            split = end - cur;
+            constexpr uint32_t G = rec_group(0);
+            if (end) {                                                              // the open chunks are full
+                const uint32_t last = (end - 1u) / kRecChunk;
+                for (uint32_t j = 0; j < G; ++j) P.rec_chunk_count[0][last - j] = kRecChunk;
+            }
+            const uint32_t ch = atomicAdd(P.rec_cursor, G);
+            if (ch + G <= P.rec_cap_chunks[0]) {
+                base1 = ch * kRecChunk;
+                st[0] = base1 + (n - split); st[4] = base1 + G * kRecChunk;
+            } else {
+                base1 = 0xffffffffu;                                                // out of chunks
+                st[0] = end;
+                atomicAdd(P.rec_cursor + 4, n - split);
+            }
+        }
+    }
+    base0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base0);
+    base1 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base1);
+    split = (uint32_t) __builtin_amdgcn_readfirstlane((int) split);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const uint32_t r = rank + (uint32_t) j;
+        uint32_t slot = 0xffffffffu;
+        if (r < split) slot = base0 + r;
+        else if (base1 != 0xffffffffu) slot = base1 + (r - split);
+        if (slot != 0xffffffffu) P.rec_buf[0][slot] = make_float4(p[j].x, p[j].y, p[j].z, v0);
+        else splat_direct(P, 0, p[j], v0);
     }
 }
 

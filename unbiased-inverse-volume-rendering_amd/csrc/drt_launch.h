@@ -16,6 +16,10 @@ hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int 
                               hipStream_t stream);
 hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
+// supergrid scenes (majorant_resolution_factor > 0): lane-level state machine stepping one supergrid cell at a time, the
+// majorant grid in LDS (drt_super.hip); the adjoint needs the record streams (deferred splatting)
+bool super_supported(const Params &P);
+hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
 // one ray per lane with wave-cooperative tracking loops (drt_coop.hip); global majorant only (P.mgrid == nullptr)
 hipError_t launch_trace_coop_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStream_t stream);
