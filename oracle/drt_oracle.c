@@ -1188,6 +1188,12 @@ static int scene_init(scene_t *sc, const drto_job *job)
             for (int z = lo[2]; z <= hi[2]; ++z) for (int y = lo[1]; y <= hi[1]; ++y) for (int x = lo[0]; x <= hi[0]; ++x)
                 mxc = fmaxf(mxc, m->sigma_t[((size_t) z * R[1] + y) * R[0] + x]);
             float mm = mxc * m->scale;
+            {   /* rounded UP to the next bf16-representable value: a majorant only has to bound (at most 0.8 % looser),
+                 * and the device keeps the supergrid as 16-bit values in on-chip memory */
+                uint32_t b; memcpy(&b, &mm, 4);
+                if (b & 0xffffu) b = (b | 0xffffu) + 1u;
+                memcpy(&mm, &b, 4);
+            }
             float *dst = sc->mgrid + 2 * (size_t)((K * G[1] + J) * G[0] + I);
             dst[0] = mm; dst[1] = mm != 0.0f ? 1.0f / mm : 0.0f;
         }

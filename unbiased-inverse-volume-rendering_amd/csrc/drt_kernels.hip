@@ -628,7 +628,7 @@ __global__ void majorant_finalize_kernel(const uint32_t *max_bits, float scale, 
 }
 
 // Majorant supergrid: cell (I,J,K) = scale * max over the voxels a trilinear lookup inside the
-// cell can touch, padded by one voxel: [floor(I*res/G) - 1, ceil((I+1)*res/G)] per axis, clamped.
+// cell can touch, padded by one voxel: [floor(I*res/G) - 1, ceil((I+1)*res/G)] per axis, clamped; rounded up to bf16.
 // One wavefront per cell.
 __global__ void __launch_bounds__(256) majorant_grid_kernel(const float *sigma_t, int rx, int ry, int rz,
                                                             int gx, int gy, int gz, float scale, float *out, uint32_t *mask)
@@ -648,8 +648,13 @@ __global__ void __launch_bounds__(256) majorant_grid_kernel(const float *sigma_t
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
     if (lane == 0) {
-        out[cell] = m * scale;
-        if (mask && m * scale > 0.0f) atomicOr(mask + (cell >> 5), 1u << (cell & 31u));   // (mask zeroed by the launcher)
+        // rounded UP to the next bf16-representable value (a majorant only has to bound; at most 0.8 % looser): the
+        // supergrid tracer keeps the cells as 16-bit values in LDS (drt_super.hip) - as oracle/drt_oracle.c scene_init
+        uint32_t b = __float_as_uint(m * scale);
+        if (b & 0xffffu) b = (b | 0xffffu) + 1u;
+        const float mm = __uint_as_float(b);
+        out[cell] = mm;
+        if (mask && mm > 0.0f) atomicOr(mask + (cell >> 5), 1u << (cell & 31u));   // (mask zeroed by the launcher)
     }
 }
 

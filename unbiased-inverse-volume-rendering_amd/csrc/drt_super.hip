@@ -1,53 +1,62 @@
 // drt_super.hip -- the tracer for scenes with a majorant supergrid (majorant_resolution_factor > 0, the reference's
 // default: python/scene_config.py:36, optimize.py:182-199): VolpathSimpleIntegrator.sample
-// (python/integrators/volpathsimple.py:38-655), both AD modes, as a lane-level state machine whose micro-step is ONE
-// SUPERGRID CELL of a free flight.
+// (python/integrators/volpathsimple.py:38-655), both AD modes.
 //
-// Why (measured): with a supergrid a tracking step is a 3-D DDA through 1..60 cells (mean 12.6,
-// bimodal) followed by one grid lookup, and a walk is ~25 cells but only 0.7..2 lookups: 80 % of the work is cell
-// stepping.  The one-ray-per-lane tracer ran it at 11.8 % VALU lane utilisation (every lane waits for the longest flight
-// of the few lanes that have one), the older state machine (drt_wavefront.hip, one whole flight per step) at 18 %.
-// Here every lane is a state machine with three kinds of work,
-//   (D) one cell of its current flight            - the hot loop, ~30 instructions, majorants read from LDS,
-//   (F) a flight boundary                          - the collision a flight ended in (grid lookup, acceptance / ratio /
-//                                                    reservoir epilogue of its walk) and the set-up of the next flight,
-//   (B) a path transition                          - scatter / escape / emitter sampling / end of path ...,
-// and the wavefront runs ONE flat loop in which (F) and (B) are executed only when enough lanes wait for them (ballot /
-// popcount thresholds) or nothing else can run, while (D) runs for whoever is in flight.  Lanes that finish a ray pull
-// the next one from their XCD's queue, so a wavefront is never held hostage by its longest path.
+// Why (measured): with a supergrid a tracking step is a free flight through 1..60 supergrid cells
+// (3-D DDA; mean 12.6, bimodal) followed by one grid lookup, and a walk is ~25 cells but only 0.7..2 lookups: most of
+// the work is cell stepping, in flights whose lengths have nothing to do with each other.  The one-ray-per-lane tracer
+// ran it at 11.8 % VALU lane utilisation (every lane waits for the longest flight of the few lanes that have one), a
+// state machine with one whole flight per step (drt_wavefront.hip) at 18 %, a state machine with one CELL per step in
+// which every wave mixes cell steps, flight boundaries and path transitions at 23-30 % (lanes that wait for a batched
+// block still occupy the wave's issue slots).
 //
-// One workgroup of DRT_SUPER_THREADS threads per CU: the whole majorant supergrid (32^3 floats = 128 KiB for a 256^3
-// grid at factor 8) sits in that workgroup's LDS - gfx950 has 160 KiB per CU and lets one workgroup take all of it -
-// so the DDA never touches global memory.  Larger supergrids keep their non-empty-cell bitmask in LDS and load the
+// Here the kinds of work are sorted INSIDE A COMPUTE UNIT, through LDS.  One workgroup per CU:
+//   * the majorant supergrid lives in its LDS as bf16 (rounded UP when the grid is built - a majorant only has to bound -:
+//     32^3 cells = 64 KiB for a 256^3 grid at factor 8) - the DDA never touches global memory;
+//   * every lane holds one ray as a small state machine (registers) and owns one FLIGHT SLOT in LDS (12 words of DDA
+//     state).  A wave does the irregular per-ray work in batches - "heavy runs": the collision a flight ended in (grid
+//     lookup + the walk's acceptance / ratio / reservoir epilogue), path transitions (scatter / escape / emitter
+//     sampling / end of path / next ray), the set-up of the next flight, which is then POSTED: slot written, bit set in
+//     the wave's ready mask - and only when enough of its lanes have something to do;
+//   * whenever it has too few such lanes, a wave WALKS instead: it pulls up to 64 posted flights out of the ready masks -
+//     whoever posted them -, steps each through DRT_SUPER_K supergrid cells (~30 branch-free instructions per cell,
+//     majorants from LDS), writes the DDA state back and either marks the flight done in its owner's done mask ({entry
+//     distance, optical depth, majorant} of the cell it ended in) or posts it again.  Walking is stateless - nothing of a
+//     flight stays in registers - so cell steps always run on densely filled waves, lanes that wait for a heavy run cost
+//     no issue slots, and every wave of the CU shares the load.
+// Lanes that finish a ray pull the next one from their XCD's queue.
+//
+// Larger supergrids (the majorants do not fit next to the slots) keep their non-empty-cell bitmask in LDS and load the
 // majorants of non-empty cells from L2 (template flag MGL = false).
 //
 // Arithmetic, random-number consumption and event counts are those of the scalar restatement (oracle/drt_oracle.c):
 // radiance is bit-exact per ray, counters are equal; gradients differ by summation order only.  The adjoint emits its
 // splats as records (drt_deferred.hip) and reads the path cache its primal pass wrote.  Not handled here (the host
 // keeps the one-ray-per-lane kernels for them): quadratic DRT (use_drt && !use_drt_subsampling), the atomic gradient
-// path, supergrids with more than 1023 cells along an axis.
+// path, supergrids with more than 511 cells along an axis.
 #include "drt_device.h"
 #include "drt_launch.h"
 
 #ifndef DRT_SUPER_THREADS
-#define DRT_SUPER_THREADS 768      // primal pass: threads per workgroup = per CU (12 waves, 3 per SIMD: 168 registers; with
-                                   // 1024 threads = 128 registers it spills 60 B per lane: 5.2 vs 4.0 ms)
-#endif
-#ifndef DRT_SUPER_THREADS_ADJ
-#define DRT_SUPER_THREADS_ADJ 768  // adjoint pass: its state wants 178 registers; 768 threads (168 registers, 32 B of scratch):
-                                   // 8.3 ms, 512 threads (no scratch): 9.6 ms, 1024 threads (176 B of scratch): 14.1 ms
+#define DRT_SUPER_THREADS 768      // threads per workgroup = per CU: 12 waves, 3 per SIMD (168 registers)
 #endif
 #ifndef DRT_SUPER_K
-#define DRT_SUPER_K 2              // cells per lane and loop iteration
+#define DRT_SUPER_K 8              // cells per walker lane between two looks at the masks
 #endif
-#ifndef DRT_SUPER_FMIN
-#define DRT_SUPER_FMIN 20          // lanes waiting at a flight boundary before (F) runs
-#endif
-#ifndef DRT_SUPER_BMIN
-#define DRT_SUPER_BMIN 24          // lanes waiting at a path transition before (B) runs
+#ifndef DRT_SUPER_REFILL_MIN
+#define DRT_SUPER_REFILL_MIN 16    // free walker lanes before more flights are pulled
 #endif
 #ifndef DRT_SUPER_REGEN_MIN
-#define DRT_SUPER_REGEN_MIN 8      // idle lanes before the ray prologue runs
+#define DRT_SUPER_REGEN_MIN 16     // finished lanes of a path wave before it takes new rays
+#endif
+#ifndef DRT_SUPER_HMIN
+#define DRT_SUPER_HMIN 40          // lanes of a wave with something to do before it makes a heavy run (it walks otherwise)
+#endif
+#ifndef DRT_SUPER_BMIN
+#define DRT_SUPER_BMIN 12          // lanes of a wave waiting for a path transition before the transition blocks run
+#endif
+#ifndef DRT_SUPER_MAXPOLL
+#define DRT_SUPER_MAXPOLL 8        // ... or after this many polls with nothing to walk and at least one lane ready
 #endif
 #ifndef DRT_SUPER_CHUNK
 #define DRT_SUPER_CHUNK 128        // queue positions a wave reserves per refill (divides DRT_SUPER_RUN)
@@ -70,7 +79,15 @@ enum Phase : int {
     PH_HEAD, PH_SCAT, PH_ESC, PH_TR, PH_POST, PH_NEE, PH_RT_END, PH_RTA_END, PH_PHASE, PH_END, PH_DRT_END,
     PH_IDLE, PH_DEAD
 };
-enum Flight : int { FL_NEW = 0, FL_FLY = 1, FL_END = 2 };   // first flight of a walk to set up | in flight | flight ended
+enum Flight : int { FL_NEW = 0, FL_NEXT = 1, FL_WAIT = 2 };   // first flight of a walk to set up | next flight to set up | posted
+// flight slot: q0 = {tn.x, tn.y, tn.z, cell}, q1 = {td.x, td.y, td.z, steps left (9 bits per axis) + direction signs},
+// q2 = {tau, tmax, t, acc}; a finished flight leaves its cell's majorant (0: left the segment) in q0.x
+constexpr int kSlotWords = 12;
+
+// LDS of one wave is accessed through volatile LDS pointers: other waves write it
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+typedef __attribute__((address_space(3))) volatile unsigned long long lds_vu64;
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ uint32_t xcc_id()
 {
@@ -80,47 +97,53 @@ __device__ __forceinline__ uint32_t xcc_id()
 }  // namespace
 
 template <bool ADJ, bool COUNT, bool ENV, bool MGL>
-__global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREADS) trace_super_kernel(const Params P)
+__global__ void __launch_bounds__(DRT_SUPER_THREADS) trace_super_kernel(const Params P)
 {
+    constexpr int NWV = DRT_SUPER_THREADS / 64;                              // waves = 64-lane groups of flight slots
+    constexpr int NS = NWV * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    // LDS: [majorant grid (MGL) | non-empty-cell bitmask][empty-space bitmask of the voxel grid][record state per wave]
+    // LDS: [flight slots: 3 x uint4 each][majorants as bf16 (MGL) | non-empty-cell bitmask][record state per wave]
+    //      [ready masks: 2 words per wave][done masks][pull lists: 64 words per wave]
     const int n_cells = P.gx * P.gy * P.gz;
-    const int mg_words = MGL ? n_cells : P.mocc_words;
-    uint32_t *mg_lds = lds;
-    uint32_t *occ_lds = lds + ((mg_words + 3) & ~3);
-    uint32_t *rec_lds = occ_lds + kOccWords;
-    {
-        const uint32_t *src = MGL ? (const uint32_t *) P.mgrid : P.mocc;
-        for (int w = threadIdx.x; w < mg_words; w += blockDim.x) mg_lds[w] = src[w];
+    const int mg_words = MGL ? (n_cells + 1) / 2 : P.mocc_words;
+    uint4 *slot_lds = (uint4 *) lds;
+    uint32_t *mg_lds = lds + kSlotWords * NS;
+    uint32_t *rec_lds = mg_lds + ((mg_words + 3) & ~3);
+    unsigned long long *ready_lds = (unsigned long long *) (rec_lds + NWV * 8);   // (8-byte aligned: every part is a multiple of 4 words)
+    unsigned long long *done_lds = ready_lds + NWV;
+    uint32_t *list_lds = (uint32_t *) (done_lds + NWV);
+    if constexpr (MGL) {                                                     // (the grid's values are bf16-representable: exact)
+        for (int w = threadIdx.x; w < mg_words; w += blockDim.x) {
+            const uint32_t a = __float_as_uint(P.mgrid[2 * w]), b = 2 * w + 1 < n_cells ? __float_as_uint(P.mgrid[2 * w + 1]) : 0u;
+            mg_lds[w] = (a >> 16) | (b & 0xffff0000u);
+        }
+    } else {
+        for (int w = threadIdx.x; w < mg_words; w += blockDim.x) mg_lds[w] = P.mocc[w];
     }
-    const uint32_t *occ = nullptr;
-    if (P.occ) {
-        for (int w = threadIdx.x; w < P.occ_words; w += blockDim.x) occ_lds[w] = P.occ[w];
-        occ = occ_lds;
-    }
-    uint32_t *rec = rec_lds + (threadIdx.x >> 6) * 8;           // record-stream state of this wave (emit_record)
-    if ((threadIdx.x & 63) < 8) rec[threadIdx.x & 63] = 0;
+    for (int w = threadIdx.x; w < NWV * 12; w += blockDim.x) rec_lds[w] = 0;  // record state; ready + done masks
     __syncthreads();
+    const uint32_t *occ = nullptr;   // (tentative collisions lie in non-empty supergrid cells: the voxel bitmask would rarely say "empty")
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t xcc = xcc_id();
-    const uint64_t n_runs = (P.n_rays - P.ray_first + DRT_SUPER_RUN - 1) / DRT_SUPER_RUN;
-    // queue x serves the runs x, x + 8, ...; a wave starts on the queue of the XCD it runs on (L2 locality) and moves on
-    // to the next ones when that one is drained: every ray is traced whatever the placement of the workgroups
-    uint32_t qsel = 0, qx = xcc;
-    uint64_t my_len = (n_runs > qx ? (n_runs - qx + 7) / 8 : 0) * DRT_SUPER_RUN;
-    unsigned long long *queue = P.queues + qx;
-    uint64_t pool_next = 0, pool_end = 0;      // wave-uniform: this wave's reserved queue positions
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));   // (wave-uniform: tell the compiler, or every mask operation below becomes vector code)
+    lds_vu64 *ready = (lds_vu64 *) ready_lds, *done = (lds_vu64 *) done_lds;
+    lds_vu32 *list = (lds_vu32 *) list_lds + wave * 64;
+    const uint16_t *mg16 = (const uint16_t *) mg_lds;
     uint32_t cnt[C_COUNT];
 #pragma unroll
     for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
 #if DRT_SUPER_PROFILE
     // experiment build (tools/mk_variant.sh NAME -DDRT_SUPER_PROFILE=1): the counting kernels' slots hold, summed over waves,
-    // [1] loop iterations, [2] (B) runs, [3] lanes waiting when (B) ran, [4] (F) runs, [5] lanes served by (F), [6] (D) runs,
-    // [7] lanes in flight summed over the cell steps, [8] passes of (B)
+    // [1] polls, [2] heavy runs, [3] lanes with something to do when the wave ran, [4] lanes served by the flight epilogue,
+    // [5] lanes that posted a flight, [8] passes of the transition block, [6] pulls, [7] flights pulled, [0] cell steps taken
 #define DRT_COUNT(slot) do { } while (0)
-#define DRT_PROF(slot, v) do { if (COUNT && lane == 0) cnt[slot] += (uint32_t) (v); } while (0)
+#define DRT_PROF(slot, v) do { if (DRT_SUPER_PROFILE == 1 && COUNT && lane == 0) cnt[slot] += (uint32_t) (v); } while (0)
+    // DRT_SUPER_PROFILE=2: shader clock (units of 64 cycles) per wave spent - [1] polling / sleeping, [3] flight epilogue,
+    // [4] regeneration, [5] transitions, [8] flight set-up, [6] pulling flights, [7] cell steps + write-back; [2] heavy runs
+    uint64_t pt_last = __builtin_readcyclecounter();
+#define DRT_STAMP(slot) do { if (DRT_SUPER_PROFILE == 2 && COUNT) { const uint64_t t_ = __builtin_readcyclecounter(); if (lane == 0) cnt[slot] += (uint32_t) ((t_ - pt_last) >> 6); pt_last = t_; } } while (0)
 #else
+#define DRT_STAMP(slot) do { } while (0)
 #define DRT_COUNT(slot) do { if (COUNT) cnt[slot]++; } while (0)
 #define DRT_PROF(slot, v) do { } while (0)
 #endif
@@ -130,9 +153,23 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
     const float fgx = (float) gx, fgy = (float) gy, fgz = (float) gz;
     const int lin_y = gx, lin_z = gx * gy;
 
+    const int pw = wave;
+    const uint32_t my_slot = threadIdx.x;             // = 64 * wave + lane
+    uint32_t *rec = rec_lds + pw * 8;                                           // record-stream state of this wave (emit_record)
+    const uint32_t xcc = xcc_id();
+    const uint64_t n_runs = (P.n_rays - P.ray_first + DRT_SUPER_RUN - 1) / DRT_SUPER_RUN;
+    // queue x serves the runs x, x + 8, ...; a wave starts on the queue of the XCD it runs on (L2 locality) and moves on
+    // to the next ones when that one is drained: every ray is traced whatever the placement of the workgroups
+    uint32_t qsel = 0, qx = xcc;
+    uint64_t my_len = (n_runs > qx ? (n_runs - qx + 7) / 8 : 0) * DRT_SUPER_RUN;
+    unsigned long long *queue = P.queues + qx;
+    uint64_t pool_next = 0, pool_end = 0;      // wave-uniform: this wave's reserved queue positions
+    int rr = wave;                             // wave whose ready mask is looked at first when pulling flights
+
     // ---- per-lane state ------------------------------------------------------------------------------
     // (registers are what limits this kernel's occupancy: state that is dead in some phase carries another phase's values)
     int ph = PH_IDLE, fl = FL_NEW;
+    // (the compiler keeps these as lane masks in scalar registers: packing them into a vector register costs more)
     bool rec_mode = false;          // detached recursive path of the DRT estimator (:610-655)
     bool rec_first = false;         // its first phase sample still has the :647 / :99 prologue to run
     bool escaped = false, has_scattered = false, scat_once = false;
@@ -158,23 +195,223 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
     float r_wsum[3] = { 0, 0, 0 }, r_cw[3] = { 0, 0, 0 };
     // path cache: bounce-loop iteration of this ray, steps of the current walk, cache usable for this ray
     int pc_it = 0; uint32_t pc_steps = 0; bool pc_on = false;
-    // flight (DDA) registers: next crossing time and crossing-time increment per axis, linear cell index and linear
-    // strides (0: parallel), steps left to the grid border (10 bits per axis), position / optical depth so far /
-    // target optical depth / end of the segment.  After the flight: f_t = distance (inf: left the segment), f_acc = the
-    // majorant it was sampled with.
-    float tnx = kInf, tny = kInf, tnz = kInf, tdx = kInf, tdy = kInf, tdz = kInf;
-    int cell = 0, sx = 0, sy = 0, sz = 0;
-    uint32_t rem = 0;
-    float f_t = 0.0f, f_acc = 0.0f, f_tau = 0.0f, f_tmax = 0.0f;
+    int polls = 0;                  // (wave-uniform) polls since this wave last ran
 
     for (;;) {
-        DRT_PROF(1, 1);
+        // ---- what can this wave do now? ---------------------------------------------------------------------
+        const bool walking = ph < PH_HEAD;
+        const unsigned long long dword = done[pw];
+        const bool back = walking && fl == FL_WAIT && ((dword >> lane) & 1ull) != 0ull;   // my flight's result is in my slot
+        // (finished lanes take new rays DRT_SUPER_REGEN_MIN at a time - the ray prologue is long - or when nothing else is left)
+        const uint64_t m_idle = __ballot(ph == PH_IDLE);
+        const bool regen_ok = __popcll(m_idle) >= DRT_SUPER_REGEN_MIN || !__ballot(ph < PH_IDLE);
+        // (path transitions are a dozen short blocks, each for the few lanes in its phase: they run when DRT_SUPER_BMIN
+        //  lanes wait for one, or when no flight of this wave is under way any more)
+        const uint64_t m_wait = __ballot(walking && fl == FL_WAIT && !back);
+        const uint64_t m_tr = __ballot(ph >= PH_HEAD && ph < PH_IDLE);
+        const bool trans_ok = __popcll(m_tr) >= DRT_SUPER_BMIN || !m_wait;
+        const bool can = back || (walking && fl != FL_WAIT) || (trans_ok && ph >= PH_HEAD && ph < PH_IDLE) || (regen_ok && ph == PH_IDLE);
+        const uint64_t m_can = __ballot(can);
+        if (!m_can && !m_wait) break;                                            // every lane is dead
+        if (__popcll(m_can) < DRT_SUPER_HMIN) {
+            // ================= walk: posted flights -> supergrid cells -> results ==============================
+            // The wave turns into a walker until enough of its own lanes have something to do: flights are pulled
+            // out of the ready masks (whoever posted them) into its free lanes, stepped DRT_SUPER_K cells at a time,
+            // and leave a result + a bit in their owner's done mask when they end; on the way out the flights that
+            // are still under way are written back to their slots and posted again.  Nothing of it outlives this block.
+            bool fly = false, walked = false;
+            uint32_t slot = my_slot;
+            float tnx = kInf, tny = kInf, tnz = kInf, tdx = kInf, tdy = kInf, tdz = kInf, t = 0.0f, acc = 0.0f, tau = 0.0f, tmax = 0.0f;
+            int cell = 0, sx = 0, sy = 0, sz = 0;
+            uint32_t rem = 0;
+            for (;;) {
+                const uint64_t flym = __ballot(fly);
+                const int nfree = 64 - __popcll(flym);
+                if (nfree >= DRT_SUPER_REFILL_MIN) {
+                    const unsigned long long peek = lane < (uint32_t) NWV ? ready[lane] : 0ull;
+                    const uint64_t havem = __ballot(peek != 0ull);
+                    if (havem) {
+                        // Choose whole masks, starting at wave `rr`, while they fit into the free lanes (the peeked values are
+                        // hints), take them with ONE exchange (lane w takes wave w's), hand the flights out by rank; what does
+                        // not fit after all (bits that arrived between the look and the exchange) is put back.
+                        const int np = __popcll(peek);
+                        uint64_t choose = 0;
+                        int room = nfree;
+                        for (int i = 0; i < NWV; ++i) {
+                            const int w = rr + i < NWV ? rr + i : rr + i - NWV;
+                            if (!((havem >> w) & 1ull)) continue;
+                            const int n = __builtin_amdgcn_readlane(np, w);
+                            if (choose && n > room) continue;
+                            choose |= 1ull << w; room -= n;
+                            if (room <= 0) break;
+                        }
+                        rr = rr + 1 < NWV ? rr + 1 : 0;
+                        unsigned long long bits = 0ull;
+                        if ((choose >> lane) & 1ull) bits = atomicExch(ready_lds + lane, 0ull);
+                        int got = 0;
+                        for (uint64_t c = choose; c; c &= c - 1ull) {
+                            const int w = __ffsll((long long) c) - 1;
+                            const uint64_t b = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (bits >> 32), w) << 32) |
+                                               (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) bits, w);
+                            if (!b) continue;
+                            const bool mine = ((b >> lane) & 1ull) != 0ull;
+                            const int rank = __popcll(b & ((1ull << lane) - 1ull));
+                            const bool keep = mine && got + rank < nfree;
+                            const uint64_t kept = __ballot(keep), putback = b & ~kept;
+                            if (putback && lane == 0) atomicOr(ready_lds + w, (unsigned long long) putback);
+                            if (keep) list[got + rank] = (uint32_t) (w * 64) + lane;
+                            got += __popcll(kept);
+                        }
+                        if (got) {
+                            DRT_PROF(6, 1); DRT_PROF(7, got);
+                            lds_fence();
+                            const int frank = __popcll(~flym & ((1ull << lane) - 1ull));   // my rank among the free lanes
+                            if (!fly && frank < got) {
+                                slot = list[frank];
+                                const uint4 *sp = slot_lds + 3 * slot;
+                                const uint4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+                                tnx = __uint_as_float(q0.x); tny = __uint_as_float(q0.y); tnz = __uint_as_float(q0.z); cell = (int) q0.w;
+                                tdx = __uint_as_float(q1.x); tdy = __uint_as_float(q1.y); tdz = __uint_as_float(q1.z); rem = q1.w;
+                                tau = __uint_as_float(q2.x); tmax = __uint_as_float(q2.y); t = __uint_as_float(q2.z); acc = __uint_as_float(q2.w);
+                                sx = (rem & (1u << 27)) ? -1 : 1; sy = (rem & (1u << 28)) ? -lin_y : lin_y; sz = (rem & (1u << 29)) ? -lin_z : lin_z;
+                                fly = true;
+                            }
+                        }
+                    }
+                }
+                DRT_STAMP(6);
+                if (!__ballot(fly)) break;                                       // nothing to walk (any more)
+                walked = true;
+                bool fin = false; float res_mc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < DRT_SUPER_K; ++k) {
+#if DRT_SUPER_PROFILE == 1
+                    { const int nf = __popcll(__ballot(fly)); DRT_PROF(0, nf); }
+#endif
+                    // one supergrid cell (oracle: the loop of sample_collision).  Crossing times are finite or +inf, never NaN.
+                    const float tmin = fminf(fminf(tnx, tny), tnz);
+                    const float texit = fminf(tmin, tmax);
+                    float mc;
+                    if constexpr (MGL) mc = __uint_as_float((uint32_t) mg16[cell] << 16);
+                    else mc = ((mg_lds[cell >> 5] >> (cell & 31)) & 1u) ? P.mgrid[cell] : 0.0f;
+                    const float nacc = acc + mc * (texit - t);                  // (an empty cell adds an exact zero)
+                    const bool hit = mc > 0.0f && nacc >= tau;                  // the tentative collision lies in this cell
+                    const bool isx = tnx == tmin, isy = !isx && tny == tmin;     // first axis with the earliest crossing
+                    const uint32_t sh = isx ? 0u : isy ? 9u : 18u;
+                    const bool end = !(texit < tmax) || ((rem >> sh) & 511u) == 0u;   // end of the segment / of the grid
+                    if (fly && (hit || end)) { fin = true; res_mc = hit ? mc : 0.0f; fly = false; }
+                    const bool go = fly;                                        // (lanes without a flight compute garbage, harmlessly)
+                    acc = go ? nacc : acc;
+                    t = go ? texit : t;
+                    rem = go ? rem - (1u << sh) : rem;
+                    cell += go ? (isx ? sx : isy ? sy : sz) : 0;
+                    const float tnn = tmin + (isx ? tdx : isy ? tdy : tdz);
+                    tnx = (go && isx) ? tnn : tnx; tny = (go && isy) ? tnn : tny; tnz = (go && !isx && !isy) ? tnn : tnz;
+                }
+                if (__ballot(fin)) {
+                    // result: where the last cell was entered, the optical depth up to there, its majorant (0: left the segment)
+                    if (fin) {
+                        uint4 *sp = slot_lds + 3 * slot;
+                        sp[0].x = __float_as_uint(res_mc);
+                        sp[2].z = __float_as_uint(t); sp[2].w = __float_as_uint(acc);
+                    }
+                    lds_fence();
+                    if (fin) atomicOr(done_lds + (slot >> 6), 1ull << (slot & 63u));
+                }
+                DRT_STAMP(7);
+                // enough of my own lanes ready by now?  (results of my flights, walked by me or by others)
+                const unsigned long long dw = done[pw];
+                const bool bk = ph < PH_HEAD && fl == FL_WAIT && ((dw >> lane) & 1ull) != 0ull;
+                if (__popcll(m_can | __ballot(bk)) >= DRT_SUPER_HMIN) break;
+            }
+            if (__ballot(fly)) {                                                 // flights still under way: back to their slots
+                if (fly) {
+                    uint4 *sp = slot_lds + 3 * slot;
+                    sp[0] = make_uint4(__float_as_uint(tnx), __float_as_uint(tny), __float_as_uint(tnz), (uint32_t) cell);
+                    sp[1].w = rem;
+                    sp[2].z = __float_as_uint(t); sp[2].w = __float_as_uint(acc);
+                }
+                lds_fence();
+                if (fly) atomicOr(ready_lds + (slot >> 6), 1ull << (slot & 63u));
+            }
+            DRT_STAMP(7);
+            if (walked) { polls = 0; continue; }
+            // nothing to walk
+            if (!m_can || (m_wait && polls < DRT_SUPER_MAXPOLL)) {              // results are on their way: wait for them
+                ++polls;
+                DRT_PROF(1, 1);
+                __builtin_amdgcn_s_sleep(2);
+                DRT_STAMP(1);
+                continue;
+            }
+        }
+        polls = 0;
+        DRT_STAMP(1);
+        if (DRT_SUPER_PROFILE == 2 && COUNT && lane == 0) cnt[2] += 1;
+        DRT_PROF(2, 1); DRT_PROF(3, __popcll(m_can));
+
+        // ================= (Fe) the collision a flight ended in =========================================
+        {
+            const uint64_t m_back = __ballot(back);
+            if (m_back) {
+                DRT_PROF(4, __popcll(m_back));
+                if (lane == 0) atomicAnd(done_lds + pw, (unsigned long long) ~m_back);   // results consumed: clear their bits
+                if (back) {
+                    const bool drt = ph == PH_DRT;
+                    const bool useA = ADJ && !rec_mode && drt;
+                    Pcg32 R; R.state = useA ? A.state : S.state; R.inc = useA ? A.inc : S.inc;
+                    // Medium::sample_interaction [M3-ext] (oracle: sample_collision): the walker left {entry distance of the
+                    // last cell, optical depth up to there, that cell's majorant (0: the flight left the segment)}
+                    const uint4 q2 = slot_lds[3 * my_slot + 2];
+                    const float lm = __uint_as_float(slot_lds[3 * my_slot].x), tau = __uint_as_float(q2.x);
+                    const float c_t = __uint_as_float(q2.z), c_acc = __uint_as_float(q2.w);
+                    const float lim = lm > 0.0f ? 1.0f / lm : 0.0f;
+                    const float dt = lm > 0.0f ? fmaf(tau - c_acc, lim, c_t) : kInf;
+                    bool inside; V3 p;
+                    if (drt) { const float tm = wmax - wt; (void) tm; wt += dt; inside = wt <= wmax; p = ray_at(ro, rd, wt); }
+                    else { inside = dt <= wmax; p = ray_at(wo, rd, dt); }
+                    const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
+                    fl = FL_NEXT;
+                    if (!inside) {                                              // left the segment
+                        ph = drt ? PH_DRT_END : (ph == PH_DT) ? PH_ESC : (ph == PH_RT ? PH_RT_END : PH_RTA_END);
+                    } else if (drt) {                                           // Medium::sample_interaction_drt (:549-551); wo = {T, wsum, selected t}
+                        DRT_COUNT(C_DRT);
+                        const float w = wo.x * lim;
+                        wo.y += w;
+                        const float u2 = R.next_1d();
+                        if (w > 0.0f && u2 * wo.y <= w) wo.z = wt;
+                        wo.x *= (lm - sig) * lim;
+                        if (wo.x == 0.0f) ph = PH_DRT_END;
+                    } else if (ph == PH_DT) {                                   // :348-367
+                        DRT_COUNT(C_DT); ++pc_steps;
+                        const float r = sig * lim;
+                        const float u2 = R.next_1d();
+                        if (!(u2 >= r)) { wt = wt + dt; ph = PH_SCAT; }          // mei.t
+                        else { wo = p; wmax -= dt; wt += dt; }
+                    } else {                                                    // ratio tracking :465-502
+                        DRT_COUNT(C_RT); ++pc_steps;
+                        const float tr = (lm - sig) * lim;
+                        if constexpr (ADJ) {
+                            if (ph == PH_RTA && tr > 0.0f) {                    // :487-492
+                                splat_sigma_t<true>(P, p, -(adjsum * lim) / tr, rec);
+                                DRT_COUNT(C_RT_ADJ);
+                            }
+                        }
+                        wt *= tr; wo = p; wmax -= dt;
+                        if (wt == 0.0f) ph = (ph == PH_RT) ? PH_RT_END : PH_RTA_END;
+                    }
+                    if (useA) A.state = R.state; else S.state = R.state;
+                }
+            }
+        }
+
+        DRT_STAMP(3);
         // ================= (A) regeneration ===========================================================
         // Ray indices come from a wave-local pool refilled DRT_SUPER_CHUNK at a time with ONE returning atomic on the
-        // XCD's queue head; idle lanes wait until DRT_SUPER_REGEN_MIN of them can run the ray prologue together.
+        // XCD's queue head.
         {
-            const uint64_t wmask = __ballot(ph == PH_IDLE);
-            if (wmask && (__popcll(wmask) >= DRT_SUPER_REGEN_MIN || !__ballot(ph < PH_IDLE))) {
+            const uint64_t wmask = m_idle;
+            if (wmask && regen_ok) {
                 while (pool_next >= pool_end && qsel < 8) {                      // refill (wave-uniform)
                     const int leader = __ffsll((long long) wmask) - 1;
                     unsigned long long base = 0;
@@ -253,18 +490,15 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                 }
             }
         }
-        if (!__ballot(ph != PH_DEAD)) break;
 
-        // ================= (B) path transitions (batched) ==============================================
-        {
-            const uint64_t heavy = __ballot(ph >= PH_HEAD && ph < PH_IDLE);
-            const uint64_t flying = __ballot(ph < PH_HEAD && fl == FL_FLY);
-            if (heavy && (__popcll(heavy) >= DRT_SUPER_BMIN || !flying)) {
-                // A pass takes every waiting lane to its next walk (or to the end of its ray); lanes whose walk comes
-                // out of the path cache (adjoint pass) go round once more.
-                DRT_PROF(2, 1); DRT_PROF(3, __popcll(heavy));
-                do {
+        DRT_STAMP(4);
+        // ================= (B) path transitions ==========================================================
+        if (trans_ok && __ballot(ph >= PH_HEAD && ph < PH_IDLE)) {
+            // A pass takes every waiting lane to its next walk (or to the end of its ray); lanes whose walk comes
+            // out of the path cache (adjoint pass) go round once more.
+            do {
                 DRT_PROF(8, 1);
+                uint4 pce1 = make_uint4(0u, 0u, 0u, 0u); bool pce1_ok = false;   // this iteration's NEE entry of the path cache, read at the loop head
                 // ---- end of a path (:249-287) -----------------------------------------------------
                 if (ph == PH_END) {
                     if (!ADJ || rec_mode) {                                     // envmap block, primal only
@@ -395,7 +629,9 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                     if (!active) ph = PH_END;
                     else if (ADJ && !rec_mode && pc_on && pc_it < (int) P.path_cache_cap) {
                         // the adjoint takes this iteration's delta-tracking walk from the primal pass of the same job
-                        const uint4 e = P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2];
+                        const uint4 *pce = P.path_cache + ((size_t) li * P.path_cache_cap + pc_it) * 2;
+                        const uint4 e = pce[0];
+                        pce1 = pce[1]; pce1_ok = true;                          // (adjacent: one round trip for both)
                         wt = __uint_as_float(e.x);                              // mei.t
                         S.state = ((uint64_t) e.z << 32) | e.y;
                         if (COUNT && !DRT_SUPER_PROFILE) cnt[C_DT] += e.w;
@@ -484,7 +720,8 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                     nt0 = h.valid ? h.t : kInf;
                     if (ADJ && !rec_mode && pc_on && pc_it < (int) P.path_cache_cap) {
                         // the value walk of the main path comes out of the path cache: transmittance, stream, steps
-                        const uint4 e = P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1];
+                        uint4 e = pce1;
+                        if (!pce1_ok) e = P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1];
                         wt = __uint_as_float(e.x);
                         S.state = ((uint64_t) e.z << 32) | e.y;
                         if (COUNT && !DRT_SUPER_PROFILE) cnt[C_RT] += e.w;
@@ -492,139 +729,64 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                     } else if (h.valid) { wo = ro; wmax = h.t; wt = 1.0f; ph = PH_RT; fl = FL_NEW; }
                     else { wt = 0.0f; ph = PH_RT_END; }
                 }
-                } while (__ballot(ph >= PH_HEAD && ph < PH_IDLE));
-            }
+            } while (__ballot(ph >= PH_HEAD && ph < PH_IDLE));
         }
 
-        // ================= (F) flight boundaries (batched) ===============================================
-        // the collision the previous flight of a walk ended in (lookup + the walk's epilogue), then the next flight's
-        // set-up: draw -> target optical depth, DDA state at the new origin
+        DRT_STAMP(5);
+        // ================= (Fs) the next flight: set up and post =========================================
         {
-            const bool walking = ph < PH_HEAD;
-            const bool need_f = walking && fl != FL_FLY;
-            const uint64_t mF = __ballot(need_f);
-            const uint64_t mD = __ballot(walking && fl == FL_FLY);
-            if (mF && (__popcll(mF) >= DRT_SUPER_FMIN || !mD)) {
-                DRT_PROF(4, 1); DRT_PROF(5, __popcll(mF));
-                if (need_f) {
+            const bool setup = ph < PH_HEAD && fl != FL_WAIT;
+            const uint64_t m_set = __ballot(setup);
+            if (m_set) {
+                DRT_PROF(5, __popcll(m_set));
+                if (setup) {
                     const bool drt = ph == PH_DRT;
                     const bool useA = ADJ && !rec_mode && drt;
                     Pcg32 R; R.state = useA ? A.state : S.state; R.inc = useA ? A.inc : S.inc;
-                    bool cont = true;
-                    if (fl == FL_END) {
-                        const float dt = f_t, lm = f_acc;
-                        const float lim = lm > 0.0f ? 1.0f / lm : 0.0f;
-                        bool inside; V3 p;
-                        if (drt) { wt += dt; inside = wt <= wmax; p = ray_at(ro, rd, wt); }
-                        else { inside = dt <= f_tmax; p = ray_at(wo, rd, dt); }
-                        const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
-                        if (!inside) {                                          // left the segment
-                            ph = drt ? PH_DRT_END : (ph == PH_DT) ? PH_ESC : (ph == PH_RT ? PH_RT_END : PH_RTA_END);
-                            cont = false;
-                        } else if (drt) {                                       // Medium::sample_interaction_drt (:549-551); wo = {T, wsum, selected t}
-                            DRT_COUNT(C_DRT);
-                            const float w = wo.x * lim;
-                            wo.y += w;
-                            const float u2 = R.next_1d();
-                            if (w > 0.0f && u2 * wo.y <= w) wo.z = wt;
-                            wo.x *= (lm - sig) * lim;
-                            if (wo.x == 0.0f) { ph = PH_DRT_END; cont = false; }
-                        } else if (ph == PH_DT) {                               // :348-367
-                            DRT_COUNT(C_DT); ++pc_steps;
-                            const float r = sig * lim;
-                            const float u2 = R.next_1d();
-                            if (!(u2 >= r)) { wt = wt + dt; ph = PH_SCAT; cont = false; }   // mei.t
-                            else { wo = p; wmax -= dt; wt += dt; }
-                        } else {                                                // ratio tracking :465-502
-                            DRT_COUNT(C_RT); ++pc_steps;
-                            const float tr = (lm - sig) * lim;
-                            if constexpr (ADJ) {
-                                if (ph == PH_RTA && tr > 0.0f) {                // :487-492
-                                    splat_sigma_t<true>(P, p, -(adjsum * lim) / tr, rec);
-                                    DRT_COUNT(C_RT_ADJ);
-                                }
-                            }
-                            wt *= tr; wo = p; wmax -= dt;
-                            if (wt == 0.0f) { ph = (ph == PH_RT) ? PH_RT_END : PH_RTA_END; cont = false; }
-                        }
-                    } else {
-                        // first flight of a walk: the direction's share of the DDA (Medium::sample_interaction [M3-ext];
-                        // oracle: sample_collision) - crossing-time increments 1 / |dg| and the linear cell strides
+                    // the direction's share of the DDA (oracle: sample_collision): crossing-time increments 1 / |dg|, direction
+                    // signs.  It is the same for every flight of a walk: kept in the slot, recomputed for a walk's first flight.
+                    float tdx, tdy, tdz; int sgx, sgy, sgz;
+                    if (fl == FL_NEW) {
                         const float dgx = (rd.x * P.inv_ext[0]) * fgx, dgy = (rd.y * P.inv_ext[1]) * fgy, dgz = (rd.z * P.inv_ext[2]) * fgz;
-                        if (dgx >= 1e-20f) { tdx = 1.0f / dgx; sx = 1; } else if (dgx <= -1e-20f) { tdx = 1.0f / -dgx; sx = -1; } else { tdx = kInf; sx = 0; }
-                        if (dgy >= 1e-20f) { tdy = 1.0f / dgy; sy = lin_y; } else if (dgy <= -1e-20f) { tdy = 1.0f / -dgy; sy = -lin_y; } else { tdy = kInf; sy = 0; }
-                        if (dgz >= 1e-20f) { tdz = 1.0f / dgz; sz = lin_z; } else if (dgz <= -1e-20f) { tdz = 1.0f / -dgz; sz = -lin_z; } else { tdz = kInf; sz = 0; }
+                        if (dgx >= 1e-20f) { tdx = 1.0f / dgx; sgx = 1; } else if (dgx <= -1e-20f) { tdx = 1.0f / -dgx; sgx = -1; } else { tdx = kInf; sgx = 0; }
+                        if (dgy >= 1e-20f) { tdy = 1.0f / dgy; sgy = 1; } else if (dgy <= -1e-20f) { tdy = 1.0f / -dgy; sgy = -1; } else { tdy = kInf; sgy = 0; }
+                        if (dgz >= 1e-20f) { tdz = 1.0f / dgz; sgz = 1; } else if (dgz <= -1e-20f) { tdz = 1.0f / -dgz; sgz = -1; } else { tdz = kInf; sgz = 0; }
+                    } else {
+                        const uint4 q1 = slot_lds[3 * my_slot + 1];             // (the walk's previous flight left them there)
+                        tdx = __uint_as_float(q1.x); tdy = __uint_as_float(q1.y); tdz = __uint_as_float(q1.z);
+                        sgx = tdx == kInf ? 0 : (q1.w & (1u << 27)) ? -1 : 1;
+                        sgy = tdy == kInf ? 0 : (q1.w & (1u << 28)) ? -1 : 1;
+                        sgz = tdz == kInf ? 0 : (q1.w & (1u << 29)) ? -1 : 1;
                     }
-                    if (cont) {
-                        const float u = R.next_1d();
-                        f_tau = -drt_logf(1.0f - u);
-                        const V3 o = drt ? ray_at(ro, rd, wt) : wo;
-                        f_tmax = drt ? wmax - wt : wmax;
-                        const float gxf = ((o.x - P.bmin[0]) * P.inv_ext[0]) * fgx;
-                        const float gyf = ((o.y - P.bmin[1]) * P.inv_ext[1]) * fgy;
-                        const float gzf = ((o.z - P.bmin[2]) * P.inv_ext[2]) * fgz;
-                        const float flx = fminf(fmaxf(floorf(gxf), 0.0f), (float) (gx - 1));
-                        const float fly = fminf(fmaxf(floorf(gyf), 0.0f), (float) (gy - 1));
-                        const float flz = fminf(fmaxf(floorf(gzf), 0.0f), (float) (gz - 1));
-                        const int cx = (int) flx, cy = (int) fly, cz = (int) flz;
-                        tnx = sx > 0 ? ((flx + 1.0f) - gxf) * tdx : sx < 0 ? (gxf - flx) * tdx : kInf;
-                        tny = sy > 0 ? ((fly + 1.0f) - gyf) * tdy : sy < 0 ? (gyf - fly) * tdy : kInf;
-                        tnz = sz > 0 ? ((flz + 1.0f) - gzf) * tdz : sz < 0 ? (gzf - flz) * tdz : kInf;
-                        const uint32_t rx_ = (uint32_t) (sx > 0 ? gx - 1 - cx : cx), ry_ = (uint32_t) (sy > 0 ? gy - 1 - cy : cy),
-                                       rz_ = (uint32_t) (sz > 0 ? gz - 1 - cz : cz);
-                        rem = rx_ | (ry_ << 10) | (rz_ << 20);
-                        cell = (cz * gy + cy) * gx + cx;
-                        f_t = 0.0f; f_acc = 0.0f;
-                        fl = FL_FLY;
-                    }
+                    const float u = R.next_1d();
+                    const float tau = -drt_logf(1.0f - u);
+                    const V3 o = drt ? ray_at(ro, rd, wt) : wo;
+                    const float tmax = drt ? wmax - wt : wmax;
+                    const float gxf = ((o.x - P.bmin[0]) * P.inv_ext[0]) * fgx;
+                    const float gyf = ((o.y - P.bmin[1]) * P.inv_ext[1]) * fgy;
+                    const float gzf = ((o.z - P.bmin[2]) * P.inv_ext[2]) * fgz;
+                    const float flx = fminf(fmaxf(floorf(gxf), 0.0f), (float) (gx - 1));
+                    const float fly = fminf(fmaxf(floorf(gyf), 0.0f), (float) (gy - 1));
+                    const float flz = fminf(fmaxf(floorf(gzf), 0.0f), (float) (gz - 1));
+                    const int cx = (int) flx, cy = (int) fly, cz = (int) flz;
+                    const float tnx = sgx > 0 ? ((flx + 1.0f) - gxf) * tdx : sgx < 0 ? (gxf - flx) * tdx : kInf;
+                    const float tny = sgy > 0 ? ((fly + 1.0f) - gyf) * tdy : sgy < 0 ? (gyf - fly) * tdy : kInf;
+                    const float tnz = sgz > 0 ? ((flz + 1.0f) - gzf) * tdz : sgz < 0 ? (gzf - flz) * tdz : kInf;
+                    const uint32_t rx_ = (uint32_t) (sgx > 0 ? gx - 1 - cx : cx), ry_ = (uint32_t) (sgy > 0 ? gy - 1 - cy : cy),
+                                   rz_ = (uint32_t) (sgz > 0 ? gz - 1 - cz : cz);
+                    const uint32_t rem = rx_ | (ry_ << 9) | (rz_ << 18) | (sgx < 0 ? 1u << 27 : 0u) | (sgy < 0 ? 1u << 28 : 0u) | (sgz < 0 ? 1u << 29 : 0u);
+                    uint4 *sp = slot_lds + 3 * my_slot;
+                    sp[0] = make_uint4(__float_as_uint(tnx), __float_as_uint(tny), __float_as_uint(tnz), (uint32_t) ((cz * gy + cy) * gx + cx));
+                    sp[1] = make_uint4(__float_as_uint(tdx), __float_as_uint(tdy), __float_as_uint(tdz), rem);
+                    sp[2] = make_uint4(__float_as_uint(tau), __float_as_uint(tmax), 0u, 0u);
+                    fl = FL_WAIT;
                     if (useA) A.state = R.state; else S.state = R.state;
                 }
+                lds_fence();                                                     // the slots are written ...
+                if (lane == 0) atomicOr(ready_lds + pw, (unsigned long long) m_set);    // ... before the flights are posted
             }
         }
-
-        // ================= (D) supergrid cells ============================================================
-        {
-            bool fly = ph < PH_HEAD && fl == FL_FLY;
-            if (__ballot(fly)) {
-                DRT_PROF(6, 1);
-#pragma unroll
-                for (int k = 0; k < DRT_SUPER_K; ++k) {
-#if DRT_SUPER_PROFILE
-                    DRT_PROF(7, __popcll(__ballot(fly)));
-#endif
-                    if (fly) {
-                        const float tmin = fminf(fminf(tnx, tny), tnz);         // (crossing times are finite or +inf, never NaN)
-                        const float texit = fminf(tmin, f_tmax);
-                        float mc;
-                        if constexpr (MGL) mc = __uint_as_float(mg_lds[cell]);
-                        else mc = ((mg_lds[cell >> 5] >> (cell & 31)) & 1u) ? P.mgrid[cell] : 0.0f;
-                        bool hit = false;
-                        if (mc > 0.0f) {
-                            const float dtau = mc * (texit - f_t);
-                            if (f_acc + dtau >= f_tau) hit = true;
-                            else f_acc += dtau;
-                        }
-                        if (hit) {                                              // the tentative collision lies in this cell
-                            f_t = fmaf(f_tau - f_acc, 1.0f / mc, f_t); f_acc = mc;
-                            fly = false;
-                        } else {
-                            f_t = texit;
-                            const bool isx = tnx == tmin, isy = !isx && tny == tmin;   // first axis with the earliest crossing
-                            const uint32_t sh = isx ? 0u : isy ? 10u : 20u;
-                            if (!(texit < f_tmax) || ((rem >> sh) & 1023u) == 0u) {    // end of the segment / of the grid
-                                f_t = kInf; f_acc = 0.0f;
-                                fly = false;
-                            } else {
-                                rem -= 1u << sh;
-                                cell += isx ? sx : isy ? sy : sz;
-                                if (isx) tnx += tdx; else if (isy) tny += tdy; else tnz += tdz;
-                            }
-                        }
-                        if (!fly) fl = FL_END;
-                    }
-                }
-            }
-        }
+        DRT_STAMP(8);
     }
 
     if constexpr (ADJ) close_records(P, rec);
@@ -639,16 +801,19 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
     }
 #undef DRT_COUNT
 #undef DRT_PROF
+#undef DRT_STAMP
 }
 
 // LDS bytes of a launch; 0: this supergrid cannot be served (the host keeps the one-ray-per-lane kernels)
 static size_t super_lds_bytes(const Params &P, bool &mgl)
 {
     const size_t cells = (size_t) P.gx * P.gy * P.gz;
-    const size_t fixed = ((size_t) kOccWords + (1024 / 64) * 8) * 4;
+    constexpr size_t nwv = DRT_SUPER_THREADS / 64;
+    // (the kernel's layout: flight slots, record state, ready + done masks, pull lists)
+    const size_t fixed = ((size_t) kSlotWords * 64 * nwv + nwv * 8 + 4 * nwv + 64 * nwv) * 4;
     const size_t limit = 160u * 1024u;
-    mgl = ((cells + 3) & ~(size_t) 3) * 4 + fixed <= limit;
-    const size_t words = mgl ? cells : (size_t) P.mocc_words;
+    mgl = ((((cells + 1) / 2) + 3) & ~(size_t) 3) * 4 + fixed <= limit;
+    const size_t words = mgl ? (cells + 1) / 2 : (size_t) P.mocc_words;
     const size_t need = ((words + 3) & ~(size_t) 3) * 4 + fixed;
     return need <= limit ? need : 0;
 }
@@ -656,7 +821,7 @@ static size_t super_lds_bytes(const Params &P, bool &mgl)
 bool super_supported(const Params &P)
 {
     bool mgl;
-    return P.mgrid && P.mocc && P.gx <= 1023 && P.gy <= 1023 && P.gz <= 1023 && super_lds_bytes(P, mgl) != 0;
+    return P.mgrid && P.mocc && P.gx <= 511 && P.gy <= 511 && P.gz <= 511 && super_lds_bytes(P, mgl) != 0;
 }
 
 hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream)
@@ -666,11 +831,9 @@ hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_c
     const size_t lds = super_lds_bytes(P, mgl);
     if (!lds) return hipErrorInvalidValue;
     // one workgroup per CU when the majorants live in LDS; with the bitmask only, as many as fit
-    const unsigned threads = adjoint ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREADS;
-    unsigned per_cu = 1;
-    if (!mgl) { per_cu = (unsigned) ((160u * 1024u) / lds); if (per_cu > 1024 / threads) per_cu = 1024 / threads; if (per_cu < 1) per_cu = 1; }
-    unsigned blocks = (unsigned) n_cus * per_cu;
-    const uint64_t need = (P.n_rays - P.ray_first + 63) / 64;                  // no more waves than 64-ray groups
+    const unsigned threads = DRT_SUPER_THREADS;
+    unsigned blocks = (unsigned) n_cus;                                         // one workgroup per CU
+    const uint64_t need = (P.n_rays - P.ray_first + 63) / 64;                  // no more path waves than 64-ray groups
     const uint64_t waves_per_block = threads / 64;
     if ((need + waves_per_block - 1) / waves_per_block < blocks) blocks = (unsigned) ((need + waves_per_block - 1) / waves_per_block);
     dim3 block(threads), grid(blocks);
