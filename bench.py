@@ -26,6 +26,23 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 measured copy
 
 
+def kernel_source_sha16():
+    """sha256[:16] over the kernel / C-ABI sources (csrc/*.hip, *.h, *.cpp, include/*.h): ties a committed counter profile
+    to the code it was taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "unbiased-inverse-volume-rendering_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "unbiased-inverse-volume-rendering_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "unbiased-inverse-volume-rendering_amd", "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(cnt, n_samples, primal_io=True, adjoint_io=True):
     """32 B per sigma_t lookup, 96 B per albedo lookup, 64 B per sigma_t
     splat, 192 B per albedo splat; ray I/O: primal out 12 B L (+24 B o,d when rays are
@@ -40,8 +57,11 @@ def algorithmic_bytes(cnt, n_samples, primal_io=True, adjoint_io=True):
     return b + io * n_samples
 
 
-def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=None):
-    """Msamples/s of H1 steps (primal -> film -> loss gradient -> adjoint) over the local rays of `shard`."""
+def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=None, roofline=True):
+    """Msamples/s of H1 steps (primal -> film -> loss gradient -> adjoint) over the local rays of `shard`, and - with
+    `roofline` - the same evidence as the headline line carries: HIP-event times of the tracing launches and of the
+    gradient reduction, the event counters of one step, the algorithmic bytes they stand for and the
+    achieved fraction of the HBM roofline of the adjoint pass (tracer + reductions) and of the primal launch."""
     sensor = scene.sensors[0]
     n_pixels = sensor.width * sensor.height
     sh = shard or u.ShardSpec()
@@ -50,6 +70,7 @@ def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=Non
     batch = u.RayBatch(n_rays=n_local * spp, spp=spp, sensor=sensor, ray_offset=off, interleave=inter)
     grads = u.alloc_grads(scene, keys or integ.param_keys)
     loss_scale = 2.0 / (n_pixels * 3)
+    h = integ.native_handle(scene)
 
     def step(i):
         sampler = u.IndependentSampler(u.sample_tea_32(2 * i + 1, 988378)[0], spp)
@@ -58,18 +79,50 @@ def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=Non
         img = integ.develop(scene, L, spp)
         dL = integ.film_backward(scene, loss_scale * (img - 0.5), spp)
         integ.sample(u.ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state, grads=grads)
+        return sampler, state, dL
 
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
+    h.enable_timing(True)
     t0 = time.perf_counter()
     for i in range(steps):
-        step(warmup + i)
+        sampler, state, dL = step(warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    integ.native_handle(scene).release_scratch()
-    return {"value": round(n_local * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
-            "n_samples_per_step": n_local * spp}
+    t_p, t_a, t_r, t_pass = (h.read_timings(k) for k in range(4))
+    h.enable_timing(False)
+    out = {"value": round(n_local * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+           "n_samples_per_step": n_local * spp}
+    if roofline:
+        n = n_local * spp
+        h.enable_counters(True)
+        h.reset_counters()
+        integ.sample(u.ADMode.Primal, scene, sampler.clone(), batch)
+        cp = {k: int(v) for k, v in h.get_counters().items()}
+        h.reset_counters()
+        grads["_flat"].zero_()
+        integ.sample(u.ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state, grads=grads)
+        ca = {k: int(v) for k, v in h.get_counters().items()}
+        h.enable_counters(False)
+        b_p = algorithmic_bytes(cp, n, primal_io=True, adjoint_io=False) - 24 * n        # rays generated on device
+        b_a = algorithmic_bytes(ca, n, primal_io=False, adjoint_io=True)
+        per = max(1, len(t_pass))
+        avg_p = sum(t_p) / max(1, len(t_p))
+        avg_pass, avg_a, avg_r = sum(t_pass) / per, sum(t_a) / per, sum(t_r) / per
+        ach_a = b_a / (avg_pass * 1e-3) / 1e9 if avg_pass > 0 else 0.0
+        ach_p = b_p / (avg_p * 1e-3) / 1e9 if avg_p > 0 else 0.0
+        out.update({"t_primal_ms": round(avg_p, 3), "t_adjoint_ms": round(avg_a, 3), "t_grad_reduce_ms": round(avg_r, 3),
+                    "counters_primal": cp, "counters_adjoint": ca,
+                    "roofline": {"bound": "hbm", "kernel": "adjoint pass (tracer + record partition + tile_reduce)",
+                                 "achieved": round(ach_a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_a / HBM_PEAK_GBS, 5),
+                                 "traffic": None, "algorithmic_bytes_per_launch": b_a, "avg_launch_ms": round(avg_pass, 4),
+                                 "sum_tracer_ms": round(avg_a, 4), "sum_reduction_ms": round(avg_r, 4),
+                                 "bytes_per_sample_h1": round((b_p + b_a) / n, 1),
+                                 "primal": {"achieved": round(ach_p, 2), "frac": round(ach_p / HBM_PEAK_GBS, 5),
+                                            "algorithmic_bytes_per_launch": b_p, "avg_launch_ms": round(avg_p, 4)}}})
+    h.release_scratch()
+    return out
 
 
 def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
@@ -94,7 +147,8 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
         sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
         sc.medium.majorant_resolution_factor = 8
         r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 32)
-        r["workload"] = "headline scene with the reference's default majorant_resolution_factor 8 (scene_config.py:36)"
+        r["workload"] = ("headline scene at the REFERENCE'S DEFAULT majorant_resolution_factor 8 (scene_config.py:36, "
+                         "optimize.py:182-199): supergrid tracer drt_super.hip, both passes")
         return r
 
     def envmap():
@@ -118,27 +172,52 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
         sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
         sc.medium.emission = sc.medium.albedo
         integ = u.get_int_config("nerf").create(max_depth=64)
-        r = h1_rate(torch, u, sc, integ, 32, steps=3, warmup=1)
+        r = h1_rate(torch, u, sc, integ, 32, steps=3, warmup=1, roofline=False)
         r["workload"] = "config 5 (nerf IntegratorConfig, 128 queries): 256^3 sigma_t + emission grids, 512x512x32spp"
         return r
 
     def cfg3():
-        sc = synthetic.dust_devil_scene(res=256, film=512, device=dev, n_sensors=63)
-        scfg = u.SceneConfig(name="dust-devil", scene=sc, param_keys=[u.SIGMA_T_KEY, u.ALBEDO_KEY], sensors=list(range(63)),
-                             start_from_value={u.SIGMA_T_KEY: 0.04, u.ALBEDO_KEY: 0.6}, majorant_resolution_factor=8)
-        ref = torch.full((63, 512, 512, 3), 0.5, device=dev)
+        # loop throughput (it/s) AND the loss decrease over 200 iterations from the constant init, against
+        # reference renderings of the target volume (optimize.py:56-87, 325-358; reproduce.py:45-59), at the reference's
+        # default majorant_resolution_factor 8 and, for comparison, with the global majorant
+        target = synthetic.dust_devil_scene(res=256, film=512, device=dev, n_sensors=63)
         res = {}
-        for n_iter in (5, 25):                     # warm-up run, then the timed one
-            oc = u.OptimizationConfig(name="b", spp=16, n_iter=n_iter, lr=5e-3, primal_spp_factor=64, batch_size=32768)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            u.run_optimization(None, oc, scfg, integ_name, ref_images=ref)
-            torch.cuda.synchronize()
-            res = {"value": round(n_iter / (time.perf_counter() - t0), 2), "unit": "iterations/s", "n_iter": n_iter}
-        res["workload"] = ("config 3: full optimisation loop, dust devil 256^3, 63 sensors 512^2, batch 32768 px, spp_grad 16, "
-                           "spp_primal 1024, Adam, l1, constant init, majorant_resolution_factor 8 (reproduce.py:45-59)")
-        res["msamples_per_s"] = round(res["value"] * 32768 * (1024 + 2 * 16) / 1e6, 1)
-        return res
+        for factor in (8, 0):
+            target.medium.majorant_resolution_factor = factor
+            scfg = u.SceneConfig(name="dust-devil", scene=target, param_keys=[u.SIGMA_T_KEY, u.ALBEDO_KEY], sensors=list(range(63)),
+                                 start_from_value={u.SIGMA_T_KEY: 0.04, u.ALBEDO_KEY: 0.6}, majorant_resolution_factor=factor,
+                                 ref_spp=64)
+            if "ref" not in res:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rendered = u.render_reference_image(scfg, {s_: None for s_ in scfg.sensors})
+                ref = torch.stack([rendered[s_] for s_ in scfg.sensors])
+                torch.cuda.synchronize()
+                res["ref"] = ref
+                res["reference_render_s"] = round(time.perf_counter() - t0, 2)
+            r = {}
+            for n_iter in (10, 200):                   # warm-up run, then the timed one
+                oc = u.OptimizationConfig(name="b", spp=16, n_iter=n_iter, lr=5e-3, primal_spp_factor=64, batch_size=32768)
+                stamps = []
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, _, _, hist = u.run_optimization(None, oc, scfg, integ_name, ref_images=res["ref"],
+                                                   progress=lambda i, l: stamps.append(time.perf_counter()))
+                torch.cuda.synchronize()
+                r = {"value": round(n_iter / (time.perf_counter() - t0), 2), "unit": "iterations/s", "n_iter": n_iter,
+                     "loss_first20_mean": round(sum(hist[:20]) / max(1, len(hist[:20])), 6),
+                     "loss_last20_mean": round(sum(hist[-20:]) / max(1, len(hist[-20:])), 6)}
+            r["loss_decreased"] = bool(r["loss_last20_mean"] < r["loss_first20_mean"])
+            res[f"factor{factor}"] = r
+        ref = res.pop("ref"); del ref
+        out3 = dict(res["factor8"])
+        out3["global_majorant"] = res["factor0"]
+        out3["reference_render_s"] = res["reference_render_s"]
+        out3["workload"] = ("config 3: full optimisation loop, dust devil 256^3, 63 sensors 512^2, batch 32768 px, spp_grad 16, "
+                            "spp_primal 1024, Adam lr 5e-3, l1, constant init (0.04, 0.6), 200 iterations against reference renderings "
+                            "of the target volume (64 spp), majorant_resolution_factor 8 = the reference's default (reproduce.py:45-59)")
+        out3["msamples_per_s"] = round(out3["value"] * 32768 * (1024 + 2 * 16) / 1e6, 1)
+        return out3
 
     def cfg5_fused():
         sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
@@ -368,18 +447,25 @@ def main():
     avg_pass = sum(t_pass) / per_step
     ach_a = bytes_a / (avg_pass * 1e-3) / 1e9 if avg_pass > 0 else 0.0
     ach_p = bytes_p / (avg_p * 1e-3) / 1e9 if avg_p > 0 else 0.0
-    traffic = None
+    # HBM-side traffic of the adjoint pass: a hardware-counter figure (rocprofv3 --pmc passes, tools/pmc_to_traffic.py) that
+    # this run cannot measure itself.  The committed profile is quoted ONLY if it was taken from the very kernel sources
+    # this run executes (hash over csrc/ + include/, recorded by tools/pmc_to_traffic.py); otherwise the field is null.
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get(f"{args.workload}-{args.res}-{args.film}x{spp}")
+                tj = json.load(f)
+            key = f"{args.workload}-{args.res}-{args.film}x{spp}" + (f"-factor{args.majorant_factor}" if args.majorant_factor else "")
+            if tj.get("source_sha16") == kernel_source_sha16():
+                traffic = tj.get(key)
+                traffic_source = f"profiles/roofline_traffic.json (rocprofv3 PMC passes over these kernel sources, sha16 {tj.get('source_sha16')})"
         except Exception:
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": "adjoint pass (sample(Backward)): trace_coop_kernel<adjoint> (dominant, sum_tracer_ms) + record partition + tile_reduce",
+        "bound": "hbm", "kernel": ("adjoint pass (sample(Backward)): " + ("trace_super_kernel<adjoint>" if args.majorant_factor else "trace_coop_kernel<adjoint>") + " (dominant, sum_tracer_ms) + record partition + tile_reduce"),
         "achieved": round(ach_a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(ach_a / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "frac": round(ach_a / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": bytes_a, "avg_launch_ms": round(avg_pass, 4),
         "sum_tracer_ms": round(avg_a, 4), "sum_reduction_ms": round(avg_r, 4),
         "bytes_per_sample_h1": round((bytes_p + bytes_a) / n_local, 1),
@@ -443,7 +529,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} {args.res}^3 sigma_t+albedo, {sensor.width}x{sensor.height}x{spp}spp, "
-                                   f"{args.integrator}, max_depth 64, majorant_resolution_factor {args.majorant_factor}, single sensor, "
+                                   f"{args.integrator}, max_depth 64, majorant_resolution_factor {args.majorant_factor} "
+                                   f"({'the reference default' if args.majorant_factor == 8 else 'global majorant; the reference default 8 is reported under other_configs.headline_majorant_factor8'}), single sensor, "
                                    f"image tiles sharded over {world} GPU(s)",
                        "n_samples_per_step": n_total, "grid": [args.res] * 3, "film": [sensor.width, sensor.height],
                        "spp": spp, "integrator": args.integrator},

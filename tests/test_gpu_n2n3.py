@@ -172,3 +172,33 @@ def test_fused_adam_step_equals_elementwise_sequence(uivr, gpu):
     big = torch.zeros(64, device=gpu)
     with pytest.raises(RuntimeError):
         native().adam_step(0, big.data_ptr() + 4, big.data_ptr(), big.data_ptr(), big.data_ptr(), 8, 0.9, 0.999, 1e-8, 1e-3)
+
+
+def test_adam_step_on_odd_sized_grids(uivr, gpu):
+    """3^3 / 5^3 grids (the finite-difference fixtures): gradient views out of `alloc_grads` are 16-byte aligned, so the
+    fused kernel takes them; a deliberately misaligned or mismatched gradient falls back to the torch ops - same result."""
+    from uivr_amd.optimize import _fused_adam_ok
+    for res in (3, 5):
+        scene = uivr.scene_to(uivr.cube_test_scene(8, 8), gpu)
+        scene.medium.sigma_t = torch.rand(res, res, res, 1, device=gpu)
+        scene.medium.albedo = torch.rand(res, res, res, 3, device=gpu)
+        keys = (uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY)
+        params = {keys[0]: scene.medium.sigma_t.clone(), keys[1]: scene.medium.albedo.clone()}
+        twin = {k: v.clone() for k, v in params.items()}
+        grads = uivr.alloc_grads(scene)
+        for k in keys:
+            grads[k].copy_(torch.randn_like(grads[k]))
+            assert _fused_adam_ok(params[k], grads[k], torch.zeros_like(params[k]), torch.zeros_like(params[k]))
+        opt = uivr.Adam(lr=1e-2, params=params)
+        opt.step(grads)
+        # the same step with gradients at a misaligned offset of another buffer: torch path
+        n0, n1 = params[keys[0]].numel(), params[keys[1]].numel()
+        buf = torch.zeros(1 + n0 + n1, device=gpu)
+        mis = {keys[0]: buf[1:1 + n0].view_as(params[keys[0]]), keys[1]: buf[1 + n0:].view_as(params[keys[1]])}
+        for k in keys:
+            mis[k].copy_(grads[k])
+        assert not _fused_adam_ok(twin[keys[0]], mis[keys[0]], torch.zeros_like(twin[keys[0]]), torch.zeros_like(twin[keys[0]]))
+        opt2 = uivr.Adam(lr=1e-2, params=twin)
+        opt2.step(mis)
+        for k in keys:
+            torch.testing.assert_close(params[k], twin[k], rtol=0, atol=3e-7)

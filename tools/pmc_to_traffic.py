@@ -6,8 +6,13 @@ HBM-side bytes per launch = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B + 64*WR
 The adjoint PASS is the adjoint tracer plus the gradient reduction kernels that finish its splats.
 
     python tools/pmc_to_traffic.py <dir with *counter_collection.csv> <workload key> [out.json]
+
+An existing out.json taken from the SAME kernel sources (source_sha16, bench.kernel_source_sha16) is extended with the new
+key; one from other sources is replaced - bench.py quotes the file only when the hash matches the sources it runs.
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha16
 
 root, key = sys.argv[1], sys.argv[2]
 out = sys.argv[3] if len(sys.argv) > 3 else "profiles/roofline_traffic.json"
@@ -36,12 +41,22 @@ for k in acc:
     detail[k] = {"read_bytes": rd, "write_bytes": wr, "total": rd + wr, "fetch_size_kib": mean(k, "FETCH_SIZE"),
                  "write_size_kib": mean(k, "WRITE_SIZE"), "atomics": mean(k, "TCC_EA0_ATOMIC_sum"),
                  "launches_seen": len(acc[k].get("TCC_EA0_RDREQ_sum", []))}
-adj = [k for k in detail if "trace_kernel<true, false" in k or "trace_coop_kernel<true, false" in k or "bin_" in k or "tile_reduce" in k or "untile" in k]
-pri = [k for k in detail if "trace_wavefront_kernel<false, false" in k or "trace_coop_kernel<false, false" in k]
-res = {key: sum(detail[k]["total"] for k in adj),
-       key + ":primal": sum(detail[k]["total"] for k in pri),
-       "_adjoint_pass_kernels": adj, "_detail": detail,
-       "_method": __doc__.split("\n\n")[1]}
+adj = [k for k in detail if "trace_kernel<true, false" in k or "trace_coop_kernel<true, false" in k or "trace_super_kernel<true, false" in k or
+       "bin_" in k or "tile_reduce" in k or "untile" in k]
+pri = [k for k in detail if "trace_wavefront_kernel<false, false" in k or "trace_coop_kernel<false, false" in k or "trace_super_kernel<false, false" in k]
+sha = kernel_source_sha16()
+res = {}
+if os.path.exists(out):
+    try:
+        old = json.load(open(out))
+        if old.get("source_sha16") == sha:
+            res = old
+    except Exception:
+        res = {}
+res.update({"source_sha16": sha, key: sum(detail[k]["total"] for k in adj),
+            key + ":primal": sum(detail[k]["total"] for k in pri),
+            "_adjoint_pass_kernels:" + key: adj, "_detail:" + key: detail,
+            "_method": __doc__.split("\n\n")[1]})
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1))
 for k in adj + pri:

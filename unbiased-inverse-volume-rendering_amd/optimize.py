@@ -115,6 +115,15 @@ class SceneConfig:
             self.param_lr_factors = {k: 2.0 for k in self.param_keys if '.albedo.' in k}   # scene_config.py:67-71
 
 
+def _fused_adam_ok(p, g, m, v) -> bool:
+    """True iff the one-pass device kernel (drt_adam_step: float4 accesses) can take this parameter: device tensors on ONE
+    device, float32, contiguous, equal sizes, every pointer 16-byte aligned.  Anything else - e.g. the gradient view of a
+    grid whose voxel count is not a multiple of 4 behind another grid in `alloc_grads`' flat buffer - takes the torch ops."""
+    ts = (p, g, m, v)
+    return (p.is_cuda and all(t.device == p.device and t.dtype == torch.float32 and t.is_contiguous() and
+                              t.numel() == p.numel() and t.data_ptr() % 16 == 0 for t in ts))
+
+
 class Adam:
     """mi.ad.Adam [M3-ext] as the reference uses it (opt_config.py:46-48, optimize.py:329,352-354):
     bias-corrected Adam (beta1 0.9, beta2 0.999, epsilon 1e-8), per-parameter learning rates, state
@@ -154,7 +163,7 @@ class Adam:
             t += 1
             lr = self.lr.get(k, self.lr_default)
             lr_t = lr * (1 - self.beta_2 ** t) ** 0.5 / (1 - self.beta_1 ** t)
-            if p.is_cuda and p.is_contiguous() and g.is_contiguous() and g.dtype == torch.float32 and p.dtype == torch.float32:
+            if _fused_adam_ok(p, g, m, v):
                 # one fused pass on the device (drt_adam_step) instead of seven elementwise kernels
                 from ._native import native
                 with torch.cuda.device(p.device):

@@ -34,11 +34,14 @@ def alloc_grads(scene: Scene, keys=(SIGMA_T_KEY, ALBEDO_KEY)) -> Dict[str, torch
     be pooled; the cost is one caching-allocator hit plus a 256 MiB memset = 0.05 ms at 256^3, and the
     benchmark's step pays the same memset.)"""
     grids = [_grid(scene, k) for k in keys]
-    flat = torch.zeros(sum(g.numel() for g in grids), dtype=torch.float32, device=grids[0].device)
+    # every grid starts at a multiple of 4 floats: its view is 16-byte aligned whatever the voxel counts (the fused Adam
+    # step and the block-mask kernel read float4s); the up to 3 padding floats per grid stay zero
+    pad = lambda n: (n + 3) // 4 * 4
+    flat = torch.zeros(sum(pad(g.numel()) for g in grids), dtype=torch.float32, device=grids[0].device)
     out, off = {"_flat": flat}, 0
     for k, g in zip(keys, grids):
         out[k] = flat[off:off + g.numel()].view(g.shape)
-        off += g.numel()
+        off += pad(g.numel())
     return out
 
 
