@@ -45,3 +45,12 @@ def test_bench_two_ranks_on_one_device(gpu):
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["frac"] > 0
     ar = out["allreduce"]                                   # the moved size of the (compacted) gradient all-reduce
     assert ar["mode"] in ("dense", "compact") and 0 < ar["MiB"] <= ar["of_MiB"] and 0 < ar["active_fraction"] <= 1
+
+
+def test_rccl_backend_runs_the_gradient_collectives_on_one_rank(gpu):
+    """The `nccl` (= RCCL) code path of bench.py / distributed.py, executed: communicator init on the device and the uint8
+    MAX + float SUM collectives of the compacted / dense gradient all-reduce, in a world of one rank (a single-GPU box
+    cannot do more; the multi-rank logic is covered on gloo by the world-2 and world-8 tests)."""
+    r = _torchrun([os.path.join(ROOT, "tests", "workers", "nccl_smoke_worker.py")], world=1, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
+    assert "NCCL_SMOKE_OK" in r.stdout

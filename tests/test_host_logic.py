@@ -290,3 +290,99 @@ def test_compacted_allreduce_equals_dense_gloo(uivr):
             assert stats["floats"] < 200 * B * (0.35 if name == "sparse" else 1.01) + 37
     assert out["small"] == (True, "dense")
     assert out["bad"]
+
+
+def _world8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import uivr_amd as u
+    from uivr_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        out = {}
+        B = D.COMPACT_BLOCK_FLOATS
+        # (1) ragged batch shares: 1001 entries over 8 ranks - contiguous, disjoint, complete, sizes differ by at most one
+        sh = u.ShardSpec(rank, world, 16)
+        first, count = sh.batch_range(1001)
+        mine = torch.zeros(1001)
+        mine[first:first + count] = 1.0
+        dist.all_reduce(mine)
+        out["cover"] = (bool((mine == 1).all()), count)
+        # (2) pixel chunks of an image: every pixel on exactly one rank
+        pix = sh.pixel_indices(16 * 8 * 4)
+        seen = torch.zeros(16 * 8 * 4)
+        seen[pix] = 1.0
+        dist.all_reduce(seen)
+        out["pixels"] = bool((seen == 1).all())
+        # (3) gradient all-reduce: sparse (compact), dense, and a block set that grows past the capacity of the step before
+        n = 300 * B + 5
+        g = torch.Generator().manual_seed(99 + rank)
+        for step, active in enumerate((0.05, 0.06, 0.5, 0.95)):
+            flat = torch.zeros(n)
+            blocks = torch.rand(300, generator=g) < active / world * 2          # per-rank sets, different on every rank
+            flat[:300 * B] = (torch.randn(300, B, generator=g) * blocks[:, None]).reshape(-1)
+            flat[300 * B:] = float(rank)
+            ref = flat.clone()
+            dist.all_reduce(ref)
+            st = {}
+            u.allreduce_gradients({"_flat": flat}, stats=st, shard=sh)
+            out[("step", step)] = (bool(torch.allclose(flat, ref, rtol=0, atol=1e-5)), st["mode"], st["active_fraction"])
+        # (4) an all-zero buffer (nothing to pack) and an unsharded call under the process group (no communication)
+        z = torch.zeros(128 * B)
+        u.allreduce_gradients({"_flat": z}, compact="always")
+        out["zeros"] = bool((z == 0).all())
+        one = torch.ones(128 * B)
+        u.allreduce_gradients({"_flat": one}, shard=u.ShardSpec())
+        out["unsharded"] = bool((one == 1).all())
+        res = [None] * world
+        dist.all_gather_object(res, out)
+        if rank == 0:
+            q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_8_ragged_shares_and_allreduce_modes_gloo(uivr):
+    """the N = 8 path on CPU - ragged batch shares and pixel chunks partition the work, the gradient
+    all-reduce gives the dense sums in its compact and dense modes (and when the non-zero block set outgrows the packed
+    buffer sized from the step before), all-zero buffers and unsharded calls do not communicate."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    counts = [r["cover"][1] for r in res]
+    assert sum(counts) == 1001 and max(counts) - min(counts) <= 1
+    for r in res:
+        assert r["cover"][0] and r["pixels"] and r["zeros"] and r["unsharded"]
+        for step in range(4):
+            ok, mode, frac = r[("step", step)]
+            assert ok, (step, mode, frac)
+        assert r[("step", 0)][1] == "compact" and r[("step", 3)][1] == "dense"
+    assert len({tuple(sorted((k, v[1]) for k, v in r.items() if isinstance(k, tuple))) for r in res}) == 1   # same mode on every rank
+
+
+def test_sharded_run_optimization_rejects_what_it_cannot_shard(uivr):
+    """Round-2 advisor findings: an empty share (batch_size < world) gives a 0 / 0 loss whose NaN the all-reduce spreads;
+    the per-rank loss scaling is the global gradient only for losses that are sums over entries; the fused two-image
+    integrator cannot be compared with one reference image."""
+    scene = uivr.cube_test_scene(8, 8)
+    sc = uivr.SceneConfig(name="c", scene=scene, param_keys=[uivr.SIGMA_T_KEY], sensors=[0], start_from_value={uivr.SIGMA_T_KEY: 0.1})
+    ref = torch.zeros(1, 8, 8, 3)
+    oc = uivr.OptimizationConfig(name="o", spp=1, n_iter=1, lr=1e-2, batch_size=2)
+    with pytest.raises(ValueError, match="batch_size"):
+        uivr.run_optimization(None, oc, sc, "volpathsimple-drt", ref_images=ref, shard=uivr.ShardSpec(1, 4, 16))
+    from uivr_amd import losses
+    oc2 = uivr.OptimizationConfig(name="o", spp=1, n_iter=1, lr=1e-2, batch_size=64, loss=losses.psnr)
+    with pytest.raises(ValueError, match="sum over image entries"):
+        uivr.run_optimization(None, oc2, sc, "volpathsimple-drt", ref_images=ref, shard=uivr.ShardSpec(0, 2, 16))
+    with pytest.raises(ValueError, match="nerf-drt-fused"):
+        uivr.run_optimization(None, oc, sc, "nerf-drt-fused", ref_images=ref)

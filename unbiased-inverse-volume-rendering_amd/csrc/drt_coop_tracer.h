@@ -734,8 +734,16 @@ struct CoopTracer {
                 // the workgroup's last few paths: to the tail pool, if it has room
                 uint32_t base = 0xffffffffu;
                 if (lane == 0) {
-                    base = atomicAdd(P.tail_count, (uint32_t) n);
-                    if (base + (uint32_t) n > P.tail_cap) { atomicSub(P.tail_count, (uint32_t) n); base = 0xffffffffu; }
+                    // compare-and-swap reservation: the counter never exceeds the capacity, so a reservation that fails
+                    // cannot disturb one that succeeds (an add followed by a subtract on overflow is not linearizable:
+                    // another workgroup's range could start inside the inflated count)
+                    uint32_t old = __atomic_load_n(P.tail_count, __ATOMIC_RELAXED);
+                    for (;;) {
+                        if (old + (uint32_t) n > P.tail_cap) break;
+                        const uint32_t prev = atomicCAS(P.tail_count, old, old + (uint32_t) n);
+                        if (prev == old) { base = old; break; }
+                        old = prev;
+                    }
                 }
                 base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
                 if (base != 0xffffffffu) {

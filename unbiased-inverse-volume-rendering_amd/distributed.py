@@ -103,6 +103,13 @@ def _block_mask(body: torch.Tensor) -> torch.Tensor:
     return (body != 0).any(dim=1).to(torch.uint8)
 
 
+_PACK_CAPACITY: Dict[tuple, int] = {}     # (device, buffer size) -> blocks the packed buffer was sized for last time
+
+
+def _capacity_for(count: int, n_blocks: int) -> int:
+    return min(n_blocks, count + count // 4 + 64)
+
+
 def _allreduce_flat(flat: torch.Tensor, group, compact, stats: Optional[dict]) -> None:
     """Sum `flat` over the group in place.  `compact`: "auto" (default) | "never" | "always".
 
@@ -112,7 +119,12 @@ def _allreduce_flat(flat: torch.Tensor, group, compact, stats: Optional[dict]) -
     agree on the set of 256-B blocks that are non-zero on ANY rank (an all-reduce(MAX) of one byte per block:
     1 MiB for a 256^3 medium), and, when that set is small enough to pay for the packing, all-reduce only those
     blocks.  Blocks outside the set are zero on every rank, so the sum is the same as the dense one (up to the
-    summation order inside the collective); non-finite values count as non-zero and propagate."""
+    summation order inside the collective); non-finite values count as non-zero and propagate.
+
+    No pipeline stall: the packed buffer is sized from the PREVIOUS call's block count (+25 %), so the packing kernels
+    are enqueued without knowing this call's count; the count travels to the host meanwhile (asynchronous copy + event)
+    and is only waited for right before the collective is enqueued - the device is busy packing by then.  A count beyond
+    the capacity (the block set grew by more than 25 % since the last step) falls back to the dense collective."""
     import torch.distributed as dist
     n = flat.numel()
     B = COMPACT_BLOCK_FLOATS
@@ -123,23 +135,55 @@ def _allreduce_flat(flat: torch.Tensor, group, compact, stats: Optional[dict]) -
         return
     n_full = (n // B) * B
     body = flat[:n_full].view(-1, B)
+    tail = flat[n_full:]
     mask = _block_mask(body)
     dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
-    idx = mask.nonzero(as_tuple=False).squeeze(1)          # host sync: the collective below needs its size
-    frac = idx.numel() / mask.numel()
-    if compact != "always" and frac > COMPACT_MAX_ACTIVE:
+    n_blocks = mask.numel()
+    cs = torch.cumsum(mask, dim=0, dtype=torch.int32)      # inclusive: cs[b] = non-zero blocks up to and including b
+    key = (str(flat.device), n)
+    cap = _PACK_CAPACITY.get(key)
+    count_host, ready = None, None
+    if flat.is_cuda and cap is not None:                   # the count goes to the host behind the packing kernels
+        count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        count_host.copy_(cs[-1:], non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+    else:                                                  # first call for this buffer (nothing to size from), or host tensors
+        count = int(cs[-1])
+        if cap is None:
+            cap = _capacity_for(count, n_blocks)
+
+    def pack(capacity):
+        # row j of the packed buffer = the j-th non-zero block (a search in the running count), zeros past the count
+        j = torch.arange(1, capacity + 1, dtype=torch.int32, device=flat.device)
+        src = torch.searchsorted(cs, j).clamp_(max=n_blocks - 1)
+        rows = torch.where((j <= cs[-1])[:, None], body.index_select(0, src), torch.zeros((), dtype=flat.dtype, device=flat.device))
+        return src, torch.cat([rows.reshape(-1), tail])
+
+    src, packed = pack(cap)
+    if ready is not None:
+        ready.synchronize()                                # (the packing above is still running or queued)
+        count = int(count_host[0])
+    frac = count / n_blocks
+    _PACK_CAPACITY[key] = _capacity_for(count, n_blocks)
+    if count == 0 and tail.numel() == 0:                   # all zeros on every rank: nothing to sum
+        if stats is not None:
+            stats.update(mode="compact", floats=0, active_fraction=0.0)
+        return
+    if count > cap and compact == "always":
+        cap = count
+        src, packed = pack(cap)
+    if (compact != "always" and frac > COMPACT_MAX_ACTIVE) or count > cap:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if stats is not None:
             stats.update(mode="dense", floats=n, active_fraction=frac)
         return
-    tail = flat[n_full:]
-    packed = torch.cat([body.index_select(0, idx).reshape(-1), tail])
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-    body.index_copy_(0, idx, packed[:idx.numel() * B].view(-1, B))
+    body.index_copy_(0, src[:count].to(torch.int64), packed[:count * B].view(-1, B))
     if tail.numel():
-        tail.copy_(packed[idx.numel() * B:])
+        tail.copy_(packed[cap * B:])
     if stats is not None:
-        stats.update(mode="compact", floats=packed.numel(), active_fraction=frac)
+        stats.update(mode="compact", floats=count * B + tail.numel(), sent_floats=packed.numel(), active_fraction=frac)
 
 
 def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, shard: Optional[ShardSpec] = None,

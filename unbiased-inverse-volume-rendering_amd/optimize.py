@@ -349,8 +349,23 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
     gradient grids are summed with one all-reduce per backward; every rank then takes the identical
     optimizer step."""
     from .distributed import ShardSpec, allreduce_scalar, local_loss_scale
+    from . import losses as _losses
     shard = shard or ShardSpec()
+    if shard.partitioned:
+        # every rank back-propagates its share n_local / n_global of the loss: that is the global gradient only for losses
+        # that are sums over entries, and needs at least one entry per rank (an empty share's loss is 0 / 0)
+        separable = (_losses.l1, _losses.l2, _losses.huber, _losses.average, _losses.mean_relative_absolute_error,
+                     _losses.mean_relative_squared_error)
+        if opt_config.loss not in separable:
+            raise ValueError(f"sharded run_optimization needs a loss that is a sum over image entries (l1, l2, huber, "
+                             f"mean_relative_*), not {getattr(opt_config.loss, '__name__', opt_config.loss)!r}: its gradient "
+                             f"is not the sum of the ranks' partial gradients")
+        if opt_config.batch_size is not None and opt_config.batch_size < shard.world:
+            raise ValueError(f"batch_size {opt_config.batch_size} < world size {shard.world}: some ranks would get no entry")
     int_config = get_int_config(int_config)
+    if int_config.name == 'nerf-drt-fused':
+        raise ValueError("'nerf-drt-fused' renders two images per ray ([n, 6]: nerf | volpathsimple) for the fused benchmark pass; "
+                         "run_optimization compares one image with the references - use 'nerf' or 'volpathsimple-drt'")
     scene0 = scene_config.scene
     dev = scene0.medium.sigma_t.device
     integrator = int_config.create(max_depth=scene_config.max_depth)
