@@ -43,6 +43,22 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def committed_traffic(key):
+    """(bytes per adjoint pass, source) of the committed counter profile for workload `key`, or (None, None) when the
+    profile was taken from other kernel sources than the ones this run executes."""
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("source_sha16") == kernel_source_sha16() and tj.get(key) is not None:
+                return tj.get(key), (f"profiles/roofline_traffic.json (rocprofv3 PMC passes over these kernel sources, "
+                                     f"sha16 {tj.get('source_sha16')})")
+        except Exception:
+            pass
+    return None, None
+
+
 def algorithmic_bytes(cnt, n_samples, primal_io=True, adjoint_io=True):
     """32 B per sigma_t lookup, 96 B per albedo lookup, 64 B per sigma_t
     splat, 192 B per albedo splat; ray I/O: primal out 12 B L (+24 B o,d when rays are
@@ -57,7 +73,7 @@ def algorithmic_bytes(cnt, n_samples, primal_io=True, adjoint_io=True):
     return b + io * n_samples
 
 
-def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=None, roofline=True):
+def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=None, roofline=True, traffic_key=None):
     """Msamples/s of H1 steps (primal -> film -> loss gradient -> adjoint) over the local rays of `shard`, and - with
     `roofline` - the same evidence as the headline line carries: HIP-event times of the tracing launches and of the
     gradient reduction, the event counters of one step, the algorithmic bytes they stand for and the
@@ -116,7 +132,8 @@ def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=Non
                     "counters_primal": cp, "counters_adjoint": ca,
                     "roofline": {"bound": "hbm", "kernel": "adjoint pass (tracer + record partition + tile_reduce)",
                                  "achieved": round(ach_a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_a / HBM_PEAK_GBS, 5),
-                                 "traffic": None, "algorithmic_bytes_per_launch": b_a, "avg_launch_ms": round(avg_pass, 4),
+                                 "traffic": committed_traffic(traffic_key)[0] if traffic_key else None,
+                                 "algorithmic_bytes_per_launch": b_a, "avg_launch_ms": round(avg_pass, 4),
                                  "sum_tracer_ms": round(avg_a, 4), "sum_reduction_ms": round(avg_r, 4),
                                  "bytes_per_sample_h1": round((b_p + b_a) / n, 1),
                                  "primal": {"achieved": round(ach_p, 2), "frac": round(ach_p / HBM_PEAK_GBS, 5),
@@ -146,7 +163,8 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
     def factor8():
         sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
         sc.medium.majorant_resolution_factor = 8
-        r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 32)
+        r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 32, steps=10, warmup=3,
+                    traffic_key="dust-devil-256-512x32-factor8")
         r["workload"] = ("headline scene at the REFERENCE'S DEFAULT majorant_resolution_factor 8 (scene_config.py:36, "
                          "optimize.py:182-199): supergrid tracer drt_super.hip, both passes")
         return r
@@ -450,18 +468,8 @@ def main():
     # HBM-side traffic of the adjoint pass: a hardware-counter figure (rocprofv3 --pmc passes, tools/pmc_to_traffic.py) that
     # this run cannot measure itself.  The committed profile is quoted ONLY if it was taken from the very kernel sources
     # this run executes (hash over csrc/ + include/, recorded by tools/pmc_to_traffic.py); otherwise the field is null.
-    traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            key = f"{args.workload}-{args.res}-{args.film}x{spp}" + (f"-factor{args.majorant_factor}" if args.majorant_factor else "")
-            if tj.get("source_sha16") == kernel_source_sha16():
-                traffic = tj.get(key)
-                traffic_source = f"profiles/roofline_traffic.json (rocprofv3 PMC passes over these kernel sources, sha16 {tj.get('source_sha16')})"
-        except Exception:
-            traffic = None
+    traffic, traffic_source = committed_traffic(f"{args.workload}-{args.res}-{args.film}x{spp}" +
+                                                (f"-factor{args.majorant_factor}" if args.majorant_factor else ""))
     roofline = {
         "bound": "hbm", "kernel": ("adjoint pass (sample(Backward)): " + ("trace_super_kernel<adjoint>" if args.majorant_factor else "trace_coop_kernel<adjoint>") + " (dominant, sum_tracer_ms) + record partition + tile_reduce"),
         "achieved": round(ach_a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
