@@ -173,7 +173,8 @@ def test_config4_512_rank0_share_of_1024x64(uivr, oracle, gpu):
 
 def test_config3_optimize_loop_256_63_sensors(uivr, oracle, gpu):
     """dust devil 256^3, 63 sensors 512^2, batch 32768 px, spp_grad 16, spp_primal 1024 (reproduce.py:48-52):
-    batch rays and radiance of a window bit-exact vs the oracle, window gradients, then 3 iterations of the loop."""
+    batch rays and radiance of a window bit-exact vs the oracle, window gradients, then the loop itself: 200 iterations
+    against reference renderings of the target volume, loss decrease asserted."""
     from uivr_amd import synthetic
     sg = synthetic.dust_devil_scene(res=256, film=512, device=gpu, n_sensors=63)
     props = props_for("drt")
@@ -224,13 +225,21 @@ def test_config3_optimize_loop_256_63_sensors(uivr, oracle, gpu):
     _close_on_device(grads[uivr.ALBEDO_KEY], ga, "config 3 window grad albedo")
     del params, image, loss, grads
 
-    # 3 iterations of the optimisation loop at the registered sizes (reproduce.py:45-59; Adam, l1, constant init)
+    # the optimisation loop as SURVEY.md 8d states it (reproduce.py:45-59; Adam, l1): reference renderings of the TARGET volume
+    # (reduced ref_spp), 200 iterations from the constant init at the reference's default majorant_resolution_factor 8,
+    # and the loss has to come down
+    del ref, ref_values
     sc = uivr.SceneConfig(name="dust-devil", scene=sg, param_keys=[uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY],
                           sensors=list(range(63)), start_from_value={uivr.SIGMA_T_KEY: 0.04, uivr.ALBEDO_KEY: 0.6},
-                          majorant_resolution_factor=8)
-    oc = uivr.OptimizationConfig(name="t", spp=16, n_iter=3, lr=5e-3, primal_spp_factor=64, batch_size=32768)
+                          majorant_resolution_factor=8, ref_spp=32)
+    rendered = uivr.render_reference_image(sc, {s_: None for s_ in sc.sensors})
+    ref = torch.stack([rendered[s_] for s_ in sc.sensors])
+    assert ref.shape == (63, 512, 512, 3) and torch.isfinite(ref).all() and float(ref.std()) > 0
+    oc = uivr.OptimizationConfig(name="t", spp=16, n_iter=200, lr=5e-3, primal_spp_factor=64, batch_size=32768)
     _, p, _, hist = uivr.run_optimization(None, oc, sc, "volpathsimple-drt", ref_images=ref)
-    assert len(hist) == 3 and all(np.isfinite(hist))
+    assert len(hist) == 200 and all(np.isfinite(hist))
+    first, last = float(np.mean(hist[:20])), float(np.mean(hist[-20:]))
+    assert last < 0.95 * first, (first, last)                                   # (measured: 0.1420 -> 0.1247)
     assert float(p[uivr.SIGMA_T_KEY].min()) >= 0 and float(p[uivr.SIGMA_T_KEY].max()) <= 250
     assert float(p[uivr.ALBEDO_KEY].min()) >= 0 and float(p[uivr.ALBEDO_KEY].max()) <= 1
     assert float((p[uivr.SIGMA_T_KEY] - 0.04).abs().max()) > 0                  # the parameters moved
