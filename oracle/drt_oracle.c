@@ -554,8 +554,11 @@ static inline si_t box_hit(const scene_t *sc, v3 o, v3 d)
     const float hi[3] = { sc->bmax.x, sc->bmax.y, sc->bmax.z };
     for (int a = 0; a < 3; ++a) {
         if (dd[a] != 0.0f) {
-            float t0 = (lo[a] - oo[a]) / dd[a];
-            float t1 = (hi[a] - oo[a]) / dd[a];
+            /* slab distances through the reciprocal direction, as Mitsuba's BoundingBox::ray_intersect forms them
+             * (d_rcp = rcp(ray.d); t = (plane - o) * d_rcp): one IEEE division per axis instead of two */
+            float rcp = 1.0f / dd[a];
+            float t0 = (lo[a] - oo[a]) * rcp;
+            float t1 = (hi[a] - oo[a]) * rcp;
             if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
             if (t0 > tn) { tn = t0; an = a; }
             if (t1 < tf) { tf = t1; af = a; }

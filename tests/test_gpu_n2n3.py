@@ -177,7 +177,7 @@ def test_fused_adam_step_equals_elementwise_sequence(uivr, gpu):
 def test_adam_step_on_odd_sized_grids(uivr, gpu):
     """3^3 / 5^3 grids (the finite-difference fixtures): gradient views out of `alloc_grads` are 16-byte aligned, so the
     fused kernel takes them; a deliberately misaligned or mismatched gradient falls back to the torch ops - same result."""
-    from uivr_amd.optimize import _fused_adam_ok
+    _fused_adam_ok = uivr.optimize._fused_adam_ok
     for res in (3, 5):
         scene = uivr.scene_to(uivr.cube_test_scene(8, 8), gpu)
         scene.medium.sigma_t = torch.rand(res, res, res, 1, device=gpu)

@@ -135,7 +135,7 @@ def test_gradient_views_are_aligned_and_fused_adam_gate(uivr):
     so for grids whose voxel count is not a multiple of 4 (3^3, 5^3, the fd fixtures) its pointer was not 16-byte aligned
     and the fused Adam kernel refused it.  Every view now starts at a multiple of 4 floats, and `Adam.step` takes the
     fused path only for device tensors that the kernel accepts (anything else: the torch ops)."""
-    from uivr_amd.optimize import _fused_adam_ok
+    _fused_adam_ok = uivr.optimize._fused_adam_ok
     for res in (3, 5, 8):
         scene = uivr.cube_test_scene(8, 8)
         scene.medium.sigma_t = torch.zeros(res, res, res, 1)

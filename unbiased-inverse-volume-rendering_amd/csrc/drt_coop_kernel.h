@@ -165,7 +165,9 @@ hipError_t launch_trace_coop_t(const Params &P, bool adjoint, bool count, hipStr
     // ... each followed by its tail launch (the workgroups' last few paths, pooled: wg_handoff) when the caller gave a pool
     // (adjoint only: a tail launch exposes the longest path of the job - ~0.5 ms - which the primal pass has nothing to
     // hide behind: primal 2.58 -> 2.85 ms with it, adjoint tracer 6.19 -> 5.99 ms)
-    const bool tail = !SUPER && adjoint && P.tail_pool && P.tail_count && P.tail_cap >= 256u && !dbg(P.debug_flags, 33554432u);
+    // (capacity invariant of the pool's reservation, CoopTracer::wg_handoff: one push of <= DRT_TAIL_PUSH entries per workgroup)
+    const bool tail = !SUPER && adjoint && P.tail_pool && P.tail_count && P.tail_cap >= 256u && !dbg(P.debug_flags, 33554432u) &&
+                      (uint64_t) P.tail_cap >= (uint64_t) DRT_TAIL_PUSH * grid.x;
     Params T = P;
     if (spec && (!adjoint || defer)) {
         if (tail) {

@@ -734,16 +734,13 @@ struct CoopTracer {
                 // the workgroup's last few paths: to the tail pool, if it has room
                 uint32_t base = 0xffffffffu;
                 if (lane == 0) {
-                    // compare-and-swap reservation: the counter never exceeds the capacity, so a reservation that fails
-                    // cannot disturb one that succeeds (an add followed by a subtract on overflow is not linearizable:
-                    // another workgroup's range could start inside the inflated count)
-                    uint32_t old = __atomic_load_n(P.tail_count, __ATOMIC_RELAXED);
-                    for (;;) {
-                        if (old + (uint32_t) n > P.tail_cap) break;
-                        const uint32_t prev = atomicCAS(P.tail_count, old, old + (uint32_t) n);
-                        if (prev == old) { base = old; break; }
-                        old = prev;
-                    }
+                    // every workgroup reserves at most ONCE (its wave 0 ends with the push) and at most DRT_TAIL_PUSH entries, and
+                    // the launcher only binds a pool with tail_cap >= DRT_TAIL_PUSH * gridDim.x (launch_trace_coop_t): the
+                    // reservation cannot overflow, so a plain add is linearizable here (a compare-and-swap loop was measured:
+                    // 10x slower adjoint - 32 k workgroups retrying on one address).  The overflow branch only guards against
+                    // a caller that breaks the invariant: the paths then stay where they are.
+                    base = atomicAdd(P.tail_count, (uint32_t) n);
+                    if (base + (uint32_t) n > P.tail_cap) { atomicSub(P.tail_count, (uint32_t) n); base = 0xffffffffu; }
                 }
                 base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
                 if (base != 0xffffffffu) {

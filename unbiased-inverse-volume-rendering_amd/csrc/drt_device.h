@@ -974,8 +974,10 @@ __device__ __forceinline__ Hit box_hit(const Params &P, V3 o, V3 d)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         if (dd[a] != 0.0f) {
-            float t0 = (P.bmin[a] - oo[a]) / dd[a];
-            float t1 = (P.bmax[a] - oo[a]) / dd[a];
+            // (through the reciprocal direction, as BoundingBox::ray_intersect: one IEEE division per axis instead of two)
+            const float rcp = 1.0f / dd[a];
+            float t0 = (P.bmin[a] - oo[a]) * rcp;
+            float t1 = (P.bmax[a] - oo[a]) * rcp;
             if (t0 > t1) { float t = t0; t0 = t1; t1 = t; }
             if (t0 > tn) { tn = t0; an = a; }
             if (t1 < tf) { tf = t1; af = a; }
