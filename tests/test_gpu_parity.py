@@ -629,3 +629,73 @@ def test_heavy_tailed_ratio_tracking_splats_keep_ordinary_voxels_accurate(uivr, 
             assert np.percentile(rel, 99.9) <= 1e-3, (key, name, float(np.percentile(rel, 99.9)), float(rel.max()))
             assert np.median(rel) <= 2e-5, (key, name, float(np.median(rel)))
             print(key, name, "spread %.1f  rel err: median %.2e  p99.9 %.2e  max %.2e" % (spread, np.median(rel), np.percentile(rel, 99.9), rel.max()))
+
+
+@pytest.mark.parametrize("flags,variant", [(0, "drt"), (0, "drt-nomis"), (0, "basic"), (134217728, "drt"), (128, "drt"),
+                                           (1048576, "drt"), (16384, "drt"), (0, "quadratic")])
+def test_supergrid_tracer_and_its_fallbacks_match_oracle(uivr, oracle, gpu, flags, variant):
+    """Scenes with a majorant supergrid run in the cell-stepping tracer (drt_super.hip): every estimator it takes
+    (subsampled DRT with / without MIS, basic), with the path cache on and off (1048576), with the job cut into ray
+    sub-batches (16384: launches with ray_first > 0); and what it hands back to the older kernels stays verified:
+    134217728 = the round-2 kernels for both passes, 128 = the atomic gradient path (no record streams), quadratic DRT.
+    Radiance bit-exact, counters equal, gradients close - against the oracle."""
+    rng = np.random.default_rng(17)
+    res = (24, 20, 28)                                   # X, Y, Z
+    st = rng.random((res[2], res[1], res[0], 1), dtype=np.float32) * 7.0
+    st[rng.random(st.shape) < 0.55] = 0.0
+    st[:, :, 16:] = 0.0                                  # empty supercells
+    al = (rng.random((res[2], res[1], res[0], 3), dtype=np.float32) * 0.8 + 0.1).astype(np.float32)
+    medium = uivr.GridMedium(sigma_t=st, albedo=al, bbox_min=(-1, -0.8, -1.2), bbox_max=(1, 0.9, 1.3), scale=1.2,
+                             majorant_resolution_factor=4)
+    sensor = uivr.PerspectiveSensor(origin=(3.0, 2.0, 4.0), target=(0, 0, 0), fov=32.0, width=40, height=40)
+    scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter((0.9, 1.0, 1.1)), sensors=[sensor])
+    props, spp, seed = props_for(variant), 8, 515
+    osc = oracle.OracleScene(scene)
+    ref = oracle.h1_step(osc, props, spp, seed)
+    _, c_primal = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props, hooks=True)
+    h = integ.native_handle(sg)
+    h.set_debug_flags(flags)
+    h.enable_counters(True)
+    h.reset_counters()
+    batch = uivr.RayBatch(n_rays=40 * 40 * spp, spp=spp, sensor=sg.sensors[0])
+    L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(seed, spp), batch)
+    np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), ref["L"].view(np.uint32))
+    img, grads = _h1_gpu(uivr, sg, integ, spp, seed)
+    cnt = {k: int(v) for k, v in h.get_counters().items()}
+    h.enable_counters(False)
+    h.set_debug_flags(0)
+    assert cnt == {k: ref["counters"][k] + 2 * c_primal[k] for k in ref["counters"]}
+    _assert_grads_close(grads[uivr.SIGMA_T_KEY], ref["grad_sigma_t"], "grad sigma_t")
+    _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], "grad albedo")
+
+
+def test_supergrid_too_large_for_lds_keeps_its_bitmask_there(uivr, oracle, gpu):
+    """A supergrid whose majorants do not fit the tracer's LDS next to the flight slots (160^3 voxels at factor 4 = 40^3
+    = 64000 cells: 125 KiB as bf16) runs the instantiation that keeps the non-empty-cell bitmask in LDS and loads the
+    majorants of non-empty cells from L2 (drt_super.hip, MGL = false).  A window of rays against the oracle."""
+    rng = np.random.default_rng(3)
+    res = 160
+    lat = rng.random((20, 20, 20), dtype=np.float32)
+    st = np.repeat(np.repeat(np.repeat(lat, 8, 0), 8, 1), 8, 2)[..., None] * 9.0     # blocky medium, sparse
+    st[st < 5.0] = 0.0
+    st = st.astype(np.float32)
+    al = np.full((res, res, res, 3), 0.7, np.float32)
+    medium = uivr.GridMedium(sigma_t=st, albedo=al, bbox_min=(-1, -1, -1), bbox_max=(1, 1, 1), scale=1.0,
+                             majorant_resolution_factor=4)
+    sensor = uivr.PerspectiveSensor(origin=(3.0, 2.0, 4.0), target=(0, 0, 0), fov=30.0, width=32, height=32)
+    scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter((1.0, 1.0, 1.0)), sensors=[sensor])
+    props, spp, seed = props_for("drt"), 4, 99
+    ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
+    sg = uivr.scene_to(scene, gpu)
+    integ = _integrator(uivr, props)
+    batch = uivr.RayBatch(n_rays=32 * 32 * spp, spp=spp, sensor=sg.sensors[0])
+    L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(seed, spp), batch)
+    np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), ref["L"].view(np.uint32))
+    img, grads = _h1_gpu(uivr, sg, integ, spp, seed)
+    g = grads[uivr.SIGMA_T_KEY].detach().cpu().numpy().astype(np.float64)
+    tol = GRAD_RTOL * np.abs(ref["grad_sigma_t"]).max() + 1e-9
+    assert np.abs(g - ref["grad_sigma_t"]).max() <= tol
+    ga = grads[uivr.ALBEDO_KEY].detach().cpu().numpy().astype(np.float64)
+    assert np.abs(ga - ref["grad_albedo"]).max() <= GRAD_RTOL * np.abs(ref["grad_albedo"]).max() + 1e-9
