@@ -469,7 +469,7 @@ def test_sigma_t_gradient_vs_finite_differences(uivr, gpu, variant):
                                            (256, "basic"), (16384, "drt"), (16384 + 2048, "drt"), (2048, "basic"),
                                            (32768, "drt"), (32768, "quadratic"), (65536, "drt"), (65536, "basic"),
                                            (65536, "quadratic-nomis"), (262144, "drt"), (1048576, "drt"),
-                                           (16384 + 524288, "drt"), (2097152, "drt"), (2097152 + 128, "drt")])
+                                           (16384 + 524288, "drt"), (2097152, "drt"), (2097152 + 128, "drt"), (268435456, "drt")])
 def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     """The production path uses the wave-synchronous state machine for the primal and the
     one-ray-per-lane kernel for the adjoint (measured faster).  The other combinations
@@ -483,7 +483,8 @@ def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     65536 = state-machine kernel for the primal (no path cache), 262144 = record streams "cannot be
     allocated" (fallback to the atomic path), 1048576 = path cache off, 524288 (with 16384) = the record memory
     "runs out" after the first ray sub-batch (the rest of the job takes the atomic path), 2097152 = generic
-    instead of the specialised `volpathsimple-drt` kernels."""
+    instead of the specialised `volpathsimple-drt` kernels, 268435456 = without the early histogram pass (production: the
+    histogram of the main adjoint launch's records runs on a side stream next to the tail launch)."""
     props = props_for(variant)
     scene = uivr.cube_test_scene(32, 32, density_scale=2.0)
     spp, seed = 16, 777

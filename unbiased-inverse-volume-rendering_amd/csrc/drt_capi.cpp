@@ -54,7 +54,12 @@ struct drt_handle_s {
         hipEvent_t traced = nullptr, reduced = nullptr;
         bool busy = false;             // `reduced` is pending on the side stream
     } rec[2];
-    hipStream_t side = nullptr;        // high-priority stream of the overlapped reductions
+    hipStream_t side = nullptr;        // high-priority stream of the overlapped reductions / of the early histogram pass
+    // early histogram (drt_deferred.hip: launch_deferred_early_histogram): run_backward names the plan of the launch that
+    // follows; the adjoint launcher takes the histogram of the main launch's records on `side` next to the tail launch
+    const drt::DeferredPlan *early_plan = nullptr;
+    bool early_done = false;
+    hipEvent_t ev_split = nullptr, ev_hist = nullptr;
     // path cache (drt_coop.hip): written by the primal launch of an H1 step, read by the adjoint launch of the
     // same job if nothing happened to the handle in between
     void *d_pcache = nullptr;          // [rays][kPathCacheCap][2] uint4 | [rays] hash words
@@ -228,6 +233,22 @@ void bind_path_cache_read(drt_handle h, drt::Params &P, uint64_t job_rays)
     if (h->perm_valid && !dbg(h->debug_flags, 4194304u)) P.ray_perm = perm_base(P.ray_hash, job_rays);
 }
 
+struct EarlyCtx { drt_handle h; const drt::Params *P; };
+
+// between the main and the tail launch of the adjoint tracer: snapshot the chunk cursors, histogram of the complete chunks on
+// the side stream (the tail launch keeps few workgroups busy for as long as the job's longest path)
+hipError_t early_histogram_between(void *ctx)
+{
+    EarlyCtx *c = (EarlyCtx *) ctx;
+    drt_handle h = c->h;
+    hipError_t e = drt::launch_deferred_split(*h->early_plan, h->stream);
+    if (e == hipSuccess) e = hipEventRecord(h->ev_split, h->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ev_split, 0);
+    if (e == hipSuccess) e = drt::launch_deferred_early_histogram(*c->P, *h->early_plan, h->side);
+    if (e == hipSuccess) e = hipEventRecord(h->ev_hist, h->side);
+    return e;
+}
+
 int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
 {
     hipEvent_t a = nullptr, b = nullptr;
@@ -289,7 +310,21 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
             Q.ray_perm = nullptr;
             DRT_HIP_CHECK(h, drt::launch_trace_coop(Q, adjoint, h->counting, h->stream));
         } else {
-            DRT_HIP_CHECK(h, drt::launch_trace_coop(PT, adjoint, h->counting, h->stream));
+            // (test hook 268435456: no early histogram pass)
+            const bool early = adjoint && h->early_plan && PT.rec_buf[0] && PT.tail_pool && !dbg(h->debug_flags, 268435456u);
+            if (early && !h->side) {
+                int lo = 0, hi = 0;
+                DRT_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                DRT_HIP_CHECK(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
+            }
+            if (early && !h->ev_split) {
+                DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_split, hipEventDisableTiming));
+                DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_hist, hipEventDisableTiming));
+            }
+            EarlyCtx ctx{ h, &PT };
+            bool called = false;
+            DRT_HIP_CHECK(h, drt::launch_trace_coop(PT, adjoint, h->counting, h->stream, early ? early_histogram_between : nullptr, &ctx, &called));
+            h->early_done = called;
         }
     }
 #ifdef DRT_TEST_HOOKS
@@ -393,7 +428,7 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
     return DRT_OK;
 }
 
-int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream);
+int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream, bool early_hist = false);
 int timed_untile(drt_handle h, const drt::Params &P);
 
 // Adjoint launch + gradient reduction of one job.  Deferred path: the job is cut into sub-batches of rays
@@ -468,10 +503,14 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
             }
             if (rc) return rc;
             P.ray_first = first; P.n_rays = first + count;
+            h->early_plan = overlap ? nullptr : &R.plan; h->early_done = false;
             rc = launch(P);
-            if (rc) return rc;
+            if (rc) { h->early_plan = nullptr; return rc; }
             if (!overlap) {
-                rc = timed_reduce(h, P, R.plan, h->stream);
+                const bool early = h->early_done;
+                h->early_plan = nullptr; h->early_done = false;
+                if (early) DRT_HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_hist, 0));
+                rc = timed_reduce(h, P, R.plan, h->stream, early);
                 if (rc) return rc;
                 continue;
             }
@@ -494,7 +533,7 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
     return DRT_OK;
 }
 
-int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream)
+int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream, bool early_hist)
 {
     hipEvent_t a = nullptr, b = nullptr;
     if (h->timing) {
@@ -502,7 +541,7 @@ int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D,
         DRT_HIP_CHECK(h, hipEventCreate(&b));
         DRT_HIP_CHECK(h, hipEventRecord(a, stream));
     }
-    DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, D, stream));
+    DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, D, stream, nullptr, early_hist));
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventRecord(b, stream));
         h->timed[2].emplace_back(a, b);
@@ -607,6 +646,8 @@ int drt_destroy(drt_handle h)
         if (R.reduced) (void) hipEventDestroy(R.reduced);
     }
     if (h->side) (void) hipStreamDestroy(h->side);
+    if (h->ev_split) (void) hipEventDestroy(h->ev_split);
+    if (h->ev_hist) (void) hipEventDestroy(h->ev_hist);
     if (h->d_pcache) (void) hipFree(h->d_pcache);
     clear_timings(h);
     delete h;

@@ -112,10 +112,11 @@ hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStream_t stream)
+hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStream_t stream, coop_between_fn between, void *between_ctx,
+                             bool *called)
 {
     if (P.mgrid) return launch_trace_coop_super(P, adjoint, count, stream);      // drt_coop_super.hip
-    return launch_trace_coop_t<false>(P, adjoint, count, stream);
+    return launch_trace_coop_t<false>(P, adjoint, count, stream, between, between_ctx, called);
 }
 
 }  // namespace drt

@@ -147,7 +147,8 @@ __global__ void __launch_bounds__(256, ADJ ? DRT_COOP_WAVES : DRT_COOP_WAVES_PRI
 
 // launch of the instantiation that fits the job
 template <bool SUPER>
-hipError_t launch_trace_coop_t(const Params &P, bool adjoint, bool count, hipStream_t stream)
+hipError_t launch_trace_coop_t(const Params &P, bool adjoint, bool count, hipStream_t stream, coop_between_fn between = nullptr,
+                               void *between_ctx = nullptr, bool *called = nullptr)
 {
     if (P.n_rays <= P.ray_first) return hipSuccess;
     dim3 block(256), grid((unsigned)((P.n_rays - P.ray_first + 255) / 256));
@@ -190,6 +191,11 @@ hipError_t launch_trace_coop_t(const Params &P, bool adjoint, bool count, hipStr
         if (env) hipLaunchKernelGGL((trace_coop_kernel<true, false, true, true, true, SUPER>), grid, block, 0, stream, M);
         else hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true, SUPER>), grid, block, 0, stream, M);
         if constexpr (!SUPER) if (tail) {
+            if (between) {                                     // (e.g. the early histogram pass of the record streams)
+                hipError_t e = between(between_ctx);
+                if (e != hipSuccess) return e;
+                if (called) *called = true;
+            }
             if (env) hipLaunchKernelGGL((trace_coop_kernel<true, false, true, true, true, false, true>), tgrid, block, 0, stream, T);
             else hipLaunchKernelGGL((trace_coop_kernel<true, false, false, true, true, false, true>), tgrid, block, 0, stream, T);
         }

@@ -82,13 +82,16 @@ __device__ __forceinline__ float plane_max(float vmax, float v)
     return a > vmax ? a : vmax;
 }
 
+// part 0: every chunk; part 1: the chunks below the split (D.cursor[2 + S], launch_deferred_split) - what the adjoint
+// tracer's main launch wrote -; part 2: the chunks from the split on, ADDED to part 1's counts
 template <int S>
-__device__ __forceinline__ void bin_histogram_stream(const Params &P, const DeferredPlan &D, uint32_t *h)
+__device__ __forceinline__ void bin_histogram_stream(const Params &P, const DeferredPlan &D, uint32_t *h, int part)
 {
     constexpr int kPlanes = S == 0 ? 1 : 4, kQuads = S == 0 ? 1 : 2;
     for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) h[b] = 0;
     __syncthreads();
-    const uint32_t used = min(D.cursor[S], D.cap_chunks[S]);
+    const uint32_t all = min(D.cursor[S], D.cap_chunks[S]), split = min(D.cursor[2 + S], all);
+    const uint32_t lo = part == 2 ? split : 0u, used = part == 1 ? split : all;
     float vmax[kPlanes];
 #pragma unroll
     for (int c = 0; c < kPlanes; ++c) vmax[c] = 0.0f;
@@ -101,7 +104,7 @@ __device__ __forceinline__ void bin_histogram_stream(const Params &P, const Defe
 #pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) {                   // kPartUnroll chunks in flight per thread
             const uint32_t c = c0 + k * kSub * gridDim.x;
-            ok[k] = c < used && rec < D.chunk_count[S][c];
+            ok[k] = c >= lo && c < used && rec < D.chunk_count[S][c];
             if (ok[k]) {
                 const float4 *src = D.in[S] + ((size_t) c * kRecChunk + rec) * kQuads;
                 r[k] = src[0];
@@ -129,7 +132,8 @@ __device__ __forceinline__ void bin_histogram_stream(const Params &P, const Defe
     lds_atomics_barrier();
     if (threadIdx.x < kPlanes && wg_vmax[threadIdx.x]) atomicMax(D.vmax + (S == 0 ? 0 : 1) + threadIdx.x, wg_vmax[threadIdx.x]);
     uint32_t *dst = D.hist + ((size_t) S * gridDim.x + blockIdx.x) * D.n_bins;
-    for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) dst[b] = h[b];
+    if (part == 2) { for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) dst[b] += h[b]; }
+    else for (int b = threadIdx.x; b < D.n_bins; b += blockDim.x) dst[b] = h[b];
 }
 
 // per tile: exclusive prefix over the partition workgroups (in place) and the tile total.  One wave
@@ -186,10 +190,16 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const DeferredPlan D)
 }
 
 // both streams in one launch (blockIdx.y): the small stream's workgroups fill the tail of the large one's
-__global__ void __launch_bounds__(kPartThreads) bin_histogram_kernel(const Params P, const DeferredPlan D)
+__global__ void __launch_bounds__(kPartThreads) bin_histogram_kernel(const Params P, const DeferredPlan D, int part)
 {
     extern __shared__ uint32_t h[];
-    if (blockIdx.y == 0) bin_histogram_stream<0>(P, D, h); else bin_histogram_stream<1>(P, D, h);
+    if (blockIdx.y == 0) bin_histogram_stream<0>(P, D, h, part); else bin_histogram_stream<1>(P, D, h, part);
+}
+
+// snapshot of the chunk cursors: the chunks below it are complete once the launch that precedes this kernel has ended
+__global__ void rec_split_kernel(const DeferredPlan D)
+{
+    if (threadIdx.x < kRecStreams) D.cursor[2 + threadIdx.x] = min(D.cursor[threadIdx.x], D.cap_chunks[threadIdx.x]);
 }
 
 template <int S>
@@ -366,12 +376,25 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const 
 
 }  // namespace
 
-hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev)
+hipError_t launch_deferred_split(const DeferredPlan &D, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rec_split_kernel, dim3(1), dim3(64), 0, stream, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_deferred_early_histogram(const Params &P, const DeferredPlan &D, hipStream_t side)
+{
+    const size_t lds = (size_t) D.n_bins * sizeof(uint32_t);
+    hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, side, P, D, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev, bool early_hist)
 {
     const size_t lds = (size_t) D.n_bins * sizeof(uint32_t);
     auto mark = [&](int k) { if (ev) (void) hipEventRecord(ev[k], stream); };
     mark(0);
-    hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D);
+    hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D, early_hist ? 2 : 0);
     mark(1);
     hipLaunchKernelGGL(bin_offsets_kernel, dim3((D.n_bins + 3) / 4, kRecStreams), dim3(256), 0, stream, D, kPartWGs);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(kRecStreams), dim3(1024), 0, stream, D);

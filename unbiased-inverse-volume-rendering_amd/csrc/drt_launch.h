@@ -22,7 +22,11 @@ bool super_supported(const Params &P);
 hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
 // one ray per lane with wave-cooperative tracking loops (drt_coop.hip); global majorant only (P.mgrid == nullptr)
 hipError_t launch_trace_coop_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
-hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStream_t stream);
+// `between` (optional): called on the host after the main launch has been enqueued and before the tail launch (adjoint of the
+// specialised kernels with a tail pool); returns whether it was called through *called
+typedef hipError_t (*coop_between_fn)(void *ctx);
+hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStream_t stream, coop_between_fn between = nullptr,
+                             void *between_ctx = nullptr, bool *called = nullptr);
 hipError_t launch_ray_perm(const uint8_t *iters, uint64_t n_rays, uint16_t *perm, uint32_t *block_cost, hipStream_t stream);
 hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t *order, bool heavy_first, hipStream_t stream);
 hipError_t launch_untile(const Params &P, hipStream_t stream);
@@ -59,7 +63,13 @@ struct DeferredPlan {
     uint32_t max_units;              // launch bound of the reduce kernel (any stream)
 };
 // ev: optional 5 events recorded before/after the stages (histogram | offsets+scan | scatter | reduce)
-hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev = nullptr);
+// early_hist: the histogram of the chunks below the split (launch_deferred_early_histogram) has been taken already
+hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev = nullptr, bool early_hist = false);
+// The adjoint tracer's tail launch keeps few workgroups busy for as long as the job's longest path: between the main and
+// the tail launch the record streams' chunk cursors are snapshot (`split`, on `stream`), and the histogram pass over the
+// chunks below the split - everything the main launch wrote - runs on `side` next to the tail launch.
+hipError_t launch_deferred_split(const DeferredPlan &D, hipStream_t stream);
+hipError_t launch_deferred_early_histogram(const Params &P, const DeferredPlan &D, hipStream_t side);
 hipError_t launch_majorant(const float *sigma_t, size_t n, float scale, uint32_t *scratch_bits,
                            float *majorant, hipStream_t stream);
 hipError_t launch_batch_raygen(const float *sensors, int n_sensors, uint32_t batch_first, uint32_t batch_size, uint32_t spp,
