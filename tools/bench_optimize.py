@@ -26,15 +26,17 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--primal-spp-factor", type=int, default=64)
     ap.add_argument("--ref-spp", type=int, default=256)
+    ap.add_argument("--majorant-factor", type=int, default=8, help="reference default: 8 (scene_config.py:36); 0 = global majorant")
     args = ap.parse_args()
     import torch
     import uivr_amd as u
     from uivr_amd import synthetic
     dev = torch.device("cuda:0")
     scene = synthetic.dust_devil_scene(res=args.res, film=args.film, device=dev, n_sensors=args.sensors)
+    scene.medium.majorant_resolution_factor = args.majorant_factor
     sc = u.SceneConfig(name="dust-devil-synthetic", scene=scene, param_keys=[u.SIGMA_T_KEY, u.ALBEDO_KEY],
                        sensors=list(range(args.sensors)), start_from_value={u.SIGMA_T_KEY: 0.04, u.ALBEDO_KEY: 0.6},
-                       max_depth=64, ref_spp=args.ref_spp, majorant_resolution_factor=0)
+                       max_depth=64, ref_spp=args.ref_spp, majorant_resolution_factor=args.majorant_factor)
     oc = u.OptimizationConfig("config3", spp=args.spp, n_iter=args.iters, lr=3e-4 * 100, batch_size=args.batch,
                               primal_spp_factor=args.primal_spp_factor, lr_schedule=u.Schedule.Last25,
                               checkpoint_initial=False, checkpoint_final=False, checkpoint_stride=0)
