@@ -319,10 +319,17 @@ def test_error_behaviour(uivr, gpu):
         uivr.render(sg, integrator=integ, spp=1, seed=5, seed_grad=5)
 
 
-def test_sharded_equals_unsharded(uivr, gpu):
+@pytest.mark.parametrize("factor", [0, 3])
+def test_sharded_equals_unsharded(uivr, gpu, factor):
     """Logical shards on one device: image tiles dealt to `world` ranks,
-    global-index random streams => identical pixels, gradients equal up to fp order."""
+    global-index random streams => identical pixels, gradients equal up to fp order - with the global majorant
+    (cooperative tracer) and with a majorant supergrid (drt_super.hip: interleaved ray chunks through its ray queues)."""
     scene = uivr.cube_test_scene(32, 32, density_scale=2.0)
+    if factor:
+        st = np.repeat(np.repeat(np.repeat(np.asarray(scene.medium.sigma_t), 4, 0), 4, 1), 4, 2)     # 3^3 -> 12^3 voxels: 4^3 supergrid cells
+        al = np.repeat(np.repeat(np.repeat(np.asarray(scene.medium.albedo), 4, 0), 4, 1), 4, 2)
+        scene.medium.sigma_t, scene.medium.albedo = st.copy(), al.copy()
+        scene.medium.majorant_resolution_factor = factor
     sg = uivr.scene_to(scene, gpu)
     integ = _integrator(uivr, props_for("drt"))
     spp, seed = 8, 321
