@@ -266,8 +266,9 @@ def test_majorant_supergrid(uivr, oracle, gpu, factor):
     _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], "grad albedo")
 
 
-def test_edge_cases(uivr, oracle, gpu):
-    """Empty batch, all rays missing the box, zero density, zero albedo, max_depth 0/1."""
+@pytest.mark.parametrize("factor", [0, 2])
+def test_edge_cases(uivr, oracle, gpu, factor):
+    """Empty batch, all rays missing the box, zero density, zero albedo, max_depth 0/1 - global majorant and supergrid tracer."""
     scene = uivr.cube_test_scene(8, 8, density_scale=2.0)
     sg = uivr.scene_to(scene, gpu)
     integ = _integrator(uivr, props_for("drt"))
@@ -286,6 +287,10 @@ def test_edge_cases(uivr, oracle, gpu):
                       ("depth1", dict(max_depth=1)), ("russian_roulette", dict(rr_depth=2)),
                       ("no_nee", dict(use_nee=False)), ("hide_emitters", dict(hide_emitters=True))]:
         sc = uivr.cube_test_scene(8, 8, density_scale=2.0)
+        if factor:                                          # 3^3 -> 6^3 voxels, 3^3 supergrid cells
+            sc.medium.sigma_t = np.repeat(np.repeat(np.repeat(np.asarray(sc.medium.sigma_t), 2, 0), 2, 1), 2, 2).copy()
+            sc.medium.albedo = np.repeat(np.repeat(np.repeat(np.asarray(sc.medium.albedo), 2, 0), 2, 1), 2, 2).copy()
+            sc.medium.majorant_resolution_factor = factor
         if mod == "zero_density":
             sc.medium.sigma_t[...] = 0.0
         if mod == "zero_albedo":
