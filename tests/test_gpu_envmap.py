@@ -20,8 +20,12 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def _env_scene(uivr, film=32, **kw):
+def _env_scene(uivr, film=32, factor=0, **kw):
     scene = uivr.cube_test_scene(film, film, density_scale=2.0)
+    if factor:                                              # 3^3 -> 9^3 voxels with a 3^3 majorant supergrid
+        scene.medium.sigma_t = np.repeat(np.repeat(np.repeat(np.asarray(scene.medium.sigma_t), 3, 0), 3, 1), 3, 2).copy()
+        scene.medium.albedo = np.repeat(np.repeat(np.repeat(np.asarray(scene.medium.albedo), 3, 0), 3, 1), 3, 2).copy()
+        scene.medium.majorant_resolution_factor = factor
     scene.emitter = uivr.EnvmapEmitter(pixels=_blob_map(**kw), scale=0.5, to_world=uivr.EnvmapEmitter.rotation_y(-40.0))
     return scene
 
@@ -65,10 +69,13 @@ def test_envmap_primitives_bit_exact(uivr, oracle, gpu):
     np.testing.assert_array_equal(_bits(got), _bits(ref))
 
 
-@pytest.mark.parametrize("flags,variant", [(0, "drt"), (0, "basic"), (0, "quadratic"), (8, "drt"), (32, "drt"), (32, "basic")])
+@pytest.mark.parametrize("flags,variant", [(0, "drt"), (0, "basic"), (0, "quadratic"), (8, "drt"), (32, "drt"), (32, "basic"),
+                                           (-3, "drt"), (-3, "basic")])
 def test_envmap_render_matches_oracle(uivr, oracle, gpu, flags, variant):
+    """(flags -3: a majorant supergrid of factor 3 - the envmap instantiations of the supergrid tracer, drt_super.hip)"""
     props = props_for(variant)
-    scene = _env_scene(uivr)
+    scene = _env_scene(uivr, factor=3 if flags < 0 else 0)
+    flags = max(flags, 0)
     spp, seed = 8, 4242
     ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
     _, c_primal = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)
