@@ -401,8 +401,16 @@ hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStr
     mark(2);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D);
     mark(3);
-    static const hipError_t attr = hipFuncSetAttribute((const void *) tile_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTile * 8);
-    if (attr != hipSuccess) return attr;
+    {   // (the attribute belongs to the function on a device: set once per device)
+        static bool attr_set[64] = { false };
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+        if (!attr_set[dev] || dev == 63) {
+            const hipError_t attr = hipFuncSetAttribute((const void *) tile_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTile * 8);
+            if (attr != hipSuccess) return attr;
+            attr_set[dev] = true;
+        }
+    }
     const uint32_t wgs = D.max_units < kReduceWGs ? D.max_units : kReduceWGs;
     hipLaunchKernelGGL(tile_reduce_kernel, dim3(wgs, 5), dim3(256), (size_t) kLdsTile * 8, stream, P, D);
     mark(4);

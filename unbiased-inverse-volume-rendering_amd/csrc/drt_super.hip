@@ -864,11 +864,15 @@ hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_c
 #define DRT_SUPER_LAUNCH(A, C, E, M)                                                                              \
     do {                                                                                                          \
         auto kern = trace_super_kernel<A, C, E, M>;                                                               \
-        static size_t lds_set = 0;                                                                                \
-        if (lds > lds_set) {                                                                                      \
+        /* (the attribute belongs to the function ON A DEVICE: remembered per device; the kernels of one handle are \
+            launched from one host thread, handles on different devices keep different entries) */                 \
+        static size_t lds_set[64] = { 0 };                                                                        \
+        int dev_ = 0;                                                                                             \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 63;                               \
+        if (lds > lds_set[dev_] || dev_ == 63) {                                                                  \
             e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
             if (e != hipSuccess) return e;                                                                        \
-            lds_set = lds;                                                                                        \
+            lds_set[dev_] = lds;                                                                                  \
         }                                                                                                         \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, P);                                                    \
     } while (0)
