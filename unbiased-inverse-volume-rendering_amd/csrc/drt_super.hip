@@ -2,7 +2,7 @@
 // default: python/scene_config.py:36, optimize.py:182-199): VolpathSimpleIntegrator.sample
 // (python/integrators/volpathsimple.py:38-655), both AD modes.
 //
-// Why (measured, DESIGN.md section 9): with a supergrid a tracking step is a free flight through 1..60 supergrid cells
+// Why (measured, DESIGN.md section 6.1): with a supergrid a tracking step is a free flight through 1..60 supergrid cells
 // (3-D DDA; mean 12.6, bimodal) followed by one grid lookup, and a walk is ~25 cells but only 0.7..2 lookups: most of
 // the work is cell stepping, in flights whose lengths have nothing to do with each other.  The one-ray-per-lane tracer
 // ran it at 11.8 % VALU lane utilisation (every lane waits for the longest flight of the few lanes that have one), a
@@ -18,12 +18,14 @@
 //     lookup + the walk's acceptance / ratio / reservoir epilogue), path transitions (scatter / escape / emitter
 //     sampling / end of path / next ray), the set-up of the next flight, which is then POSTED: slot written, bit set in
 //     the wave's ready mask - and only when enough of its lanes have something to do;
-//   * whenever it has too few such lanes, a wave WALKS instead: it pulls up to 64 posted flights out of the ready masks -
-//     whoever posted them -, steps each through DRT_SUPER_K supergrid cells (~30 branch-free instructions per cell,
-//     majorants from LDS), writes the DDA state back and either marks the flight done in its owner's done mask ({entry
-//     distance, optical depth, majorant} of the cell it ended in) or posts it again.  Walking is stateless - nothing of a
-//     flight stays in registers - so cell steps always run on densely filled waves, lanes that wait for a heavy run cost
-//     no issue slots, and every wave of the CU shares the load.
+//   * whenever it has too few such lanes, a wave WALKS instead: it pulls posted flights out of the ready masks - whoever
+//     posted them - into its free walker lanes (whole masks with one 64-bit exchange, handed out by rank), steps them
+//     through the supergrid DRT_SUPER_K cells at a time (~26 branch-free vector instructions per cell, majorants from
+//     LDS), refilling lanes as flights end; a flight that ends leaves {entry distance, optical depth, majorant} of its last
+//     cell in its slot and a bit in its owner's done mask.  When enough of the wave's own lanes are ready again, the
+//     flights still under way are written back to their slots and posted again: nothing of a flight outlives the
+//     walking block in registers, so walking costs the heavy code no registers, cell steps run on densely refilled
+//     lanes whoever owns the flights, and lanes that wait for a heavy run cost no issue slots.
 // Lanes that finish a ray pull the next one from their XCD's queue.
 //
 // Larger supergrids (the majorants do not fit next to the slots) keep their non-empty-cell bitmask in LDS and load the
@@ -82,7 +84,7 @@ enum Phase : int {
     // walk phases: the lane is inside a tracking walk (its flight state `fl` says where)
     PH_DT = 0, PH_RT, PH_RTA, PH_DRT,
     // transition phases
-    PH_HEAD, PH_SCAT, PH_ESC, PH_TR, PH_POST, PH_NEE, PH_RT_END, PH_RTA_END, PH_PHASE, PH_END, PH_DRT_END,
+    PH_HEAD, PH_SCAT, PH_ESC, PH_NEE, PH_RT_END, PH_RTA_END, PH_PHASE, PH_END, PH_DRT_END,
     PH_IDLE, PH_DEAD
 };
 enum Flight : int { FL_NEW = 0, FL_NEXT = 1, FL_WAIT = 2 };   // first flight of a walk to set up | next flight to set up | posted
