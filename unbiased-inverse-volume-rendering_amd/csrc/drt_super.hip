@@ -40,7 +40,10 @@
 #include "drt_launch.h"
 
 #ifndef DRT_SUPER_THREADS
-#define DRT_SUPER_THREADS 768      // threads per workgroup = per CU: 12 waves, 3 per SIMD (168 registers)
+#define DRT_SUPER_THREADS 768      // threads per workgroup = per CU of the primal kernels: 12 waves, 3 per SIMD (168 registers)
+#endif
+#ifndef DRT_SUPER_THREADS_ADJ
+#define DRT_SUPER_THREADS_ADJ 768  // ... of the adjoint kernels
 #endif
 #ifndef DRT_SUPER_K
 #define DRT_SUPER_K 8              // cells per walker lane between two looks at the masks
@@ -105,9 +108,9 @@ __device__ __forceinline__ uint32_t xcc_id()
 }  // namespace
 
 template <bool ADJ, bool COUNT, bool ENV, bool MGL>
-__global__ void __launch_bounds__(DRT_SUPER_THREADS) trace_super_kernel(const Params P)
+__global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREADS) trace_super_kernel(const Params P)
 {
-    constexpr int NWV = DRT_SUPER_THREADS / 64;                              // waves = 64-lane groups of flight slots
+    constexpr int NWV = (ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREADS) / 64;                              // waves = 64-lane groups of flight slots
     constexpr int NS = NWV * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // LDS: [flight slots: 3 x uint4 each][majorants as bf16 (MGL) | non-empty-cell bitmask][record state per wave]
@@ -829,10 +832,10 @@ __global__ void __launch_bounds__(DRT_SUPER_THREADS) trace_super_kernel(const Pa
 }
 
 // LDS bytes of a launch; 0: this supergrid cannot be served (the host keeps the one-ray-per-lane kernels)
-static size_t super_lds_bytes(const Params &P, bool &mgl)
+static size_t super_lds_bytes(const Params &P, bool adjoint, bool &mgl)
 {
     const size_t cells = (size_t) P.gx * P.gy * P.gz;
-    constexpr size_t nwv = DRT_SUPER_THREADS / 64;
+    const size_t nwv = (adjoint ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREADS) / 64;
     // (the kernel's layout: flight slots, record state, ready + done masks, pull lists)
     const size_t fixed = ((size_t) kSlotWords * 64 * nwv + nwv * 8 + 4 * nwv + 64 * nwv) * 4;
     const size_t limit = 160u * 1024u;
@@ -845,17 +848,17 @@ static size_t super_lds_bytes(const Params &P, bool &mgl)
 bool super_supported(const Params &P)
 {
     bool mgl;
-    return P.mgrid && P.mocc && P.gx <= 511 && P.gy <= 511 && P.gz <= 511 && super_lds_bytes(P, mgl) != 0;
+    return P.mgrid && P.mocc && P.gx <= 511 && P.gy <= 511 && P.gz <= 511 && super_lds_bytes(P, false, mgl) != 0 && super_lds_bytes(P, true, mgl) != 0;
 }
 
 hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream)
 {
     if (P.n_rays <= P.ray_first) return hipSuccess;
     bool mgl = false;
-    const size_t lds = super_lds_bytes(P, mgl);
+    const size_t lds = super_lds_bytes(P, adjoint, mgl);
     if (!lds) return hipErrorInvalidValue;
     // one workgroup per CU when the majorants live in LDS; with the bitmask only, as many as fit
-    const unsigned threads = DRT_SUPER_THREADS;
+    const unsigned threads = adjoint ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREADS;
     unsigned blocks = (unsigned) n_cus;                                         // one workgroup per CU
     const uint64_t need = (P.n_rays - P.ray_first + 63) / 64;                  // no more path waves than 64-ray groups
     const uint64_t waves_per_block = threads / 64;
