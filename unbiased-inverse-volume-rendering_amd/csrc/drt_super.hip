@@ -526,53 +526,6 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
             do {
                 DRT_PROF(8, 1);
                 uint4 pce1 = make_uint4(0u, 0u, 0u, 0u); bool pce1_ok = false;   // this iteration's NEE entry of the path cache, read at the loop head
-                // ---- end of a path (:249-287) -----------------------------------------------------
-                if (ph == PH_END) {
-                    if (!ADJ || rec_mode) {                                     // envmap block, primal only
-                        if (escaped && !(depth <= 0 && P.hide_emitters)) {
-                            float w = 1.0f, Le[3];
-                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? emitter_pdf<ENV>(P, rd) : 0.0f);
-                            emitter_eval<ENV>(P, rd, Le);
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
-                        }
-                    }
-                    if constexpr (!ADJ) {
-                        const size_t o3 = 3 * (size_t) li;
-                        P.L_out[o3] = result[0]; P.L_out[o3 + 1] = result[1]; P.L_out[o3 + 2] = result[2];
-                        if (P.ray_iters) P.ray_iters[li] = (uint8_t) (pc_it < 255 ? pc_it : 255);
-                        ph = PH_IDLE;
-                    } else {
-                        if (rec_mode) {
-                            // result = Li': gradient splat at x' (:577-581)
-                            float alb[3];
-                            eval_albedo(P, r_o, alb);                           // :578
-                            DRT_COUNT(C_ALB);
-                            float gs = 0.0f, ga[3];
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                float a = r_cw[k] * result[k];
-                                gs += a * alb[k];
-                                ga[k] = a * r_si_t;
-                            }
-                            splat_scatter<true>(P, r_o, gs, ga, rec); DRT_COUNT(C_SC); DRT_COUNT(C_SC_ALB);
-                            ph = PH_IDLE;
-                        } else if (P.use_drt && r_depth >= 0) {                 // :249-259, DRTReservoir.get :756-760
-                            const float d = ((r_cw[0] + r_cw[1]) + r_cw[2]) / 3.0f;
-                            const float ws = ((r_wsum[0] + r_wsum[1]) + r_wsum[2]) / 3.0f;
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) r_cw[k] = (d != 0.0f ? (ws * r_cw[k]) / d : 0.0f) * dL[k];   // adjoint
-                            // sample_interaction_drt along the selected segment (:543-551)
-                            wmax = isfinite(r_si_t) ? r_si_t : kLargest;
-                            ro = r_o; rd = r_d;
-                            wt = 0.0f; wo = v3(1.0f, 0.0f, kInf);               // T, wsum, selected t
-                            ph = PH_DRT; fl = FL_NEW;
-                        } else {
-                            ph = PH_IDLE;
-                        }
-                    }
-                }
-
                 // ---- DRT vertex selected: enter the detached recursive path (:553-575, :610-655) -----
                 if constexpr (ADJ) {
                     if (ph == PH_DRT_END) {
@@ -755,6 +708,52 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                         ph = PH_RT_END;
                     } else if (h.valid) { wo = ro; wmax = h.t; wt = 1.0f; ph = PH_RT; fl = FL_NEW; }
                     else { wt = 0.0f; ph = PH_RT_END; }
+                }
+                // ---- end of a path (:249-287) -----------------------------------------------------
+                if (ph == PH_END) {
+                    if (!ADJ || rec_mode) {                                     // envmap block, primal only
+                        if (escaped && !(depth <= 0 && P.hide_emitters)) {
+                            float w = 1.0f, Le[3];
+                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? emitter_pdf<ENV>(P, rd) : 0.0f);
+                            emitter_eval<ENV>(P, rd, Le);
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
+                        }
+                    }
+                    if constexpr (!ADJ) {
+                        const size_t o3 = 3 * (size_t) li;
+                        P.L_out[o3] = result[0]; P.L_out[o3 + 1] = result[1]; P.L_out[o3 + 2] = result[2];
+                        if (P.ray_iters) P.ray_iters[li] = (uint8_t) (pc_it < 255 ? pc_it : 255);
+                        ph = PH_IDLE;
+                    } else {
+                        if (rec_mode) {
+                            // result = Li': gradient splat at x' (:577-581)
+                            float alb[3];
+                            eval_albedo(P, r_o, alb);                           // :578
+                            DRT_COUNT(C_ALB);
+                            float gs = 0.0f, ga[3];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                float a = r_cw[k] * result[k];
+                                gs += a * alb[k];
+                                ga[k] = a * r_si_t;
+                            }
+                            splat_scatter<true>(P, r_o, gs, ga, rec); DRT_COUNT(C_SC); DRT_COUNT(C_SC_ALB);
+                            ph = PH_IDLE;
+                        } else if (P.use_drt && r_depth >= 0) {                 // :249-259, DRTReservoir.get :756-760
+                            const float d = ((r_cw[0] + r_cw[1]) + r_cw[2]) / 3.0f;
+                            const float ws = ((r_wsum[0] + r_wsum[1]) + r_wsum[2]) / 3.0f;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) r_cw[k] = (d != 0.0f ? (ws * r_cw[k]) / d : 0.0f) * dL[k];   // adjoint
+                            // sample_interaction_drt along the selected segment (:543-551)
+                            wmax = isfinite(r_si_t) ? r_si_t : kLargest;
+                            ro = r_o; rd = r_d;
+                            wt = 0.0f; wo = v3(1.0f, 0.0f, kInf);               // T, wsum, selected t
+                            ph = PH_DRT; fl = FL_NEW;
+                        } else {
+                            ph = PH_IDLE;
+                        }
+                    }
                 }
             } while (__ballot(ph >= PH_HEAD && ph < PH_IDLE));
         }
