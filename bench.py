@@ -142,12 +142,14 @@ def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=Non
     return out
 
 
-def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
+def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only=None):
     """BASELINE.json `configs` 2-5 and the reference's default majorant_resolution_factor on the headline scene,
     each at its registered size, a few H1 steps each (wall clock around synchronised steps, 1 GPU)."""
     out = {}
 
     def guarded(name, fn):
+        if only and name != only:
+            return
         try:
             out[name] = fn()
         except Exception as e:                     # a failure here must not take the headline line with it
@@ -304,7 +306,14 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt"):
                 "nerf_queries_per_step": n_q, "t_primal_ms": round(avg_p, 3), "t_adjoint_pass_ms": round(avg_pass, 3),
                 "roofline_adjoint": {"achieved_GBs": round(b_a / (avg_pass * 1e-3) / 1e9, 1) if avg_pass else None,
                                      "frac": round(b_a / (avg_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_pass else None,
-                                     "algorithmic_bytes": b_a},
+                                     "algorithmic_bytes": b_a,
+                                     # HBM-side bytes of the adjoint pass from the request-size counters (committed profile of
+                                     # these kernel sources, or null) and the bandwidth they mean over the measured pass time
+                                     "traffic": committed_traffic("fused-256-512x32")[0],
+                                     "traffic_GBs": (round(committed_traffic("fused-256-512x32")[0] / (avg_pass * 1e-3) / 1e9, 1)
+                                                     if avg_pass and committed_traffic("fused-256-512x32")[0] else None),
+                                     "traffic_frac": (round(committed_traffic("fused-256-512x32")[0] / (avg_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                      if avg_pass and committed_traffic("fused-256-512x32")[0] else None)},
                 "roofline_primal": {"achieved_GBs": round(b_p / (avg_p * 1e-3) / 1e9, 1) if avg_p else None,
                                     "frac": round(b_p / (avg_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_p else None,
                                     "algorithmic_bytes": b_p},
@@ -339,6 +348,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the other BASELINE configurations (reported under `other_configs`, outside the timed loop)")
+    ap.add_argument("--only-config", default=None,
+                    help="run ONE entry of other_configs and print it (counter passes of a single configuration under rocprofv3)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU sample (0 = auto)")
     ap.add_argument("--debug-flags", type=int, default=0, help="profiling ablations (drt_set_debug_flags); invalidates the result")
     args = ap.parse_args()
@@ -368,6 +379,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+
+    if args.only_config:
+        print(json.dumps(other_configs(torch, u, synthetic, dev, integ_name=args.integrator, only=args.only_config)), flush=True)
+        return
 
     # ---- workload (synthetic, seeded; resident in HBM) ---------------------------------
     if args.workload == "dust-devil":

@@ -16,6 +16,7 @@ for f in 0 8; do
   (timeout 600 rocprofv3 -i /root/repo/tools/pmc_util.txt --kernel-trace --output-format csv -d $R/pmc_util$f -- $B --steps 3 --warmup 1 --majorant-factor $f > /dev/null 2>> $R/err.txt)
   (timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic$f -- $B --steps 3 --warmup 1 --majorant-factor $f > /dev/null 2>> $R/err.txt)
 done
+(timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic_fused -- $B --only-config config5_fused_nerf_drt_256_512x32 > /dev/null 2>> $R/err.txt)
 cd /root/repo
 rm -f $R/roofline_traffic.json
 python tools/rocpd_stats.py $R/prof0/hl_results.db --csv $R/kernel_stats.csv --top 14
@@ -24,7 +25,8 @@ python tools/pmc_summary.py $R/pmc_util0 > $R/pmc_util.txt
 python tools/pmc_summary.py $R/pmc_util8 > $R/factor8_pmc_util.txt
 python tools/pmc_to_traffic.py $R/pmc_traffic0 dust-devil-256-512x32 $R/roofline_traffic.json > $R/pmc_traffic.txt
 python tools/pmc_to_traffic.py $R/pmc_traffic8 dust-devil-256-512x32-factor8 $R/roofline_traffic.json > $R/pmc_traffic_factor8.txt
-rm -rf $R/pmc_util0 $R/pmc_util8 $R/pmc_traffic0 $R/pmc_traffic8 $R/prof0 $R/prof8
+python tools/pmc_to_traffic.py $R/pmc_traffic_fused fused-256-512x32 $R/roofline_traffic.json > $R/pmc_traffic_fused.txt
+rm -rf $R/pmc_util0 $R/pmc_util8 $R/pmc_traffic0 $R/pmc_traffic8 $R/pmc_traffic_fused $R/prof0 $R/prof8
 cp $R/roofline_traffic.json profiles/roofline_traffic.json      # the bench lines below quote it (same kernel sources: hash checked)
 (timeout 1500 python bench.py > $R/bench.json 2>> $R/err.txt)
 (timeout 600 python bench.py --majorant-factor 8 --no-extra-configs --no-cpu-baseline > $R/bench_factor8.json 2>> $R/err.txt)

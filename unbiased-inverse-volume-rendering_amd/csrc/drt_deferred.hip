@@ -249,7 +249,10 @@ __global__ void __launch_bounds__(kPartThreads) bin_scatter_kernel(const Params 
 // blockIdx.y = reduce plane: 0: sigma_t of stream 0 AND of stream 1 (for every tile that has stream-0 records: the
 // workgroup that starts such a tile's first unit also adds stream 1's sigma_t values of that tile - one zero / flush
 // of the LDS tile instead of two); 1: sigma_t of stream 1 for the tiles WITHOUT stream-0 records; 2..4: r, g, b of stream 1
-__global__ void __launch_bounds__(256) tile_reduce_kernel(const Params P, const DeferredPlan D)
+#ifndef DRT_REDUCE_THREADS
+#define DRT_REDUCE_THREADS 512      // (256: 1.15 ms per headline launch, 512 / 1024: 0.85 ms - more waves per CU behind the LDS tile)
+#endif
+__global__ void __launch_bounds__(DRT_REDUCE_THREADS) tile_reduce_kernel(const Params P, const DeferredPlan D)
 {
     extern __shared__ unsigned long long tile[];                 // kLdsTile signed 64-bit fixed-point accumulators
     const int plane = blockIdx.y;
@@ -412,7 +415,7 @@ hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStr
         }
     }
     const uint32_t wgs = D.max_units < kReduceWGs ? D.max_units : kReduceWGs;
-    hipLaunchKernelGGL(tile_reduce_kernel, dim3(wgs, 5), dim3(256), (size_t) kLdsTile * 8, stream, P, D);
+    hipLaunchKernelGGL(tile_reduce_kernel, dim3(wgs, 5), dim3(DRT_REDUCE_THREADS), (size_t) kLdsTile * 8, stream, P, D);
     mark(4);
     return hipGetLastError();
 }
