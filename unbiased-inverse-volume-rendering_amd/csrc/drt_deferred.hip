@@ -53,7 +53,7 @@ __device__ __forceinline__ void lds_atomics_barrier()
 }
 constexpr int kPartUnroll = DRT_PART_UNROLL;   // chunks a partition thread keeps in flight
 constexpr uint32_t kRideRecords = 4096;  // stream-1 records per tile that plane 0 takes along (a quarter of a reduce unit)
-constexpr uint32_t kReduceWGs = 1024;   // per stream: 4 workgroups per CU, looping over the reduce units
+constexpr uint32_t kReduceWGs = 1024;   // per plane: 4 workgroups per CU, looping over the reduce units (512 .. 4096: the same)
 
 struct Cell { int x0, x1, y0, y1, z0, z1; float w[8]; };
 
