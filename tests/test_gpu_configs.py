@@ -294,3 +294,17 @@ def test_config5_nerf_256_512x32_128_queries(uivr, oracle, gpu):
     assert ca == c_a
     _close_on_device(grads[uivr.SIGMA_T_KEY], gs, "nerf window grad sigma_t")
     _close_on_device(grads[uivr.EMISSION_KEY], ge, "nerf window grad emission")
+
+
+def test_supergrid_tracer_repeats_bitwise_at_size(gpu):
+    """tools/stress_super.py: the supergrid tracer's flights travel through LDS slots and masks shared by the twelve waves
+    of a workgroup - a lost, duplicated or stale flight would change rays.  The headline scene at factor 8 (and three
+    smaller shapes that end their kernels differently), the same seeds over and over: radiance bitwise the same every time,
+    gradients equal up to summation order and finite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_super.py"), "--reps", "9"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "STRESS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
