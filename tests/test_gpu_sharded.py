@@ -28,8 +28,10 @@ def _torchrun(script_args, world=2, env_extra=None, timeout=900):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-def test_sharded_batched_render_and_optimisation_two_processes(gpu):
-    r = _torchrun([os.path.join(ROOT, "tests", "workers", "sharded_worker.py")])
+@pytest.mark.parametrize("factor", [0, 4])
+def test_sharded_batched_render_and_optimisation_two_processes(gpu, factor):
+    """(factor 4: a majorant supergrid - two processes run the supergrid tracer's CU-wide workgroups side by side on one device)"""
+    r = _torchrun([os.path.join(ROOT, "tests", "workers", "sharded_worker.py")], env_extra={"DRT_TEST_FACTOR": str(factor)})
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
     assert "SHARDED_WORKER_OK" in r.stdout
 

@@ -31,6 +31,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     scene = synthetic.smoke_scene(res=24, film=32, device=dev, optical_side=10.0)
+    scene.medium.majorant_resolution_factor = int(os.environ.get("DRT_TEST_FACTOR", "0"))   # > 0: the supergrid tracer (drt_super.hip)
     scene.sensors = synthetic.ring_sensors(5, radius=5.0, height=0.8, fov=30.0, width=32, film_height=32)
     integ = u.get_int_config("volpathsimple-drt").create(max_depth=32)
     shard = u.ShardSpec(rank, world)
