@@ -647,6 +647,18 @@ def test_heavy_tailed_ratio_tracking_splats_keep_ordinary_voxels_accurate(uivr, 
 @pytest.mark.parametrize("flags,variant", [(0, "drt"), (0, "drt-nomis"), (0, "basic"), (134217728, "drt"), (128, "drt"),
                                            (1048576, "drt"), (16384, "drt"), (0, "quadratic")])
 def test_supergrid_tracer_and_its_fallbacks_match_oracle(uivr, oracle, gpu, flags, variant):
+    _supergrid_case(uivr, oracle, gpu, flags, variant, 7.0)
+
+
+@pytest.mark.parametrize("variant,density", [("drt", 0.05), ("drt", 0.6), ("basic", 0.2), ("drt-nomis", 1.5), ("drt", 0.0)])
+def test_supergrid_flights_that_cannot_collide_are_not_walked(uivr, oracle, gpu, variant, density):
+    """Optically thin media (optimisations start from sigma_t = 0.04, scene_config.py:117): the tracer does not walk a
+    flight whose target optical depth exceeds (largest majorant) x (segment length) - most flights at 0.05, about half
+    at 0.6, a few at 1.5, all of them in an empty medium.  Radiance bit-exact, counters equal, gradients close."""
+    _supergrid_case(uivr, oracle, gpu, 0, variant, density)
+
+
+def _supergrid_case(uivr, oracle, gpu, flags, variant, density):
     """Scenes with a majorant supergrid run in the cell-stepping tracer (drt_super.hip): every estimator it takes
     (subsampled DRT with / without MIS, basic), with the path cache on and off (1048576), with the job cut into ray
     sub-batches (16384: launches with ray_first > 0); and what it hands back to the older kernels stays verified:
@@ -654,7 +666,7 @@ def test_supergrid_tracer_and_its_fallbacks_match_oracle(uivr, oracle, gpu, flag
     Radiance bit-exact, counters equal, gradients close - against the oracle."""
     rng = np.random.default_rng(17)
     res = (24, 20, 28)                                   # X, Y, Z
-    st = rng.random((res[2], res[1], res[0], 1), dtype=np.float32) * 7.0
+    st = rng.random((res[2], res[1], res[0], 1), dtype=np.float32) * np.float32(density)
     st[rng.random(st.shape) < 0.55] = 0.0
     st[:, :, 16:] = 0.0                                  # empty supercells
     al = (rng.random((res[2], res[1], res[0], 3), dtype=np.float32) * 0.8 + 0.1).astype(np.float32)
