@@ -397,7 +397,7 @@ def main():
     spp = args.spp
     n_total = n_pixels * spp
     # --debug-flags (profiling ablations) need the library flavour with test hooks; the default run uses the production one
-    integ = u.get_int_config(args.integrator).create(max_depth=64, **({"test_hooks": True} if args.debug_flags else {}))
+    integ = u.get_int_config(args.integrator).create(max_depth=int(os.environ.get("DRT_BENCH_MAX_DEPTH", "64")), **({"test_hooks": True} if args.debug_flags else {}))
     shard = u.ShardSpec(rank, world, u.ShardSpec.default_chunk(n_pixels, world)) if world > 1 else None
     batch_shard = shard or u.ShardSpec()
     n_local_pix = batch_shard.n_local_pixels(n_pixels)

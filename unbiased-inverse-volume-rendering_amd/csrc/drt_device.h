@@ -296,6 +296,12 @@ struct Params {
     uint32_t *tail_count;          // entries written (zeroed before the main launch)
     uint32_t tail_cap, tail_mode;  // capacity in entries; 1 = this launch finishes the pool's paths
     unsigned long long *queues;     // 8 per-XCD ray queue heads (wavefront kernel), zeroed per launch
+    // Ray order of the supergrid tracer (drt_super.hip, build_super_order): queue position g takes ray
+    // ray_first + order[g / order_unit] * order_unit + g % order_unit - units of consecutive rays, the expensive ones first, so
+    // that the longest paths of a launch start at its beginning instead of running on alone at its end (a schedule
+    // only: every ray's result is independent of when it is traced).  nullptr: rays in index order
+    const uint32_t *order;
+    uint32_t order_unit, order_units;
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
 };

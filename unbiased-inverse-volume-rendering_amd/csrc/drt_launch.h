@@ -20,6 +20,11 @@ hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int
 // majorant grid in LDS (drt_super.hip); the adjoint needs the record streams (deferred splatting)
 bool super_supported(const Params &P);
 hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
+// Ray order for launch_trace_super (Params::order): units of `unit` consecutive rays of [P.ray_first, P.n_rays) sorted by a
+// cost key - the majorant optical depth along the unit's first ray through the supergrid -, most expensive first.
+// work: super_order_bytes(units) bytes; the permutation is the first `units` words of it.
+size_t super_order_bytes(uint32_t units);
+hipError_t build_super_order(const Params &P, uint32_t unit, uint32_t units, void *work, hipStream_t stream);
 // one ray per lane with wave-cooperative tracking loops (drt_coop.hip); global majorant only (P.mgrid == nullptr)
 hipError_t launch_trace_coop_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
 // `between` (optional): called on the host after the main launch has been enqueued and before the tail launch (adjoint of the

@@ -169,6 +169,9 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
     // DRT_SUPER_PROFILE=2: shader clock (units of 64 cycles) per wave spent - [1] polling / sleeping, [3] flight epilogue,
     // [4] regeneration, [5] transitions, [8] flight set-up, [6] pulling flights, [7] cell steps + write-back; [2] heavy runs
     uint64_t pt_last = __builtin_readcyclecounter();
+#if DRT_SUPER_PROFILE == 3
+    const unsigned long long pt_start = wall_clock64(); unsigned long long pt_drained = 0;
+#endif
 #define DRT_STAMP(slot) do { if (DRT_SUPER_PROFILE == 2 && COUNT) { const uint64_t t_ = __builtin_readcyclecounter(); if (lane == 0) cnt[slot] += (uint32_t) ((t_ - pt_last) >> 6); pt_last = t_; } } while (0)
 #else
 #define DRT_STAMP(slot) do { } while (0)
@@ -185,7 +188,9 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
     const uint32_t my_slot = threadIdx.x;             // = 64 * wave + lane
     uint32_t *rec = rec_lds + pw * 8;                                           // record-stream state of this wave (emit_record)
     const uint32_t xcc = xcc_id();
-    const uint64_t n_runs = (P.n_rays - P.ray_first + DRT_SUPER_RUN - 1) / DRT_SUPER_RUN;
+    // (with a ray order the queue positions cover whole units: the last unit may reach past the launch's last ray)
+    const uint64_t span = P.order ? (uint64_t) P.order_units * P.order_unit : P.n_rays - P.ray_first;
+    const uint64_t n_runs = (span + DRT_SUPER_RUN - 1) / DRT_SUPER_RUN;
     // queue x serves the runs x, x + 8, ...; a wave starts on the queue of the XCD it runs on (L2 locality) and moves on
     // to the next ones when that one is drained: every ray is traced whatever the placement of the workgroups
     uint32_t qsel = 0, qx = xcc;
@@ -471,13 +476,21 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                     }
                 }
                 const bool drained = qsel >= 8;
+#if DRT_SUPER_PROFILE == 3
+                if (drained && !pt_drained) pt_drained = wall_clock64();
+#endif
                 const uint64_t q = pool_next + (uint64_t) __popcll(wmask & ((1ull << lane) - 1ull));
                 const bool take = (ph == PH_IDLE) && !drained && q < pool_end;
                 if (drained && ph == PH_IDLE) ph = PH_DEAD;                      // all eight queues are empty
                 pool_next += (uint64_t) __popcll(wmask);
                 if (pool_next > pool_end) pool_next = pool_end;
                 if (take && q < my_len) {
-                    const uint64_t i = P.ray_first + ((q / DRT_SUPER_RUN) * 8 + qx) * DRT_SUPER_RUN + (q % DRT_SUPER_RUN);
+                    uint64_t i = ((q / DRT_SUPER_RUN) * 8 + qx) * DRT_SUPER_RUN + (q % DRT_SUPER_RUN);
+                    if (P.order) {                                              // position -> unit of the order -> ray
+                        const uint32_t g = (uint32_t) i, u = P.order_unit == 1u ? g : g / P.order_unit;
+                        i = i < span ? (uint64_t) P.order[u] * P.order_unit + (g - u * P.order_unit) : P.n_rays;
+                    }
+                    i += P.ray_first;
                     if (i < P.n_rays) {
                         // ---- sample() prologue (:51-108) + reach_medium (:292-319) ----
                         li = (uint32_t) i;
@@ -844,7 +857,20 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
     }
 
     if constexpr (ADJ) close_records(P, rec);
+#if DRT_SUPER_PROFILE == 3
+    // experiment build: when do the waves run dry, when do they end (100 MHz clock; slots: [0] 2^62 - first start, [1] 2^62 -
+    // first end, [2] last end, [3] sum of (end - start), [4] waves, [5] sum of (queues dry - start), [6] 2^62 - first dry)
+    if (COUNT && lane == 0) {
+        const unsigned long long te = wall_clock64(), q62 = 1ull << 62;
+        if (!pt_drained) pt_drained = te;
+        atomicMax(P.counters + 0, q62 - pt_start); atomicMax(P.counters + 1, q62 - te); atomicMax(P.counters + 2, te);
+        atomicAdd(P.counters + 3, te - pt_start); atomicAdd(P.counters + 4, 1ull);
+        atomicAdd(P.counters + 5, pt_drained - pt_start); atomicMax(P.counters + 6, q62 - pt_drained);
+    }
+    if (false) {
+#else
     if (COUNT) {
+#endif
 #pragma unroll
         for (int s = 0; s < C_COUNT; ++s) {
             uint32_t v = cnt[s];
@@ -859,6 +885,178 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
 }
 
 // LDS bytes of a launch; 0: this supergrid cannot be served (the host keeps the one-ray-per-lane kernels)
+// ---- ray order (Params::order) --------------------------------------------------------------------------------------------
+// A path of depth 64 takes about a millisecond of flight round trips however empty the chip is.  In index order the last
+// such paths start when the queues run dry, and the launch then waits for them (measured on the headline scene at factor 8:
+// launch time = 1.3 ms + 0.089 ms x spp in the primal pass, 1.9 ms + 0.187 ms x spp in the adjoint pass; the constant grows
+// with max_depth: 0.5 / 0.9 / 1.3 ms at depth 4 / 16 / 64).  Units of consecutive rays are therefore started by descending
+// cost: a stable-per-block counting sort over 64 keys.
+namespace {
+
+constexpr int kOrderKeys = 64, kOrderBlock = 2048, kOrderThreads = 256, kOrderFlatBelow = 8;
+
+// key of a unit: the majorant optical depth along the unit's first ray (pixel centre for sensor rays) through the
+// supergrid, on a logarithmic scale - paths get long where the medium is thick.  The box is clipped by the slab test; the
+// key orders launches, it enters no result.  (Tried for the adjoint pass, where the primal pass of the job
+// has counted every ray's bounce-loop iterations: rays sorted one by one by that count - 6.06 instead of 4.94 ms at 16 spp,
+// lanes of a wave then move in lock-step and neighbours in the image are torn apart -, and units by their longest ray:
+// 7.30 ms against 7.23 ms with this key.)
+__global__ void __launch_bounds__(kOrderThreads) order_keys_depth_kernel(const Params P, uint32_t unit, uint32_t units, uint8_t *keys)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    const uint64_t i = P.ray_first + (uint64_t) u * unit;
+    V3 o, d;
+    if (P.sensor_flow) {
+        const uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
+        sensor_ray(P, (uint32_t) g64 / P.spp, 0.5f, 0.5f, o, d);
+    } else {
+        o = v3(P.rays_o[3 * i], P.rays_o[3 * i + 1], P.rays_o[3 * i + 2]);
+        d = v3(P.rays_d[3 * i], P.rays_d[3 * i + 1], P.rays_d[3 * i + 2]);
+    }
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    float t0 = 0.0f, t1 = kInf;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (dd[a] != 0.0f) {
+            const float rcp = 1.0f / dd[a];
+            float ta = (P.bmin[a] - oo[a]) * rcp, tb = (P.bmax[a] - oo[a]) * rcp;
+            if (ta > tb) { const float t = ta; ta = tb; tb = t; }
+            t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+        } else if (oo[a] < P.bmin[a] || oo[a] > P.bmax[a]) miss = true;
+    }
+    // (16 samples of the majorant at the midpoints of equal pieces of the chord: independent loads, one memory latency - a
+    //  cell-by-cell walk of dependent loads took longer than the sort it feeds.  Tried: 24 trilinear samples of sigma_t
+    //  itself - headline at factor 8 635 instead of 655 Msamples/s: the majorants are what the flights see)
+    float od = 0.0f;
+    if (!miss && t0 < t1 && t1 < kInf) {
+        constexpr int kSamples = 16;
+        const int gn[3] = { P.gx, P.gy, P.gz };
+        const float dt = (t1 - t0) * (1.0f / kSamples);
+        float m[kSamples];
+#pragma unroll
+        for (int j = 0; j < kSamples; ++j) {
+            const float t = fmaf((float) j + 0.5f, dt, t0);
+            int c[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float gf = ((fmaf(dd[a], t, oo[a]) - P.bmin[a]) * P.inv_ext[a]) * (float) gn[a];
+                c[a] = (int) fminf(fmaxf(floorf(gf), 0.0f), (float) (gn[a] - 1));
+            }
+            m[j] = P.mgrid[((size_t) c[2] * P.gy + c[1]) * P.gx + c[0]];
+        }
+#pragma unroll
+        for (int j = 0; j < kSamples; ++j) od += m[j];
+        od *= dt;
+    }
+    int k = (int) (8.0f * log2f(1.0f + od));
+    k = k < 0 ? 0 : k > kOrderKeys - 1 ? kOrderKeys - 1 : k;
+    keys[u] = (uint8_t) k;
+}
+
+// counts per (key, block), keys by descending cost: hist[(63 - key) * n_blocks + block]
+__global__ void __launch_bounds__(kOrderThreads) order_hist_kernel(const uint8_t *keys, uint32_t units, uint32_t n_blocks, uint32_t *hist)
+{
+    __shared__ uint32_t h[kOrderKeys];
+    if (threadIdx.x < kOrderKeys) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * kOrderBlock;
+    for (uint32_t k = threadIdx.x; k < kOrderBlock && first + k < units; k += kOrderThreads) atomicAdd(&h[keys[first + k]], 1u);
+    __syncthreads();
+    if (threadIdx.x < kOrderKeys) hist[(size_t) (kOrderKeys - 1 - threadIdx.x) * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of the n counts in place (one workgroup: n = 64 x blocks <= a few hundred thousand)
+__global__ void __launch_bounds__(1024) order_scan_kernel(uint32_t *hist, uint32_t n)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t k = lo; k < hi; ++k) sum += hist[k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = (int) threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t k = lo; k < hi; ++k) { const uint32_t v = hist[k]; hist[k] = run; run += v; }
+}
+
+// units -> their places (inside a block of 2048 units and one key in any order: neighbours stay neighbours)
+__global__ void __launch_bounds__(kOrderThreads) order_scatter_kernel(const uint8_t *keys, uint32_t units, uint32_t n_blocks, const uint32_t *offs, uint32_t *order)
+{
+    __shared__ uint32_t cur[kOrderKeys];
+    if (threadIdx.x < kOrderKeys) cur[threadIdx.x] = offs[(size_t) (kOrderKeys - 1 - threadIdx.x) * n_blocks + blockIdx.x];
+    __syncthreads();
+    const uint32_t first = blockIdx.x * kOrderBlock;
+    // no unit reaches optical depth 1 (key 8): paths are short everywhere, nothing to bring forward - index order (an
+    // order by chord length made the optimisation loop's launches over its thin starting medium 9 % slower)
+    const bool flat = offs[(size_t) (kOrderKeys - kOrderFlatBelow) * n_blocks] == 0u;
+    for (uint32_t k = threadIdx.x; k < kOrderBlock && first + k < units; k += kOrderThreads) {
+        const uint32_t place = atomicAdd(&cur[keys[first + k]], 1u);
+        order[flat ? first + k : place] = first + k;
+    }
+}
+
+// launches of up to kOrderSmall units (the optimisation loop's: 10^4 pixels of 1024 rays): the three passes in ONE workgroup
+// (every launch of the tracer pays for its order: 4 kernels were 3 % of the loop's iteration)
+constexpr uint32_t kOrderSmall = 65536;
+__global__ void __launch_bounds__(1024) order_small_kernel(const uint8_t *keys, uint32_t units, uint32_t *order)
+{
+    __shared__ uint32_t h[kOrderKeys], cur[kOrderKeys];
+    if (threadIdx.x < kOrderKeys) h[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < units; k += 1024u) atomicAdd(&h[keys[k]], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int key = kOrderKeys - 1; key >= 0; --key) { cur[key] = run; run += h[key]; }
+    }
+    __syncthreads();
+    const bool flat = cur[kOrderFlatBelow - 1] == 0u;            // = units with key >= kOrderFlatBelow
+    for (uint32_t k0 = 0; k0 < units; k0 += 1024u) {              // (round by round: neighbours stay neighbours)
+        const uint32_t k = k0 + threadIdx.x;
+        if (k < units) {
+            const uint32_t place = atomicAdd(&cur[keys[k]], 1u);
+            order[flat ? k : place] = k;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+static inline size_t order_align(size_t n) { return (n + 255) & ~(size_t) 255; }
+
+size_t super_order_bytes(uint32_t units)
+{
+    const size_t n_blocks = ((size_t) units + kOrderBlock - 1) / kOrderBlock;
+    return order_align((size_t) units * 4) + order_align((size_t) units) + order_align(n_blocks * kOrderKeys * 4);
+}
+
+hipError_t build_super_order(const Params &P, uint32_t unit, uint32_t units, void *work, hipStream_t stream)
+{
+    if (!units) return hipSuccess;
+    const uint32_t n_blocks = (units + kOrderBlock - 1) / kOrderBlock;
+    uint32_t *order = (uint32_t *) work;
+    uint8_t *keys = (uint8_t *) work + order_align((size_t) units * 4);
+    uint32_t *hist = (uint32_t *) (keys + order_align((size_t) units));
+    const unsigned key_blocks = (units + kOrderThreads - 1) / kOrderThreads;
+    hipLaunchKernelGGL(order_keys_depth_kernel, dim3(key_blocks), dim3(kOrderThreads), 0, stream, P, unit, units, keys);
+    if (units <= kOrderSmall) {
+        hipLaunchKernelGGL(order_small_kernel, dim3(1), dim3(1024), 0, stream, keys, units, order);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(order_hist_kernel, dim3(n_blocks), dim3(kOrderThreads), 0, stream, keys, units, n_blocks, hist);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, n_blocks * (uint32_t) kOrderKeys);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(kOrderThreads), 0, stream, keys, units, n_blocks, hist, order);
+    return hipGetLastError();
+}
+
 static size_t super_lds_bytes(const Params &P, bool adjoint, bool &mgl)
 {
     const size_t cells = (size_t) P.gx * P.gy * P.gz;
