@@ -645,7 +645,8 @@ def test_heavy_tailed_ratio_tracking_splats_keep_ordinary_voxels_accurate(uivr, 
 
 
 @pytest.mark.parametrize("flags,variant", [(0, "drt"), (0, "drt-nomis"), (0, "basic"), (134217728, "drt"), (128, "drt"),
-                                           (1048576, "drt"), (16384, "drt"), (536870912, "drt"), (0, "quadratic")])
+                                           (1048576, "drt"), (16384, "drt"), (1073741824, "drt"), (1073741824 | 16384, "drt"),
+                                           (1073741824, "basic"), (0, "quadratic")])
 def test_supergrid_tracer_and_its_fallbacks_match_oracle(uivr, oracle, gpu, flags, variant):
     _supergrid_case(uivr, oracle, gpu, flags, variant, 7.0)
 
@@ -661,8 +662,9 @@ def test_supergrid_flights_that_cannot_collide_are_not_walked(uivr, oracle, gpu,
 def _supergrid_case(uivr, oracle, gpu, flags, variant, density):
     """Scenes with a majorant supergrid run in the cell-stepping tracer (drt_super.hip): every estimator it takes
     (subsampled DRT with / without MIS, basic), with the path cache on and off (1048576), with the job cut into ray
-    sub-batches (16384: launches with ray_first > 0), with its rays in index order instead of thick pixels first
-    (536870912); and what it hands back to the older kernels stays verified:
+    sub-batches (16384: launches with ray_first > 0), with its rays started thick pixels first as launches of millions of
+    rays are (1073741824: from 4096 rays on; the at-size tests of test_gpu_configs.py run ordered by default, 536870912
+    would keep index order); and what it hands back to the older kernels stays verified:
     134217728 = the round-2 kernels for both passes, 128 = the atomic gradient path (no record streams), quadratic DRT.
     Radiance bit-exact, counters equal, gradients close - against the oracle."""
     rng = np.random.default_rng(17)
