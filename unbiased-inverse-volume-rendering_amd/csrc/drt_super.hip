@@ -61,7 +61,7 @@
 #define DRT_SUPER_REGEN_MIN 16     // finished lanes of a path wave before it takes new rays
 #endif
 #ifndef DRT_SUPER_HMIN
-#define DRT_SUPER_HMIN 40          // lanes of a wave with something to do before it makes a heavy run (it walks otherwise)
+#define DRT_SUPER_HMIN 32          // lanes of a wave with something to do before it makes a heavy run (it walks otherwise); with the ray order: 16 / 24 / 32 / 40 / 52 -> 634 / 657 / 660 / 654 / 568 Msamples/s
 #endif
 #ifndef DRT_SUPER_BMIN
 #define DRT_SUPER_BMIN 12          // lanes of a wave waiting for a path transition before the transition blocks run
@@ -73,7 +73,7 @@
 #define DRT_SUPER_EARLY_OUT 1      // flights that cannot collide (target optical depth > largest majorant x segment length) are not walked
 #endif
 #ifndef DRT_SUPER_CHUNK
-#define DRT_SUPER_CHUNK 128        // queue positions a wave reserves per refill (divides DRT_SUPER_RUN)
+#define DRT_SUPER_CHUNK 256        // queue positions a wave reserves per refill (64 / 128 / 256 / 512 / 1024: 616 / 652 / 670 / 659 / 471 Msamples/s; reservations that shrink towards the end of the queue: 530)
 #endif
 #ifndef DRT_SUPER_PROFILE
 #define DRT_SUPER_PROFILE 0
@@ -464,10 +464,11 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                 while (pool_next >= pool_end && qsel < 8) {                      // refill (wave-uniform)
                     const int leader = __ffsll((long long) wmask) - 1;
                     unsigned long long base = 0;
+                    constexpr unsigned long long chunk = DRT_SUPER_CHUNK;
                     if ((int) lane == leader) base = atomicAdd(queue, (unsigned long long) DRT_SUPER_CHUNK);
                     base = ((unsigned long long)(unsigned int) __shfl((int)(base >> 32), leader, 64) << 32)
                          | (unsigned int) __shfl((int) base, leader, 64);
-                    if (base < my_len) { pool_next = base; pool_end = base + DRT_SUPER_CHUNK; }
+                    if (base < my_len) { pool_next = base; pool_end = base + chunk; }
                     else {                                                       // this queue is drained: next one
                         ++qsel;
                         qx = (xcc + qsel) & 7u;
@@ -893,7 +894,13 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
 // cost: a stable-per-block counting sort over 64 keys.
 namespace {
 
-constexpr int kOrderKeys = 64, kOrderBlock = 2048, kOrderThreads = 256, kOrderFlatBelow = 8;
+#ifndef DRT_ORDER_BLOCK
+#define DRT_ORDER_BLOCK 2048
+#endif
+#ifndef DRT_ORDER_SCALE
+#define DRT_ORDER_SCALE 8.0f
+#endif
+constexpr int kOrderKeys = 64, kOrderBlock = DRT_ORDER_BLOCK, kOrderThreads = 256, kOrderFlatBelow = 8;
 
 // key of a unit: the majorant optical depth along the unit's first ray (pixel centre for sensor rays) through the
 // supergrid, on a logarithmic scale - paths get long where the medium is thick.  The box is clipped by the slab test; the
@@ -950,7 +957,7 @@ __global__ void __launch_bounds__(kOrderThreads) order_keys_depth_kernel(const P
         for (int j = 0; j < kSamples; ++j) od += m[j];
         od *= dt;
     }
-    int k = (int) (8.0f * log2f(1.0f + od));
+    int k = (int) (DRT_ORDER_SCALE * log2f(1.0f + od));
     k = k < 0 ? 0 : k > kOrderKeys - 1 ? kOrderKeys - 1 : k;
     keys[u] = (uint8_t) k;
 }
