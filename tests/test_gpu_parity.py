@@ -481,7 +481,7 @@ def test_sigma_t_gradient_vs_finite_differences(uivr, gpu, variant):
                                            (256, "basic"), (16384, "drt"), (16384 + 2048, "drt"), (2048, "basic"),
                                            (32768, "drt"), (32768, "quadratic"), (65536, "drt"), (65536, "basic"),
                                            (65536, "quadratic-nomis"), (262144, "drt"), (1048576, "drt"),
-                                           (16384 + 524288, "drt"), (2097152, "drt"), (2097152 + 128, "drt"), (268435456, "drt")])
+                                           (16384 + 524288, "drt"), (2097152, "drt"), (2097152 + 128, "drt"), (1073741824, "drt"), (1073741824 + 268435456, "drt")])
 def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     """The production path uses the wave-synchronous state machine for the primal and the
     one-ray-per-lane kernel for the adjoint (measured faster).  The other combinations
@@ -495,8 +495,9 @@ def test_every_kernel_variant_matches_oracle(uivr, oracle, gpu, flags, variant):
     65536 = state-machine kernel for the primal (no path cache), 262144 = record streams "cannot be
     allocated" (fallback to the atomic path), 1048576 = path cache off, 524288 (with 16384) = the record memory
     "runs out" after the first ray sub-batch (the rest of the job takes the atomic path), 2097152 = generic
-    instead of the specialised `volpathsimple-drt` kernels, 268435456 = without the early histogram pass (production: the
-    histogram of the main adjoint launch's records runs on a side stream next to the tail launch)."""
+    instead of the specialised `volpathsimple-drt` kernels, 1073741824 = a launch this small scheduled like the large ones (tail launch for the
+    workgroups' last recursive paths, the histogram of the main launch's records on a side stream next to it), with
+    268435456 = without that early histogram pass."""
     props = props_for(variant)
     scene = uivr.cube_test_scene(32, 32, density_scale=2.0)
     spp, seed = 16, 777
@@ -583,8 +584,11 @@ def test_workgroup_handoff_of_recursive_paths(uivr, oracle, gpu, factor):
     ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
     sg = uivr.scene_to(scene, gpu)
     got = {}
-    for name, hooks, flags in (("production", False, 0), ("hand-off", True, 0), ("no hand-off", True, 33554432),
-                               ("adjoint hand-off only", True, 67108864), ("hand-off, 8 MB record budget: many sub-batches", True, 16384)):
+    # (1073741824: launches this small are scheduled like the large ones - tail pool + early histogram for the adjoint)
+    for name, hooks, flags in (("production", False, 0), ("hand-off", True, 1073741824), ("no hand-off", True, 33554432),
+                               ("hand-off inside the workgroup only (small launch)", True, 0),
+                               ("tail launch without the early histogram", True, 1073741824 | 268435456),
+                               ("adjoint hand-off only", True, 67108864), ("hand-off, 8 MB record budget: many sub-batches", True, 16384 | 1073741824)):
         integ = _integrator(uivr, props, hooks=hooks)
         if hooks:
             integ.native_handle(sg).set_debug_flags(flags)

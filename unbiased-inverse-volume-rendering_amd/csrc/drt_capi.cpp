@@ -322,7 +322,11 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         // without it (allocation failed) the kernels simply finish every path where it is
         drt::Params PT = P;
         PT.tail_pool = nullptr; PT.tail_count = nullptr; PT.tail_cap = 0; PT.tail_mode = 0;
-        if (adjoint && !P.mgrid && P.n_rays > P.ray_first) {
+        // (launches of fewer than 1.5 M rays finish every path where it is: the tail launch costs them the job's longest
+        //  path once more - 512^2 x 4 spp, an eighth of the headline: adjoint 1.81 -> 1.65 ms without it, x 8 spp 2.22 / 2.20,
+        //  x 32 spp 5.78 / 6.88; test hook 1073741824: small launches are scheduled like large ones)
+        const bool tail_pays = P.n_rays - P.ray_first >= (3u << 19) || dbg(h->debug_flags, 1073741824u);
+        if (adjoint && !P.mgrid && P.n_rays > P.ray_first && tail_pays) {
             const size_t want = (((size_t) (P.n_rays - P.ray_first) / 8 + 255) / 256) * 256;
             if (want > h->tail_entries) {
                 if (h->d_tail) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_tail); h->d_tail = nullptr; h->tail_entries = 0; }
