@@ -262,13 +262,13 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         DRT_HIP_CHECK(h, hipEventCreate(&b));
         DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
     }
-    // Kernel choice (measured on MI355X, headline workload):
-    //   the one-ray-per-lane kernels of drt_coop*.hip (CoopTracer) - wave-cooperative tracking rounds with the global
-    //   majorant, own-lane tracking steps with a majorant supergrid - for every pass but one: the PRIMAL pass over a
-    //   supergrid, which the wave-synchronous state machine (drt_wavefront.hip) runs 1.6x faster (5.9 vs 9.6 ms: it
-    //   refills lanes whose paths ended).  Every primal kernel writes the path cache the adjoint pass of the job reads.
-    //   The plain per-lane Tracer (drt_kernels.hip; bits 8 / 32768) exists only in the library flavour with test
-    //   hooks, where the variant tests keep it (and the state machine's adjoint, bit 32) in lock-step with the rest.
+    // Kernel choice (measured on MI355X, headline workload; DESIGN.md sections 6.1, 9):
+    //   global majorant: the one-ray-per-lane kernels of drt_coop.hip (CoopTracer: wave-cooperative tracking rounds) for both
+    //   passes; majorant supergrid: the cell-stepping state machine of drt_super.hip for both passes (quadratic DRT, a
+    //   supergrid beyond its limits and the variant tests: the round-2 kernels - state machine of whole flights,
+    //   drt_wavefront.hip, for the primal pass, CoopTracer<SUPER> for the adjoint).  Every primal kernel writes the path
+    //   cache the adjoint pass of the job reads.  The plain per-lane Tracer (drt_kernels.hip; bits 8 / 32768) exists only in
+    //   the library flavour with test hooks, where the variant tests keep it in lock-step with the rest.
     const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
 #ifndef DRT_SUPER_COOP_PRIMAL
 #define DRT_SUPER_COOP_PRIMAL 0     // experiment: 1 = the supergrid primal runs in CoopTracer<SUPER> too (measured slower)
