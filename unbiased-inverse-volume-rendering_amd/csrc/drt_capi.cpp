@@ -839,7 +839,7 @@ int drt_set_emitter_constant(drt_handle h, const float radiance[3])
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
     if (!radiance) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null radiance");
     for (int k = 0; k < 3; ++k) h->base.Le[k] = radiance[k];
-    h->base.env_pix = h->base.env_marg = h->base.env_cond = nullptr;
+    h->base.env_pix = h->base.env_marg = h->base.env_cond = nullptr; h->base.env_gmarg = h->base.env_gcond = nullptr;
     h->have_emitter = true; h->scene_version++;
     return DRT_OK;
 }
@@ -900,8 +900,22 @@ int drt_set_emitter_envmap(drt_handle h, const float *pixels, int32_t width, int
     for (int j = 0; j < height; ++j) { run += rowsum[j]; marg[j + 1] = (float)(run / total); }
     marg[hh] = 1.0f;
 
+    // guide tables (cdf_find_guided, drt_device.h): guide[k] = largest index in [0, n - 1] with cdf[index] <= k / n
+    auto make_guide = [](const float *cdf, size_t n, uint32_t *guide) {
+        size_t idx = 0;
+        for (size_t k = 0; k <= n; ++k) {
+            const float x = (float) ((double) k / (double) n);
+            while (idx + 1 < n && cdf[idx + 1] <= x) ++idx;
+            guide[k] = (uint32_t) idx;
+        }
+    };
+    std::vector<uint32_t> gmarg(hh + 1), gcond(hh * (w + 1));
+    make_guide(marg.data(), hh, gmarg.data());
+    for (size_t j = 0; j < hh; ++j) make_guide(cond.data() + j * (w + 1), w, gcond.data() + j * (w + 1));
+
     if (h->d_env) { (void) hipFree(h->d_env); h->d_env = nullptr; }
-    const size_t n_all = n_pix + marg.size() + cond.size();
+    const size_t n_tab = marg.size() + cond.size();
+    const size_t n_all = n_pix + 2 * n_tab;
     DRT_HIP_CHECK(h, hipMalloc(&h->d_env, n_all * sizeof(float)));
     DRT_HIP_CHECK(h, hipMemcpy(h->d_env, pix.data(), n_pix * sizeof(float), hipMemcpyHostToDevice));
     DRT_HIP_CHECK(h, hipMemcpy(h->d_env + n_pix, marg.data(), marg.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -909,6 +923,10 @@ int drt_set_emitter_envmap(drt_handle h, const float *pixels, int32_t width, int
     h->base.env_pix = h->d_env;
     h->base.env_marg = h->d_env + n_pix;
     h->base.env_cond = h->d_env + n_pix + marg.size();
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + n_pix + n_tab, gmarg.data(), gmarg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + n_pix + n_tab + gmarg.size(), gcond.data(), gcond.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->base.env_gmarg = (const uint32_t *) (h->d_env + n_pix + n_tab);
+    h->base.env_gcond = (const uint32_t *) (h->d_env + n_pix + n_tab + gmarg.size());
     h->base.env_w = width; h->base.env_h = height; h->base.env_scale = scale;
     for (int k = 0; k < 9; ++k) h->base.env_R[k] = to_world[k];
     for (int k = 0; k < 3; ++k) h->base.Le[k] = 0.0f;

@@ -228,6 +228,7 @@ struct Params {
     // [env_h][env_w][3] (library-owned device copy), row-major to_world rotation, scale, and the
     // importance-sampling tables (marginal CDF over rows [h+1], conditional CDFs [h][w+1])
     const float *env_pix, *env_marg, *env_cond;
+    const uint32_t *env_gmarg, *env_gcond;   // guide tables of the two CDF families (cdf_find_guided): [h + 1], [h][w + 1]
     int env_w, env_h;
     float env_R[9], env_scale;
     // nerf integrator (python/integrators/nerf.py): emission grid (Z,Y,X,3) and properties
@@ -391,15 +392,30 @@ __device__ __forceinline__ int cdf_find(const float *cdf, int n, float x)
     return lo;
 }
 
+// The same index through a guide table: guide[k] = largest index with cdf <= k / n, so the answer for x in
+// [(k - 1) / n, (k + 1) / n) lies in [guide[k - 1], guide[k + 1]] - a bracket of two or three entries where the density is
+// high, i.e. where the samples fall - and the bisection starts there instead of at [0, n]: ~4 dependent loads instead of
+// log2(n) + 1 = 9 / 10 per CDF (the bracket is one interval wider on both sides than x * n says: its rounding cannot matter).
+__device__ __forceinline__ int cdf_find_guided(const float *cdf, const uint32_t *guide, int n, float x)
+{
+    const int k = min((int) (x * (float) n), n - 1);
+    int lo = (int) guide[max(k - 1, 0)], hi = min((int) guide[min(k + 1, n)] + 1, n);
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // Scene::sample_emitter_direction (volpathsimple.py:419).  The pdf and the radiance are evaluated
 // FROM THE DIRECTION (envmap_pdf / envmap_eval, as for an escaped ray), so NEE and the escape-side
 // MIS weight see the same density and the state machine only has to keep the direction.
 __device__ __forceinline__ V3 envmap_sample_dir(const Params &P, float u1, float u2)
 {
     const int w = P.env_w, h = P.env_h;
-    int j = cdf_find(P.env_marg, h, u2);
+    int j = cdf_find_guided(P.env_marg, P.env_gmarg, h, u2);
     const float *c = P.env_cond + (size_t) j * (w + 1);
-    int i = cdf_find(c, w, u1);
+    int i = cdf_find_guided(c, P.env_gcond + (size_t) j * (w + 1), w, u1);
     float dv = fminf((u2 - P.env_marg[j]) / (P.env_marg[j + 1] - P.env_marg[j]), kOneMinusEps);
     float du = fminf((u1 - c[i]) / (c[i + 1] - c[i]), kOneMinusEps);
     float u = ((float) i + du) / (float) w, v = ((float) j + dv) / (float) h;
