@@ -600,6 +600,10 @@ static inline float sample_distance(const scene_t *sc, float u)
  * supergrid: walk the cells the ray crosses, accumulating majorant * length until the target
  * optical depth tau = -log(1-u) is reached.  Returns the distance (INFINITY if the ray leaves
  * [0,tmax] first) and the local majorant / its reciprocal at the collision. */
+#ifndef DRTO_DDA_VISIT            /* experiment hooks (tools/dda_stats.c includes this file with them defined) */
+#define DRTO_DDA_VISIT(sc, cx, cy, cz, m) ((void) 0)
+#define DRTO_DDA_END(sc) ((void) 0)
+#endif
 static float sample_collision(const scene_t *sc, v3 o, v3 d, float tmax, float u, float *m_out, float *im_out)
 {
     if (!sc->mgrid) {
@@ -632,9 +636,11 @@ static float sample_collision(const scene_t *sc, v3 o, v3 d, float tmax, float u
         float texit = fminf(tnext[a], tmax);
         const float *mc = sc->mgrid + 2 * (size_t)((cell[2] * G[1] + cell[1]) * G[0] + cell[0]);
         float m = mc[0];
+        DRTO_DDA_VISIT(sc, cell[0], cell[1], cell[2], m);
         if (m > 0.0f) {
             float dtau = m * (texit - t);
             if (acc + dtau >= tau) {
+                DRTO_DDA_END(sc);
                 *m_out = m; *im_out = mc[1];
                 return fmaf(tau - acc, mc[1], t);
             }
@@ -646,6 +652,7 @@ static float sample_collision(const scene_t *sc, v3 o, v3 d, float tmax, float u
         if (cell[a] < 0 || cell[a] >= G[a]) break;
         tnext[a] += tdelta[a];
     }
+    DRTO_DDA_END(sc);
     *m_out = 0.0f; *im_out = 0.0f;
     return INFINITY;
 }

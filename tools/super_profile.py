@@ -1,0 +1,47 @@
+"""Raw profile slots of an experiment build of the supergrid tracer (drt_super.hip, -DDRT_SUPER_PROFILE=1|2|4):
+
+    tools/mk_variant.sh prof4 "-DDRT_SUPER_PROFILE=4"; LD_LIBRARY_PATH=variants/prof4 python tools/super_profile.py
+
+(headline scene at majorant_resolution_factor 8; the meaning of the slots is next to DRT_PROF / DRT_PROF4 / DRT_STAMP in the source)
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import uivr_amd as u
+from uivr_amd import synthetic
+
+dev = torch.device("cuda", 0)
+scene = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+scene.medium.majorant_resolution_factor = int(os.environ.get("DRT_PROFILE_FACTOR", "8"))
+spp = int(os.environ.get("DRT_PROFILE_SPP", "32"))
+sensor = scene.sensors[0]
+integ = u.get_int_config("volpathsimple-drt").create(max_depth=64)
+batch = u.RayBatch(n_rays=sensor.width * sensor.height * spp, spp=spp, sensor=sensor, ray_offset=0, interleave=None)
+grads = u.alloc_grads(scene)
+h = integ.native_handle(scene)
+sampler = u.IndependentSampler(u.sample_tea_32(7, 988378)[0], spp)
+L, _, state = integ.sample(u.ADMode.Primal, scene, sampler.clone(), batch)
+h.enable_counters(True)
+h.reset_counters()
+L, _, state = integ.sample(u.ADMode.Primal, scene, sampler.clone(), batch)
+cp = [int(v) for v in h.get_counters().values()]
+img = integ.develop(scene, L, spp)
+dL = integ.film_backward(scene, (2.0 / (img.numel())) * (img - 0.5), spp)
+h.reset_counters()
+integ.sample(u.ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state, grads=grads)
+ca = [int(v) for v in h.get_counters().values()]
+print("primal ", cp)
+print("adjoint", ca)
+mode = os.environ.get("DRT_PROFILE_MODE", "4")
+for tag, c in (("primal", cp), ("adjoint", ca)):
+    if mode == "4":
+        print(f"{tag}: lane steps {c[0]/1e6:.1f} M, wave steps {c[1]/1e6:.2f} M -> {c[0]/max(1,c[1]):.1f} lanes per step; batches {c[2]/1e6:.2f} M, "
+              f"{c[3]/max(1,c[2]):.1f} flying at batch start, {c[4]/max(1,c[2]):.1f} finish per batch; transition passes {c[6]/1e6:.2f} M with "
+              f"{c[5]/max(1,c[6]):.1f} lanes; regeneration blocks {c[7]/1e6:.3f} M, {c[8]/max(1,c[7]):.1f} rays each")
+    elif mode == "2":
+        tot = sum(c[k] for k in (1, 3, 4, 5, 6, 7, 8))
+        names = {1: "poll/sleep", 3: "epilogue", 4: "regen", 5: "transitions", 8: "set-up", 6: "pull", 7: "steps+writeback"}
+        print(tag, {names[k]: round(c[k] / tot, 3) for k in names}, "heavy runs", c[2])
+    else:
+        print(f"{tag}: cell steps {c[0]/1e6:.1f} M, polls {c[1]/1e6:.2f} M, heavy runs {c[2]/1e6:.2f} M with {c[3]/max(1,c[2]):.1f} lanes ready, "
+              f"epilogue lanes {c[4]/max(1,c[2]):.1f}, posted {c[5]/max(1,c[2]):.1f}; pulls {c[6]/1e6:.2f} M x {c[7]/max(1,c[6]):.1f} flights; transition passes {c[8]/1e6:.2f} M")

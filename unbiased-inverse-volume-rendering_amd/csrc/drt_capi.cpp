@@ -29,6 +29,7 @@ struct drt_handle_s {
     unsigned long long *d_counters = nullptr;   // [C_COUNT]
     float *d_gt = nullptr;         // gradient scratch, 4 planes (always zero between launches)
     unsigned long long *d_queues = nullptr;   // 8 per-XCD ray queue heads (wavefront kernel)
+    void *d_sq_cold = nullptr;                // queued supergrid tracer: adjoint path state kept in global memory (drt_sq.hip)
     void *d_order = nullptr;                  // ray order of the supergrid tracer's current launch (build_super_order)
     size_t order_bytes = 0;
     uint64_t order_first = 0, order_end = 0;  // ... made by the primal launch over these rays of the job the path cache describes:
@@ -306,6 +307,16 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         }
         Q.ray_perm = nullptr; Q.block_order = nullptr;
         DRT_HIP_CHECK(h, hipMemsetAsync(h->d_queues, 0, 8 * sizeof(unsigned long long), h->stream));
+        // round 4: the queued tracer (drt_sq.hip) where the ray records fit LDS next to the majorants; test hook 4096 keeps
+        // the round-3 kernel (drt_super.hip), which also serves what the queued one does not take
+        bool queued = !dbg(h->debug_flags, 4096u) && drt::sq_supported(P);
+        if (queued && adjoint && !h->d_sq_cold) {
+            if (hipMalloc(&h->d_sq_cold, drt::sq_cold_bytes(h->n_cus)) != hipSuccess) { (void) hipGetLastError(); h->d_sq_cold = nullptr; queued = false; }
+        }
+        if (queued) {
+            Q.sq_cold = h->d_sq_cold;
+            DRT_HIP_CHECK(h, drt::launch_trace_sq(Q, adjoint, h->counting, h->n_cus, h->stream));
+        } else
         DRT_HIP_CHECK(h, drt::launch_trace_super(Q, adjoint, h->counting, h->n_cus, h->stream));
         if (h->timing) {
             DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
@@ -668,6 +679,7 @@ int drt_destroy(drt_handle h)
     if (h->d_gt) (void) hipFree(h->d_gt);
     if (h->d_queues) (void) hipFree(h->d_queues);
     if (h->d_order) (void) hipFree(h->d_order);
+    if (h->d_sq_cold) (void) hipFree(h->d_sq_cold);
     if (h->d_tail) (void) hipFree(h->d_tail);
     if (h->d_sigma_b) (void) hipFree(h->d_sigma_b);
     if (h->d_mgrid) (void) hipFree(h->d_mgrid);

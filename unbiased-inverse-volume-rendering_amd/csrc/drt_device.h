@@ -303,6 +303,9 @@ struct Params {
     // only: every ray's result is independent of when it is traced).  nullptr: rays in index order
     const uint32_t *order;
     uint32_t order_unit, order_units;
+    // queued supergrid tracer (drt_sq.hip), adjoint: per workgroup [5][DRT_SQ_RAYS] uint4 of path state that only the main
+    // path's transitions use (dL, the sampler clone, the DRT reservoir); library-owned, L2-resident
+    void *sq_cold;
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
 };

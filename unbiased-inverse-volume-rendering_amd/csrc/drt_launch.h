@@ -23,6 +23,12 @@ hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_c
 // Ray order for launch_trace_super (Params::order): units of `unit` consecutive rays of [P.ray_first, P.n_rays) sorted by a
 // cost key - the majorant optical depth along the unit's first ray through the supergrid -, most expensive first.
 // work: super_order_bytes(units) bytes; the permutation is the first `units` words of it.
+// the same scenes as work queues inside a compute unit: rays live in LDS records and belong to no lane, waves take batches of
+// one kind of work (drt_sq.hip; round 4).  Uses the ray order and the XCD queues of launch_trace_super; the adjoint needs
+// Params::sq_cold (sq_cold_bytes(n_cus) bytes)
+bool sq_supported(const Params &P);
+size_t sq_cold_bytes(int n_cus);
+hipError_t launch_trace_sq(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
 size_t super_order_bytes(uint32_t units);
 hipError_t build_super_order(const Params &P, uint32_t unit, uint32_t units, void *work, hipStream_t stream);
 // one ray per lane with wave-cooperative tracking loops (drt_coop.hip); global majorant only (P.mgrid == nullptr)

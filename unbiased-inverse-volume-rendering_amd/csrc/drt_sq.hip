@@ -1,0 +1,942 @@
+// drt_sq.hip -- the tracer for scenes with a majorant supergrid (majorant_resolution_factor > 0, the reference's default:
+// python/scene_config.py:36, optimize.py:182-199), round 4: VolpathSimpleIntegrator.sample
+// (python/integrators/volpathsimple.py:38-655), both AD modes, as WORK QUEUES INSIDE A COMPUTE UNIT.
+//
+// Why (measured): the round-3 tracer (drt_super.hip) keeps every ray in the registers of the lane that
+// owns it.  Flights travel to whichever wave walks them, but everything else of a ray - the collision a flight ended in,
+// the next flight's set-up, the path transitions, the ray prologue - can only run on the owner lane, so those blocks run
+// when "enough" of a wave's 64 lanes happen to be ready: 23-28 of 64 in the collision / set-up blocks, fewer in the
+// transition blocks, and every block of a heavy run is issued if a single lane needs it.  78 % of that kernel's vector
+// instructions are such heavy runs; cell stepping is 22 %.
+//
+// Here a ray lives in LDS (its flight slot + 28..32 words of path state: DRT_SQ_RAYS records per compute unit) and belongs to
+// no lane.  Four ring buffers of ray ids - flights to walk, collisions to evaluate, path transitions, free records - say
+// what is to be done; a wave takes up to 64 ids of ONE kind, loads those rays, runs that kind's code with all its lanes,
+// stores them and pushes their ids to the queues of what they need next.  A wave that finds no full batch walks flights
+// (as in drt_super.hip: DRT_SQ_K cells per look, lanes refilled from the flight queue).  The adjoint keeps the state only
+// its main-path transitions use (the reservoir, dL, the sampler clone) in global memory (Params::sq_cold, L2-resident).
+//
+// Arithmetic, random-number consumption and event counts are those of the scalar restatement (oracle/drt_oracle.c):
+// radiance is bit-exact per ray, counters are equal; gradients differ by summation order only.  A ray computes the same
+// numbers whichever lanes run its pieces.  Not handled here (the host keeps drt_super.hip / the one-ray-per-lane kernels):
+// supergrids whose bf16 majorants do not fit LDS next to the ray records, quadratic DRT, the atomic gradient path.
+#include "drt_device.h"
+#include "drt_launch.h"
+
+#ifndef DRT_SQ_THREADS
+#define DRT_SQ_THREADS 768         // threads per workgroup = per CU: 12 waves
+#endif
+#ifndef DRT_SQ_RAYS
+#define DRT_SQ_RAYS 512            // ray records per workgroup (power of two: ring buffers of ids)
+#endif
+#ifndef DRT_SQ_K
+#define DRT_SQ_K 8                 // cells per walker lane between two looks at the queues
+#endif
+#ifndef DRT_SQ_REFILL_MIN
+#define DRT_SQ_REFILL_MIN 16       // free walker lanes before more flights are taken
+#endif
+#ifndef DRT_SQ_BATCH
+#define DRT_SQ_BATCH 64            // entries of a heavy queue that make a batch worth taking at once
+#endif
+#ifndef DRT_SQ_REGEN_MIN
+#define DRT_SQ_REGEN_MIN 48        // free records before new rays are started (the prologue is long)
+#endif
+#ifndef DRT_SQ_LEAVE_MAX
+#define DRT_SQ_LEAVE_MAX 40        // a walker with at most this many flights under way leaves for a full heavy batch
+#endif
+#ifndef DRT_SQ_MAXPOLL
+#define DRT_SQ_MAXPOLL 3           // polls with nothing full to do before a partial batch is taken
+#endif
+#ifndef DRT_SQ_EARLY_OUT
+#define DRT_SQ_EARLY_OUT 1         // flights that cannot collide (target optical depth > largest majorant x segment length) are not walked
+#endif
+#ifndef DRT_SQ_CHUNK
+#define DRT_SQ_CHUNK 256           // queue positions a wave reserves per refill of its ray pool
+#endif
+#ifndef DRT_SQ_RUN
+#define DRT_SQ_RUN 16384           // consecutive rays per XCD-owned run
+#endif
+#ifndef DRT_SQ_PROFILE
+#define DRT_SQ_PROFILE 0
+#endif
+
+namespace drt {
+
+namespace {
+
+enum SqPhase : int {
+    // walk phases: the ray is inside a tracking walk
+    SP_DT = 0, SP_RT, SP_RTA, SP_DRT,
+    // transition phases
+    SP_HEAD, SP_SCAT, SP_ESC, SP_NEE, SP_RT_END, SP_RTA_END, SP_PHASE, SP_END, SP_DRT_END,
+    SP_IDLE, SP_NONE
+};
+enum SqFlight : int { SF_NEW = 0, SF_NEXT = 1, SF_WAIT = 2 };   // first flight of a walk to set up | next flight to set up | posted
+enum SqKind : int { SQ_WALK = 0, SQ_COLL, SQ_TRANS, SQ_REGEN, SQ_KINDS };
+constexpr uint32_t kSqEmpty = 0xffffu;
+
+typedef __attribute__((address_space(3))) volatile uint32_t sq_vu32;
+typedef __attribute__((address_space(3))) volatile uint16_t sq_vu16;
+typedef __attribute__((address_space(3))) volatile unsigned long long sq_vu64;
+__device__ __forceinline__ void sq_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t sq_xcc_id()
+{
+    return __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u;   // HW_REG_XCC_ID[3:0]
+}
+
+// Ring buffers of ray ids: ctl[kind] = {tail (pushes reserved) : head (pops reserved)}, both counting up.  A ray is in at
+// most one queue, so DRT_SQ_RAYS entries per ring never overflow; an entry is kSqEmpty until its id has been written
+// (a pop may be reserved between a push's reservation and its write: the popping lane waits for the id).
+
+// up to max_n entries, none if fewer than min_n are there; returns the count, the first position in `h` (wave-uniform)
+__device__ __forceinline__ uint32_t sq_pop(unsigned long long *ctl, int kind, uint32_t max_n, uint32_t min_n, uint32_t lane, uint32_t &h)
+{
+    uint32_t hh = 0, n = 0;
+    if (lane == 0) {
+        for (;;) {
+            const unsigned long long c = ((sq_vu64 *) ctl)[kind];
+            const uint32_t head = (uint32_t) c, avail = (uint32_t) (c >> 32) - head;
+            const uint32_t take = avail < max_n ? avail : max_n;
+            if (take == 0u || take < min_n) break;
+            if (atomicCAS(ctl + kind, c, c + take) == c) { hh = head; n = take; break; }
+        }
+    }
+    h = (uint32_t) __builtin_amdgcn_readfirstlane((int) hh);
+    return (uint32_t) __builtin_amdgcn_readfirstlane((int) n);
+}
+
+// the id at ring position pos of `kind` (taken: the entry is emptied)
+__device__ __forceinline__ uint32_t sq_take(uint16_t *q, int kind, uint32_t pos)
+{
+    sq_vu16 *e = (sq_vu16 *) q + kind * DRT_SQ_RAYS + (pos & (DRT_SQ_RAYS - 1u));
+    uint32_t id = *e;
+    while (id == kSqEmpty) { __builtin_amdgcn_s_sleep(1); id = *e; }
+    *e = (uint16_t) kSqEmpty;
+    return id;
+}
+
+// ids of the lanes with `pred` (what they wrote to their records before must be visible: sq_fence first)
+__device__ __forceinline__ void sq_push(unsigned long long *ctl, uint16_t *q, int kind, bool pred, uint32_t id, uint32_t lane)
+{
+    const uint64_t m = __ballot(pred);
+    if (!m) return;
+    const int leader = __ffsll((long long) m) - 1;
+    uint32_t tail = 0;
+    if ((int) lane == leader) tail = (uint32_t) (atomicAdd(ctl + kind, (unsigned long long) __popcll(m) << 32) >> 32);
+    tail = (uint32_t) __builtin_amdgcn_readlane((int) tail, leader);
+    if (pred) {
+        const uint32_t rank = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+        ((sq_vu16 *) q)[kind * DRT_SQ_RAYS + ((tail + rank) & (DRT_SQ_RAYS - 1u))] = (uint16_t) id;
+    }
+}
+
+}  // namespace
+
+template <bool ADJ, bool COUNT, bool ENV>
+__global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P)
+{
+    constexpr int NWV = DRT_SQ_THREADS / 64;
+    constexpr int NRAY = DRT_SQ_RAYS;
+    constexpr int R4 = ADJ ? 11 : 10;                                        // uint4 per ray record
+    // ray record: [0] {tn.x, tn.y, tn.z, cell} [1] {td.x, td.y, td.z, steps left (9 bits per axis) + direction signs}
+    // [2] {tau, tmax, t, acc} - the flight (a finished flight leaves its cell's majorant, 0: left the segment, in [0].x) -
+    // [3] {ro, si_t} [4] {rd, wmax} [5] {beta, wt} [6] {result, nt0} [7] {S.state, S.inc} [8] {wo, flags}
+    // [9] {li, pc_steps, adjsum, -} [10] {A.state, A.inc} (adjoint)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int n_cells = P.gx * P.gy * P.gz;
+    const int mg_words = (n_cells + 1) / 2;
+    uint4 *rec4 = (uint4 *) lds;
+    uint32_t *mg_lds = lds + NRAY * R4 * 4;
+    uint16_t *q_lds = (uint16_t *) (mg_lds + ((mg_words + 3) & ~3));
+    unsigned long long *ctl = (unsigned long long *) (q_lds + SQ_KINDS * NRAY);
+    unsigned long long *pool = ctl + SQ_KINDS;                                // [0] next, [1] end of the workgroup's reserved positions of the ray queues
+    uint32_t *misc = (uint32_t *) (pool + 2);                                 // [0] dead records, [1] bits of the largest majorant, [2] lock of the pool, [3] ray queues tried
+    uint32_t *recst = misc + 4;                                              // record-stream state per wave (emit_record)
+    for (int i = threadIdx.x; i < SQ_KINDS * NRAY; i += blockDim.x) q_lds[i] = (uint16_t) (i >= SQ_REGEN * NRAY ? i - SQ_REGEN * NRAY : (int) kSqEmpty);
+    if (threadIdx.x < SQ_KINDS) ctl[threadIdx.x] = threadIdx.x == SQ_REGEN ? ((unsigned long long) NRAY << 32) : 0ull;
+    if (threadIdx.x < 4) misc[threadIdx.x] = 0u;
+    if (threadIdx.x < 2) pool[threadIdx.x] = 0ull;
+    for (int w = threadIdx.x; w < NWV * 8; w += blockDim.x) recst[w] = 0u;
+    __syncthreads();
+    {                                                                        // (the grid's values are bf16-representable: exact)
+        uint32_t top = 0u;                                                   // (non-negative floats order like their bit patterns)
+        for (int w = threadIdx.x; w < mg_words; w += blockDim.x) {
+            const uint32_t a = __float_as_uint(P.mgrid[2 * w]), b = 2 * w + 1 < n_cells ? __float_as_uint(P.mgrid[2 * w + 1]) : 0u;
+            mg_lds[w] = (a >> 16) | (b & 0xffff0000u);
+            top = max(top, max(a, b));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) top = max(top, (uint32_t) __shfl_down((int) top, off, 64));
+        if ((threadIdx.x & 63u) == 0u && top) atomicMax(misc + 1, top);
+    }
+    __syncthreads();
+    // A flight whose target optical depth exceeds (largest majorant) x (length of its segment) cannot end in a collision
+    // whatever cells it crosses: it is not walked (flight set-up below; the bound is drt_super.hip's).
+    const float mmax = __uint_as_float(__builtin_amdgcn_readfirstlane((int) misc[1]));
+    const uint32_t *occ = nullptr;   // (tentative collisions lie in non-empty supergrid cells: the voxel bitmask would rarely say "empty")
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const uint16_t *mg16 = (const uint16_t *) mg_lds;
+    uint32_t cnt[C_COUNT];
+#pragma unroll
+    for (int i = 0; i < C_COUNT; ++i) cnt[i] = 0;
+#if DRT_SQ_PROFILE
+    // experiment build (tools/mk_variant.sh NAME -DDRT_SQ_PROFILE=1 drt_sq.hip): the counting kernels' slots hold, summed over
+    // waves, [0] lane cell steps, [1] wave cell steps, [2] collision batches, [3] rays in them, [4] transition batches, [5] rays
+    // in them, [6] regeneration batches, [7] records in them, [8] polls
+#define SQ_COUNT(slot) do { } while (0)
+#define SQ_PROF(slot, v) do { if (COUNT) { const uint32_t v_ = (uint32_t) (v); if (lane == 0) cnt[slot] += v_; } } while (0)
+#else
+#define SQ_COUNT(slot) do { if (COUNT) cnt[slot]++; } while (0)
+#define SQ_PROF(slot, v) do { } while (0)
+#endif
+
+    // uniform supergrid constants
+    const int gx = P.gx, gy = P.gy, gz = P.gz;
+    const float fgx = (float) gx, fgy = (float) gy, fgz = (float) gz;
+    const int lin_y = gx, lin_z = gx * gy;
+
+    uint32_t *rec = recst + wave * 8;                                          // record-stream state of this wave (emit_record)
+    uint4 *cold = nullptr;                                                     // adjoint: [5][NRAY] uint4 of this workgroup
+    if constexpr (ADJ) cold = (uint4 *) P.sq_cold + (size_t) blockIdx.x * 5 * NRAY;
+    const uint32_t xcc = sq_xcc_id();
+    // (with a ray order the queue positions cover whole units: the last unit may reach past the launch's last ray)
+    const uint64_t span = P.order ? (uint64_t) P.order_units * P.order_unit : P.n_rays - P.ray_first;
+    const uint64_t n_runs = (span + DRT_SQ_RUN - 1) / DRT_SQ_RUN;
+    // queue x serves the runs x, x + 8, ...; a workgroup starts on the queue of the XCD it runs on (L2 locality) and moves on
+    // to the next ones when that one is drained: every ray is traced whatever the placement of the workgroups.  The
+    // positions a workgroup has reserved (DRT_SQ_CHUNK at a time) are handed out from LDS under a lock: any wave starts rays.
+    int polls = 0;
+
+    for (;;) {
+        // ---- what is there to do? ---------------------------------------------------------------------------
+        uint32_t qn = 0;
+        if (lane < (uint32_t) SQ_KINDS) { const unsigned long long c = ((sq_vu64 *) ctl)[lane]; qn = (uint32_t) (c >> 32) - (uint32_t) c; }
+        const uint32_t n_walk = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_WALK), n_coll = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_COLL);
+        const uint32_t n_trans = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_TRANS), n_regen = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_REGEN);
+        const uint32_t dead = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[0]);
+        if (dead >= (uint32_t) NRAY) break;
+        const bool drained = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[3]) >= 8u;
+        int kind = -1; uint32_t min_n = DRT_SQ_BATCH;
+        if (n_coll >= DRT_SQ_BATCH) kind = SQ_COLL;
+        else if (n_trans >= DRT_SQ_BATCH) kind = SQ_TRANS;
+        else if (n_regen >= DRT_SQ_REGEN_MIN || (drained && n_regen)) { kind = SQ_REGEN; min_n = 1; }
+        else if (n_walk) kind = SQ_WALK;
+        else if (n_coll | n_trans | n_regen) {
+            if (polls < DRT_SQ_MAXPOLL) { ++polls; SQ_PROF(8, 1); __builtin_amdgcn_s_sleep(4); continue; }
+            kind = (n_coll >= n_trans && n_coll >= n_regen) ? SQ_COLL : (n_trans >= n_regen ? SQ_TRANS : SQ_REGEN);
+            min_n = 1;
+        } else { SQ_PROF(8, 1); __builtin_amdgcn_s_sleep(8); continue; }
+
+        if (kind == SQ_WALK) {
+            // ================= walk: posted flights -> supergrid cells -> results ==============================
+            bool fly = false, walked = false;
+            uint32_t slot = 0;
+            float tnx = kInf, tny = kInf, tnz = kInf, tdx = kInf, tdy = kInf, tdz = kInf, t = 0.0f, acc = 0.0f, tau = 0.0f, tmax = 0.0f;
+            int cell = 0, sx = 0, sy = 0, sz = 0;
+            uint32_t rem = 0;
+            for (;;) {
+                const uint64_t flym = __ballot(fly);
+                const int nfree = 64 - __popcll(flym);
+                if (nfree >= DRT_SQ_REFILL_MIN) {
+                    uint32_t h0;
+                    const uint32_t got = sq_pop(ctl, SQ_WALK, (uint32_t) nfree, 1u, lane, h0);
+                    if (got) {
+                        const uint32_t frank = (uint32_t) __popcll(~flym & ((1ull << lane) - 1ull));   // my rank among the free lanes
+                        if (!fly && frank < got) {
+                            slot = sq_take(q_lds, SQ_WALK, h0 + frank);
+                            const uint4 *sp = rec4 + R4 * slot;
+                            const uint4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+                            tnx = __uint_as_float(q0.x); tny = __uint_as_float(q0.y); tnz = __uint_as_float(q0.z); cell = (int) q0.w;
+                            tdx = __uint_as_float(q1.x); tdy = __uint_as_float(q1.y); tdz = __uint_as_float(q1.z); rem = q1.w;
+                            tau = __uint_as_float(q2.x); tmax = __uint_as_float(q2.y); t = __uint_as_float(q2.z); acc = __uint_as_float(q2.w);
+                            sx = (rem & (1u << 27)) ? -1 : 1; sy = (rem & (1u << 28)) ? -lin_y : lin_y; sz = (rem & (1u << 29)) ? -lin_z : lin_z;
+                            fly = true;
+                        }
+                    }
+                }
+                if (!__ballot(fly)) break;                                       // nothing to walk (any more)
+                walked = true;
+                // (primal kernels: the steps are not predicated on `fly`, as in drt_super.hip)
+                constexpr bool kLoose = !ADJ;
+                bool fin = false; float res_mc = 0.0f, res_t = 0.0f, res_acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < DRT_SQ_K; ++k) {
+#if DRT_SQ_PROFILE
+                    { const int nf = __popcll(__ballot(fly)); SQ_PROF(0, nf); SQ_PROF(1, 1); }
+#endif
+                    // one supergrid cell (oracle: the loop of sample_collision).  Crossing times are finite or +inf, never NaN.
+                    const float tmin = fminf(fminf(tnx, tny), tnz);
+                    const float texit = fminf(tmin, tmax);
+                    const uint32_t ci = kLoose ? min((uint32_t) cell, (uint32_t) (n_cells - 1)) : (uint32_t) cell;
+                    const float mc = __uint_as_float((uint32_t) mg16[ci] << 16);
+                    const float nacc = acc + mc * (texit - t);                  // (an empty cell adds an exact zero)
+                    const bool hit = mc > 0.0f && nacc >= tau;                  // the tentative collision lies in this cell
+                    const bool isx = tnx == tmin, isy = !isx && tny == tmin;     // first axis with the earliest crossing
+                    const uint32_t sh = isx ? 0u : isy ? 9u : 18u;
+                    const bool end = !(texit < tmax) || ((rem >> sh) & 511u) == 0u;   // end of the segment / of the grid
+                    const float tnn = tmin + (isx ? tdx : isy ? tdy : tdz);
+                    if constexpr (kLoose) {
+                        const bool ends = fly && (hit || end);
+                        res_mc = ends ? (hit ? mc : 0.0f) : res_mc; res_t = ends ? t : res_t; res_acc = ends ? acc : res_acc;
+                        fin = fin || ends; fly = fly && !ends;
+                        acc = nacc; t = texit;
+                        rem -= 1u << sh;
+                        cell += isx ? sx : isy ? sy : sz;
+                        tnx = isx ? tnn : tnx; tny = isy ? tnn : tny; tnz = (isx || isy) ? tnz : tnn;
+                    } else {
+                        if (fly && (hit || end)) { fin = true; res_mc = hit ? mc : 0.0f; fly = false; }
+                        const bool go = fly;
+                        acc = go ? nacc : acc;
+                        t = go ? texit : t;
+                        rem = go ? rem - (1u << sh) : rem;
+                        cell += go ? (isx ? sx : isy ? sy : sz) : 0;
+                        tnx = (go && isx) ? tnn : tnx; tny = (go && isy) ? tnn : tny; tnz = (go && !isx && !isy) ? tnn : tnz;
+                    }
+                }
+                if (__ballot(fin)) {
+                    // result: where the last cell was entered, the optical depth up to there, its majorant (0: left the segment)
+                    if (fin) {
+                        uint4 *sp = rec4 + R4 * slot;
+                        sp[0].x = __float_as_uint(res_mc);
+                        sp[2].z = __float_as_uint(kLoose ? res_t : t); sp[2].w = __float_as_uint(kLoose ? res_acc : acc);
+                    }
+                    sq_fence();
+                    sq_push(ctl, q_lds, SQ_COLL, fin, slot, lane);
+                }
+                // a full heavy batch is waiting and this wave has little under way: leave
+                const int nfly = __popcll(__ballot(fly));
+                if (nfly <= DRT_SQ_LEAVE_MAX) {
+                    uint32_t hn = 0;
+                    if (lane >= (uint32_t) SQ_COLL && lane < (uint32_t) SQ_KINDS) { const unsigned long long c = ((sq_vu64 *) ctl)[lane]; hn = (uint32_t) (c >> 32) - (uint32_t) c; }
+                    if (__ballot(hn >= DRT_SQ_BATCH)) break;
+                }
+            }
+            if (__ballot(fly)) {                                                 // flights still under way: back to their records
+                if (fly) {
+                    uint4 *sp = rec4 + R4 * slot;
+                    sp[0] = make_uint4(__float_as_uint(tnx), __float_as_uint(tny), __float_as_uint(tnz), (uint32_t) cell);
+                    sp[1].w = rem;
+                    sp[2].z = __float_as_uint(t); sp[2].w = __float_as_uint(acc);
+                }
+                sq_fence();
+                sq_push(ctl, q_lds, SQ_WALK, fly, slot, lane);
+            }
+            if (walked) polls = 0;
+            continue;
+        }
+
+        // ================= a heavy batch: up to 64 rays of one kind ==========================================
+        uint32_t h0;
+        const uint32_t nb = sq_pop(ctl, kind, 64u, min_n, lane, h0);
+        if (!nb) continue;                                                       // (another wave was faster)
+        polls = 0;
+        const bool act = lane < nb;
+        uint32_t id = 0;
+        if (act) id = sq_take(q_lds, kind, h0 + lane);
+        sq_fence();
+        uint4 *R = rec4 + R4 * id;
+
+        // ---- per-ray state (registers of this batch only) ----------------------------------------------------
+        int ph = SP_NONE, fl = SF_WAIT;
+        bool rec_mode = false, rec_first = false, escaped = false, has_scattered = false, scat_once = false, pc_on = false;
+        int depth = 0, pc_it = 0;
+        uint32_t li = 0, pc_steps = 0;
+        V3 ro = v3(0, 0, 0), rd = v3(0, 0, 1), wo = v3(0, 0, 0);
+        float si_t = kInf, wmax = 0.0f, wt = 0.0f, nt0 = 0.0f, adjsum = 0.0f;
+        float beta[3] = { 1, 1, 1 }, result[3] = { 0, 0, 0 }, dL[3] = { 0, 0, 0 };
+        Pcg32 S; S.state = 0; S.inc = 1;
+        Pcg32 A; A.state = 0; A.inc = 1;
+        uint64_t Cst = 0;
+        int r_depth = -1; float r_si_t = kInf; V3 r_o = ro, r_d = rd;
+        float r_wsum[3] = { 0, 0, 0 }, r_cw[3] = { 0, 0, 0 };
+        float c_lm = 0.0f, c_tau = 0.0f, c_t = 0.0f, c_acc = 0.0f;              // the finished flight (collision batches)
+        float w_tdx = kInf, w_tdy = kInf, w_tdz = kInf; uint32_t w_rem = 0;      // the walk's direction share of the DDA
+
+        if (kind != SQ_REGEN) {
+            if (act) {
+                const uint4 q3 = R[3], q4 = R[4], q5 = R[5], q6 = R[6], q7 = R[7], q8 = R[8], q9 = R[9];
+                ro = v3(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z)); si_t = __uint_as_float(q3.w);
+                rd = v3(__uint_as_float(q4.x), __uint_as_float(q4.y), __uint_as_float(q4.z)); wmax = __uint_as_float(q4.w);
+                beta[0] = __uint_as_float(q5.x); beta[1] = __uint_as_float(q5.y); beta[2] = __uint_as_float(q5.z); wt = __uint_as_float(q5.w);
+                result[0] = __uint_as_float(q6.x); result[1] = __uint_as_float(q6.y); result[2] = __uint_as_float(q6.z); nt0 = __uint_as_float(q6.w);
+                S.state = ((uint64_t) q7.y << 32) | q7.x; S.inc = ((uint64_t) q7.w << 32) | q7.z;
+                wo = v3(__uint_as_float(q8.x), __uint_as_float(q8.y), __uint_as_float(q8.z));
+                const uint32_t f = q8.w;
+                ph = (int) (f & 15u); fl = (int) ((f >> 4) & 3u);
+                rec_mode = (f >> 6) & 1u; rec_first = (f >> 7) & 1u; escaped = (f >> 8) & 1u; has_scattered = (f >> 9) & 1u;
+                scat_once = (f >> 10) & 1u; pc_on = (f >> 11) & 1u;
+                depth = (int) ((f >> 12) & 1023u); pc_it = (int) (f >> 22);
+                li = q9.x; pc_steps = q9.y; adjsum = __uint_as_float(q9.z);
+                if constexpr (ADJ) { const uint4 q10 = R[10]; A.state = ((uint64_t) q10.y << 32) | q10.x; A.inc = ((uint64_t) q10.w << 32) | q10.z; }
+                if (kind == SQ_COLL) {
+                    const uint4 q1 = R[1], q2 = R[2];
+                    c_lm = __uint_as_float(R[0].x); c_tau = __uint_as_float(q2.x); c_t = __uint_as_float(q2.z); c_acc = __uint_as_float(q2.w);
+                    w_tdx = __uint_as_float(q1.x); w_tdy = __uint_as_float(q1.y); w_tdz = __uint_as_float(q1.z); w_rem = q1.w;
+                }
+                if constexpr (ADJ) {
+                    if (kind == SQ_TRANS) {
+                        const uint4 c0 = cold[id], c1 = cold[NRAY + id], c2 = cold[2 * NRAY + id], c3 = cold[3 * NRAY + id], c4 = cold[4 * NRAY + id];
+                        dL[0] = __uint_as_float(c0.x); dL[1] = __uint_as_float(c0.y); dL[2] = __uint_as_float(c0.z); r_si_t = __uint_as_float(c0.w);
+                        Cst = ((uint64_t) c1.y << 32) | c1.x; r_depth = (int) c1.z;
+                        r_o = v3(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); r_wsum[0] = __uint_as_float(c2.w);
+                        r_d = v3(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z)); r_wsum[1] = __uint_as_float(c3.w);
+                        r_cw[0] = __uint_as_float(c4.x); r_cw[1] = __uint_as_float(c4.y); r_cw[2] = __uint_as_float(c4.z); r_wsum[2] = __uint_as_float(c4.w);
+                    }
+                }
+            }
+        }
+
+        if (kind == SQ_COLL) {
+            // ================= (Fe) the collision a flight ended in =========================================
+            SQ_PROF(2, 1); SQ_PROF(3, nb);
+            if (act) {
+                const bool drt = ph == SP_DRT;
+                const bool useA = ADJ && !rec_mode && drt;
+                Pcg32 Rg; Rg.state = useA ? A.state : S.state; Rg.inc = useA ? A.inc : S.inc;
+                // Medium::sample_interaction [M3-ext] (oracle: sample_collision): the walker left {entry distance of the
+                // last cell, optical depth up to there, that cell's majorant (0: the flight left the segment)}
+                const float lm = c_lm, tau = c_tau;
+                const float lim = lm > 0.0f ? 1.0f / lm : 0.0f;
+                const float dt = lm > 0.0f ? fmaf(tau - c_acc, lim, c_t) : kInf;
+                bool inside; V3 p;
+                if (drt) { wt += dt; inside = wt <= wmax; p = ray_at(ro, rd, wt); }
+                else { inside = dt <= wmax; p = ray_at(wo, rd, dt); }
+                const float sig = inside ? eval_sigma_t(P, p, occ) : 0.0f;
+                fl = SF_NEXT;
+                if (!inside) {                                              // left the segment
+                    ph = drt ? SP_DRT_END : (ph == SP_DT) ? SP_ESC : (ph == SP_RT ? SP_RT_END : SP_RTA_END);
+                } else if (drt) {                                           // Medium::sample_interaction_drt (:549-551); wo = {T, wsum, selected t}
+                    SQ_COUNT(C_DRT);
+                    const float w = wo.x * lim;
+                    wo.y += w;
+                    const float u2 = Rg.next_1d();
+                    if (w > 0.0f && u2 * wo.y <= w) wo.z = wt;
+                    wo.x *= (lm - sig) * lim;
+                    if (wo.x == 0.0f) ph = SP_DRT_END;
+                } else if (ph == SP_DT) {                                   // :348-367
+                    SQ_COUNT(C_DT); ++pc_steps;
+                    const float r = sig * lim;
+                    const float u2 = Rg.next_1d();
+                    if (!(u2 >= r)) { wt = wt + dt; ph = SP_SCAT; }          // mei.t
+                    else { wo = p; wmax -= dt; wt += dt; }
+                } else {                                                    // ratio tracking :465-502
+                    SQ_COUNT(C_RT); ++pc_steps;
+                    const float tr = (lm - sig) * lim;
+                    if constexpr (ADJ) {
+                        if (ph == SP_RTA && tr > 0.0f) {                    // :487-492
+                            splat_sigma_t<true>(P, p, -(adjsum * lim) / tr, rec);
+                            SQ_COUNT(C_RT_ADJ);
+                        }
+                    }
+                    wt *= tr; wo = p; wmax -= dt;
+                    if (wt == 0.0f) ph = (ph == SP_RT) ? SP_RT_END : SP_RTA_END;
+                }
+                if (useA) A.state = Rg.state; else S.state = Rg.state;
+            }
+        } else if (kind == SQ_REGEN) {
+            // ================= (A) regeneration ===========================================================
+            // Ray indices come from a wave-local pool refilled DRT_SQ_CHUNK at a time with ONE returning atomic on the
+            // XCD's queue head.
+            SQ_PROF(6, 1); SQ_PROF(7, nb);
+            const uint64_t wmask = __ballot(act);
+            uint64_t first = 0; uint32_t got = 0, qx = 0, qs_ = 0;
+            if (lane == 0) {
+                while (atomicCAS(misc + 2, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+                uint64_t pn = ((sq_vu64 *) pool)[0], pe = ((sq_vu64 *) pool)[1];
+                uint32_t qs = ((sq_vu32 *) misc)[3];
+                while (pn >= pe && qs < 8u) {                                // refill from the ray queues
+                    const uint32_t x = (xcc + qs) & 7u;
+                    const uint64_t len = (n_runs > x ? (n_runs - x + 7) / 8 : 0) * DRT_SQ_RUN;
+                    const unsigned long long base = atomicAdd(P.queues + x, (unsigned long long) DRT_SQ_CHUNK);
+                    if (base < len) { pn = base; pe = base + DRT_SQ_CHUNK < len ? base + DRT_SQ_CHUNK : len; }
+                    else ++qs;                                               // this queue is drained: next one
+                }
+                qx = (xcc + qs) & 7u; qs_ = qs;
+                const uint64_t want = (uint64_t) __popcll(wmask);
+                got = (uint32_t) (pe - pn < want ? pe - pn : want);
+                if (qs >= 8u) got = 0;
+                first = pn; pn += got;
+                ((sq_vu64 *) pool)[0] = pn; ((sq_vu64 *) pool)[1] = pe; ((sq_vu32 *) misc)[3] = qs;
+                sq_fence();
+                ((sq_vu32 *) misc)[2] = 0u;                                  // unlock
+            }
+            first = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (first >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) first);
+            got = (uint32_t) __builtin_amdgcn_readfirstlane((int) got); qx = (uint32_t) __builtin_amdgcn_readfirstlane((int) qx);
+            qs_ = (uint32_t) __builtin_amdgcn_readfirstlane((int) qs_);
+            if (qs_ >= 8u && !got) {                       // all eight queues are empty: these records are done
+                if (lane == 0) atomicAdd(misc, nb);
+                continue;
+            }
+            const uint32_t myr = (uint32_t) __popcll(wmask & ((1ull << lane) - 1ull));
+            const bool take = act && myr < got;
+            const uint64_t q = first + myr;
+            if (act) ph = SP_IDLE;                                           // (no ray for this record: it stays free and draws again)
+            if (take) {
+                uint64_t i = ((q / DRT_SQ_RUN) * 8 + qx) * DRT_SQ_RUN + (q % DRT_SQ_RUN);
+                if (P.order) {                                              // position -> unit of the order -> ray
+                    const uint32_t g = (uint32_t) i, u = P.order_unit == 1u ? g : g / P.order_unit;
+                    i = i < span ? (uint64_t) P.order[u] * P.order_unit + (g - u * P.order_unit) : P.n_rays;
+                }
+                i += P.ray_first;
+                if (i < P.n_rays) {
+                    // ---- sample() prologue (:51-108) + reach_medium (:292-319) ----
+                    li = (uint32_t) i;
+                    const uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
+                    const uint32_t gi = (uint32_t) g64;
+                    S.seed(P.seed, gi);
+                    if (P.sensor_flow) {
+                        float ux = S.next_1d(), uy = S.next_1d();
+                        sensor_ray(P, gi / P.spp, ux, uy, ro, rd);
+                    } else {
+                        ro = v3(P.rays_o[3 * i], P.rays_o[3 * i + 1], P.rays_o[3 * i + 2]);
+                        rd = v3(P.rays_d[3 * i], P.rays_d[3 * i + 1], P.rays_d[3 * i + 2]);
+                    }
+                    SQ_COUNT(C_RAYS);
+                    pc_on = false; pc_it = 0;
+                    if (P.path_cache_mode) {
+                        // one word per ray ties the cache entries to THIS ray: explicit rays are hashed (the buffers
+                        // may have been refilled between the two passes), sensor rays follow from the job signature
+                        uint32_t hsh = 0x9e3779b9u ^ gi;
+                        if (!P.sensor_flow) {
+                            const uint32_t w[6] = { __float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z),
+                                                    __float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z) };
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) hsh = (hsh ^ w[k]) * 0x01000193u + (hsh >> 15);
+                        }
+                        if (!ADJ && P.path_cache_mode == 1) { P.ray_hash[i] = hsh; pc_on = true; }
+                        if (ADJ && P.path_cache_mode == 2) pc_on = P.ray_hash[i] == hsh;
+                    }
+                    beta[0] = beta[1] = beta[2] = 1.0f;
+                    result[0] = result[1] = result[2] = 0.0f;
+                    if constexpr (ADJ) {
+                        dL[0] = P.dL[3 * i]; dL[1] = P.dL[3 * i + 1]; dL[2] = P.dL[3 * i + 2];
+                        result[0] = P.L_in[3 * i]; result[1] = P.L_in[3 * i + 1]; result[2] = P.L_in[3 * i + 2];
+                    }
+                    depth = 0; escaped = false; has_scattered = false; scat_once = false;
+                    rec_mode = false; rec_first = false;
+                    (void) S.next_1d();                                     // :71
+                    bool active = true;
+                    Hit si = box_hit(P, ro, rd);
+                    if (!si.valid) { escaped = true; active = false; }
+                    else {
+                        ro = offset_p(si, rd);
+                        Hit sn = box_hit(P, ro, rd);
+                        if (!sn.valid) active = false; else si_t = sn.t;
+                    }
+                    r_depth = -1;
+                    r_wsum[0] = r_wsum[1] = r_wsum[2] = 0.0f;
+                    r_cw[0] = r_cw[1] = r_cw[2] = 0.0f;
+                    if (active) (void) S.next_1d();                         // :99
+                    if constexpr (ADJ) A.seed(P.alt_seed, gi);              // :100-107
+                    ph = active ? SP_HEAD : SP_END;
+                }
+            }
+        } else {
+            SQ_PROF(4, 1); SQ_PROF(5, nb);
+        }
+
+        // ================= (B) path transitions (transition / regeneration batches), (Fs) the next flight ==============
+        // A pass takes every ray of the batch to its next walk (or to the end of its path); rays whose walk comes out of
+        // the path cache (adjoint pass), or whose next flight cannot collide, go round once more.
+        for (;;) {
+            if (kind != SQ_COLL && __ballot(ph >= SP_HEAD && ph < SP_IDLE)) {
+                uint4 pce1 = make_uint4(0u, 0u, 0u, 0u); bool pce1_ok = false;   // this iteration's NEE entry of the path cache, read at the loop head
+                // ---- DRT vertex selected: enter the detached recursive path (:553-575, :610-655) -----
+                if constexpr (ADJ) {
+                    if (ph == SP_DRT_END) {
+                        if (!(wo.z < kInf)) ph = SP_IDLE;                       // no tentative collision (:558)
+                        else {
+                            const V3 xp = ray_at(ro, rd, wo.z);
+                            r_o = xp; ro = xp;
+                            const float sig = eval_sigma_t(P, xp, occ);         // :553-554
+                            r_si_t = sig;
+                            SQ_COUNT(C_DRT);
+                            const float w = P.use_drt_mis ? 1.0f / (1.0f + sig * sig) : 1.0f;
+                            const float ww = w * wo.y;
+                            r_cw[0] = ww * r_cw[0]; r_cw[1] = ww * r_cw[1]; r_cw[2] = ww * r_cw[2];
+                            S = A;                                              // the recursion samples with alt_sampler
+                            rec_mode = true; rec_first = true;
+                            result[0] = result[1] = result[2] = 0.0f;
+                            beta[0] = beta[1] = beta[2] = 1.0f;
+                            depth = r_depth + 1;
+                            escaped = false; scat_once = true; has_scattered = false;
+                            ph = P.use_nee ? SP_NEE : SP_PHASE;                 // :621-624 NEE at x' whatever the depth
+                        }
+                    }
+                }
+
+                // ---- NEE walk finished (:388-403) -------------------------------------------------------------
+                if constexpr (!ADJ) {
+                    if (ph == SP_RT_END && pc_on && pc_it < (int) P.path_cache_cap)
+                        P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1] =
+                            make_uint4(__float_as_uint(wt), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
+                }
+                if (ph == SP_RT_END) {
+                    float val[3], contrib[3];
+                    const float ds_pdf = emitter_sample_value<ENV>(P, rd, val);      // recomputed from the direction
+                    const float w = mis_weight(ds_pdf, kInvFourPi);             // :391
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        contrib[k] = ((beta[k] * kInvFourPi) * w) * (val[k] * wt);
+                        result[k] = (ADJ && !rec_mode) ? result[k] - contrib[k] : result[k] + contrib[k];   // :211-214
+                    }
+                    ph = SP_PHASE;
+                    if constexpr (ADJ) {
+                        if (!rec_mode) {                                        // replay with the clone (:393-401)
+                            adjsum = (dL[0] * contrib[0] + dL[1] * contrib[1]) + dL[2] * contrib[2];
+                            uint64_t tmp = S.state; S.state = Cst; Cst = tmp;
+                            (void) S.next_1d(); (void) S.next_1d();             // same direction again (:418)
+                            if (nt0 < kInf) { wo = ro; wmax = nt0; wt = 1.0f; ph = SP_RTA; fl = SF_NEW; }
+                            else ph = SP_RTA_END;
+                        }
+                    }
+                }
+                if constexpr (ADJ) {
+                    if (ph == SP_RTA_END) { S.state = Cst; ph = SP_PHASE; }     // back to the primary stream
+                }
+
+                // ---- phase sampling + new segment (:221-246) -------------------------------------------------------
+                if (ph == SP_PHASE) {
+                    ++pc_it;                                                    // next bounce-loop iteration (path cache index)
+                    (void) S.next_1d();
+                    float ux = S.next_1d(), uy = S.next_1d();
+                    rd = square_to_uniform_sphere(ux, uy);                      // (ro is the scatter point already)
+                    scat_once = true;
+                    Hit h = box_hit(P, ro, rd);                                 // :233-235
+                    si_t = h.valid ? h.t : kLargest;
+                    bool active = h.valid;                                      // :240-241 accidental escape
+                    if (rec_first) {                                            // sample_recursive -> sample() (:641-651)
+                        rec_first = false;
+                        active = active && (depth < P.max_depth);               // :647 (+ DESIGN.md deviation)
+                        has_scattered = active;                                 // :84-85
+                        if (active) (void) S.next_1d();                         // :99 of the recursive sample()
+                    }
+                    ph = active ? SP_HEAD : SP_END;
+                }
+
+                // ---- loop head: Russian roulette, start delta tracking (:116-127) -------------------------------------
+                if (ph == SP_HEAD) {
+                    float q = fminf(fmaxf(beta[0], fmaxf(beta[1], beta[2])), 0.99f);
+                    bool perform_rr = depth > P.rr_depth;
+                    float u_rr = S.next_1d();
+                    bool active = (beta[0] != 0.0f || beta[1] != 0.0f || beta[2] != 0.0f) && (!perform_rr || (u_rr < q));
+                    if (perform_rr) { float iq = 1.0f / q; beta[0] *= iq; beta[1] *= iq; beta[2] *= iq; }
+                    if (!active) ph = SP_END;
+                    else if (ADJ && !rec_mode && pc_on && pc_it < (int) P.path_cache_cap) {
+                        // the adjoint takes this iteration's delta-tracking walk from the primal pass of the same job
+                        const uint4 *pce = P.path_cache + ((size_t) li * P.path_cache_cap + pc_it) * 2;
+                        const uint4 e = pce[0];
+                        pce1 = pce[1]; pce1_ok = true;                          // (adjacent: one round trip for both)
+                        wt = __uint_as_float(e.x);                              // mei.t
+                        S.state = ((uint64_t) e.z << 32) | e.y;
+                        if (COUNT && !DRT_SQ_PROFILE) cnt[C_DT] += e.w;
+                        ph = wt < kInf ? SP_SCAT : SP_ESC;
+                    } else { wo = ro; wmax = si_t; wt = 0.0f; ph = SP_DT; fl = SF_NEW; pc_steps = 0; }
+                }
+
+                // ---- the walk found a real collision (wt = mei.t) or left the medium (:130-215, :244-245) -----------
+                if constexpr (!ADJ) {                                           // path cache: what this iteration's walk returned
+                    if ((ph == SP_SCAT || ph == SP_ESC) && pc_on && pc_it < (int) P.path_cache_cap)
+                        P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2] =
+                            make_uint4(__float_as_uint(ph == SP_SCAT ? wt : kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
+                }
+                if (ph == SP_SCAT || ph == SP_ESC) {
+                    const bool scat = ph == SP_SCAT;
+                    const bool adj_lane = ADJ && !rec_mode;
+                    float albedo[3] = { 1.0f, 1.0f, 1.0f }, mei_sig = 0.0f;
+                    V3 mp = ro;
+                    if (scat) {
+                        mp = ray_at(ro, rd, wt);                                // :371
+                        if (adj_lane) { mei_sig = eval_sigma_t(P, mp, occ); SQ_COUNT(C_DT); }   // :373-375
+                        has_scattered = true;
+                        eval_albedo(P, mp, albedo);                             // :141
+                        SQ_COUNT(C_ALB);
+                    }
+                    if constexpr (ADJ) {
+                        if (adj_lane) {
+                            if (P.use_drt) {                                    // DRTReservoir.update :745-753
+                                float u = A.next_1d();
+                                float m = 0.0f;
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) { r_wsum[k] += beta[k]; m += beta[k] / r_wsum[k]; }
+                                m = m / 3.0f;
+                                if (u <= m) {
+                                    r_cw[0] = beta[0]; r_cw[1] = beta[1]; r_cw[2] = beta[2];
+                                    r_depth = depth; r_si_t = si_t; r_o = ro; r_d = rd;
+                                }
+                            }
+                            if (scat && (!P.use_drt || P.use_drt_mis)) {        // :152-172
+                                float w = 1.0f;
+                                if (P.use_drt && P.use_drt_mis) { float s2 = mei_sig * mei_sig; w = s2 / (1.0f + s2); }
+                                float inv_pdf = 1.0f / mei_sig;
+                                float gs = 0.0f, ga[3];
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) {
+                                    float Li = result[k] / fmaxf(1e-8f, albedo[k]);
+                                    float a = ((w * dL[k]) * Li) * inv_pdf;
+                                    gs += a * albedo[k];
+                                    ga[k] = a * mei_sig;
+                                }
+                                splat_scatter<true>(P, mp, gs, ga, rec); SQ_COUNT(C_SC); SQ_COUNT(C_SC_ALB);
+                            }
+                            // backpropagate_transmittance: 4 resampled points on the segment (:181-189, :584-607)
+                            const float tr_int = scat ? wt : si_t;
+                            const float tr_g = -(((dL[0] * result[0] + dL[1] * result[1]) + dL[2] * result[2]) * (tr_int / 4.0f));
+                            V3 pts[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float u = A.next_1d();                    // :595
+                                pts[j] = ray_at(ro, rd, u * tr_int);
+                                SQ_COUNT(C_TR);
+                            }
+                            if (tr_g != 0.0f) emit_records0<4>(P, pts, tr_g * P.scale, rec);
+                        }
+                    }
+                    if (scat) {
+                        beta[0] *= albedo[0]; beta[1] *= albedo[1]; beta[2] *= albedo[2];   // :193
+                        depth += 1;                                             // :199
+                        ro = mp;
+                        if (depth < P.max_depth) ph = P.use_nee ? SP_NEE : SP_PHASE;   // :200, :206-207
+                        else ph = SP_END;          // killed inside the medium; its phase draws are unobservable
+                    } else {
+                        escaped = true;                                         // :245
+                        ph = SP_END;
+                    }
+                }
+
+                // ---- emitter direction + boundary exit for NEE (:406-433) ------------------------------------------
+                if (ph == SP_NEE) {
+                    if (ADJ && !rec_mode) Cst = S.state;                        // :383
+                    float ux = S.next_1d(), uy = S.next_1d();                   // :418
+                    rd = emitter_sample_dir<ENV>(P, ux, uy);
+                    Hit h = box_hit(P, ro, rd);                                 // :427-428
+                    if constexpr (ENV) { if (envmap_pdf(P, rd) == 0.0f) h.valid = false; }   // sampling_worked :421-423
+                    pc_steps = 0;
+                    nt0 = h.valid ? h.t : kInf;
+                    if (ADJ && !rec_mode && pc_on && pc_it < (int) P.path_cache_cap) {
+                        // the value walk of the main path comes out of the path cache: transmittance, stream, steps
+                        uint4 e = pce1;
+                        if (!pce1_ok) e = P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1];
+                        wt = __uint_as_float(e.x);
+                        S.state = ((uint64_t) e.z << 32) | e.y;
+                        if (COUNT && !DRT_SQ_PROFILE) cnt[C_RT] += e.w;
+                        ph = SP_RT_END;
+                    } else if (h.valid) { wo = ro; wmax = h.t; wt = 1.0f; ph = SP_RT; fl = SF_NEW; }
+                    else { wt = 0.0f; ph = SP_RT_END; }
+                }
+                // ---- end of a path (:249-287) -----------------------------------------------------
+                if (ph == SP_END) {
+                    if (!ADJ || rec_mode) {                                     // envmap block, primal only
+                        if (escaped && !(depth <= 0 && P.hide_emitters)) {
+                            float w = 1.0f, Le[3];
+                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? emitter_pdf<ENV>(P, rd) : 0.0f);
+                            emitter_eval<ENV>(P, rd, Le);
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
+                        }
+                    }
+                    if constexpr (!ADJ) {
+                        const size_t o3 = 3 * (size_t) li;
+                        P.L_out[o3] = result[0]; P.L_out[o3 + 1] = result[1]; P.L_out[o3 + 2] = result[2];
+                        if (P.ray_iters) P.ray_iters[li] = (uint8_t) (pc_it < 255 ? pc_it : 255);
+                        ph = SP_IDLE;
+                    } else {
+                        if (rec_mode) {
+                            // result = Li': gradient splat at x' (:577-581)
+                            float alb[3];
+                            eval_albedo(P, r_o, alb);                           // :578
+                            SQ_COUNT(C_ALB);
+                            float gs = 0.0f, ga[3];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                float a = r_cw[k] * result[k];
+                                gs += a * alb[k];
+                                ga[k] = a * r_si_t;
+                            }
+                            splat_scatter<true>(P, r_o, gs, ga, rec); SQ_COUNT(C_SC); SQ_COUNT(C_SC_ALB);
+                            ph = SP_IDLE;
+                        } else if (P.use_drt && r_depth >= 0) {                 // :249-259, DRTReservoir.get :756-760
+                            const float d = ((r_cw[0] + r_cw[1]) + r_cw[2]) / 3.0f;
+                            const float ws = ((r_wsum[0] + r_wsum[1]) + r_wsum[2]) / 3.0f;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) r_cw[k] = (d != 0.0f ? (ws * r_cw[k]) / d : 0.0f) * dL[k];   // adjoint
+                            // sample_interaction_drt along the selected segment (:543-551)
+                            wmax = isfinite(r_si_t) ? r_si_t : kLargest;
+                            ro = r_o; rd = r_d;
+                            wt = 0.0f; wo = v3(1.0f, 0.0f, kInf);               // T, wsum, selected t
+                            ph = SP_DRT; fl = SF_NEW;
+                        } else {
+                            ph = SP_IDLE;
+                        }
+                    }
+                }
+            }
+
+            // ================= (Fs) the next flight: set up and post =========================================
+            {
+                const bool setup = ph < SP_HEAD && fl != SF_WAIT;
+                if (__ballot(setup)) {
+                    if (setup) {
+                        const bool drt = ph == SP_DRT;
+                        const bool useA = ADJ && !rec_mode && drt;
+                        Pcg32 Rg; Rg.state = useA ? A.state : S.state; Rg.inc = useA ? A.inc : S.inc;
+                        // the direction's share of the DDA (oracle: sample_collision): crossing-time increments 1 / |dg|, direction
+                        // signs.  It is the same for every flight of a walk: kept in the record, recomputed for a walk's first flight.
+                        float tdx, tdy, tdz; int sgx, sgy, sgz;
+                        if (fl == SF_NEW) {
+                            const float dgx = (rd.x * P.inv_ext[0]) * fgx, dgy = (rd.y * P.inv_ext[1]) * fgy, dgz = (rd.z * P.inv_ext[2]) * fgz;
+                            if (dgx >= 1e-20f) { tdx = 1.0f / dgx; sgx = 1; } else if (dgx <= -1e-20f) { tdx = 1.0f / -dgx; sgx = -1; } else { tdx = kInf; sgx = 0; }
+                            if (dgy >= 1e-20f) { tdy = 1.0f / dgy; sgy = 1; } else if (dgy <= -1e-20f) { tdy = 1.0f / -dgy; sgy = -1; } else { tdy = kInf; sgy = 0; }
+                            if (dgz >= 1e-20f) { tdz = 1.0f / dgz; sgz = 1; } else if (dgz <= -1e-20f) { tdz = 1.0f / -dgz; sgz = -1; } else { tdz = kInf; sgz = 0; }
+                        } else {
+                            tdx = w_tdx; tdy = w_tdy; tdz = w_tdz;                  // (the walk's previous flight left them in the record)
+                            sgx = tdx == kInf ? 0 : (w_rem & (1u << 27)) ? -1 : 1;
+                            sgy = tdy == kInf ? 0 : (w_rem & (1u << 28)) ? -1 : 1;
+                            sgz = tdz == kInf ? 0 : (w_rem & (1u << 29)) ? -1 : 1;
+                        }
+                        const float u = Rg.next_1d();
+                        const float tau = -drt_logf(1.0f - u);
+                        const V3 o = drt ? ray_at(ro, rd, wt) : wo;
+                        const float tmax = drt ? wmax - wt : wmax;
+                        const float gxf = ((o.x - P.bmin[0]) * P.inv_ext[0]) * fgx;
+                        const float gyf = ((o.y - P.bmin[1]) * P.inv_ext[1]) * fgy;
+                        const float gzf = ((o.z - P.bmin[2]) * P.inv_ext[2]) * fgz;
+                        const float flx = fminf(fmaxf(floorf(gxf), 0.0f), (float) (gx - 1));
+                        const float fly_ = fminf(fmaxf(floorf(gyf), 0.0f), (float) (gy - 1));
+                        const float flz = fminf(fmaxf(floorf(gzf), 0.0f), (float) (gz - 1));
+                        const int cx = (int) flx, cy = (int) fly_, cz = (int) flz;
+                        const float tnx = sgx > 0 ? ((flx + 1.0f) - gxf) * tdx : sgx < 0 ? (gxf - flx) * tdx : kInf;
+                        const float tny = sgy > 0 ? ((fly_ + 1.0f) - gyf) * tdy : sgy < 0 ? (gyf - fly_) * tdy : kInf;
+                        const float tnz = sgz > 0 ? ((flz + 1.0f) - gzf) * tdz : sgz < 0 ? (gzf - flz) * tdz : kInf;
+                        const uint32_t rx_ = (uint32_t) (sgx > 0 ? gx - 1 - cx : cx), ry_ = (uint32_t) (sgy > 0 ? gy - 1 - cy : cy),
+                                       rz_ = (uint32_t) (sgz > 0 ? gz - 1 - cz : cz);
+                        const uint32_t rem = rx_ | (ry_ << 9) | (rz_ << 18) | (sgx < 0 ? 1u << 27 : 0u) | (sgy < 0 ? 1u << 28 : 0u) | (sgz < 0 ? 1u << 29 : 0u);
+                        if (DRT_SQ_EARLY_OUT && tau > (mmax * tmax) * 1.001f) {
+                            // no cell of this segment can bring the optical depth to tau: the flight leaves the segment, as
+                            // the epilogue above finds it after a walk (majorant 0 in the record: dt = inf, not inside)
+                            if (drt) wt += kInf;
+                            fl = SF_NEXT;
+                            w_tdx = tdx; w_tdy = tdy; w_tdz = tdz; w_rem = rem;
+                            ph = drt ? SP_DRT_END : (ph == SP_DT) ? SP_ESC : (ph == SP_RT ? SP_RT_END : SP_RTA_END);
+                        } else {
+                            R[0] = make_uint4(__float_as_uint(tnx), __float_as_uint(tny), __float_as_uint(tnz), (uint32_t) ((cz * gy + cy) * gx + cx));
+                            R[1] = make_uint4(__float_as_uint(tdx), __float_as_uint(tdy), __float_as_uint(tdz), rem);
+                            R[2] = make_uint4(__float_as_uint(tau), __float_as_uint(tmax), 0u, 0u);
+                            fl = SF_WAIT;
+                        }
+                        if (useA) A.state = Rg.state; else S.state = Rg.state;
+                    }
+                }
+            }
+            if (kind == SQ_COLL || !__ballot(ph >= SP_HEAD && ph < SP_IDLE)) break;
+        }
+
+        // ================= store the rays, hand them on ====================================================
+        const bool go_walk = act && ph < SP_HEAD;                               // (posted: fl == SF_WAIT)
+        const bool go_trans = act && ph >= SP_HEAD && ph < SP_IDLE;            // (collision batches only: the walk ended)
+        const bool go_free = act && ph == SP_IDLE;
+        if (go_walk || go_trans) {
+            R[3] = make_uint4(__float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z), __float_as_uint(si_t));
+            R[4] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), __float_as_uint(wmax));
+            R[5] = make_uint4(__float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]), __float_as_uint(wt));
+            R[6] = make_uint4(__float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]), __float_as_uint(nt0));
+            R[7] = make_uint4((uint32_t) S.state, (uint32_t) (S.state >> 32), (uint32_t) S.inc, (uint32_t) (S.inc >> 32));
+            const uint32_t f = (uint32_t) ph | ((uint32_t) fl << 4) | (rec_mode ? 1u << 6 : 0u) | (rec_first ? 1u << 7 : 0u) | (escaped ? 1u << 8 : 0u) |
+                               (has_scattered ? 1u << 9 : 0u) | (scat_once ? 1u << 10 : 0u) | (pc_on ? 1u << 11 : 0u) |
+                               ((uint32_t) min(depth, 1023) << 12) | ((uint32_t) min(pc_it, 1023) << 22);
+            R[8] = make_uint4(__float_as_uint(wo.x), __float_as_uint(wo.y), __float_as_uint(wo.z), f);
+            R[9] = make_uint4(li, pc_steps, __float_as_uint(adjsum), 0u);
+            if constexpr (ADJ) {
+                R[10] = make_uint4((uint32_t) A.state, (uint32_t) (A.state >> 32), (uint32_t) A.inc, (uint32_t) (A.inc >> 32));
+                if (kind != SQ_COLL) {
+                    cold[id] = make_uint4(__float_as_uint(dL[0]), __float_as_uint(dL[1]), __float_as_uint(dL[2]), __float_as_uint(r_si_t));
+                    cold[NRAY + id] = make_uint4((uint32_t) Cst, (uint32_t) (Cst >> 32), (uint32_t) r_depth, 0u);
+                    cold[2 * NRAY + id] = make_uint4(__float_as_uint(r_o.x), __float_as_uint(r_o.y), __float_as_uint(r_o.z), __float_as_uint(r_wsum[0]));
+                    cold[3 * NRAY + id] = make_uint4(__float_as_uint(r_d.x), __float_as_uint(r_d.y), __float_as_uint(r_d.z), __float_as_uint(r_wsum[1]));
+                    cold[4 * NRAY + id] = make_uint4(__float_as_uint(r_cw[0]), __float_as_uint(r_cw[1]), __float_as_uint(r_cw[2]), __float_as_uint(r_wsum[2]));
+                }
+            }
+            if (go_trans && kind == SQ_COLL) { R[1] = make_uint4(__float_as_uint(w_tdx), __float_as_uint(w_tdy), __float_as_uint(w_tdz), w_rem); }
+        }
+        if constexpr (ADJ) { if (kind != SQ_COLL) __threadfence_block(); }
+        sq_fence();
+        sq_push(ctl, q_lds, SQ_WALK, go_walk, id, lane);
+        sq_push(ctl, q_lds, SQ_TRANS, go_trans, id, lane);
+        sq_push(ctl, q_lds, SQ_REGEN, go_free, id, lane);
+    }
+
+    if constexpr (ADJ) close_records(P, rec);
+    if (COUNT) {
+#pragma unroll
+        for (int s = 0; s < C_COUNT; ++s) {
+            uint32_t v = cnt[s];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && v) atomicAdd(P.counters + s, (unsigned long long) v);
+        }
+    }
+#undef SQ_COUNT
+#undef SQ_PROF
+}
+
+// LDS bytes of a launch; 0: this supergrid cannot be served (the host keeps drt_super.hip)
+static size_t sq_lds_bytes(const Params &P, bool adjoint)
+{
+    const size_t cells = (size_t) P.gx * P.gy * P.gz;
+    const size_t nwv = DRT_SQ_THREADS / 64;
+    const size_t r4 = adjoint ? 11 : 10;
+    const size_t words = (size_t) DRT_SQ_RAYS * r4 * 4 + ((((cells + 1) / 2) + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RAYS / 2 + 2 * SQ_KINDS + 4 + nwv * 8;
+    const size_t need = words * 4;
+    return need <= 160u * 1024u ? need : 0;
+}
+
+size_t sq_cold_bytes(int n_cus) { return (size_t) n_cus * 5 * DRT_SQ_RAYS * sizeof(uint4); }
+
+bool sq_supported(const Params &P)
+{
+    return P.mgrid && P.gx <= 511 && P.gy <= 511 && P.gz <= 511 && P.max_depth <= 1000 && sq_lds_bytes(P, false) != 0 && sq_lds_bytes(P, true) != 0;
+}
+
+hipError_t launch_trace_sq(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream)
+{
+    if (P.n_rays <= P.ray_first) return hipSuccess;
+    const size_t lds = sq_lds_bytes(P, adjoint);
+    if (!lds || (adjoint && !P.sq_cold)) return hipErrorInvalidValue;
+    unsigned blocks = (unsigned) n_cus;                                         // one workgroup per CU
+    const uint64_t need = (P.n_rays - P.ray_first + DRT_SQ_RAYS - 1) / DRT_SQ_RAYS;   // no more workgroups than groups of records
+    if (need < blocks) blocks = (unsigned) need;
+    dim3 block(DRT_SQ_THREADS), grid(blocks);
+    const bool env = P.env_pix != nullptr;
+    hipError_t e = hipSuccess;
+#define DRT_SQ_LAUNCH(A, C, E)                                                                                    \
+    do {                                                                                                          \
+        auto kern = trace_sq_kernel<A, C, E>;                                                                     \
+        static size_t lds_set[64] = { 0 };                                                                        \
+        int dev_ = 0;                                                                                             \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 63;                               \
+        if (lds > lds_set[dev_] || dev_ == 63) {                                                                  \
+            e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+            if (e != hipSuccess) return e;                                                                        \
+            lds_set[dev_] = lds;                                                                                  \
+        }                                                                                                         \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, P);                                                    \
+    } while (0)
+    const int variant = (adjoint ? 4 : 0) | (count ? 2 : 0) | (env ? 1 : 0);
+    switch (variant) {
+        case 0: DRT_SQ_LAUNCH(false, false, false); break;
+        case 1: DRT_SQ_LAUNCH(false, false, true); break;
+        case 2: DRT_SQ_LAUNCH(false, true, false); break;
+        case 3: DRT_SQ_LAUNCH(false, true, true); break;
+        case 4: DRT_SQ_LAUNCH(true, false, false); break;
+        case 5: DRT_SQ_LAUNCH(true, false, true); break;
+        case 6: DRT_SQ_LAUNCH(true, true, false); break;
+        default: DRT_SQ_LAUNCH(true, true, true); break;
+    }
+#undef DRT_SQ_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace drt

@@ -165,7 +165,11 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
     // [1] polls, [2] heavy runs, [3] lanes with something to do when the wave ran, [4] lanes served by the flight epilogue,
     // [5] lanes that posted a flight, [8] passes of the transition block, [6] pulls, [7] flights pulled, [0] cell steps taken
 #define DRT_COUNT(slot) do { } while (0)
-#define DRT_PROF(slot, v) do { if (DRT_SUPER_PROFILE == 1 && COUNT && lane == 0) cnt[slot] += (uint32_t) (v); } while (0)
+#define DRT_PROF(slot, v) do { if (DRT_SUPER_PROFILE == 1 && COUNT) { const uint32_t v_ = (uint32_t) (v); if (lane == 0) cnt[slot] += v_; } } while (0)
+    // DRT_SUPER_PROFILE=4: the walker's and the transition blocks' occupancy - [0] lane cell steps, [1] wave cell steps, [2] batches,
+    // [3] lanes flying at batch start, [4] flights finished, [5] lanes in a transition phase at pass start, [6] transition passes,
+    // [7] regeneration blocks, [8] rays started
+#define DRT_PROF4(slot, v) do { if (DRT_SUPER_PROFILE == 4 && COUNT) { const uint32_t v_ = (uint32_t) (v); if (lane == 0) cnt[slot] += v_; } } while (0)
     // DRT_SUPER_PROFILE=2: shader clock (units of 64 cycles) per wave spent - [1] polling / sleeping, [3] flight epilogue,
     // [4] regeneration, [5] transitions, [8] flight set-up, [6] pulling flights, [7] cell steps + write-back; [2] heavy runs
     uint64_t pt_last = __builtin_readcyclecounter();
@@ -177,6 +181,7 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
 #define DRT_STAMP(slot) do { } while (0)
 #define DRT_COUNT(slot) do { if (COUNT) cnt[slot]++; } while (0)
 #define DRT_PROF(slot, v) do { } while (0)
+#define DRT_PROF4(slot, v) do { } while (0)
 #endif
 
     // uniform supergrid constants
@@ -323,8 +328,8 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                 bool fin = false; float res_mc = 0.0f, res_t = 0.0f, res_acc = 0.0f;
 #pragma unroll
                 for (int k = 0; k < (ADJ ? DRT_SUPER_K_ADJ : DRT_SUPER_K); ++k) {
-#if DRT_SUPER_PROFILE == 1
-                    { const int nf = __popcll(__ballot(fly)); DRT_PROF(0, nf); }
+#if DRT_SUPER_PROFILE == 1 || DRT_SUPER_PROFILE == 4
+                    { const int nf = __popcll(__ballot(fly)); DRT_PROF(0, nf); DRT_PROF4(0, nf); DRT_PROF4(1, 1); if (k == 0) { DRT_PROF4(2, 1); DRT_PROF4(3, nf); } }
 #endif
                     // one supergrid cell (oracle: the loop of sample_collision).  Crossing times are finite or +inf, never NaN.
                     const float tmin = fminf(fminf(tnx, tny), tnz);
@@ -357,6 +362,7 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                         tnx = (go && isx) ? tnn : tnx; tny = (go && isy) ? tnn : tny; tnz = (go && !isx && !isy) ? tnn : tnz;
                     }
                 }
+                DRT_PROF4(4, __popcll(__ballot(fin)));
                 if (__ballot(fin)) {
                     // result: where the last cell was entered, the optical depth up to there, its majorant (0: left the segment)
                     if (fin) {
@@ -461,6 +467,7 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
         {
             const uint64_t wmask = m_idle;
             if (wmask && regen_ok) {
+                DRT_PROF4(7, 1); DRT_PROF4(8, __popcll(wmask));
                 while (pool_next >= pool_end && qsel < 8) {                      // refill (wave-uniform)
                     const int leader = __ffsll((long long) wmask) - 1;
                     unsigned long long base = 0;
@@ -555,7 +562,7 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
             // A pass takes every waiting lane to its next walk (or to the end of its ray); lanes whose walk comes
             // out of the path cache (adjoint pass) go round once more.
             do {
-                DRT_PROF(8, 1);
+                DRT_PROF(8, 1); DRT_PROF4(6, 1); DRT_PROF4(5, __popcll(__ballot(ph >= PH_HEAD && ph < PH_IDLE)));
                 uint4 pce1 = make_uint4(0u, 0u, 0u, 0u); bool pce1_ok = false;   // this iteration's NEE entry of the path cache, read at the loop head
                 // ---- DRT vertex selected: enter the detached recursive path (:553-575, :610-655) -----
                 if constexpr (ADJ) {
@@ -882,6 +889,7 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
     }
 #undef DRT_COUNT
 #undef DRT_PROF
+#undef DRT_PROF4
 #undef DRT_STAMP
 }
 
