@@ -310,7 +310,7 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         // round 4: the queued tracer (drt_sq.hip) where the ray records fit LDS next to the majorants; test hook 4096 keeps
         // the round-3 kernel (drt_super.hip), which also serves what the queued one does not take
         bool queued = !dbg(h->debug_flags, 4096u) && drt::sq_supported(P);
-        if (queued && adjoint && !h->d_sq_cold) {
+        if (queued && !h->d_sq_cold) {
             if (hipMalloc(&h->d_sq_cold, drt::sq_cold_bytes(h->n_cus)) != hipSuccess) { (void) hipGetLastError(); h->d_sq_cold = nullptr; queued = false; }
         }
         if (queued) {

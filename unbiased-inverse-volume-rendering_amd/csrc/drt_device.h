@@ -303,9 +303,11 @@ struct Params {
     // only: every ray's result is independent of when it is traced).  nullptr: rays in index order
     const uint32_t *order;
     uint32_t order_unit, order_units;
-    // queued supergrid tracer (drt_sq.hip), adjoint: per workgroup [5][DRT_SQ_RAYS] uint4 of path state that only the main
-    // path's transitions use (dL, the sampler clone, the DRT reservoir); library-owned, L2-resident
+    // queued supergrid tracer (drt_sq.hip): per workgroup [3 | 9][sq_rays] uint4 of path state that only the path
+    // transitions use (throughput, radiance; adjoint: dL, the sampler clone, the DRT reservoir); library-owned, L2-resident.
+    // sq_rays: ray records per workgroup (set by launch_trace_sq: what fits LDS next to the majorants)
     void *sq_cold;
+    uint32_t sq_rays;
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
 };

@@ -9,12 +9,14 @@
 // transition blocks, and every block of a heavy run is issued if a single lane needs it.  78 % of that kernel's vector
 // instructions are such heavy runs; cell stepping is 22 %.
 //
-// Here a ray lives in LDS (its flight slot + 28..32 words of path state: DRT_SQ_RAYS records per compute unit) and belongs to
-// no lane.  Four ring buffers of ray ids - flights to walk, collisions to evaluate, path transitions, free records - say
+// Here a ray lives in a RECORD and belongs to no lane: 112 bytes in LDS (its flight + what the collision / flight set-up
+// code needs: direction, moving origin, the active generator, flags) and 48 (adjoint: 144) bytes in global memory
+// (Params::sq_cold, per workgroup, L2-resident: what only the path transitions touch - throughput, radiance, reservoir, dL).
+// As many records as fit LDS next to the majorants (up to DRT_SQ_MAX_RAYS; 768 with a 32^3 supergrid): measured, the
+// number of rays a compute unit holds is what the speed of this tracer follows (256 / 512 records: 5.45 / 3.35 ms primal).  Four ring buffers of ray ids - flights to walk, collisions to evaluate, path transitions, free records - say
 // what is to be done; a wave takes up to 64 ids of ONE kind, loads those rays, runs that kind's code with all its lanes,
 // stores them and pushes their ids to the queues of what they need next.  A wave that finds no full batch walks flights
-// (as in drt_super.hip: DRT_SQ_K cells per look, lanes refilled from the flight queue).  The adjoint keeps the state only
-// its main-path transitions use (the reservoir, dL, the sampler clone) in global memory (Params::sq_cold, L2-resident).
+// (as in drt_super.hip: DRT_SQ_K cells per look, lanes refilled from the flight queue).
 //
 // Arithmetic, random-number consumption and event counts are those of the scalar restatement (oracle/drt_oracle.c):
 // radiance is bit-exact per ray, counters are equal; gradients differ by summation order only.  A ray computes the same
@@ -26,8 +28,12 @@
 #ifndef DRT_SQ_THREADS
 #define DRT_SQ_THREADS 768         // threads per workgroup = per CU: 12 waves
 #endif
-#ifndef DRT_SQ_RAYS
-#define DRT_SQ_RAYS 512            // ray records per workgroup (power of two: ring buffers of ids)
+#ifndef DRT_SQ_MAX_RAYS
+#define DRT_SQ_MAX_RAYS 1024       // most ray records per workgroup (a launch takes what fits LDS, a multiple of 64: Params::sq_rays)
+#endif
+#define DRT_SQ_RING 1024           // entries per ring buffer of ids (a power of two >= DRT_SQ_MAX_RAYS)
+#ifndef DRT_SQ_MIN_RAYS
+#define DRT_SQ_MIN_RAYS 256        // fewer records than this: the host keeps drt_super.hip
 #endif
 #ifndef DRT_SQ_K
 #define DRT_SQ_K 8                 // cells per walker lane between two looks at the queues
@@ -86,7 +92,7 @@ __device__ __forceinline__ uint32_t sq_xcc_id()
 }
 
 // Ring buffers of ray ids: ctl[kind] = {tail (pushes reserved) : head (pops reserved)}, both counting up.  A ray is in at
-// most one queue, so DRT_SQ_RAYS entries per ring never overflow; an entry is kSqEmpty until its id has been written
+// most one queue, so DRT_SQ_RING >= (records) entries per ring never overflow; an entry is kSqEmpty until its id has been written
 // (a pop may be reserved between a push's reservation and its write: the popping lane waits for the id).
 
 // up to max_n entries, none if fewer than min_n are there; returns the count, the first position in `h` (wave-uniform)
@@ -109,7 +115,7 @@ __device__ __forceinline__ uint32_t sq_pop(unsigned long long *ctl, int kind, ui
 // the id at ring position pos of `kind` (taken: the entry is emptied)
 __device__ __forceinline__ uint32_t sq_take(uint16_t *q, int kind, uint32_t pos)
 {
-    sq_vu16 *e = (sq_vu16 *) q + kind * DRT_SQ_RAYS + (pos & (DRT_SQ_RAYS - 1u));
+    sq_vu16 *e = (sq_vu16 *) q + kind * DRT_SQ_RING + (pos & (DRT_SQ_RING - 1u));
     uint32_t id = *e;
     while (id == kSqEmpty) { __builtin_amdgcn_s_sleep(1); id = *e; }
     *e = (uint16_t) kSqEmpty;
@@ -127,7 +133,7 @@ __device__ __forceinline__ void sq_push(unsigned long long *ctl, uint16_t *q, in
     tail = (uint32_t) __builtin_amdgcn_readlane((int) tail, leader);
     if (pred) {
         const uint32_t rank = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-        ((sq_vu16 *) q)[kind * DRT_SQ_RAYS + ((tail + rank) & (DRT_SQ_RAYS - 1u))] = (uint16_t) id;
+        ((sq_vu16 *) q)[kind * DRT_SQ_RING + ((tail + rank) & (DRT_SQ_RING - 1u))] = (uint16_t) id;
     }
 }
 
@@ -137,23 +143,29 @@ template <bool ADJ, bool COUNT, bool ENV>
 __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P)
 {
     constexpr int NWV = DRT_SQ_THREADS / 64;
-    constexpr int NRAY = DRT_SQ_RAYS;
-    constexpr int R4 = ADJ ? 11 : 10;                                        // uint4 per ray record
-    // ray record: [0] {tn.x, tn.y, tn.z, cell} [1] {td.x, td.y, td.z, steps left (9 bits per axis) + direction signs}
+    constexpr int R4 = 7;                                                    // uint4 per ray record in LDS
+    constexpr int NC = ADJ ? 9 : 3;                                          // uint4 per ray in global memory (Params::sq_cold)
+    // LDS record: [0] {tn.x, tn.y, tn.z, cell} [1] {td.x, td.y, td.z, steps left (9 bits per axis) + direction signs}
     // [2] {tau, tmax, t, acc} - the flight (a finished flight leaves its cell's majorant, 0: left the segment, in [0].x) -
-    // [3] {ro, si_t} [4] {rd, wmax} [5] {beta, wt} [6] {result, nt0} [7] {S.state, S.inc} [8] {wo, flags}
-    // [9] {li, pc_steps, adjsum, -} [10] {A.state, A.inc} (adjoint)
+    // [3] {rd, wmax} [4] {wo, wt} [5] {G.state, G.inc}: the generator the current walk draws from (the alt sampler in the main
+    // path's DRT walk, the sampler everywhere else) [6] {DRT walk: ro | other walks: adjsum, steps of the walk, -; flags}
+    // global record ([k][records] per workgroup): [0] {ro, si_t} [1] {beta, nt0} [2] {result, ray index}; adjoint: [3] {dL, r_si_t}
+    // [4] {sampler clone, r_depth, -} [5] {r_o, r_wsum.x} [6] {r_d, r_wsum.y} [7] {r_cw, r_wsum.z} [8] {the other generator}
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int NRAY = (int) P.sq_rays;                                        // records of this launch (a multiple of 64)
     const int n_cells = P.gx * P.gy * P.gz;
     const int mg_words = (n_cells + 1) / 2;
     uint4 *rec4 = (uint4 *) lds;
     uint32_t *mg_lds = lds + NRAY * R4 * 4;
     uint16_t *q_lds = (uint16_t *) (mg_lds + ((mg_words + 3) & ~3));
-    unsigned long long *ctl = (unsigned long long *) (q_lds + SQ_KINDS * NRAY);
+    unsigned long long *ctl = (unsigned long long *) (q_lds + SQ_KINDS * DRT_SQ_RING);
     unsigned long long *pool = ctl + SQ_KINDS;                                // [0] next, [1] end of the workgroup's reserved positions of the ray queues
     uint32_t *misc = (uint32_t *) (pool + 2);                                 // [0] dead records, [1] bits of the largest majorant, [2] lock of the pool, [3] ray queues tried
     uint32_t *recst = misc + 4;                                              // record-stream state per wave (emit_record)
-    for (int i = threadIdx.x; i < SQ_KINDS * NRAY; i += blockDim.x) q_lds[i] = (uint16_t) (i >= SQ_REGEN * NRAY ? i - SQ_REGEN * NRAY : (int) kSqEmpty);
+    for (int i = threadIdx.x; i < SQ_KINDS * DRT_SQ_RING; i += blockDim.x) {
+        const int k = i - SQ_REGEN * DRT_SQ_RING;                            // every record starts in the ring of free records
+        q_lds[i] = (uint16_t) (k >= 0 && k < NRAY ? k : (int) kSqEmpty);
+    }
     if (threadIdx.x < SQ_KINDS) ctl[threadIdx.x] = threadIdx.x == SQ_REGEN ? ((unsigned long long) NRAY << 32) : 0ull;
     if (threadIdx.x < 4) misc[threadIdx.x] = 0u;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0ull;
@@ -199,8 +211,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     const int lin_y = gx, lin_z = gx * gy;
 
     uint32_t *rec = recst + wave * 8;                                          // record-stream state of this wave (emit_record)
-    uint4 *cold = nullptr;                                                     // adjoint: [5][NRAY] uint4 of this workgroup
-    if constexpr (ADJ) cold = (uint4 *) P.sq_cold + (size_t) blockIdx.x * 5 * NRAY;
+    uint4 *cold = (uint4 *) P.sq_cold + (size_t) blockIdx.x * NC * NRAY;      // [NC][NRAY] uint4 of this workgroup
     const uint32_t xcc = sq_xcc_id();
     // (with a ray order the queue positions cover whole units: the last unit may reach past the launch's last ray)
     const uint64_t span = P.order ? (uint64_t) P.order_units * P.order_unit : P.n_rays - P.ray_first;
@@ -357,33 +368,41 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
 
         if (kind != SQ_REGEN) {
             if (act) {
-                const uint4 q3 = R[3], q4 = R[4], q5 = R[5], q6 = R[6], q7 = R[7], q8 = R[8], q9 = R[9];
-                ro = v3(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z)); si_t = __uint_as_float(q3.w);
-                rd = v3(__uint_as_float(q4.x), __uint_as_float(q4.y), __uint_as_float(q4.z)); wmax = __uint_as_float(q4.w);
-                beta[0] = __uint_as_float(q5.x); beta[1] = __uint_as_float(q5.y); beta[2] = __uint_as_float(q5.z); wt = __uint_as_float(q5.w);
-                result[0] = __uint_as_float(q6.x); result[1] = __uint_as_float(q6.y); result[2] = __uint_as_float(q6.z); nt0 = __uint_as_float(q6.w);
-                S.state = ((uint64_t) q7.y << 32) | q7.x; S.inc = ((uint64_t) q7.w << 32) | q7.z;
-                wo = v3(__uint_as_float(q8.x), __uint_as_float(q8.y), __uint_as_float(q8.z));
-                const uint32_t f = q8.w;
+                const uint4 q3 = R[3], q4 = R[4], q5 = R[5], q6 = R[6];
+                rd = v3(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z)); wmax = __uint_as_float(q3.w);
+                wo = v3(__uint_as_float(q4.x), __uint_as_float(q4.y), __uint_as_float(q4.z)); wt = __uint_as_float(q4.w);
+                const uint32_t f = q6.w;
                 ph = (int) (f & 15u); fl = (int) ((f >> 4) & 3u);
                 rec_mode = (f >> 6) & 1u; rec_first = (f >> 7) & 1u; escaped = (f >> 8) & 1u; has_scattered = (f >> 9) & 1u;
                 scat_once = (f >> 10) & 1u; pc_on = (f >> 11) & 1u;
                 depth = (int) ((f >> 12) & 1023u); pc_it = (int) (f >> 22);
-                li = q9.x; pc_steps = q9.y; adjsum = __uint_as_float(q9.z);
-                if constexpr (ADJ) { const uint4 q10 = R[10]; A.state = ((uint64_t) q10.y << 32) | q10.x; A.inc = ((uint64_t) q10.w << 32) | q10.z; }
+                const bool drtw = ph == SP_DRT || ph == SP_DRT_END;             // (in / just out of the DRT walk)
+                const bool gA = ADJ && !rec_mode && drtw;                       // the record's generator is the alt sampler
+                {
+                    const uint64_t gs = ((uint64_t) q5.y << 32) | q5.x, gi = ((uint64_t) q5.w << 32) | q5.z;
+                    if (gA) { A.state = gs; A.inc = gi; } else { S.state = gs; S.inc = gi; }
+                }
+                if (drtw) ro = v3(__uint_as_float(q6.x), __uint_as_float(q6.y), __uint_as_float(q6.z));
+                else { adjsum = __uint_as_float(q6.x); pc_steps = q6.y; }
                 if (kind == SQ_COLL) {
                     const uint4 q1 = R[1], q2 = R[2];
                     c_lm = __uint_as_float(R[0].x); c_tau = __uint_as_float(q2.x); c_t = __uint_as_float(q2.z); c_acc = __uint_as_float(q2.w);
                     w_tdx = __uint_as_float(q1.x); w_tdy = __uint_as_float(q1.y); w_tdz = __uint_as_float(q1.z); w_rem = q1.w;
-                }
-                if constexpr (ADJ) {
-                    if (kind == SQ_TRANS) {
-                        const uint4 c0 = cold[id], c1 = cold[NRAY + id], c2 = cold[2 * NRAY + id], c3 = cold[3 * NRAY + id], c4 = cold[4 * NRAY + id];
-                        dL[0] = __uint_as_float(c0.x); dL[1] = __uint_as_float(c0.y); dL[2] = __uint_as_float(c0.z); r_si_t = __uint_as_float(c0.w);
-                        Cst = ((uint64_t) c1.y << 32) | c1.x; r_depth = (int) c1.z;
-                        r_o = v3(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z)); r_wsum[0] = __uint_as_float(c2.w);
-                        r_d = v3(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z)); r_wsum[1] = __uint_as_float(c3.w);
-                        r_cw[0] = __uint_as_float(c4.x); r_cw[1] = __uint_as_float(c4.y); r_cw[2] = __uint_as_float(c4.z); r_wsum[2] = __uint_as_float(c4.w);
+                } else {                                                        // transitions: the rest of the ray, from global memory
+                    const uint4 c0 = cold[id], c1 = cold[NRAY + id], c2 = cold[2 * NRAY + id];
+                    ro = v3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z)); si_t = __uint_as_float(c0.w);
+                    beta[0] = __uint_as_float(c1.x); beta[1] = __uint_as_float(c1.y); beta[2] = __uint_as_float(c1.z); nt0 = __uint_as_float(c1.w);
+                    result[0] = __uint_as_float(c2.x); result[1] = __uint_as_float(c2.y); result[2] = __uint_as_float(c2.z); li = c2.w;
+                    if constexpr (ADJ) {
+                        const uint4 c3 = cold[3 * NRAY + id], c4 = cold[4 * NRAY + id], c5 = cold[5 * NRAY + id], c6 = cold[6 * NRAY + id],
+                                    c7 = cold[7 * NRAY + id], c8 = cold[8 * NRAY + id];
+                        dL[0] = __uint_as_float(c3.x); dL[1] = __uint_as_float(c3.y); dL[2] = __uint_as_float(c3.z); r_si_t = __uint_as_float(c3.w);
+                        Cst = ((uint64_t) c4.y << 32) | c4.x; r_depth = (int) c4.z;
+                        r_o = v3(__uint_as_float(c5.x), __uint_as_float(c5.y), __uint_as_float(c5.z)); r_wsum[0] = __uint_as_float(c5.w);
+                        r_d = v3(__uint_as_float(c6.x), __uint_as_float(c6.y), __uint_as_float(c6.z)); r_wsum[1] = __uint_as_float(c6.w);
+                        r_cw[0] = __uint_as_float(c7.x); r_cw[1] = __uint_as_float(c7.y); r_cw[2] = __uint_as_float(c7.z); r_wsum[2] = __uint_as_float(c7.w);
+                        const uint64_t os = ((uint64_t) c8.y << 32) | c8.x, oi = ((uint64_t) c8.w << 32) | c8.z;
+                        if (gA) { S.state = os; S.inc = oi; } else { A.state = os; A.inc = oi; }
                     }
                 }
             }
@@ -839,29 +858,35 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         const bool go_trans = act && ph >= SP_HEAD && ph < SP_IDLE;            // (collision batches only: the walk ended)
         const bool go_free = act && ph == SP_IDLE;
         if (go_walk || go_trans) {
-            R[3] = make_uint4(__float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z), __float_as_uint(si_t));
-            R[4] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), __float_as_uint(wmax));
-            R[5] = make_uint4(__float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]), __float_as_uint(wt));
-            R[6] = make_uint4(__float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]), __float_as_uint(nt0));
-            R[7] = make_uint4((uint32_t) S.state, (uint32_t) (S.state >> 32), (uint32_t) S.inc, (uint32_t) (S.inc >> 32));
+            const bool drtw = ph == SP_DRT || ph == SP_DRT_END;
+            const bool gA = ADJ && !rec_mode && drtw;
+            const uint64_t gs = gA ? A.state : S.state, gi = gA ? A.inc : S.inc;
+            R[3] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), __float_as_uint(wmax));
+            R[4] = make_uint4(__float_as_uint(wo.x), __float_as_uint(wo.y), __float_as_uint(wo.z), __float_as_uint(wt));
+            R[5] = make_uint4((uint32_t) gs, (uint32_t) (gs >> 32), (uint32_t) gi, (uint32_t) (gi >> 32));
             const uint32_t f = (uint32_t) ph | ((uint32_t) fl << 4) | (rec_mode ? 1u << 6 : 0u) | (rec_first ? 1u << 7 : 0u) | (escaped ? 1u << 8 : 0u) |
                                (has_scattered ? 1u << 9 : 0u) | (scat_once ? 1u << 10 : 0u) | (pc_on ? 1u << 11 : 0u) |
                                ((uint32_t) min(depth, 1023) << 12) | ((uint32_t) min(pc_it, 1023) << 22);
-            R[8] = make_uint4(__float_as_uint(wo.x), __float_as_uint(wo.y), __float_as_uint(wo.z), f);
-            R[9] = make_uint4(li, pc_steps, __float_as_uint(adjsum), 0u);
-            if constexpr (ADJ) {
-                R[10] = make_uint4((uint32_t) A.state, (uint32_t) (A.state >> 32), (uint32_t) A.inc, (uint32_t) (A.inc >> 32));
-                if (kind != SQ_COLL) {
-                    cold[id] = make_uint4(__float_as_uint(dL[0]), __float_as_uint(dL[1]), __float_as_uint(dL[2]), __float_as_uint(r_si_t));
-                    cold[NRAY + id] = make_uint4((uint32_t) Cst, (uint32_t) (Cst >> 32), (uint32_t) r_depth, 0u);
-                    cold[2 * NRAY + id] = make_uint4(__float_as_uint(r_o.x), __float_as_uint(r_o.y), __float_as_uint(r_o.z), __float_as_uint(r_wsum[0]));
-                    cold[3 * NRAY + id] = make_uint4(__float_as_uint(r_d.x), __float_as_uint(r_d.y), __float_as_uint(r_d.z), __float_as_uint(r_wsum[1]));
-                    cold[4 * NRAY + id] = make_uint4(__float_as_uint(r_cw[0]), __float_as_uint(r_cw[1]), __float_as_uint(r_cw[2]), __float_as_uint(r_wsum[2]));
+            // (component by component: `drtw ? make_uint4(..) : make_uint4(..)` stored adjsum in .x whatever drtw said - hipcc 7.2)
+            R[6] = make_uint4(drtw ? __float_as_uint(ro.x) : __float_as_uint(adjsum), drtw ? __float_as_uint(ro.y) : pc_steps,
+                              drtw ? __float_as_uint(ro.z) : 0u, f);
+            if (kind != SQ_COLL) {
+                cold[id] = make_uint4(__float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z), __float_as_uint(si_t));
+                cold[NRAY + id] = make_uint4(__float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]), __float_as_uint(nt0));
+                cold[2 * NRAY + id] = make_uint4(__float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]), li);
+                if constexpr (ADJ) {
+                    const uint64_t os = gA ? S.state : A.state, oi = gA ? S.inc : A.inc;
+                    cold[3 * NRAY + id] = make_uint4(__float_as_uint(dL[0]), __float_as_uint(dL[1]), __float_as_uint(dL[2]), __float_as_uint(r_si_t));
+                    cold[4 * NRAY + id] = make_uint4((uint32_t) Cst, (uint32_t) (Cst >> 32), (uint32_t) r_depth, 0u);
+                    cold[5 * NRAY + id] = make_uint4(__float_as_uint(r_o.x), __float_as_uint(r_o.y), __float_as_uint(r_o.z), __float_as_uint(r_wsum[0]));
+                    cold[6 * NRAY + id] = make_uint4(__float_as_uint(r_d.x), __float_as_uint(r_d.y), __float_as_uint(r_d.z), __float_as_uint(r_wsum[1]));
+                    cold[7 * NRAY + id] = make_uint4(__float_as_uint(r_cw[0]), __float_as_uint(r_cw[1]), __float_as_uint(r_cw[2]), __float_as_uint(r_wsum[2]));
+                    cold[8 * NRAY + id] = make_uint4((uint32_t) os, (uint32_t) (os >> 32), (uint32_t) oi, (uint32_t) (oi >> 32));
                 }
             }
             if (go_trans && kind == SQ_COLL) { R[1] = make_uint4(__float_as_uint(w_tdx), __float_as_uint(w_tdy), __float_as_uint(w_tdz), w_rem); }
         }
-        if constexpr (ADJ) { if (kind != SQ_COLL) __threadfence_block(); }
+        if (kind != SQ_COLL) __threadfence_block();                            // (the global part of the records)
         sq_fence();
         sq_push(ctl, q_lds, SQ_WALK, go_walk, id, lane);
         sq_push(ctl, q_lds, SQ_TRANS, go_trans, id, lane);
@@ -882,31 +907,39 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
 #undef SQ_PROF
 }
 
-// LDS bytes of a launch; 0: this supergrid cannot be served (the host keeps drt_super.hip)
-static size_t sq_lds_bytes(const Params &P, bool adjoint)
+// Records per workgroup that fit LDS next to this supergrid's majorants (a multiple of 64); 0: this supergrid cannot be
+// served (the host keeps drt_super.hip).  *bytes: dynamic LDS of the launch
+static uint32_t sq_rays_for(const Params &P, size_t *bytes)
 {
     const size_t cells = (size_t) P.gx * P.gy * P.gz;
     const size_t nwv = DRT_SQ_THREADS / 64;
-    const size_t r4 = adjoint ? 11 : 10;
-    const size_t words = (size_t) DRT_SQ_RAYS * r4 * 4 + ((((cells + 1) / 2) + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RAYS / 2 + 2 * SQ_KINDS + 4 + nwv * 8;
-    const size_t need = words * 4;
-    return need <= 160u * 1024u ? need : 0;
+    const size_t fixed = (((((cells + 1) / 2) + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RING / 2 + 2 * SQ_KINDS + 4 + 4 + nwv * 8) * 4;
+    const size_t cap = 160u * 1024u;
+    if (fixed >= cap) return 0;
+    size_t n = ((cap - fixed) / (7 * 16)) & ~(size_t) 63;
+    if (n > DRT_SQ_MAX_RAYS) n = DRT_SQ_MAX_RAYS;
+    if (n < DRT_SQ_MIN_RAYS) return 0;
+    if (bytes) *bytes = fixed + n * 7 * 16;
+    return (uint32_t) n;
 }
 
-size_t sq_cold_bytes(int n_cus) { return (size_t) n_cus * 5 * DRT_SQ_RAYS * sizeof(uint4); }
+size_t sq_cold_bytes(int n_cus) { return (size_t) n_cus * 9 * DRT_SQ_MAX_RAYS * sizeof(uint4); }
 
 bool sq_supported(const Params &P)
 {
-    return P.mgrid && P.gx <= 511 && P.gy <= 511 && P.gz <= 511 && P.max_depth <= 1000 && sq_lds_bytes(P, false) != 0 && sq_lds_bytes(P, true) != 0;
+    return P.mgrid && P.gx <= 511 && P.gy <= 511 && P.gz <= 511 && P.max_depth <= 1000 && sq_rays_for(P, nullptr) != 0;
 }
 
-hipError_t launch_trace_sq(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream)
+hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cus, hipStream_t stream)
 {
-    if (P.n_rays <= P.ray_first) return hipSuccess;
-    const size_t lds = sq_lds_bytes(P, adjoint);
-    if (!lds || (adjoint && !P.sq_cold)) return hipErrorInvalidValue;
+    if (Pin.n_rays <= Pin.ray_first) return hipSuccess;
+    size_t lds = 0;
+    const uint32_t nray = sq_rays_for(Pin, &lds);
+    if (!nray || !Pin.sq_cold) return hipErrorInvalidValue;
+    Params P = Pin;
+    P.sq_rays = nray;
     unsigned blocks = (unsigned) n_cus;                                         // one workgroup per CU
-    const uint64_t need = (P.n_rays - P.ray_first + DRT_SQ_RAYS - 1) / DRT_SQ_RAYS;   // no more workgroups than groups of records
+    const uint64_t need = (P.n_rays - P.ray_first + nray - 1) / nray;           // no more workgroups than groups of records
     if (need < blocks) blocks = (unsigned) need;
     dim3 block(DRT_SQ_THREADS), grid(blocks);
     const bool env = P.env_pix != nullptr;
