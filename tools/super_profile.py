@@ -2,6 +2,7 @@
 
     tools/mk_variant.sh prof4 "-DDRT_SUPER_PROFILE=4"; LD_LIBRARY_PATH=variants/prof4 python tools/super_profile.py
 
+(drt_sq.hip: tools/mk_variant.sh sqprof "-DDRT_SQ_PROFILE=1" drt_sq.hip; DRT_PROFILE_MODE=sq)
 (headline scene at majorant_resolution_factor 8; the meaning of the slots is next to DRT_PROF / DRT_PROF4 / DRT_STAMP in the source)
 """
 import os, sys
@@ -34,7 +35,10 @@ print("primal ", cp)
 print("adjoint", ca)
 mode = os.environ.get("DRT_PROFILE_MODE", "4")
 for tag, c in (("primal", cp), ("adjoint", ca)):
-    if mode == "4":
+    if mode == "sq":
+        print(f"{tag}: lane steps {c[0]/1e6:.1f} M, wave steps {c[1]/1e6:.2f} M -> {c[0]/max(1,c[1]):.1f} lanes per step; collision batches {c[2]/1e6:.3f} M x {c[3]/max(1,c[2]):.1f} rays; "
+              f"transition batches {c[4]/1e6:.3f} M x {c[5]/max(1,c[4]):.1f}; regeneration batches {c[6]/1e6:.3f} M x {c[7]/max(1,c[6]):.1f}; polls {c[8]/1e6:.2f} M")
+    elif mode == "4":
         print(f"{tag}: lane steps {c[0]/1e6:.1f} M, wave steps {c[1]/1e6:.2f} M -> {c[0]/max(1,c[1]):.1f} lanes per step; batches {c[2]/1e6:.2f} M, "
               f"{c[3]/max(1,c[2]):.1f} flying at batch start, {c[4]/max(1,c[2]):.1f} finish per batch; transition passes {c[6]/1e6:.2f} M with "
               f"{c[5]/max(1,c[6]):.1f} lanes; regeneration blocks {c[7]/1e6:.3f} M, {c[8]/max(1,c[7]):.1f} rays each")

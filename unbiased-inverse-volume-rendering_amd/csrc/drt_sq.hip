@@ -149,8 +149,10 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     // [2] {tau, tmax, t, acc} - the flight (a finished flight leaves its cell's majorant, 0: left the segment, in [0].x) -
     // [3] {rd, wmax} [4] {wo, wt} [5] {G.state, G.inc}: the generator the current walk draws from (the alt sampler in the main
     // path's DRT walk, the sampler everywhere else) [6] {DRT walk: ro | other walks: adjsum, steps of the walk, -; flags}
-    // global record ([k][records] per workgroup): [0] {ro, si_t} [1] {beta, nt0} [2] {result, ray index}; adjoint: [3] {dL, r_si_t}
-    // [4] {sampler clone, r_depth, -} [5] {r_o, r_wsum.x} [6] {r_d, r_wsum.y} [7] {r_cw, r_wsum.z} [8] {the other generator}
+    // global record, part a ([records][3] per workgroup): [0] {ro, si_t} [1] {beta, nt0} [2] {result, ray index}; part b, adjoint
+    // ([records][6]; the main path's: a recursive path only reads r_si_t, r_o, r_cw at its end): [0] {dL, r_si_t}
+    // [1] {sampler clone, r_depth, -} [2] {r_o, r_wsum.x} [3] {r_d, r_wsum.y} [4] {r_cw, r_wsum.z} [5] {the other generator}.
+    // Records are contiguous (a batch holds arbitrary ids: one or two 128-byte lines per ray and part)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int NRAY = (int) P.sq_rays;                                        // records of this launch (a multiple of 64)
     const int n_cells = P.gx * P.gy * P.gz;
@@ -211,7 +213,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     const int lin_y = gx, lin_z = gx * gy;
 
     uint32_t *rec = recst + wave * 8;                                          // record-stream state of this wave (emit_record)
-    uint4 *cold = (uint4 *) P.sq_cold + (size_t) blockIdx.x * NC * NRAY;      // [NC][NRAY] uint4 of this workgroup
+    uint4 *cold_a = (uint4 *) P.sq_cold + (size_t) blockIdx.x * NC * NRAY;    // [NRAY][3] uint4 of this workgroup
+    uint4 *cold_b = cold_a + 3 * NRAY;                                        // [NRAY][6] (adjoint)
     const uint32_t xcc = sq_xcc_id();
     // (with a ray order the queue positions cover whole units: the last unit may reach past the launch's last ray)
     const uint64_t span = P.order ? (uint64_t) P.order_units * P.order_unit : P.n_rays - P.ray_first;
@@ -363,6 +366,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         uint64_t Cst = 0;
         int r_depth = -1; float r_si_t = kInf; V3 r_o = ro, r_d = rd;
         float r_wsum[3] = { 0, 0, 0 }, r_cw[3] = { 0, 0, 0 };
+        bool b_live = true;                                                     // part b of the global record is in registers (adjoint)
         float c_lm = 0.0f, c_tau = 0.0f, c_t = 0.0f, c_acc = 0.0f;              // the finished flight (collision batches)
         float w_tdx = kInf, w_tdy = kInf, w_tdz = kInf; uint32_t w_rem = 0;      // the walk's direction share of the DDA
 
@@ -389,13 +393,16 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     c_lm = __uint_as_float(R[0].x); c_tau = __uint_as_float(q2.x); c_t = __uint_as_float(q2.z); c_acc = __uint_as_float(q2.w);
                     w_tdx = __uint_as_float(q1.x); w_tdy = __uint_as_float(q1.y); w_tdz = __uint_as_float(q1.z); w_rem = q1.w;
                 } else {                                                        // transitions: the rest of the ray, from global memory
-                    const uint4 c0 = cold[id], c1 = cold[NRAY + id], c2 = cold[2 * NRAY + id];
+                    const uint4 *ca = cold_a + 3 * id;
+                    const uint4 c0 = ca[0], c1 = ca[1], c2 = ca[2];
                     ro = v3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z)); si_t = __uint_as_float(c0.w);
                     beta[0] = __uint_as_float(c1.x); beta[1] = __uint_as_float(c1.y); beta[2] = __uint_as_float(c1.z); nt0 = __uint_as_float(c1.w);
                     result[0] = __uint_as_float(c2.x); result[1] = __uint_as_float(c2.y); result[2] = __uint_as_float(c2.z); li = c2.w;
                     if constexpr (ADJ) {
-                        const uint4 c3 = cold[3 * NRAY + id], c4 = cold[4 * NRAY + id], c5 = cold[5 * NRAY + id], c6 = cold[6 * NRAY + id],
-                                    c7 = cold[7 * NRAY + id], c8 = cold[8 * NRAY + id];
+                      b_live = !rec_mode;
+                      if (b_live) {
+                        const uint4 *cb = cold_b + 6 * id;
+                        const uint4 c3 = cb[0], c4 = cb[1], c5 = cb[2], c6 = cb[3], c7 = cb[4], c8 = cb[5];
                         dL[0] = __uint_as_float(c3.x); dL[1] = __uint_as_float(c3.y); dL[2] = __uint_as_float(c3.z); r_si_t = __uint_as_float(c3.w);
                         Cst = ((uint64_t) c4.y << 32) | c4.x; r_depth = (int) c4.z;
                         r_o = v3(__uint_as_float(c5.x), __uint_as_float(c5.y), __uint_as_float(c5.z)); r_wsum[0] = __uint_as_float(c5.w);
@@ -403,6 +410,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                         r_cw[0] = __uint_as_float(c7.x); r_cw[1] = __uint_as_float(c7.y); r_cw[2] = __uint_as_float(c7.z); r_wsum[2] = __uint_as_float(c7.w);
                         const uint64_t os = ((uint64_t) c8.y << 32) | c8.x, oi = ((uint64_t) c8.w << 32) | c8.z;
                         if (gA) { S.state = os; S.inc = oi; } else { A.state = os; A.inc = oi; }
+                      }
                     }
                 }
             }
@@ -765,6 +773,13 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     } else {
                         if (rec_mode) {
                             // result = Li': gradient splat at x' (:577-581)
+                            if (!b_live) {                                      // (a recursive path loaded without the main path's state)
+                                const uint4 *cb = cold_b + 6 * id;
+                                const uint4 c3 = cb[0], c5 = cb[2], c7 = cb[4];
+                                r_si_t = __uint_as_float(c3.w);
+                                r_o = v3(__uint_as_float(c5.x), __uint_as_float(c5.y), __uint_as_float(c5.z));
+                                r_cw[0] = __uint_as_float(c7.x); r_cw[1] = __uint_as_float(c7.y); r_cw[2] = __uint_as_float(c7.z);
+                            }
                             float alb[3];
                             eval_albedo(P, r_o, alb);                           // :578
                             SQ_COUNT(C_ALB);
@@ -871,17 +886,21 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             R[6] = make_uint4(drtw ? __float_as_uint(ro.x) : __float_as_uint(adjsum), drtw ? __float_as_uint(ro.y) : pc_steps,
                               drtw ? __float_as_uint(ro.z) : 0u, f);
             if (kind != SQ_COLL) {
-                cold[id] = make_uint4(__float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z), __float_as_uint(si_t));
-                cold[NRAY + id] = make_uint4(__float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]), __float_as_uint(nt0));
-                cold[2 * NRAY + id] = make_uint4(__float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]), li);
+                uint4 *ca = cold_a + 3 * id;
+                ca[0] = make_uint4(__float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z), __float_as_uint(si_t));
+                ca[1] = make_uint4(__float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]), __float_as_uint(nt0));
+                ca[2] = make_uint4(__float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]), li);
                 if constexpr (ADJ) {
-                    const uint64_t os = gA ? S.state : A.state, oi = gA ? S.inc : A.inc;
-                    cold[3 * NRAY + id] = make_uint4(__float_as_uint(dL[0]), __float_as_uint(dL[1]), __float_as_uint(dL[2]), __float_as_uint(r_si_t));
-                    cold[4 * NRAY + id] = make_uint4((uint32_t) Cst, (uint32_t) (Cst >> 32), (uint32_t) r_depth, 0u);
-                    cold[5 * NRAY + id] = make_uint4(__float_as_uint(r_o.x), __float_as_uint(r_o.y), __float_as_uint(r_o.z), __float_as_uint(r_wsum[0]));
-                    cold[6 * NRAY + id] = make_uint4(__float_as_uint(r_d.x), __float_as_uint(r_d.y), __float_as_uint(r_d.z), __float_as_uint(r_wsum[1]));
-                    cold[7 * NRAY + id] = make_uint4(__float_as_uint(r_cw[0]), __float_as_uint(r_cw[1]), __float_as_uint(r_cw[2]), __float_as_uint(r_wsum[2]));
-                    cold[8 * NRAY + id] = make_uint4((uint32_t) os, (uint32_t) (os >> 32), (uint32_t) oi, (uint32_t) (oi >> 32));
+                    if (b_live) {
+                        uint4 *cb = cold_b + 6 * id;
+                        const uint64_t os = gA ? S.state : A.state, oi = gA ? S.inc : A.inc;
+                        cb[0] = make_uint4(__float_as_uint(dL[0]), __float_as_uint(dL[1]), __float_as_uint(dL[2]), __float_as_uint(r_si_t));
+                        cb[1] = make_uint4((uint32_t) Cst, (uint32_t) (Cst >> 32), (uint32_t) r_depth, 0u);
+                        cb[2] = make_uint4(__float_as_uint(r_o.x), __float_as_uint(r_o.y), __float_as_uint(r_o.z), __float_as_uint(r_wsum[0]));
+                        cb[3] = make_uint4(__float_as_uint(r_d.x), __float_as_uint(r_d.y), __float_as_uint(r_d.z), __float_as_uint(r_wsum[1]));
+                        cb[4] = make_uint4(__float_as_uint(r_cw[0]), __float_as_uint(r_cw[1]), __float_as_uint(r_cw[2]), __float_as_uint(r_wsum[2]));
+                        cb[5] = make_uint4((uint32_t) os, (uint32_t) (os >> 32), (uint32_t) oi, (uint32_t) (oi >> 32));
+                    }
                 }
             }
             if (go_trans && kind == SQ_COLL) { R[1] = make_uint4(__float_as_uint(w_tdx), __float_as_uint(w_tdy), __float_as_uint(w_tdz), w_rem); }
