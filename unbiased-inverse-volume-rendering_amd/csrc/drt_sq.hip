@@ -201,8 +201,14 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     // waves, [0] lane cell steps, [1] wave cell steps, [2] collision batches, [3] rays in them, [4] transition batches, [5] rays
     // in them, [6] regeneration batches, [7] records in them, [8] polls
 #define SQ_COUNT(slot) do { } while (0)
-#define SQ_PROF(slot, v) do { if (COUNT) { const uint32_t v_ = (uint32_t) (v); if (lane == 0) cnt[slot] += v_; } } while (0)
+#define SQ_PROF(slot, v) do { if (DRT_SQ_PROFILE == 1 && COUNT) { const uint32_t v_ = (uint32_t) (v); if (lane == 0) cnt[slot] += v_; } } while (0)
+    // DRT_SQ_PROFILE=2: shader clock (units of 64 cycles) per wave spent - [0] cell steps, [1] the walker's queue work (refill,
+    // results, hand-back), [2] loading a batch (collision batches), [3] collision code, [4] loading a batch (transition batches:
+    // LDS + global memory), [5] transition / regeneration code, [6] flight set-up, [7] storing a batch + pushes, [8] looking for work
+    uint64_t pt_last = __builtin_readcyclecounter();
+#define SQ_STAMP(slot) do { if (DRT_SQ_PROFILE == 2 && COUNT) { const uint64_t t_ = __builtin_readcyclecounter(); if (lane == 0) cnt[slot] += (uint32_t) ((t_ - pt_last) >> 6); pt_last = t_; } } while (0)
 #else
+#define SQ_STAMP(slot) do { } while (0)
 #define SQ_COUNT(slot) do { if (COUNT) cnt[slot]++; } while (0)
 #define SQ_PROF(slot, v) do { } while (0)
 #endif
@@ -244,6 +250,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             min_n = 1;
         } else { SQ_PROF(8, 1); __builtin_amdgcn_s_sleep(8); continue; }
 
+        SQ_STAMP(8);
         if (kind == SQ_WALK) {
             // ================= walk: posted flights -> supergrid cells -> results ==============================
             bool fly = false, walked = false;
@@ -273,12 +280,13 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
                 if (!__ballot(fly)) break;                                       // nothing to walk (any more)
                 walked = true;
+                SQ_STAMP(1);
                 // (primal kernels: the steps are not predicated on `fly`, as in drt_super.hip)
                 constexpr bool kLoose = !ADJ;
                 bool fin = false; float res_mc = 0.0f, res_t = 0.0f, res_acc = 0.0f;
 #pragma unroll
                 for (int k = 0; k < DRT_SQ_K; ++k) {
-#if DRT_SQ_PROFILE
+#if DRT_SQ_PROFILE == 1
                     { const int nf = __popcll(__ballot(fly)); SQ_PROF(0, nf); SQ_PROF(1, 1); }
 #endif
                     // one supergrid cell (oracle: the loop of sample_collision).  Crossing times are finite or +inf, never NaN.
@@ -310,6 +318,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                         tnx = (go && isx) ? tnn : tnx; tny = (go && isy) ? tnn : tny; tnz = (go && !isx && !isy) ? tnn : tnz;
                     }
                 }
+                SQ_STAMP(0);
                 if (__ballot(fin)) {
                     // result: where the last cell was entered, the optical depth up to there, its majorant (0: left the segment)
                     if (fin) {
@@ -339,6 +348,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 sq_push(ctl, q_lds, SQ_WALK, fly, slot, lane);
             }
             if (walked) polls = 0;
+            SQ_STAMP(1);
             continue;
         }
 
@@ -416,6 +426,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             }
         }
 
+        if (kind == SQ_COLL) SQ_STAMP(2); else SQ_STAMP(4);
         if (kind == SQ_COLL) {
             // ================= (Fe) the collision a flight ended in =========================================
             SQ_PROF(2, 1); SQ_PROF(3, nb);
@@ -565,6 +576,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             SQ_PROF(4, 1); SQ_PROF(5, nb);
         }
 
+        if (kind == SQ_COLL) SQ_STAMP(3); else SQ_STAMP(5);
         // ================= (B) path transitions (transition / regeneration batches), (Fs) the next flight ==============
         // A pass takes every ray of the batch to its next walk (or to the end of its path); rays whose walk comes out of
         // the path cache (adjoint pass), or whose next flight cannot collide, go round once more.
@@ -810,6 +822,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             }
 
             // ================= (Fs) the next flight: set up and post =========================================
+            SQ_STAMP(5);
             {
                 const bool setup = ph < SP_HEAD && fl != SF_WAIT;
                 if (__ballot(setup)) {
@@ -865,6 +878,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     }
                 }
             }
+            SQ_STAMP(6);
             if (kind == SQ_COLL || !__ballot(ph >= SP_HEAD && ph < SP_IDLE)) break;
         }
 
@@ -910,6 +924,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         sq_push(ctl, q_lds, SQ_WALK, go_walk, id, lane);
         sq_push(ctl, q_lds, SQ_TRANS, go_trans, id, lane);
         sq_push(ctl, q_lds, SQ_REGEN, go_free, id, lane);
+        SQ_STAMP(7);
     }
 
     if constexpr (ADJ) close_records(P, rec);
@@ -924,6 +939,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     }
 #undef SQ_COUNT
 #undef SQ_PROF
+#undef SQ_STAMP
 }
 
 // Records per workgroup that fit LDS next to this supergrid's majorants (a multiple of 64); 0: this supergrid cannot be
