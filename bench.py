@@ -142,7 +142,7 @@ def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=Non
     return out
 
 
-def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only=None):
+def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only=None, main_factor=8):
     """BASELINE.json `configs` 2-5 and the reference's default majorant_resolution_factor on the headline scene,
     each at its registered size, a few H1 steps each (wall clock around synchronised steps, 1 GPU)."""
     out = {}
@@ -156,36 +156,60 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
             out[name] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
 
+    def envmap_pixels(w, h):
+        g = torch.Generator().manual_seed(5)
+        return (torch.rand(h, w, 3, generator=g) ** 4 * 3.0 + 0.2).to(dev)          # a few bright texels: the importance sampler matters
+
     def cfg2():
+        # the reference's scenes all run majorant_resolution_factor 8 (scene_config.py:36): that is the entry's value; the
+        # global majorant beside it
         sc = synthetic.smoke_scene(res=128, film=512, device=dev)
+        sc.medium.majorant_resolution_factor = 8
         r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 16)
-        r["workload"] = "config 2: smoke plume 128^3 (janga-smoke stand-in), 512x512x16spp, majorant_resolution_factor 0"
+        sc.medium.majorant_resolution_factor = 0
+        r["global_majorant"] = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 16, roofline=False)
+        r["workload"] = "config 2: smoke plume 128^3 (janga-smoke stand-in), 512x512x16spp, majorant_resolution_factor 8 (16^3 supergrid)"
         return r
 
-    def factor8():
+    def other_factor():
+        # the headline scene at the majorant setting the main line does NOT run (main line: the reference's default 8)
+        f = 0 if main_factor else 8
+        sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+        sc.medium.majorant_resolution_factor = f
+        r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 32, steps=10, warmup=3,
+                    traffic_key="dust-devil-256-512x32" + ("-factor8" if f else ""))
+        r["workload"] = ("headline scene at majorant_resolution_factor 8 (the reference's default, scene_config.py:36): queued supergrid tracer drt_sq.hip"
+                         if f else "headline scene with ONE global majorant (majorant_resolution_factor 0): wave-cooperative tracer drt_coop.hip")
+        return r
+
+    def envmap8():
+        # what the paper's scenes run (scene_config.py:36,102,152): majorant supergrid AND an environment map of that size
         sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
         sc.medium.majorant_resolution_factor = 8
+        sc.emitter = u.EnvmapEmitter(pixels=envmap_pixels(2048, 1024), scale=1.0)
         r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 32, steps=10, warmup=3,
-                    traffic_key="dust-devil-256-512x32-factor8")
-        r["workload"] = ("headline scene at the REFERENCE'S DEFAULT majorant_resolution_factor 8 (scene_config.py:36, "
-                         "optimize.py:182-199): supergrid tracer drt_super.hip, both passes")
+                    traffic_key="dust-devil-256-512x32-factor8-envmap2048")
+        r["workload"] = ("headline scene as the reference's scenes are set up: majorant_resolution_factor 8 and a 2048x1024 environment map "
+                         "(importance-sampled lat-long map, MIS with phase sampling)")
         return r
 
     def envmap():
         sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
-        g = torch.Generator().manual_seed(5)
-        pix = (torch.rand(256, 512, 3, generator=g) ** 4 * 3.0 + 0.2).to(dev)      # a few bright texels: the importance sampler matters
-        sc.emitter = u.EnvmapEmitter(pixels=pix, scale=1.0)
+        sc.emitter = u.EnvmapEmitter(pixels=envmap_pixels(512, 256), scale=1.0)
         r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 32)
-        r["workload"] = "headline scene lit by a 512x256 environment map (N4: importance-sampled lat-long map, MIS with phase sampling)"
+        r["workload"] = "headline scene lit by a 512x256 environment map, global majorant (N4: importance-sampled lat-long map, MIS with phase sampling)"
         return r
 
     def cfg4():
         sc = synthetic.dust_devil_scene(res=512, film=1024, device=dev)
         r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 64, steps=3, warmup=1,
                     shard=u.ShardSpec(0, 8, 2048))
+        sc.medium.majorant_resolution_factor = 8
+        r["majorant_factor8"] = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 64, steps=3, warmup=1,
+                                        shard=u.ShardSpec(0, 8, 2048), roofline=False)
         r["workload"] = ("config 4: 512^3 grid, rank 0's share (1/8, interleaved 2048-pixel chunks) of 1024x1024x64spp; "
-                         "per-GPU compute only, the 2 GiB gradient all-reduce is not included")
+                         "per-GPU compute only, the 2 GiB gradient all-reduce is not included; global majorant (majorant_factor8: the "
+                         "same with a 64^3 supergrid, whose majorants do not fit LDS: drt_super.hip's bitmask instantiation)")
         return r
 
     def cfg5():
@@ -201,37 +225,45 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
         # reference renderings of the target volume (optimize.py:56-87, 325-358; reproduce.py:45-59), at the reference's
         # default majorant_resolution_factor 8 and, for comparison, with the global majorant
         target = synthetic.dust_devil_scene(res=256, film=512, device=dev, n_sensors=63)
+        const_emitter = target.emitter
         res = {}
-        for factor in (8, 0):
+        # (factor, environment map): the reference's set-up is (8, a 2k environment map), scene_config.py:36,102
+        for factor, env in ((8, False), (0, False), (8, True)):
             target.medium.majorant_resolution_factor = factor
+            target.emitter = u.EnvmapEmitter(pixels=envmap_pixels(2048, 1024), scale=1.0) if env else const_emitter
             scfg = u.SceneConfig(name="dust-devil", scene=target, param_keys=[u.SIGMA_T_KEY, u.ALBEDO_KEY], sensors=list(range(63)),
                                  start_from_value={u.SIGMA_T_KEY: 0.04, u.ALBEDO_KEY: 0.6}, majorant_resolution_factor=factor,
                                  ref_spp=64)
-            if "ref" not in res:
+            rkey = "ref_env" if env else "ref"
+            if rkey not in res:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 rendered = u.render_reference_image(scfg, {s_: None for s_ in scfg.sensors})
                 ref = torch.stack([rendered[s_] for s_ in scfg.sensors])
                 torch.cuda.synchronize()
-                res["ref"] = ref
-                res["reference_render_s"] = round(time.perf_counter() - t0, 2)
+                res[rkey] = ref
+                if not env:
+                    res["reference_render_s"] = round(time.perf_counter() - t0, 2)
             r = {}
             for n_iter in (10, 200):                   # warm-up run, then the timed one
                 oc = u.OptimizationConfig(name="b", spp=16, n_iter=n_iter, lr=5e-3, primal_spp_factor=64, batch_size=32768)
                 stamps = []
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                _, _, _, hist = u.run_optimization(None, oc, scfg, integ_name, ref_images=res["ref"],
+                _, _, _, hist = u.run_optimization(None, oc, scfg, integ_name, ref_images=res[rkey],
                                                    progress=lambda i, l: stamps.append(time.perf_counter()))
                 torch.cuda.synchronize()
                 r = {"value": round(n_iter / (time.perf_counter() - t0), 2), "unit": "iterations/s", "n_iter": n_iter,
                      "loss_first20_mean": round(sum(hist[:20]) / max(1, len(hist[:20])), 6),
                      "loss_last20_mean": round(sum(hist[-20:]) / max(1, len(hist[-20:])), 6)}
             r["loss_decreased"] = bool(r["loss_last20_mean"] < r["loss_first20_mean"])
-            res[f"factor{factor}"] = r
+            res[f"factor{factor}" + ("_envmap" if env else "")] = r
+        target.emitter = const_emitter
+        ref = res.pop("ref_env"); del ref
         ref = res.pop("ref"); del ref
         out3 = dict(res["factor8"])
         out3["global_majorant"] = res["factor0"]
+        out3["envmap_factor8"] = res["factor8_envmap"]      # lit by a 2048x1024 environment map: the reference's scene set-up
         out3["reference_render_s"] = res["reference_render_s"]
         out3["workload"] = ("config 3: full optimisation loop, dust devil 256^3, 63 sensors 512^2, batch 32768 px, spp_grad 16, "
                             "spp_primal 1024, Adam lr 5e-3, l1, constant init (0.04, 0.6), 200 iterations against reference renderings "
@@ -324,7 +356,8 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
                             "interleaved [sigma_t,r,g,b] grid, 256^3, 512x512x32spp"}
 
     guarded("config2_smoke128_512x16", cfg2)
-    guarded("headline_majorant_factor8", factor8)
+    guarded("headline_global_majorant" if main_factor else "headline_majorant_factor8", other_factor)
+    guarded("headline_envmap_factor8", envmap8)
     guarded("headline_envmap", envmap)
     guarded("config3_optimize_loop", cfg3)
     guarded("config4_512_rank_share_1024x64", cfg4)
@@ -343,7 +376,7 @@ def main():
     ap.add_argument("--spp", type=int, default=32, help="samples per pixel (headline: 32)")
     ap.add_argument("--workload", default="dust-devil", choices=["dust-devil", "smoke", "cube"])
     ap.add_argument("--integrator", default="volpathsimple-drt")
-    ap.add_argument("--majorant-factor", type=int, default=0,
+    ap.add_argument("--majorant-factor", type=int, default=8,
                     help="majorant_resolution_factor of the medium (reference scenes: 8, scene_config.py:36; 0 = global majorant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
@@ -381,7 +414,8 @@ def main():
             dist.init_process_group(backend=backend)
 
     if args.only_config:
-        print(json.dumps(other_configs(torch, u, synthetic, dev, integ_name=args.integrator, only=args.only_config)), flush=True)
+        print(json.dumps(other_configs(torch, u, synthetic, dev, integ_name=args.integrator, only=args.only_config,
+                                       main_factor=args.majorant_factor)), flush=True)
         return
 
     # ---- workload (synthetic, seeded; resident in HBM) ---------------------------------
@@ -486,7 +520,7 @@ def main():
     traffic, traffic_source = committed_traffic(f"{args.workload}-{args.res}-{args.film}x{spp}" +
                                                 (f"-factor{args.majorant_factor}" if args.majorant_factor else ""))
     roofline = {
-        "bound": "hbm", "kernel": ("adjoint pass (sample(Backward)): " + ("trace_super_kernel<adjoint>" if args.majorant_factor else "trace_coop_kernel<adjoint>") + " (dominant, sum_tracer_ms) + record partition + tile_reduce"),
+        "bound": "hbm", "kernel": ("adjoint pass (sample(Backward)): " + ("trace_sq_kernel<adjoint>" if args.majorant_factor else "trace_coop_kernel<adjoint>") + " (dominant, sum_tracer_ms) + record partition + tile_reduce"),
         "achieved": round(ach_a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(ach_a / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": bytes_a, "avg_launch_ms": round(avg_pass, 4),
@@ -542,7 +576,7 @@ def main():
         grads = L = state = img = dL = None          # free the headline buffers first
         torch.cuda.empty_cache()
         h.release_scratch()
-        other = other_configs(torch, u, synthetic, dev, integ_name=args.integrator)
+        other = other_configs(torch, u, synthetic, dev, integ_name=args.integrator, main_factor=args.majorant_factor)
 
     if rank == 0:
         out = {
@@ -553,7 +587,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} {args.res}^3 sigma_t+albedo, {sensor.width}x{sensor.height}x{spp}spp, "
                                    f"{args.integrator}, max_depth 64, majorant_resolution_factor {args.majorant_factor} "
-                                   f"({'the reference default' if args.majorant_factor == 8 else 'global majorant; the reference default 8 is reported under other_configs.headline_majorant_factor8'}), single sensor, "
+                                   f"({'the reference default, scene_config.py:36; the global majorant is reported under other_configs.headline_global_majorant' if args.majorant_factor == 8 else 'global majorant; the reference default 8 is reported under other_configs.headline_majorant_factor8'}), single sensor, "
                                    f"image tiles sharded over {world} GPU(s)",
                        "n_samples_per_step": n_total, "grid": [args.res] * 3, "film": [sensor.width, sensor.height],
                        "spp": spp, "integrator": args.integrator},

@@ -12,7 +12,10 @@ import uivr_amd as u
 from uivr_amd import synthetic
 
 dev = torch.device("cuda", 0)
-scene = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+if os.environ.get("DRT_PROFILE_SCENE", "dust") == "smoke":
+    scene = synthetic.smoke_scene(res=128, film=512, device=dev)
+else:
+    scene = synthetic.dust_devil_scene(res=256, film=512, device=dev)
 scene.medium.majorant_resolution_factor = int(os.environ.get("DRT_PROFILE_FACTOR", "8"))
 spp = int(os.environ.get("DRT_PROFILE_SPP", "32"))
 sensor = scene.sensors[0]

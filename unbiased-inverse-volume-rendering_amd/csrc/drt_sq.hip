@@ -62,6 +62,9 @@
 #ifndef DRT_SQ_RUN
 #define DRT_SQ_RUN 16384           // consecutive rays per XCD-owned run
 #endif
+#ifndef DRT_SQ_INLINE_K
+#define DRT_SQ_INLINE_K 4          // cells a flight is stepped by the lanes that set it up, before it is posted for the walkers
+#endif
 #ifndef DRT_SQ_PROFILE
 #define DRT_SQ_PROFILE 0
 #endif
@@ -377,6 +380,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         int r_depth = -1; float r_si_t = kInf; V3 r_o = ro, r_d = rd;
         float r_wsum[3] = { 0, 0, 0 }, r_cw[3] = { 0, 0, 0 };
         bool b_live = true;                                                     // part b of the global record is in registers (adjoint)
+        bool walk_done = false;                                                 // the flight set up here ended within its first cells
         float c_lm = 0.0f, c_tau = 0.0f, c_t = 0.0f, c_acc = 0.0f;              // the finished flight (collision batches)
         float w_tdx = kInf, w_tdy = kInf, w_tdz = kInf; uint32_t w_rem = 0;      // the walk's direction share of the DDA
 
@@ -869,10 +873,38 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                             w_tdx = tdx; w_tdy = tdy; w_tdz = tdz; w_rem = rem;
                             ph = drt ? SP_DRT_END : (ph == SP_DT) ? SP_ESC : (ph == SP_RT ? SP_RT_END : SP_RTA_END);
                         } else {
-                            R[0] = make_uint4(__float_as_uint(tnx), __float_as_uint(tny), __float_as_uint(tnz), (uint32_t) ((cz * gy + cy) * gx + cx));
-                            R[1] = make_uint4(__float_as_uint(tdx), __float_as_uint(tdy), __float_as_uint(tdz), rem);
-                            R[2] = make_uint4(__float_as_uint(tau), __float_as_uint(tmax), 0u, 0u);
+                            // The flight's first cells right here (the walker's cell step, the same arithmetic in the same order):
+                            // half of all flights end within four cells and never see the walkers' queue - their result goes into
+                            // the record as a walker leaves it, and the ray to the collision queue.
+                            float wnx = tnx, wny = tny, wnz = tnz, wt_ = 0.0f, wacc = 0.0f, res_mc = 0.0f;
+                            int wcell = (cz * gy + cy) * gx + cx;
+                            uint32_t wrem = rem;
+                            const int sx = sgx < 0 ? -1 : 1, sy = sgy < 0 ? -lin_y : lin_y, sz = sgz < 0 ? -lin_z : lin_z;
+                            bool wfly = true;
+#pragma unroll
+                            for (int k = 0; k < DRT_SQ_INLINE_K; ++k) {
+                                const float tmin = fminf(fminf(wnx, wny), wnz);
+                                const float texit = fminf(tmin, tmax);
+                                const float mc = __uint_as_float((uint32_t) mg16[wcell] << 16);
+                                const float nacc = wacc + mc * (texit - wt_);
+                                const bool hit = mc > 0.0f && nacc >= tau;
+                                const bool isx = wnx == tmin, isy = !isx && wny == tmin;
+                                const uint32_t sh = isx ? 0u : isy ? 9u : 18u;
+                                const bool end = !(texit < tmax) || ((wrem >> sh) & 511u) == 0u;
+                                const float tnn = tmin + (isx ? tdx : isy ? tdy : tdz);
+                                if (wfly && (hit || end)) { res_mc = hit ? mc : 0.0f; wfly = false; }
+                                const bool go = wfly;
+                                wacc = go ? nacc : wacc;
+                                wt_ = go ? texit : wt_;
+                                wrem = go ? wrem - (1u << sh) : wrem;
+                                wcell += go ? (isx ? sx : isy ? sy : sz) : 0;
+                                wnx = (go && isx) ? tnn : wnx; wny = (go && isy) ? tnn : wny; wnz = (go && !isx && !isy) ? tnn : wnz;
+                            }
+                            R[0] = make_uint4(wfly ? __float_as_uint(wnx) : __float_as_uint(res_mc), __float_as_uint(wny), __float_as_uint(wnz), (uint32_t) wcell);
+                            R[1] = make_uint4(__float_as_uint(tdx), __float_as_uint(tdy), __float_as_uint(tdz), wrem);
+                            R[2] = make_uint4(__float_as_uint(tau), __float_as_uint(tmax), __float_as_uint(wt_), __float_as_uint(wacc));
                             fl = SF_WAIT;
+                            walk_done = !wfly;
                         }
                         if (useA) A.state = Rg.state; else S.state = Rg.state;
                     }
@@ -921,7 +953,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         }
         if (kind != SQ_COLL) __threadfence_block();                            // (the global part of the records)
         sq_fence();
-        sq_push(ctl, q_lds, SQ_WALK, go_walk, id, lane);
+        sq_push(ctl, q_lds, SQ_WALK, go_walk && !walk_done, id, lane);
+        sq_push(ctl, q_lds, SQ_COLL, go_walk && walk_done, id, lane);
         sq_push(ctl, q_lds, SQ_TRANS, go_trans, id, lane);
         sq_push(ctl, q_lds, SQ_REGEN, go_free, id, lane);
         SQ_STAMP(7);
