@@ -249,6 +249,38 @@ def _compact_worker(rank, world, port, q):
                 u.allreduce_gradients({"_flat": f}, compact=mode, stats=stats)
                 out[(name, mode)] = (bool(torch.equal(torch.nan_to_num(f, nan=7.0), torch.nan_to_num(ref, nan=7.0))),
                                      bool(torch.isnan(f[5 * B + 3])) if name == "sparse" else None, dict(stats))
+        # ONE collective per backward.  (a) a support known beforehand: no mask collective, ever
+        D.reset_allreduce_state()
+        g = torch.Generator().manual_seed(77 + rank)
+        sup_mask = torch.zeros(200, dtype=torch.uint8)
+        sup_mask[20:60] = 1                                  # the same on every rank (from the replicated parameters)
+        sup = D.GradientSupport(sup_mask, n)
+        one = {}
+        for step in range(3):
+            flat = torch.zeros(n)
+            blocks = (torch.rand(200, generator=g) < 0.5) & sup_mask.bool()
+            flat[:200 * B] = (torch.randn(200, B, generator=g) * blocks[:, None]).reshape(-1)
+            flat[200 * B:] = float(rank + 1)
+            if step == 2 and rank == 1:
+                flat[150 * B + 1] = 5.0                      # ... violated: the check in the packed buffer finds it
+            ref = flat.clone()
+            dist.all_reduce(ref)
+            stats = {}
+            u.allreduce_gradients({"_flat": flat}, stats=stats, support=sup)
+            one[("support", step)] = (bool(torch.equal(flat, ref)), dict(stats))
+        # (b) no support: the set agreed on in the first call serves the next ones; a gradient that outgrows it is summed densely
+        D.reset_allreduce_state()
+        for step in range(4):
+            flat = torch.zeros(n)
+            hi = 60 if step < 3 else 90
+            flat[20 * B:hi * B] = float(rank + 1 + step)
+            ref = flat.clone()
+            dist.all_reduce(ref)
+            stats = {}
+            u.allreduce_gradients({"_flat": flat}, stats=stats)
+            one[("history", step)] = (bool(torch.equal(flat, ref)), dict(stats))
+        out["one"] = one
+        D.reset_allreduce_state()
         # small buffers (the 3^3 fixtures) never pay for a mask
         small = torch.full((100,), 1.0)
         st = {}
@@ -290,6 +322,21 @@ def test_compacted_allreduce_equals_dense_gloo(uivr):
             assert stats["floats"] < 200 * B * (0.35 if name == "sparse" else 1.01) + 37
     assert out["small"] == (True, "dense")
     assert out["bad"]
+    one = out["one"]
+    for step in range(3):
+        equal, st = one[("support", step)]
+        assert equal, (step, st)
+        if step < 2:                                    # one collective of the support's 40 blocks + tail + check
+            assert st["mode"] == "compact" and st["collectives"] == 1 and st["sent_floats"] == 40 * B + 37 + 1, st
+        else:                                           # support violated: dense sums, said so
+            assert st["mode"] == "dense" and st.get("outgrown") and st["collectives"] == 2, st
+    for step in range(4):
+        equal, st = one[("history", step)]
+        assert equal, (step, st)
+    assert one[("history", 0)][1]["collectives"] == 2                      # agreeing on the set + the packed sum
+    assert one[("history", 1)][1]["collectives"] == 1 and one[("history", 2)][1]["collectives"] == 1
+    assert one[("history", 1)][1]["mode"] == "compact"
+    assert one[("history", 3)][1].get("outgrown") and one[("history", 3)][1]["mode"] == "dense"
 
 
 def _world8_worker(rank, world, port, q):

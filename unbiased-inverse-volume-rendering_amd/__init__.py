@@ -10,7 +10,8 @@ from .scene import (ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, ConstantEmitter, Envm
 from .integrators import (ADMode, FusedNerfDrtIntegrator, IndependentSampler, NeRFIntegrator, RayBatch, VolpathSimpleIntegrator, load_dict,
                           register_integrator, sample_tea_32)
 from .opt_config import IntegratorConfig, add_int_config, get_int_config
-from .distributed import ShardSpec, allreduce_gradients, allreduce_scalar, from_environment, local_loss_scale
+from .distributed import (GradientSupport, ShardSpec, allreduce_gradients, allreduce_scalar, from_environment, gradient_support,
+                          local_loss_scale, reset_allreduce_state, verify_pending)
 from .render import alloc_grads, render, render_backward, render_primal
 from .batched import gather_ref_values, render_batch, sample_batch, sensors_to_device
 from . import losses
@@ -25,7 +26,8 @@ __all__ = [
     "ALBEDO_KEY", "EMISSION_KEY", "SIGMA_T_KEY", "ConstantEmitter", "EnvmapEmitter", "GridMedium", "PerspectiveSensor",
     "Scene", "cube_test_scene", "scene_to", "ADMode", "IndependentSampler", "RayBatch",
     "VolpathSimpleIntegrator", "NeRFIntegrator", "FusedNerfDrtIntegrator", "load_dict", "register_integrator", "sample_tea_32", "IntegratorConfig",
-    "add_int_config", "get_int_config", "ShardSpec", "allreduce_gradients", "allreduce_scalar",
+    "add_int_config", "get_int_config", "ShardSpec", "allreduce_gradients", "allreduce_scalar", "GradientSupport", "gradient_support",
+    "reset_allreduce_state", "verify_pending",
     "from_environment", "local_loss_scale", "alloc_grads", "render", "render_backward", "render_primal", "render_batch",
     "gather_ref_values", "sample_batch", "sensors_to_device", "losses", "Adam", "SGD", "OptimizationConfig",
     "SceneConfig", "Schedule", "adjusted_majorant_res_factor", "enforce_valid_params", "run_optimization",

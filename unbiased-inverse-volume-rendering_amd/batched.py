@@ -16,7 +16,7 @@ import torch
 
 from .distributed import ShardSpec, allreduce_gradients
 from .integrators import ADMode, IndependentSampler, RayBatch, sample_tea_32
-from .render import _grid, _with_params, alloc_grads
+from .render import _grid, _with_params, alloc_grads, sharded_support
 from .scene import PerspectiveSensor, Scene
 
 
@@ -83,8 +83,9 @@ class _BatchedRenderOp(torch.autograd.Function):
         L, _, state = integ.sample(ADMode.Primal, sc, sampler.clone(), batch)                    # :255-264
         dL = integ.film_backward(sc, grad_image.contiguous(), ctx.spp_grad)                      # :272-306
         grads = alloc_grads(sc, integ.param_keys)
+        support = sharded_support(sc, grads, ctx.shard)
         integ.sample(ADMode.Backward, sc, sampler, batch, δL=dL, state_in=state, grads=grads)    # :309-318
-        allreduce_gradients(grads, shard=ctx.shard)
+        allreduce_gradients(grads, shard=ctx.shard, support=support)
         k0, k1 = integ.param_keys
         return (grads[k0], grads[k1]) + (None,) * 9
 

@@ -87,7 +87,8 @@ def from_environment(n_pixels: Optional[int] = None) -> ShardSpec:
 
 
 COMPACT_BLOCK_FLOATS = 64           # 256 B of the flat gradient buffer per block (64 | 128 | 256)
-COMPACT_MAX_ACTIVE = 0.7            # above this fraction of non-zero blocks the dense all-reduce is cheaper
+COMPACT_MAX_ACTIVE = 0.7            # above this fraction of blocks in the packing set the dense all-reduce is cheaper
+HISTORY_RESET_CALLS = 256           # a packing set grown from the gradients seen so far is rebuilt after this many calls
 
 
 def _block_mask(body: torch.Tensor) -> torch.Tensor:
@@ -103,98 +104,245 @@ def _block_mask(body: torch.Tensor) -> torch.Tensor:
     return (body != 0).any(dim=1).to(torch.uint8)
 
 
-_PACK_CAPACITY: Dict[tuple, int] = {}     # (device, buffer size) -> blocks the packed buffer was sized for last time
+class GradientSupport:
+    """A set of 256-byte blocks of the flat gradient buffer OUTSIDE of which the gradient of every rank is zero - known
+    before the backward pass, the same on every rank (it is computed from the replicated parameters, no communication).
+
+    `gradient_support(...)` builds it at the start of a step; the number of blocks travels to the host behind the render
+    passes (asynchronous copy + event), so that the all-reduce at the end of the backward can size its packed buffer
+    without stalling the device."""
+
+    def __init__(self, mask: torch.Tensor, n_floats: int):
+        self.mask = mask.to(torch.uint8).contiguous()       # [n_blocks], 1 = the block may be non-zero
+        self.n_floats = int(n_floats)
+        self._count = None
+        self._host, self._ready = None, None
+        cnt = self.mask.sum(dtype=torch.int32).reshape(1)
+        if self.mask.is_cuda:
+            with torch.cuda.device(self.mask.device):
+                self._host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                self._host.copy_(cnt, non_blocking=True)
+                self._ready = torch.cuda.Event()
+                self._ready.record(torch.cuda.current_stream(self.mask.device))
+        else:
+            self._count = int(cnt)
+
+    @property
+    def count(self) -> int:
+        if self._count is None:
+            self._ready.synchronize()                       # (recorded a render pass ago: does not wait in a training loop)
+            self._count = int(self._host[0])
+        return self._count
 
 
-def _capacity_for(count: int, n_blocks: int) -> int:
-    return min(n_blocks, count + count // 4 + 64)
+def gradient_support(sigma_t: torch.Tensor, grads: Dict[str, torch.Tensor], sparse_keys=("medium1.albedo.data",),
+                     block_floats: int = COMPACT_BLOCK_FLOATS) -> Optional[GradientSupport]:
+    """Where can the gradient grids `grads` (render.alloc_grads: views of `grads["_flat"]`) be non-zero, given sigma_t?
+
+    * `sparse_keys` - per-voxel grids that only receive splats at REAL collisions (albedo: python/integrators/
+      volpathsimple.py:152-172 splats at a scattering vertex, whose sigma_t(x) > 0; the DRT vertex's albedo gradient
+      `:577-581` carries the factor sigma_t(x')): a voxel is reached from a point whose interpolated sigma_t is non-zero,
+      i.e. whose 8 surrounding voxels are not all zero - the voxels within one step (3x3x3 neighbourhood) of a non-zero one;
+    * every other grid (sigma_t: the four transmittance samples of backpropagate_transmittance land anywhere on a segment,
+      `:584-607`): every block.
+    None where that reasoning does not apply as is (no flat buffer, a sparse grid of another resolution)."""
+    flat = grads.get("_flat")
+    if flat is None or flat.numel() < 64 * block_floats:
+        return None
+    n_floats = flat.numel()
+    n_blocks = n_floats // block_floats
+    may = torch.zeros(n_blocks * block_floats, dtype=torch.bool, device=flat.device)
+    occ = None
+    for k, g in grads.items():
+        if k == "_flat":
+            continue
+        off = (g.data_ptr() - flat.data_ptr()) // flat.element_size()
+        lo, hi = off, min(off + g.numel(), n_blocks * block_floats)
+        if not (0 <= off and off + g.numel() <= n_floats):
+            return None                                             # not a view of the flat buffer
+        if hi <= lo:
+            continue
+        if k in sparse_keys:
+            if tuple(g.shape[:3]) != tuple(sigma_t.shape[:3]):
+                return None
+            if occ is None:
+                o = (sigma_t.reshape(sigma_t.shape[:3]) != 0).to(torch.float32)[None, None]
+                occ = torch.nn.functional.max_pool3d(o, kernel_size=3, stride=1, padding=1)[0, 0].reshape(-1) > 0     # [V]
+            ch = g.numel() // occ.numel()
+            may[lo:hi] = occ.repeat_interleave(ch)[:hi - lo]
+        else:
+            may[lo:hi] = True
+    return GradientSupport(may.view(n_blocks, block_floats).any(dim=1), n_floats)
 
 
-def _allreduce_flat(flat: torch.Tensor, group, compact, stats: Optional[dict]) -> None:
+class _ReduceState:
+    """What one (process group, buffer) remembers between backward passes."""
+    __slots__ = ("in_set", "src", "count", "calls", "pending")
+
+    def __init__(self):
+        self.in_set = None          # uint8 [n_blocks]: the packing set grown from the gradients seen so far
+        self.src = None             # int64 [count]: its block indices
+        self.count = 0
+        self.calls = 0
+        self.pending = None         # (pinned host float, event): blocks found outside a GradientSupport, not looked at yet
+
+
+_STATE: Dict[tuple, _ReduceState] = {}
+
+
+def _state_for(flat: torch.Tensor, group) -> _ReduceState:
+    key = (id(group) if group is not None else None, str(flat.device), flat.numel())
+    st = _STATE.get(key)
+    if st is None:
+        st = _STATE[key] = _ReduceState()
+    return st
+
+
+def reset_allreduce_state() -> None:
+    """Forget every packing set (a new process group, a new scene)."""
+    verify_pending()
+    _STATE.clear()
+
+
+def verify_pending() -> None:
+    """The all-reduce that packs with a `GradientSupport` does not wait for its own check (the number of non-zero blocks
+    it found outside the support, summed over the ranks, travels to the host behind the collective); the next call, or
+    this function at the end of a run, looks at it.  A non-zero count means the support was not one: that step's
+    gradient is missing the other ranks' share of those blocks - raised, never silent."""
+    for st in _STATE.values():
+        if st.pending is not None:
+            host, ev = st.pending
+            st.pending = None
+            ev.synchronize()
+            if float(host[0]) != 0.0:
+                raise RuntimeError(f"allreduce_gradients: {float(host[0]):.0f} non-zero gradient blocks lay outside the "
+                                   "GradientSupport of an earlier backward pass (its all-reduce left them unsummed); "
+                                   "pass support=None or strict=True")
+
+
+def _pack(body: torch.Tensor, tail: torch.Tensor, src: torch.Tensor, extra: torch.Tensor) -> torch.Tensor:
+    return torch.cat([body.index_select(0, src).reshape(-1), tail, extra])
+
+
+def _allreduce_flat(flat: torch.Tensor, group, compact, stats: Optional[dict], support: Optional[GradientSupport] = None,
+                    strict: Optional[bool] = None) -> None:
     """Sum `flat` over the group in place.  `compact`: "auto" (default) | "never" | "always".
 
-    The gradient of a sparse volume is mostly exact zeros: the albedo planes (3/4 of the buffer) only receive
-    splats where real scattering happens, i.e. next to voxels with sigma_t > 0, and with a majorant supergrid
-    (majorant_resolution_factor > 0) the sigma_t plane only where the local majorant is positive.  So the ranks first
-    agree on the set of 256-B blocks that are non-zero on ANY rank (an all-reduce(MAX) of one byte per block:
-    1 MiB for a 256^3 medium), and, when that set is small enough to pay for the packing, all-reduce only those
-    blocks.  Blocks outside the set are zero on every rank, so the sum is the same as the dense one (up to the
-    summation order inside the collective); non-finite values count as non-zero and propagate.
+    The gradient of a sparse volume is mostly exact zeros: the albedo planes (3/4 of the buffer) only receive splats
+    where real scattering happens, i.e. next to voxels with sigma_t > 0.  So only a SET of 256-byte blocks is packed
+    and summed - ONE collective per backward - and the packed buffer carries, as its last float, the number of non-zero
+    blocks this rank holds OUTSIDE the set: a non-zero sum says the set was too small.  Blocks outside the set are zero
+    on every rank otherwise, so the result equals the dense sum (up to the summation order inside the collective);
+    non-finite values count as non-zero and propagate.  Where the set comes from:
 
-    No pipeline stall: the packed buffer is sized from the PREVIOUS call's block count (+25 %), so the packing kernels
-    are enqueued without knowing this call's count; the count travels to the host meanwhile (asynchronous copy + event)
-    and is only waited for right before the collective is enqueued - the device is busy packing by then.  A count beyond
-    the capacity (the block set grew by more than 25 % since the last step) falls back to the dense collective."""
+    * `support` (a `GradientSupport`, from the replicated parameters: rigorous, known before the pass): one collective and
+      no host wait - the check is looked at by the NEXT call (`verify_pending`), or right away with `strict=True` / on
+      host tensors, where a violated support falls back to the dense collective;
+    * no `support`: the union of the non-zero blocks of the sums seen so far for this (group, buffer).  One collective;
+      the host looks at the check before the result is scattered (a set grown from history can be outgrown: then the
+      dense collective runs as well and the set grows).  The first call, and every HISTORY_RESET_CALLS-th, agrees on
+      the set with an all-reduce(MAX) of one byte per block first.
+    Every decision is made from values all ranks hold identically (the agreed set, its size, the summed check)."""
     import torch.distributed as dist
     n = flat.numel()
     B = COMPACT_BLOCK_FLOATS
     if compact == "never" or n < 64 * B:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if stats is not None:
-            stats.update(mode="dense", floats=n, active_fraction=1.0)
+            stats.update(mode="dense", floats=n, active_fraction=1.0, collectives=1)
         return
+    import contextlib
+    with (torch.cuda.device(flat.device) if flat.is_cuda else contextlib.nullcontext()):
+        _allreduce_flat_body(flat, group, compact, stats, support, strict, dist, n, B)
+
+
+def _allreduce_flat_body(flat, group, compact, stats, support, strict, dist, n, B) -> None:
     n_full = (n // B) * B
     body = flat[:n_full].view(-1, B)
     tail = flat[n_full:]
-    mask = _block_mask(body)
-    dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
-    n_blocks = mask.numel()
-    cs = torch.cumsum(mask, dim=0, dtype=torch.int32)      # inclusive: cs[b] = non-zero blocks up to and including b
-    key = (str(flat.device), n)
-    cap = _PACK_CAPACITY.get(key)
-    count_host, ready = None, None
-    if flat.is_cuda and cap is not None:                   # the count goes to the host behind the packing kernels
-        count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        count_host.copy_(cs[-1:], non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record()
-    else:                                                  # first call for this buffer (nothing to size from), or host tensors
-        count = int(cs[-1])
-        if cap is None:
-            cap = _capacity_for(count, n_blocks)
+    n_blocks = body.shape[0]
+    st = _state_for(flat, group)
+    verify_pending()
+    st.calls += 1
+    n_coll = 0
 
-    def pack(capacity):
-        # row j of the packed buffer = the j-th non-zero block (a search in the running count), zeros past the count
-        j = torch.arange(1, capacity + 1, dtype=torch.int32, device=flat.device)
-        src = torch.searchsorted(cs, j).clamp_(max=n_blocks - 1)
-        rows = torch.where((j <= cs[-1])[:, None], body.index_select(0, src), torch.zeros((), dtype=flat.dtype, device=flat.device))
-        return src, torch.cat([rows.reshape(-1), tail])
-
-    src, packed = pack(cap)
-    if ready is not None:
-        ready.synchronize()                                # (the packing above is still running or queued)
-        count = int(count_host[0])
-    frac = count / n_blocks
-    _PACK_CAPACITY[key] = _capacity_for(count, n_blocks)
-    if count == 0 and tail.numel() == 0:                   # all zeros on every rank: nothing to sum
-        if stats is not None:
-            stats.update(mode="compact", floats=0, active_fraction=0.0)
-        return
-    if count > cap and compact == "always":
-        cap = count
-        src, packed = pack(cap)
-    if (compact != "always" and frac > COMPACT_MAX_ACTIVE) or count > cap:
+    def dense(frac):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if stats is not None:
-            stats.update(mode="dense", floats=n, active_fraction=frac)
+            stats.update(mode="dense", floats=n, active_fraction=frac, collectives=n_coll + 1)
+
+    if support is not None and (support.n_floats != n or support.mask.numel() != n_blocks or support.mask.device != flat.device):
+        raise ValueError("allreduce_gradients: `support` was built for another buffer")
+
+    # ---- the packing set ------------------------------------------------------------------------------------------------
+    if support is not None:
+        in_set, count = support.mask, support.count
+        src = None
+    else:
+        if st.in_set is None or st.calls % HISTORY_RESET_CALLS == 0:
+            mask = _block_mask(body)                               # agree on the set: one byte per block, MAX
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
+            n_coll += 1
+            st.in_set = mask
+            st.src = torch.nonzero(mask).reshape(-1)               # (host wait: first call and resets only)
+            st.count = int(st.src.numel())
+        in_set, count, src = st.in_set, st.count, st.src
+    frac = count / n_blocks
+    if compact != "always" and frac > COMPACT_MAX_ACTIVE:          # (known before anything is packed)
+        return dense(frac)
+    if src is None:
+        cs = torch.cumsum(in_set, dim=0, dtype=torch.int32)
+        src = torch.searchsorted(cs, torch.arange(1, count + 1, dtype=torch.int32, device=flat.device)).to(torch.int64)
+
+    # ---- one collective: the set's blocks + the ragged tail + the check ---------------------------------------------------
+    local = _block_mask(body)
+    outside = (local & (1 - in_set)).sum(dtype=torch.float32).reshape(1)
+    if count == 0 and tail.numel() == 0 and support is None and n_coll:
+        if stats is not None:                                      # (the mask collective just said: zeros on every rank)
+            stats.update(mode="compact", floats=0, active_fraction=0.0, collectives=n_coll)
         return
+    packed = _pack(body, tail, src, outside)
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-    body.index_copy_(0, src[:count].to(torch.int64), packed[:count * B].view(-1, B))
+    n_coll += 1
+    lazy = support is not None and flat.is_cuda and not strict
+    if lazy:
+        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        host.copy_(packed[-1:], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flat.device))
+        st.pending = (host, ev)
+        missed = 0.0
+    else:
+        missed = float(packed[-1])                                 # the host waits for the collective here
+    if missed != 0.0:
+        # the set was outgrown: nothing has been scattered yet, `flat` still holds this rank's gradient
+        dense(frac)
+        if support is None:                                        # grow the set by what the dense sum shows
+            st.in_set = torch.maximum(st.in_set, _block_mask(body))
+            st.src = torch.nonzero(st.in_set).reshape(-1)
+            st.count = int(st.src.numel())
+        if stats is not None:
+            stats.update(outgrown=True)
+        return
+    body.index_copy_(0, src, packed[:count * B].view(-1, B))
     if tail.numel():
-        tail.copy_(packed[cap * B:])
+        tail.copy_(packed[count * B:count * B + tail.numel()])
     if stats is not None:
-        stats.update(mode="compact", floats=count * B + tail.numel(), sent_floats=packed.numel(), active_fraction=frac)
+        stats.update(mode="compact", floats=count * B + tail.numel(), sent_floats=packed.numel(), active_fraction=frac,
+                     collectives=n_coll)
 
 
 def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, shard: Optional[ShardSpec] = None,
-                        compact: str = "auto", stats: Optional[dict] = None) -> None:
-    """Sum the gradient grids over all ranks, in place: one collective per backward (plus a one-byte-per-block
-    mask, see `_allreduce_flat`).  The grids live in (or are flattened into) ONE buffer (sigma_t: V floats +
-    albedo: 3V floats) so that a single large all-reduce crosses xGMI instead of one per parameter.
+                        compact: str = "auto", stats: Optional[dict] = None, support: Optional[GradientSupport] = None,
+                        strict: Optional[bool] = None) -> None:
+    """Sum the gradient grids over all ranks, in place: ONE collective per backward (see `_allreduce_flat`).  The grids
+    live in (or are flattened into) ONE buffer (sigma_t: V floats + albedo: 3V floats) so that a single large all-reduce
+    crosses xGMI instead of one per parameter.
 
     Only PARTITIONED work is summed: with `shard` given, the call is a no-op unless `shard.world > 1`
     (every rank of an unsharded render computed the full gradient already; summing those would
-    multiply it by the world size).  `stats`, if given, receives {"mode", "floats", "active_fraction"}."""
+    multiply it by the world size).  `stats`, if given, receives {"mode", "floats", "active_fraction", "collectives"}.
+    `support`: the blocks that can be non-zero (`gradient_support`); only used with a `_flat` buffer."""
     import torch.distributed as dist
     if compact not in ("auto", "never", "always"):
         raise ValueError(f"compact must be 'auto', 'never' or 'always', not {compact!r}")
@@ -205,7 +353,7 @@ def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, shard: Optio
     if shard is not None and shard.world != dist.get_world_size(group):
         raise ValueError(f"ShardSpec.world={shard.world} does not match the process group size {dist.get_world_size(group)}")
     if "_flat" in grads:      # render.alloc_grads: the grids are views of one buffer
-        _allreduce_flat(grads["_flat"], group, compact, stats)
+        _allreduce_flat(grads["_flat"], group, compact, stats, support, strict)
         return
     keys = sorted(grads)
     flat = torch.cat([grads[k].reshape(-1) for k in keys])

@@ -17,7 +17,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .distributed import ShardSpec, allreduce_gradients
+from .distributed import ShardSpec, allreduce_gradients, gradient_support
 from .integrators import ADMode, IndependentSampler, RayBatch, sample_tea_32
 from .scene import ALBEDO_KEY, EMISSION_KEY, SIGMA_T_KEY, GridMedium, Scene
 
@@ -43,6 +43,19 @@ def alloc_grads(scene: Scene, keys=(SIGMA_T_KEY, ALBEDO_KEY)) -> Dict[str, torch
         out[k] = flat[off:off + g.numel()].view(g.shape)
         off += pad(g.numel())
     return out
+
+
+def sharded_support(scene: Scene, grads: Dict[str, torch.Tensor], shard: Optional[ShardSpec]):
+    """The blocks of the flat gradient buffer that can be non-zero, from this step's (replicated) sigma_t - computed
+    BEFORE the adjoint pass is enqueued, so that the gradient all-reduce behind it packs without a mask collective and
+    without a host wait (distributed.gradient_support).  None for unsharded work (no collective) and for integrators
+    other than volpathsimple's (sigma_t, albedo) pair."""
+    import torch.distributed as dist
+    if shard is None or not shard.partitioned or not (dist.is_available() and dist.is_initialized()):
+        return None
+    if SIGMA_T_KEY not in grads or ALBEDO_KEY not in grads:
+        return None
+    return gradient_support(scene.medium.sigma_t, grads, sparse_keys=(ALBEDO_KEY,))
 
 
 def _with_params(scene: Scene, keys, tensors) -> Scene:
@@ -89,10 +102,11 @@ def render_backward(scene: Scene, integrator, grad_image: torch.Tensor, sensor: 
     dL = integrator.film_backward(scene, grad_image, spp)                                  # :272-306
     if grads is None:
         grads = alloc_grads(scene, integrator.param_keys)
+    support = sharded_support(scene, grads, shard) if allreduce else None
     integrator.sample(ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state_out,  # :309-318
                       grads=grads)
     if allreduce:
-        allreduce_gradients(grads, shard=shard or ShardSpec())
+        allreduce_gradients(grads, shard=shard or ShardSpec(), support=support)
     return grads
 
 
