@@ -41,6 +41,9 @@ for tag, c in (("primal", cp), ("adjoint", ca)):
     if mode == "sq":
         print(f"{tag}: lane steps {c[0]/1e6:.1f} M, wave steps {c[1]/1e6:.2f} M -> {c[0]/max(1,c[1]):.1f} lanes per step; collision batches {c[2]/1e6:.3f} M x {c[3]/max(1,c[2]):.1f} rays; "
               f"transition batches {c[4]/1e6:.3f} M x {c[5]/max(1,c[4]):.1f}; regeneration batches {c[6]/1e6:.3f} M x {c[7]/max(1,c[6]):.1f}; polls {c[8]/1e6:.2f} M")
+    elif mode in ("sq3", "sq4"):
+        names = ["DRT vertex", "NEE walk finished", "phase sampling", "loop head", "collision / escape", "emitter direction", "end of path", "flight set-up", "passes"]
+        print(tag, "waves" if mode == "sq3" else "lanes", {n: round(v / 1e6, 3) for n, v in zip(names, c)})
     elif mode == "sq2":
         tot = sum(c)
         names = ["cell steps", "walker queue work", "load (collision)", "collision code", "load (transition)", "transition code", "flight set-up", "store + push", "looking for work"]

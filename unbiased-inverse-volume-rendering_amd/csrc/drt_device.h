@@ -94,6 +94,10 @@ struct Pcg32 {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float drt_logf(float x)
 {
+#ifdef DRT_FAST_MATH
+    // pricing experiment only (what bit-exactness costs): the hardware's v_log_f32.  Never a shipped flavour's default.
+    return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
+#endif
     uint32_t ix = __float_as_uint(x);
     int e = (int)(ix >> 23) - 126;
     float m = __uint_as_float((ix & 0x007fffffu) | 0x3f000000u);

@@ -210,10 +210,15 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     // LDS + global memory), [5] transition / regeneration code, [6] flight set-up, [7] storing a batch + pushes, [8] looking for work
     uint64_t pt_last = __builtin_readcyclecounter();
 #define SQ_STAMP(slot) do { if (DRT_SQ_PROFILE == 2 && COUNT) { const uint64_t t_ = __builtin_readcyclecounter(); if (lane == 0) cnt[slot] += (uint32_t) ((t_ - pt_last) >> 6); pt_last = t_; } } while (0)
+    // DRT_SQ_PROFILE=3 / 4: per block of the transition pass, the waves that ran it (3) / the lanes that needed it (4) -
+    // [0] DRT vertex, [1] NEE walk finished, [2] phase sampling, [3] loop head, [4] real collision / escape, [5] emitter
+    // direction, [6] end of a path, [7] flight set-up, [8] passes of the transition loop (profiles/r04_sq_experiments.txt)
+#define SQ_BLK(slot, pred) do { if (DRT_SQ_PROFILE >= 3 && COUNT) { const uint64_t m_ = __ballot(pred); if (m_ && lane == 0) cnt[slot] += DRT_SQ_PROFILE == 3 ? 1u : (uint32_t) __popcll(m_); } } while (0)
 #else
 #define SQ_STAMP(slot) do { } while (0)
 #define SQ_COUNT(slot) do { if (COUNT) cnt[slot]++; } while (0)
 #define SQ_PROF(slot, v) do { } while (0)
+#define SQ_BLK(slot, pred) do { } while (0)
 #endif
 
     // uniform supergrid constants
@@ -587,6 +592,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         for (;;) {
             if (kind != SQ_COLL && __ballot(ph >= SP_HEAD && ph < SP_IDLE)) {
                 uint4 pce1 = make_uint4(0u, 0u, 0u, 0u); bool pce1_ok = false;   // this iteration's NEE entry of the path cache, read at the loop head
+                SQ_BLK(8, ph >= SP_HEAD && ph < SP_IDLE); SQ_BLK(0, ph == SP_DRT_END); SQ_BLK(1, ph == SP_RT_END || ph == SP_RTA_END);
                 // ---- DRT vertex selected: enter the detached recursive path (:553-575, :610-655) -----
                 if constexpr (ADJ) {
                     if (ph == SP_DRT_END) {
@@ -642,6 +648,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
 
                 // ---- phase sampling + new segment (:221-246) -------------------------------------------------------
+                SQ_BLK(2, ph == SP_PHASE);
                 if (ph == SP_PHASE) {
                     ++pc_it;                                                    // next bounce-loop iteration (path cache index)
                     (void) S.next_1d();
@@ -661,6 +668,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
 
                 // ---- loop head: Russian roulette, start delta tracking (:116-127) -------------------------------------
+                SQ_BLK(3, ph == SP_HEAD);
                 if (ph == SP_HEAD) {
                     float q = fminf(fmaxf(beta[0], fmaxf(beta[1], beta[2])), 0.99f);
                     bool perform_rr = depth > P.rr_depth;
@@ -686,6 +694,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                         P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2] =
                             make_uint4(__float_as_uint(ph == SP_SCAT ? wt : kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
                 }
+                SQ_BLK(4, ph == SP_SCAT || ph == SP_ESC);
                 if (ph == SP_SCAT || ph == SP_ESC) {
                     const bool scat = ph == SP_SCAT;
                     const bool adj_lane = ADJ && !rec_mode;
@@ -751,6 +760,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
 
                 // ---- emitter direction + boundary exit for NEE (:406-433) ------------------------------------------
+                SQ_BLK(5, ph == SP_NEE);
                 if (ph == SP_NEE) {
                     if (ADJ && !rec_mode) Cst = S.state;                        // :383
                     float ux = S.next_1d(), uy = S.next_1d();                   // :418
@@ -771,6 +781,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     else { wt = 0.0f; ph = SP_RT_END; }
                 }
                 // ---- end of a path (:249-287) -----------------------------------------------------
+                SQ_BLK(6, ph == SP_END);
                 if (ph == SP_END) {
                     if (!ADJ || rec_mode) {                                     // envmap block, primal only
                         if (escaped && !(depth <= 0 && P.hide_emitters)) {
@@ -829,6 +840,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             SQ_STAMP(5);
             {
                 const bool setup = ph < SP_HEAD && fl != SF_WAIT;
+                SQ_BLK(7, setup);
                 if (__ballot(setup)) {
                     if (setup) {
                         const bool drt = ph == SP_DRT;
@@ -973,6 +985,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
 #undef SQ_COUNT
 #undef SQ_PROF
 #undef SQ_STAMP
+#undef SQ_BLK
 }
 
 // Records per workgroup that fit LDS next to this supergrid's majorants (a multiple of 64); 0: this supergrid cannot be
