@@ -176,7 +176,9 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
  * VolpathSimpleIntegrator.sample (volpathsimple.py:38-290; the handle's drt_config) from the same camera ray and the
  * same PCG32 stream, each bit-identical to its stand-alone call; the backward pass accumulates BOTH integrators'
  * gradients into grad_sigma_t (Z,Y,X,1) and grad_rgb (Z,Y,X,3) (albedo gradient + emission gradient: one parameter).
- * Constant emitter and global majorant only.  Ray / seed conventions as for drt_render_*. */
+ * Either emitter (constant, environment map) and either kind of majorant (global, supergrid: the volpathsimple half then
+ * tracks through the supergrid on every path's own lane) - the reference's nerf scenes use an environment map and
+ * majorant_resolution_factor 8 (python/scene_config.py:36,102-141).  Ray / seed conventions as for drt_render_*. */
 int drt_fused_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
                             uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_nerf_out, float *L_drt_out);
 int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,

@@ -74,6 +74,55 @@ def test_fused_matches_oracle_on_the_fixture(uivr, oracle, gpu, variant, nerf):
     h.enable_counters(False)
 
 
+@pytest.mark.parametrize("env,factor", [(True, 0), (False, 3), (True, 3)])
+def test_fused_with_envmap_and_supergrid_matches_oracle(uivr, oracle, gpu, env, factor):
+    """the reference's nerf scenes run an environment map AND majorant_resolution_factor 8
+    (python/scene_config.py:36,102-141) - the fused pass under either emitter and either kind of majorant
+    (drt_fused_env.hip, drt_fused_super.hip, drt_fused_env_super.hip): radiance of both halves bit-exact, counters
+    equal, gradients within tolerance, for the counting and the specialised kernels."""
+    from test_gpu_envmap import _env_scene
+    scene = _env_scene(uivr, film=24, factor=factor)
+    scene.medium.emission = np.asarray(scene.medium.albedo).copy()      # one asset for both (scene_config.py:109-110)
+    if not env:
+        scene.emitter = uivr.cube_test_scene(4, 4).emitter
+    props = props_for("drt")
+    nerf = dict(queries_per_ray=24)
+    nerf_props = dict(queries_per_ray=24, activation="identity", jittering_enabled=True, hide_emitters=False)
+    spp, seed = 8, 515
+    osc = oracle.OracleScene(scene)
+    Lr, cp = oracle.fused_render_primal(osc, props, nerf_props, spp, seed)
+    rng = np.random.default_rng(3)
+    n = Lr.shape[0]
+    dL = ((rng.random((n, 6), dtype=np.float32) - 0.5) * 1e-2).astype(np.float32)
+    gs, grgb, ca = oracle.fused_render_backward(osc, props, nerf_props, spp, seed, dL, Lr)
+    sg = uivr.scene_to(scene, gpu)
+    integ = _fused(uivr, "drt", **nerf)
+    h = integ.native_handle(sg)
+    batch = uivr.RayBatch(n_rays=n, spp=spp, sensor=sg.sensors[0])
+    samp = uivr.IndependentSampler(seed, spp)
+    for counting in (True, False):
+        h.enable_counters(counting)
+        h.reset_counters()
+        L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+        np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+        if counting:
+            assert {k: int(v) for k, v in h.get_counters().items()} == cp
+        h.reset_counters()
+        grads = uivr.alloc_grads(sg, integ.param_keys)
+        integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=st, grads=grads)
+        if counting:
+            assert {k: int(v) for k, v in h.get_counters().items()} == ca
+        _close(grads[uivr.SIGMA_T_KEY], gs, "grad sigma_t")
+        _close(grads[uivr.ALBEDO_KEY], grgb, "grad colour")
+    h.enable_counters(False)
+    # ... and equals the two stand-alone HIP integrators on the same scene
+    drt = uivr.load_dict(dict(type="volpathsimple", **props))
+    nrf = uivr.load_dict(dict(type="nerf", queries_per_ray=24))
+    Ld, _, _ = drt.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    Ln, _, _ = nrf.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    assert torch.equal(L[:, :3], Ln) and torch.equal(L[:, 3:], Ld)
+
+
 def test_fused_equals_the_two_standalone_integrators(uivr, gpu):
     from uivr_amd import synthetic
     sg = synthetic.smoke_scene(res=48, film=64, device=gpu, optical_side=12.0)

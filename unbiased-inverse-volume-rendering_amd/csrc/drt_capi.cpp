@@ -1080,8 +1080,7 @@ static int fused_prepare(drt_handle h, drt::Params &P, const drt_nerf_config *cf
 {
     if (!cfg) return fail(h, DRT_ERR_INVALID_ARGUMENT, "fused: null nerf config");
     if (cfg->queries_per_ray < 2) return fail(h, DRT_ERR_INVALID_ARGUMENT, "queries_per_ray must be >= 2");
-    if (h->base.env_pix) return fail(h, DRT_ERR_UNSUPPORTED, "the fused pass supports the constant emitter only");
-    if (h->base.mgrid) return fail(h, DRT_ERR_UNSUPPORTED, "the fused pass needs the global majorant (majorant_resolution_factor 0)");
+    // (either emitter, either kind of majorant: drt_fused.hip and its three sibling translation units)
     const drt::Params &B = h->base;
     const size_t nbx = ((size_t) B.rx + 2) / 3, quads = nbx * (size_t) B.ry * (size_t) B.rz * 16;
     if (quads > 0x7fffffffull) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the four-channel copy");

@@ -43,7 +43,10 @@ hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t 
 hipError_t launch_untile(const Params &P, hipStream_t stream);
 // fused nerf + volpathsimple pass over the interleaved four-channel grid (drt_fused.hip)
 hipError_t launch_brick_grid4(const float *sigma_t, const float *rgb, float4 *dst, int rx, int ry, int rz, int nbx, hipStream_t stream);
-hipError_t launch_fused(const Params &P, bool adjoint, bool count, hipStream_t stream);
+hipError_t launch_fused(const Params &P, bool adjoint, bool count, hipStream_t stream);   // picks one of the four below
+hipError_t launch_fused_env(const Params &P, bool adjoint, bool count, hipStream_t stream);
+hipError_t launch_fused_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
+hipError_t launch_fused_env_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
 
 // Deferred splatting (drt_deferred.hip): record streams -> tile partition -> LDS reduction.
 constexpr int kTileX = 32, kTileY = 16, kTileZ = 16;   // base-corner cells per tile; LDS tile = 33 x 17 x 17 floats
