@@ -59,6 +59,40 @@ def committed_traffic(key):
     return None, None
 
 
+LDS_ADD_U64_PEAK = 3.4e12          # ds_add_u64 on random addresses of a 9.5 k-entry tile, whole chip (tools/ubench/lds_atomic_rate.hip)
+
+
+def committed_secondary(key, counters_adjoint):
+    """SURVEY.md 8d's secondary ceilings for workload `key`, from the committed utilisation counter pass
+    (tools/pmc_to_util.py; hash-gated like `committed_traffic`): lanes active per vector instruction and VALU-busy of the
+    tracer kernels, and the LDS-atomic rate of tile_reduce (its adds follow from this run's event counters: 8 corners per
+    sigma_t record, 24 more per colour record) against the measured ds_add_u64 ceiling.  None without a matching profile."""
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    try:
+        with open(tpath) as f:
+            tj = json.load(f)
+    except Exception:
+        return None
+    util = tj.get("_util:" + key)
+    if tj.get("source_sha16") != kernel_source_sha16() or not util:
+        return None
+    out = {"source": f"profiles/roofline_traffic.json _util:{key} (rocprofv3 PMC pass + kernel trace over these kernel sources)",
+           "kernels": {}}
+    for k, v in util.items():
+        counting = "<true, true" in k or "<false, true" in k                      # (the instantiation the counter step runs)
+        if ("trace_" in k or "fused_kernel" in k) and not counting and (v.get("avg_ms") or 0) > 0.05:
+            out["kernels"][k] = {"avg_ms": v["avg_ms"], "lanes_active": v["lanes_active"], "valu_busy": v["valu_busy"]}
+    tr = next((v for k, v in util.items() if "tile_reduce_kernel" in k), None)
+    if tr and tr.get("avg_ms") and counters_adjoint:
+        c = counters_adjoint
+        adds = 8 * (c["n_tr"] + c["n_rt_adj"] + c["n_sc"]) + 24 * c["n_sc_alb"]
+        rate = adds / (tr["avg_ms"] * 1e-3)
+        out["tile_reduce"] = {"avg_ms": tr["avg_ms"], "lds_adds_per_launch": adds, "lds_add_rate": round(rate / 1e12, 3),
+                              "unit": "T adds/s", "peak": LDS_ADD_U64_PEAK / 1e12, "frac": round(rate / LDS_ADD_U64_PEAK, 4),
+                              "lanes_active": tr["lanes_active"], "valu_busy": tr["valu_busy"]}
+    return out
+
+
 def algorithmic_bytes(cnt, n_samples, primal_io=True, adjoint_io=True):
     """32 B per sigma_t lookup, 96 B per albedo lookup, 64 B per sigma_t
     splat, 192 B per albedo splat; ray I/O: primal out 12 B L (+24 B o,d when rays are
@@ -133,6 +167,7 @@ def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=Non
                     "roofline": {"bound": "hbm", "kernel": "adjoint pass (tracer + record partition + tile_reduce)",
                                  "achieved": round(ach_a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_a / HBM_PEAK_GBS, 5),
                                  "traffic": committed_traffic(traffic_key)[0] if traffic_key else None,
+                                 "secondary": committed_secondary(traffic_key, ca) if traffic_key else None,
                                  "algorithmic_bytes_per_launch": b_a, "avg_launch_ms": round(avg_pass, 4),
                                  "sum_tracer_ms": round(avg_a, 4), "sum_reduction_ms": round(avg_r, 4),
                                  "bytes_per_sample_h1": round((b_p + b_a) / n, 1),
@@ -271,8 +306,11 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
         out3["msamples_per_s"] = round(out3["value"] * 32768 * (1024 + 2 * 16) / 1e6, 1)
         return out3
 
-    def cfg5_fused():
+    def cfg5_fused(env=False, factor=0):
         sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+        sc.medium.majorant_resolution_factor = factor
+        if env:
+            sc.emitter = u.EnvmapEmitter(pixels=envmap_pixels(2048, 1024), scale=1.0)
         integ = u.get_int_config("nerf-drt-fused").create(max_depth=64)
         sensor = sc.sensors[0]
         n_pixels, spp = sensor.width * sensor.height, 32
@@ -301,6 +339,11 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
         dt = (time.perf_counter() - t0) / steps
         t_p, t_pass = h.read_timings(0), h.read_timings(3)
         h.enable_timing(False)
+        if env or factor:                            # the side entry: rate and pass times only
+            h.release_scratch()
+            return {"value": round(batch.n_rays / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+                    "t_primal_ms": round(sum(t_p) / steps, 3) if t_p else None,
+                    "t_adjoint_pass_ms": round(sum(t_pass) / steps, 3) if t_pass else None}
         # event counts of one step -> algorithmic bytes with FOUR-CHANNEL events for the nerf queries (SURVEY.md 8d:
         # 128 B per four-channel lookup, 256 B per four-channel splat); the volpathsimple events as for the headline.
         # n_q = the nerf half's queries = fused sigma_t lookups - those of a volpathsimple-only pass over the same rays.
@@ -336,9 +379,16 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
         h.release_scratch(); hd.release_scratch()
         return {"value": round(n / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "n_samples_per_step": n,
                 "nerf_queries_per_step": n_q, "t_primal_ms": round(avg_p, 3), "t_adjoint_pass_ms": round(avg_pass, 3),
-                "roofline_adjoint": {"achieved_GBs": round(b_a / (avg_pass * 1e-3) / 1e9, 1) if avg_pass else None,
-                                     "frac": round(b_a / (avg_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_pass else None,
+                "roofline_adjoint": {"bound": "hbm",
+                                     # `frac`: the HBM-side COUNTER traffic over the pass time (what the memory system moved);
+                                     # the SURVEY 8d lookup-rate figure (every march step priced as an independent 8-corner access,
+                                     # mostly served by L2: above 1) is kept beside it as lookup_rate_*
+                                     "frac": (round(committed_traffic("fused-256-512x32")[0] / (avg_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                              if avg_pass and committed_traffic("fused-256-512x32")[0] else None),
+                                     "lookup_rate_GBs": round(b_a / (avg_pass * 1e-3) / 1e9, 1) if avg_pass else None,
+                                     "lookup_rate_frac": round(b_a / (avg_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_pass else None,
                                      "algorithmic_bytes": b_a,
+                                     "secondary": committed_secondary("fused-256-512x32", ca),
                                      # HBM-side bytes of the adjoint pass from the request-size counters (committed profile of
                                      # these kernel sources, or null) and the bandwidth they mean over the measured pass time
                                      "traffic": committed_traffic("fused-256-512x32")[0],
@@ -346,12 +396,13 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
                                                      if avg_pass and committed_traffic("fused-256-512x32")[0] else None),
                                      "traffic_frac": (round(committed_traffic("fused-256-512x32")[0] / (avg_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                                       if avg_pass and committed_traffic("fused-256-512x32")[0] else None)},
-                "roofline_primal": {"achieved_GBs": round(b_p / (avg_p * 1e-3) / 1e9, 1) if avg_p else None,
-                                    "frac": round(b_p / (avg_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_p else None,
+                "roofline_primal": {"lookup_rate_GBs": round(b_p / (avg_p * 1e-3) / 1e9, 1) if avg_p else None,
+                                    "lookup_rate_frac": round(b_p / (avg_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_p else None,
                                     "algorithmic_bytes": b_p},
                 "roofline_note": "SURVEY 8d convention (every lookup / splat priced as an independent 8-corner access); "
-                                 "consecutive march steps of one ray share cache lines, so this is a lookup rate served "
-                                 "mostly by L2 and `frac` can exceed 1 - it is not HBM traffic",
+                                 "consecutive march steps of one ray share cache lines, so lookup_rate_* is a lookup rate served "
+                                 "mostly by L2 and can exceed 1 - `frac` is the counter traffic; the pass is bound by tile_reduce's "
+                                 "LDS adds (secondary.tile_reduce)",
                 "workload": "config 5 as BASELINE states it: nerf (128 queries) FUSED with volpathsimple-drt in one pass over the "
                             "interleaved [sigma_t,r,g,b] grid, 256^3, 512x512x32spp"}
 
@@ -362,7 +413,14 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
     guarded("config3_optimize_loop", cfg3)
     guarded("config4_512_rank_share_1024x64", cfg4)
     guarded("config5_nerf_256_512x32", cfg5)
-    guarded("config5_fused_nerf_drt_256_512x32", cfg5_fused)
+    def cfg5_fused_both():
+        r = cfg5_fused()
+        # the reference's nerf scenes are lit by an environment map and use majorant_resolution_factor 8 (scene_config.py:36,102-141):
+        # the same pass in that set-up (the volpathsimple half then tracks through the supergrid on every path's own lane)
+        r["envmap_factor8"] = cfg5_fused(env=True, factor=8)
+        return r
+
+    guarded("config5_fused_nerf_drt_256_512x32", cfg5_fused_both)
     return out
 
 
@@ -523,6 +581,10 @@ def main():
         "bound": "hbm", "kernel": ("adjoint pass (sample(Backward)): " + ("trace_sq_kernel<adjoint>" if args.majorant_factor else "trace_coop_kernel<adjoint>") + " (dominant, sum_tracer_ms) + record partition + tile_reduce"),
         "achieved": round(ach_a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(ach_a / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+        # what actually binds the pass (SURVEY.md 8d "secondary ceilings"): vector-instruction issue of the tracers (lanes
+        # active, VALU-busy) and the LDS-atomic rate of tile_reduce; from the committed counter pass, hash-gated like `traffic`
+        "secondary": committed_secondary(f"{args.workload}-{args.res}-{args.film}x{spp}" +
+                                         (f"-factor{args.majorant_factor}" if args.majorant_factor else ""), cnt_a),
         "algorithmic_bytes_per_launch": bytes_a, "avg_launch_ms": round(avg_pass, 4),
         "sum_tracer_ms": round(avg_a, 4), "sum_reduction_ms": round(avg_r, 4),
         "bytes_per_sample_h1": round((bytes_p + bytes_a) / n_local, 1),

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc CSVs (tools/pmc_util.txt pass) + the kernel-trace summary -> "_util:<key>" of profiles/roofline_traffic.json:
+the SECONDARY ceilings SURVEY.md 8d asks for next to the HBM roofline, per kernel of the step -
+
+  lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)      (share of the 64 lanes a vector instruction has work for)
+  valu_busy    = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles)   (SQ_ACTIVE_INST_* count quad-cycles, MI355X_MICROARCH.md;
+                 kernel cycles = SQ_BUSY_CYCLES / 32 shader engines)
+  avg_ms       = the kernel's average duration in the rocprofv3 --kernel-trace --stats pass of the same command
+
+    python tools/pmc_to_util.py <dir with *counter_collection.csv> <kernel_stats.csv> <workload key> [out.json]
+
+Hash-gated like the traffic figures (bench.kernel_source_sha16): bench.py quotes them only for the sources they came from.
+"""
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha16
+
+root, stats, key = sys.argv[1], sys.argv[2], sys.argv[3]
+out = sys.argv[4] if len(sys.argv) > 4 else "profiles/roofline_traffic.json"
+
+
+def short(k):
+    return k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    per = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        if "drt::" in r["Kernel_Name"]:
+            per[(short(r["Kernel_Name"]), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    for (k, d, c), v in per.items():
+        acc[k][c].append(v)
+ms = {}
+for r in csv.DictReader(open(stats)):
+    ms[short(r["Name"])] = float(r["AverageNs"]) / 1e6
+util = {}
+for k in acc:
+    m = lambda c: (sum(acc[k][c]) / len(acc[k][c])) if acc[k].get(c) else 0.0
+    a, t, b = m("SQ_ACTIVE_INST_VALU"), m("SQ_THREAD_CYCLES_VALU"), m("SQ_BUSY_CYCLES")
+    if a <= 0 or b <= 0:
+        continue
+    util[k] = {"lanes_active": round(t / (64.0 * a), 4), "valu_busy": round(4.0 * a / (1024.0 * b / 32.0), 4),
+               "valu_insts": m("SQ_INSTS_VALU"), "salu_insts": m("SQ_INSTS_SALU"), "avg_ms": round(ms.get(k, 0.0), 4) or None}
+sha = kernel_source_sha16()
+res = {}
+if os.path.exists(out):
+    try:
+        old = json.load(open(out))
+        if old.get("source_sha16") == sha:
+            res = old
+    except Exception:
+        res = {}
+res["source_sha16"] = sha
+res["_util:" + key] = util
+res["_util_method"] = __doc__.split("\n\n")[1]
+json.dump(res, open(out, "w"), indent=1)
+for k, v in sorted(util.items(), key=lambda kv: -(kv[1]["avg_ms"] or 0)):
+    if (v["avg_ms"] or 0) > 0.05:
+        print(f"{k:78s} {v['avg_ms']:8.3f} ms  lanes active {v['lanes_active']:.3f}  VALU busy {v['valu_busy']:.3f}")

@@ -289,7 +289,8 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         //  are too coarse to be scheduled: measured 3-5 % slower in that order than in index order)
         // (and launches of fewer than 1.5 M rays - six rounds of the chip's 196 608 lanes - gain nothing: 512^2 x 4 spp 1.53 -> 1.69 ms,
         //  x 8 spp 1.89 -> 1.79 ms, x 32 spp 4.17 -> 3.75 ms; test hook 1073741824 orders launches from 4096 rays on)
-        const uint64_t min_span = dbg(h->debug_flags, 1073741824u) ? 4096u : (3u << 19);
+        //  round 4, queued tracer: a rank's share of the headline at 8 GPUs, 512^2 x 32 spp / 8 = 1 M rays: step 3.83 -> 3.68 ms in that order)
+        const uint64_t min_span = dbg(h->debug_flags, 1073741824u) ? 4096u : (1u << 20);
         if (span >= min_span && span < (1ull << 31) && unit <= 256u && !dbg(h->debug_flags, 536870912u)) {
             const uint32_t units = (uint32_t) ((span + unit - 1) / unit);
             const size_t need = drt::super_order_bytes(units);

@@ -53,6 +53,9 @@
 #ifndef DRT_SQ_MAXPOLL
 #define DRT_SQ_MAXPOLL 3           // polls with nothing full to do before a partial batch is taken
 #endif
+#ifndef DRT_SQ_TAIL_FAST
+#define DRT_SQ_TAIL_FAST 1         // a workgroup whose ray queues are drained takes partial batches at once (no polls: its last paths are latency)
+#endif
 #ifndef DRT_SQ_EARLY_OUT
 #define DRT_SQ_EARLY_OUT 1         // flights that cannot collide (target optical depth > largest majorant x segment length) are not walked
 #endif
@@ -253,10 +256,10 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         else if (n_regen >= DRT_SQ_REGEN_MIN || (drained && n_regen)) { kind = SQ_REGEN; min_n = 1; }
         else if (n_walk) kind = SQ_WALK;
         else if (n_coll | n_trans | n_regen) {
-            if (polls < DRT_SQ_MAXPOLL) { ++polls; SQ_PROF(8, 1); __builtin_amdgcn_s_sleep(4); continue; }
+            if (polls < ((DRT_SQ_TAIL_FAST && drained) ? 0 : DRT_SQ_MAXPOLL)) { ++polls; SQ_PROF(8, 1); __builtin_amdgcn_s_sleep(4); continue; }
             kind = (n_coll >= n_trans && n_coll >= n_regen) ? SQ_COLL : (n_trans >= n_regen ? SQ_TRANS : SQ_REGEN);
             min_n = 1;
-        } else { SQ_PROF(8, 1); __builtin_amdgcn_s_sleep(8); continue; }
+        } else { SQ_PROF(8, 1); if (DRT_SQ_TAIL_FAST >= 2 && drained) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8); continue; }
 
         SQ_STAMP(8);
         if (kind == SQ_WALK) {
