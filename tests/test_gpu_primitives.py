@@ -183,6 +183,33 @@ def test_grad_block_mask_matches_definition(uivr, gpu, block):
         native().grad_block_mask(0, dev_body.data_ptr(), 1, 96, mask.data_ptr())
 
 
+@pytest.mark.parametrize("variant,factor", [("drt", 0), ("drt", 4), ("basic", 0), ("quadratic", 0)])
+def test_gradient_support_covers_every_nonzero_gradient_block(uivr, gpu, variant, factor):
+    """distributed.gradient_support (the packing set of the ONE-collective gradient all-reduce, known before the adjoint
+    pass from sigma_t alone): every non-zero 256-byte block of the gradient buffer the adjoint pass produces lies inside
+    it - for the registered estimators, with and without a majorant supergrid - and it is a real restriction (the albedo
+    planes of a sparse volume are mostly outside)."""
+    from conftest import props_for
+    from uivr_amd import synthetic
+    from uivr_amd.distributed import COMPACT_BLOCK_FLOATS as B, _block_mask, gradient_support
+    sg = synthetic.smoke_scene(res=48, film=64, device=gpu, optical_side=10.0)
+    sg.medium.majorant_resolution_factor = factor
+    assert float((sg.medium.sigma_t == 0).float().mean()) > 0.3                 # a sparse volume
+    integ = uivr.load_dict(dict(type="volpathsimple", **props_for(variant)))
+    spp = 8
+    gi = (torch.rand((64 * 64, 3), device=gpu) - 0.5) * 1e-2
+    for seed in (3, 4):
+        grads = uivr.render_backward(sg, integ, gi, sensor=0, spp=spp, seed=seed)
+        sup = gradient_support(sg.medium.sigma_t, grads, sparse_keys=(uivr.ALBEDO_KEY,))
+        assert sup is not None
+        flat = grads["_flat"]
+        n_full = (flat.numel() // B) * B
+        got = _block_mask(flat[:n_full].view(-1, B))
+        assert int((got & (1 - sup.mask)).sum()) == 0
+        assert float(grads[uivr.ALBEDO_KEY].abs().max()) > 0 and float(grads[uivr.SIGMA_T_KEY].abs().max()) > 0
+        assert sup.count < 0.8 * sup.mask.numel()
+
+
 @pytest.mark.parametrize("spp", [1, 7, 32, 128, 200, 1024])
 def test_film_develop_is_the_sample_mean(uivr, gpu, spp):
     """Box film (python/batched.py:176-197): image = mean over the pixel's samples - the thread-per-channel kernel

@@ -23,6 +23,7 @@ def main():
     B = D.COMPACT_BLOCK_FLOATS
     g = torch.Generator().manual_seed(5)
     for active in (0.1, 0.9):
+        D.reset_allreduce_state()                                     # (a packing set agreed on for other data would be outgrown)
         flat = torch.zeros(2000 * B + 13)
         blocks = torch.rand(2000, generator=g) < active
         flat[:2000 * B] = (torch.randn(2000, B, generator=g) * blocks[:, None]).reshape(-1)
@@ -36,6 +37,34 @@ def main():
             torch.cuda.synchronize()
             assert torch.equal(f, ref), (active, mode, st)
             assert st["mode"] == {"always": "compact", "never": "dense"}.get(mode, "compact" if active < 0.5 else "dense"), (mode, st)
+    # ONE collective, no host wait: the packing set is known beforehand (GradientSupport); the check travels in the packed
+    # buffer and is looked at by the next call / verify_pending
+    D.reset_allreduce_state()
+    mask = torch.zeros(2000, dtype=torch.uint8)
+    mask[100:400] = 1
+    sup = D.GradientSupport(mask.to(dev), 2000 * B + 13)
+    assert sup.count == 300
+    flat = torch.zeros(2000 * B + 13)
+    flat[150 * B:350 * B] = torch.randn(200 * B, generator=g)
+    flat[2000 * B:] = 2.0
+    flat = flat.to(dev)
+    ref = flat.clone()
+    st = {}
+    D._allreduce_flat(flat, None, "auto", st, sup)
+    assert st["mode"] == "compact" and st["collectives"] == 1 and st["sent_floats"] == 300 * B + 13 + 1, st
+    D.verify_pending()
+    assert torch.equal(flat, ref)
+    flat[1000 * B + 5] = 1.0                                          # outside the support: found, raised by the next look
+    D._allreduce_flat(flat, None, "auto", {}, sup)
+    try:
+        D.verify_pending()
+        raise AssertionError("a violated GradientSupport went unnoticed")
+    except RuntimeError as e:
+        assert "GradientSupport" in str(e)
+    st = {}
+    D._allreduce_flat(flat, None, "auto", st, sup, True)              # strict: looked at right away, dense sums
+    assert st["mode"] == "dense" and st.get("outgrown"), st
+    D.reset_allreduce_state()
     loss = torch.tensor(1.25, device=dev)
     dist.all_reduce(loss)
     assert float(loss) == 1.25

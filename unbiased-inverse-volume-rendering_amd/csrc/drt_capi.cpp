@@ -250,7 +250,11 @@ hipError_t early_histogram_between(void *ctx)
     hipError_t e = drt::launch_deferred_split(*h->early_plan, h->stream);
     if (e == hipSuccess) e = hipEventRecord(h->ev_split, h->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ev_split, 0);
+    // (timed like the rest of the reduction: its own event pair on the side stream, summed into the reduction time)
+    hipEvent_t ta = nullptr, tb = nullptr;
+    if (e == hipSuccess && h->timing) { e = hipEventCreate(&ta); if (e == hipSuccess) e = hipEventCreate(&tb); if (e == hipSuccess) e = hipEventRecord(ta, h->side); }
     if (e == hipSuccess) e = drt::launch_deferred_early_histogram(*c->P, *h->early_plan, h->side);
+    if (e == hipSuccess && h->timing) { e = hipEventRecord(tb, h->side); if (e == hipSuccess) h->timed[2].emplace_back(ta, tb); }
     if (e == hipSuccess) e = hipEventRecord(h->ev_hist, h->side);
     return e;
 }

@@ -29,6 +29,7 @@
 // one-voxel apron on the high side.  The sigma_t values already carry the medium `scale`.  Sum order differs
 // from the atomic path (as it does between two runs of the atomic path); the parity tolerance on gradients
 // is unchanged.
+#include <atomic>
 #include "drt_device.h"
 #include "drt_launch.h"
 
@@ -443,7 +444,7 @@ hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStr
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D);
     mark(3);
     {   // (the attribute belongs to the function on a device: set once per device)
-        static bool attr_set[64] = { false };
+        static std::atomic<bool> attr_set[64];                   // (zero-initialised; handles may be driven from several host threads)
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
         if (!attr_set[dev] || dev == 63) {

@@ -22,6 +22,7 @@
 // radiance is bit-exact per ray, counters are equal; gradients differ by summation order only.  A ray computes the same
 // numbers whichever lanes run its pieces.  Not handled here (the host keeps drt_super.hip / the one-ray-per-lane kernels):
 // supergrids whose bf16 majorants do not fit LDS next to the ray records, quadratic DRT, the atomic gradient path.
+#include <atomic>
 #include "drt_device.h"
 #include "drt_launch.h"
 
@@ -1031,7 +1032,7 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
 #define DRT_SQ_LAUNCH(A, C, E)                                                                                    \
     do {                                                                                                          \
         auto kern = trace_sq_kernel<A, C, E>;                                                                     \
-        static size_t lds_set[64] = { 0 };                                                                        \
+        static std::atomic<size_t> lds_set[64];                                                                        \
         int dev_ = 0;                                                                                             \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 63;                               \
         if (lds > lds_set[dev_] || dev_ == 63) {                                                                  \

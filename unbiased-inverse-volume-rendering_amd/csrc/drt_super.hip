@@ -36,6 +36,7 @@
 // splats as records (drt_deferred.hip) and reads the path cache its primal pass wrote.  Not handled here (the host
 // keeps the one-ray-per-lane kernels for them): quadratic DRT (use_drt && !use_drt_subsampling), the atomic gradient
 // path, supergrids with more than 511 cells along an axis.
+#include <atomic>
 #include "drt_device.h"
 #include "drt_launch.h"
 
@@ -1111,7 +1112,7 @@ hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_c
         auto kern = trace_super_kernel<A, C, E, M>;                                                               \
         /* (the attribute belongs to the function ON A DEVICE: remembered per device; the kernels of one handle are \
             launched from one host thread, handles on different devices keep different entries) */                 \
-        static size_t lds_set[64] = { 0 };                                                                        \
+        static std::atomic<size_t> lds_set[64];                                                                        \
         int dev_ = 0;                                                                                             \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 63;                               \
         if (lds > lds_set[dev_] || dev_ == 63) {                                                                  \

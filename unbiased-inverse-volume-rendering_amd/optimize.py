@@ -356,12 +356,23 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
         # that are sums over entries, and needs at least one entry per rank (an empty share's loss is 0 / 0)
         separable = (_losses.l1, _losses.l2, _losses.huber, _losses.average, _losses.mean_relative_absolute_error,
                      _losses.mean_relative_squared_error)
-        if opt_config.loss not in separable:
+        import functools
+        loss_fn = opt_config.loss
+        while isinstance(loss_fn, functools.partial):            # e.g. partial(huber, delta=...): still a sum over entries
+            loss_fn = loss_fn.func
+        if loss_fn not in separable:
             raise ValueError(f"sharded run_optimization needs a loss that is a sum over image entries (l1, l2, huber, "
                              f"mean_relative_*), not {getattr(opt_config.loss, '__name__', opt_config.loss)!r}: its gradient "
                              f"is not the sum of the ranks' partial gradients")
         if opt_config.batch_size is not None and opt_config.batch_size < shard.world:
             raise ValueError(f"batch_size {opt_config.batch_size} < world size {shard.world}: some ranks would get no entry")
+        if opt_config.batch_size is None:
+            # sensor mode: the image's pixels are dealt out in chunks; an image with fewer than chunk_pixels * world pixels
+            # (or not a multiple of it) leaves ranks empty - their 0 / 0 loss would spread through the all-reduce
+            for s_idx in scene_config.sensors:
+                sen = scene_config.scene.sensors[s_idx]
+                if shard.n_local_pixels(sen.width * sen.height) <= 0:      # (raises itself when the image cannot be dealt)
+                    raise ValueError(f"sensor {s_idx}: {sen.width}x{sen.height} pixels leave ranks of a world of {shard.world} empty")
     int_config = get_int_config(int_config)
     if int_config.name == 'nerf-drt-fused':
         raise ValueError("'nerf-drt-fused' renders two images per ray ([n, 6]: nerf | volpathsimple) for the fused benchmark pass; "
