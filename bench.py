@@ -621,6 +621,9 @@ def main():
         ob.h1_step(osc, integ.props(), cpu_spp, seed_c, grad_cache_log2=16)
         dt_cached = time.perf_counter() - tc
         dt = min(dt_atomic, dt_cached)
+        tc = time.perf_counter()
+        ob.render_primal(osc, integ.props(), cpu_spp, seed_c)                  # the primal pass alone (no gradient grids)
+        dt_primal = time.perf_counter() - tc
         cpu_baseline = {
             "value": round(n_pixels * cpu_spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores,
             "kind": "port",
@@ -630,6 +633,9 @@ def main():
                       f"(the reference's llvm_ad_rgb needs Mitsuba 3 / Dr.Jit, absent here)",
             "value_shared_atomics": round(n_pixels * cpu_spp / dt_atomic / 1e6, 4),
             "value_thread_local_cache": round(n_pixels * cpu_spp / dt_cached / 1e6, 4),
+            # where the port's time goes: the primal pass alone runs an order of magnitude faster than the step - the adjoint's
+            # ~100 fp64 adds per sample into grids shared by all threads (537 MB at 256^3) bound it, not the tracking
+            "primal_pass_only": round(n_pixels * cpu_spp / dt_primal / 1e6, 4),
         }
 
     # ---- the other BASELINE configurations (outside the timed loop; N = 1 only) ---------
