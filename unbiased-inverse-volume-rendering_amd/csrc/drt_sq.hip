@@ -57,6 +57,12 @@
 #ifndef DRT_SQ_TAIL_FAST
 #define DRT_SQ_TAIL_FAST 1         // a workgroup whose ray queues are drained takes partial batches at once (no polls: its last paths are latency)
 #endif
+#ifndef DRT_SQ_T_PASS
+#define DRT_SQ_T_PASS 24           // a transition batch goes round again while at least this many of its rays are not at their next walk yet (flights
+                                   // that cannot collide end their walk in the set-up; adjoint: walks out of the path cache); fewer go back to the
+                                   // transition queue and meet a full batch: a pass for a few lanes costs the wave as much as one for 64
+                                   // (measured 1 / 8 / 16 / 24 / 32 / 48: headline 792 / 809 / 815 / 823 / 815 / 804 Msamples/s, profiles/r04_sq_experiments.txt)
+#endif
 #ifndef DRT_SQ_EARLY_OUT
 #define DRT_SQ_EARLY_OUT 1         // flights that cannot collide (target optical depth > largest majorant x segment length) are not walked
 #endif
@@ -927,7 +933,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
             }
             SQ_STAMP(6);
-            if (kind == SQ_COLL || !__ballot(ph >= SP_HEAD && ph < SP_IDLE)) break;
+            if (kind == SQ_COLL || __popcll(__ballot(ph >= SP_HEAD && ph < SP_IDLE)) < DRT_SQ_T_PASS) break;   // (what is left goes to the transition queue)
         }
 
         // ================= store the rays, hand them on ====================================================
