@@ -63,6 +63,9 @@
                                    // transition queue and meet a full batch: a pass for a few lanes costs the wave as much as one for 64
                                    // (measured 1 / 8 / 16 / 24 / 32 / 48: headline 792 / 809 / 815 / 823 / 815 / 804 Msamples/s, profiles/r04_sq_experiments.txt)
 #endif
+#ifndef DRT_SQ_RT2
+#define DRT_SQ_RT2 1               // adjoint kernels: the "NEE walk finished" block a second time behind the emitter direction block
+#endif
 #ifndef DRT_SQ_EARLY_OUT
 #define DRT_SQ_EARLY_OUT 1         // flights that cannot collide (target optical depth > largest majorant x segment length) are not walked
 #endif
@@ -599,6 +602,36 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         // ================= (B) path transitions (transition / regeneration batches), (Fs) the next flight ==============
         // A pass takes every ray of the batch to its next walk (or to the end of its path); rays whose walk comes out of
         // the path cache (adjoint pass), or whose next flight cannot collide, go round once more.
+        // ---- NEE walk finished (:388-403): at the head of a pass and, in the adjoint kernels, once more behind the emitter direction
+        // block - a main path whose walks come out of the path cache then does a whole bounce (phase sampling, loop head, collision,
+        // emitter direction, this block) in ONE pass
+        auto rt_end_block = [&]() {
+            if constexpr (!ADJ) {
+                if (ph == SP_RT_END && pc_on && pc_it < (int) P.path_cache_cap)
+                    P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1] =
+                        make_uint4(__float_as_uint(wt), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
+            }
+            if (ph == SP_RT_END) {
+                float val[3], contrib[3];
+                const float ds_pdf = emitter_sample_value<ENV>(P, rd, val);      // recomputed from the direction
+                const float w = mis_weight(ds_pdf, kInvFourPi);             // :391
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    contrib[k] = ((beta[k] * kInvFourPi) * w) * (val[k] * wt);
+                    result[k] = (ADJ && !rec_mode) ? result[k] - contrib[k] : result[k] + contrib[k];   // :211-214
+                }
+                ph = SP_PHASE;
+                if constexpr (ADJ) {
+                    if (!rec_mode) {                                        // replay with the clone (:393-401)
+                        adjsum = (dL[0] * contrib[0] + dL[1] * contrib[1]) + dL[2] * contrib[2];
+                        uint64_t tmp = S.state; S.state = Cst; Cst = tmp;
+                        (void) S.next_1d(); (void) S.next_1d();             // same direction again (:418)
+                        if (nt0 < kInf) { wo = ro; wmax = nt0; wt = 1.0f; ph = SP_RTA; fl = SF_NEW; }
+                        else ph = SP_RTA_END;
+                    }
+                }
+            }
+        };
         for (;;) {
             if (kind != SQ_COLL && __ballot(ph >= SP_HEAD && ph < SP_IDLE)) {
                 uint4 pce1 = make_uint4(0u, 0u, 0u, 0u); bool pce1_ok = false;   // this iteration's NEE entry of the path cache, read at the loop head
@@ -627,32 +660,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     }
                 }
 
-                // ---- NEE walk finished (:388-403) -------------------------------------------------------------
-                if constexpr (!ADJ) {
-                    if (ph == SP_RT_END && pc_on && pc_it < (int) P.path_cache_cap)
-                        P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1] =
-                            make_uint4(__float_as_uint(wt), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
-                }
-                if (ph == SP_RT_END) {
-                    float val[3], contrib[3];
-                    const float ds_pdf = emitter_sample_value<ENV>(P, rd, val);      // recomputed from the direction
-                    const float w = mis_weight(ds_pdf, kInvFourPi);             // :391
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        contrib[k] = ((beta[k] * kInvFourPi) * w) * (val[k] * wt);
-                        result[k] = (ADJ && !rec_mode) ? result[k] - contrib[k] : result[k] + contrib[k];   // :211-214
-                    }
-                    ph = SP_PHASE;
-                    if constexpr (ADJ) {
-                        if (!rec_mode) {                                        // replay with the clone (:393-401)
-                            adjsum = (dL[0] * contrib[0] + dL[1] * contrib[1]) + dL[2] * contrib[2];
-                            uint64_t tmp = S.state; S.state = Cst; Cst = tmp;
-                            (void) S.next_1d(); (void) S.next_1d();             // same direction again (:418)
-                            if (nt0 < kInf) { wo = ro; wmax = nt0; wt = 1.0f; ph = SP_RTA; fl = SF_NEW; }
-                            else ph = SP_RTA_END;
-                        }
-                    }
-                }
+                rt_end_block();
                 if constexpr (ADJ) {
                     if (ph == SP_RTA_END) { S.state = Cst; ph = SP_PHASE; }     // back to the primary stream
                 }
@@ -791,6 +799,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     else { wt = 0.0f; ph = SP_RT_END; }
                 }
                 // ---- end of a path (:249-287) -----------------------------------------------------
+                if constexpr (ADJ && DRT_SQ_RT2) {
+                    if (__ballot(ph == SP_RT_END)) rt_end_block();              // (the value walk came out of the path cache)
+                }
                 SQ_BLK(6, ph == SP_END);
                 if (ph == SP_END) {
                     if (!ADJ || rec_mode) {                                     // envmap block, primal only
