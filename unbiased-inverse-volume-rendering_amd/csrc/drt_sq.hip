@@ -94,8 +94,22 @@ enum SqPhase : int {
     SP_IDLE, SP_NONE
 };
 enum SqFlight : int { SF_NEW = 0, SF_NEXT = 1, SF_WAIT = 2 };   // first flight of a walk to set up | next flight to set up | posted
-enum SqKind : int { SQ_WALK = 0, SQ_COLL, SQ_TRANS, SQ_REGEN, SQ_KINDS };
+#ifndef DRT_SQ_SPLIT
+#define DRT_SQ_SPLIT 1             // two queues of transitions: 1 in the adjoint kernels, 2 in all, 0 in none (measured, headline primal / adjoint
+                                   // ms: none 2.67 / 5.27, all 2.75 / 5.21; config 2: 1.98 / 3.89, 1.97 / 3.80; profiles/r04_sq_experiments.txt)
+#endif
+// queues: flights to walk | collisions to evaluate | path transitions, by the block a ray enters them with - TA: a real collision /
+// an escape / the DRT vertex / the emitter direction / the end of a path (the rays that come from a delta-tracking or DRT walk), TB:
+// the end of a transmittance walk / phase sampling / the loop head (the rays that come from a ratio-tracking walk) - | free records.
+// (One queue gave batches whose rays needed different blocks: each block ran with 14-27 of 64 lanes, profiles/r04_sq_experiments.txt.)
+enum SqKind : int { SQ_WALK = 0, SQ_COLL, SQ_TA, SQ_TB, SQ_REGEN, SQ_KINDS };
 constexpr uint32_t kSqEmpty = 0xffffu;
+template <bool SPLIT>
+__device__ __forceinline__ int sq_trans_kind(int ph)
+{
+    if (!SPLIT) return SQ_TB;
+    return (ph == SP_RT_END || ph == SP_RTA_END || ph == SP_PHASE || ph == SP_HEAD) ? SQ_TB : SQ_TA;
+}
 
 typedef __attribute__((address_space(3))) volatile uint32_t sq_vu32;
 typedef __attribute__((address_space(3))) volatile uint16_t sq_vu16;
@@ -256,18 +270,21 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         uint32_t qn = 0;
         if (lane < (uint32_t) SQ_KINDS) { const unsigned long long c = ((sq_vu64 *) ctl)[lane]; qn = (uint32_t) (c >> 32) - (uint32_t) c; }
         const uint32_t n_walk = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_WALK), n_coll = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_COLL);
-        const uint32_t n_trans = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_TRANS), n_regen = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_REGEN);
+        const uint32_t n_ta = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_TA), n_tb = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_TB);
+        const uint32_t n_regen = (uint32_t) __builtin_amdgcn_readlane((int) qn, SQ_REGEN);
         const uint32_t dead = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[0]);
         if (dead >= (uint32_t) NRAY) break;
         const bool drained = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[3]) >= 8u;
         int kind = -1; uint32_t min_n = DRT_SQ_BATCH;
         if (n_coll >= DRT_SQ_BATCH) kind = SQ_COLL;
-        else if (n_trans >= DRT_SQ_BATCH) kind = SQ_TRANS;
+        else if (n_ta >= DRT_SQ_BATCH) kind = SQ_TA;
+        else if (n_tb >= DRT_SQ_BATCH) kind = SQ_TB;
         else if (n_regen >= DRT_SQ_REGEN_MIN || (drained && n_regen)) { kind = SQ_REGEN; min_n = 1; }
         else if (n_walk) kind = SQ_WALK;
-        else if (n_coll | n_trans | n_regen) {
+        else if (n_coll | n_ta | n_tb | n_regen) {
             if (polls < ((DRT_SQ_TAIL_FAST && drained) ? 0 : DRT_SQ_MAXPOLL)) { ++polls; SQ_PROF(8, 1); __builtin_amdgcn_s_sleep(4); continue; }
-            kind = (n_coll >= n_trans && n_coll >= n_regen) ? SQ_COLL : (n_trans >= n_regen ? SQ_TRANS : SQ_REGEN);
+            const uint32_t best = max(max(n_coll, n_regen), max(n_ta, n_tb));            // the fullest queue
+            kind = n_coll == best ? SQ_COLL : n_ta == best ? SQ_TA : n_tb == best ? SQ_TB : SQ_REGEN;
             min_n = 1;
         } else { SQ_PROF(8, 1); if (DRT_SQ_TAIL_FAST >= 2 && drained) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8); continue; }
 
@@ -988,7 +1005,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         sq_fence();
         sq_push(ctl, q_lds, SQ_WALK, go_walk && !walk_done, id, lane);
         sq_push(ctl, q_lds, SQ_COLL, go_walk && walk_done, id, lane);
-        sq_push(ctl, q_lds, SQ_TRANS, go_trans, id, lane);
+        const int tk = sq_trans_kind<DRT_SQ_SPLIT == 2 || (DRT_SQ_SPLIT == 1 && ADJ)>(ph);
+        sq_push(ctl, q_lds, SQ_TA, go_trans && tk == SQ_TA, id, lane);
+        sq_push(ctl, q_lds, SQ_TB, go_trans && tk == SQ_TB, id, lane);
         sq_push(ctl, q_lds, SQ_REGEN, go_free, id, lane);
         SQ_STAMP(7);
     }
