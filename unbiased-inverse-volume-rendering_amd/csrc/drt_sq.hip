@@ -66,6 +66,9 @@
 #ifndef DRT_SQ_RT2
 #define DRT_SQ_RT2 1               // adjoint kernels: the "NEE walk finished" block a second time behind the emitter direction block
 #endif
+#ifndef DRT_SQ_PUSH_ALL
+#define DRT_SQ_PUSH_ALL 1          // a batch's rays go to their queues with ONE reserving LDS atomic (0: one sq_push per kind)
+#endif
 #ifndef DRT_SQ_EARLY_OUT
 #define DRT_SQ_EARLY_OUT 1         // flights that cannot collide (target optical depth > largest majorant x segment length) are not walked
 #endif
@@ -164,6 +167,31 @@ __device__ __forceinline__ void sq_push(unsigned long long *ctl, uint16_t *q, in
     if (pred) {
         const uint32_t rank = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
         ((sq_vu16 *) q)[kind * DRT_SQ_RING + ((tail + rank) & (DRT_SQ_RING - 1u))] = (uint16_t) id;
+    }
+}
+
+// a batch's rays to the queues of what they need next - `dest`: the lane's queue kind, or SQ_KINDS for none.  ONE LDS atomic
+// instruction reserves the positions of every kind (lane k reserves for kind k): the reservations of five sq_push calls in a
+// row each waited for their own returning atomic
+__device__ __forceinline__ void sq_push_all(unsigned long long *ctl, uint16_t *q, int dest, uint32_t id, uint32_t lane)
+{
+    uint64_t m[SQ_KINDS];
+#pragma unroll
+    for (int k = 0; k < SQ_KINDS; ++k) m[k] = __ballot(dest == k);
+    uint32_t mine = 0;                                                       // lane k: rays for kind k
+#pragma unroll
+    for (int k = 0; k < SQ_KINDS; ++k) mine = lane == (uint32_t) k ? (uint32_t) __popcll(m[k]) : mine;
+    uint32_t tail = 0;
+    if (lane < (uint32_t) SQ_KINDS && mine) tail = (uint32_t) (atomicAdd(ctl + lane, (unsigned long long) mine << 32) >> 32);
+    if (dest < SQ_KINDS) {
+        uint32_t t = 0; uint64_t mm = 0;
+#pragma unroll
+        for (int k = 0; k < SQ_KINDS; ++k) {
+            const uint32_t tk = (uint32_t) __builtin_amdgcn_readlane((int) tail, k);
+            if (dest == k) { t = tk; mm = m[k]; }
+        }
+        const uint32_t rank = (uint32_t) __popcll(mm & ((1ull << lane) - 1ull));
+        ((sq_vu16 *) q)[dest * DRT_SQ_RING + ((t + rank) & (DRT_SQ_RING - 1u))] = (uint16_t) id;
     }
 }
 
@@ -1003,12 +1031,16 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         }
         if (kind != SQ_COLL) __threadfence_block();                            // (the global part of the records)
         sq_fence();
+        const int tk = sq_trans_kind<DRT_SQ_SPLIT == 2 || (DRT_SQ_SPLIT == 1 && ADJ)>(ph);
+#if DRT_SQ_PUSH_ALL
+        sq_push_all(ctl, q_lds, go_walk ? (walk_done ? SQ_COLL : SQ_WALK) : go_trans ? tk : go_free ? SQ_REGEN : SQ_KINDS, id, lane);
+#else
         sq_push(ctl, q_lds, SQ_WALK, go_walk && !walk_done, id, lane);
         sq_push(ctl, q_lds, SQ_COLL, go_walk && walk_done, id, lane);
-        const int tk = sq_trans_kind<DRT_SQ_SPLIT == 2 || (DRT_SQ_SPLIT == 1 && ADJ)>(ph);
         sq_push(ctl, q_lds, SQ_TA, go_trans && tk == SQ_TA, id, lane);
         sq_push(ctl, q_lds, SQ_TB, go_trans && tk == SQ_TB, id, lane);
         sq_push(ctl, q_lds, SQ_REGEN, go_free, id, lane);
+#endif
         SQ_STAMP(7);
     }
 
