@@ -83,11 +83,12 @@ def committed_secondary(key, counters_adjoint):
         if ("trace_" in k or "fused_kernel" in k) and not counting and (v.get("avg_ms") or 0) > 0.05:
             out["kernels"][k] = {"avg_ms": v["avg_ms"], "lanes_active": v["lanes_active"], "valu_busy": v["valu_busy"]}
     tr = next((v for k, v in util.items() if "tile_reduce_kernel" in k), None)
-    if tr and tr.get("avg_ms") and counters_adjoint:
+    if tr and (tr.get("ms_per_step") or tr.get("avg_ms")) and counters_adjoint:
         c = counters_adjoint
         adds = 8 * (c["n_tr"] + c["n_rt_adj"] + c["n_sc"]) + 24 * c["n_sc_alb"]
-        rate = adds / (tr["avg_ms"] * 1e-3)
-        out["tile_reduce"] = {"avg_ms": tr["avg_ms"], "lds_adds_per_launch": adds, "lds_add_rate": round(rate / 1e12, 3),
+        t_ms = tr.get("ms_per_step") or tr["avg_ms"]               # (a step may run several reduce launches: ray sub-batches)
+        rate = adds / (t_ms * 1e-3)
+        out["tile_reduce"] = {"ms_per_step": t_ms, "lds_adds_per_step": adds, "lds_add_rate": round(rate / 1e12, 3),
                               "unit": "T adds/s", "peak": LDS_ADD_U64_PEAK / 1e12, "frac": round(rate / LDS_ADD_U64_PEAK, 4),
                               "lanes_active": tr["lanes_active"], "valu_busy": tr["valu_busy"]}
     return out
@@ -505,12 +506,15 @@ def main():
         seed = u.sample_tea_32(2 * i + 1, seed_base)[0]           # seed_grad of iteration i (optimize.py:328)
         sampler = u.IndependentSampler(seed, spp)
         grads["_flat"].zero_()
+        # N > 1: the blocks of the gradient buffer that can be non-zero, from the replicated sigma_t, BEFORE the passes are
+        # enqueued (as render_backward does; an optimisation's sigma_t changes every step, so it is part of the step)
+        support = u.gradient_support(scene.medium.sigma_t, grads) if world > 1 else None
         L, _, state = integ.sample(u.ADMode.Primal, scene, sampler.clone(), batch)       # batched.py:255-264
         img = integ.develop(scene, L, spp)                                                # :272-297
         grad_img = loss_scale * (img - 0.5)                                               # d mean((img-.5)^2)
         dL = integ.film_backward(scene, grad_img, spp)                                    # :298-306
         integ.sample(u.ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state, grads=grads)   # :309-318
-        u.allreduce_gradients(grads, stats=ar_stats)                                      # one RCCL all-reduce (non-zero blocks only)
+        u.allreduce_gradients(grads, stats=ar_stats, support=support)                     # ONE RCCL all-reduce (blocks that can be non-zero), no host wait
         return img
 
     def sync():
@@ -530,6 +534,7 @@ def main():
         step(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
+    u.verify_pending()                               # (the deferred check of the last step's gradient all-reduce)
     t_primal = h.read_timings(0)
     t_adjoint = h.read_timings(1)
     t_untile = h.read_timings(2)
@@ -666,7 +671,8 @@ def main():
             "counters_primal": cnt_p, "counters_adjoint": cnt_a,
             "allreduce": ({"mode": ar_stats.get("mode"), "MiB": round(ar_stats.get("floats", 0) * 4 / 2 ** 20, 1),
                            "of_MiB": round(grads["_flat"].numel() * 4 / 2 ** 20, 1) if grads else None,
-                           "active_fraction": round(ar_stats.get("active_fraction", 1.0), 4)} if world > 1 else None),
+                           "active_fraction": round(ar_stats.get("active_fraction", 1.0), 4),
+                           "collectives_per_backward": ar_stats.get("collectives")} if world > 1 else None),
             "other_configs": other,
         }
         if args.debug_flags:

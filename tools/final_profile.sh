@@ -28,13 +28,14 @@ python tools/rocpd_stats.py $R/prof0/hl_results.db --csv $R/kernel_stats_factor0
 python tools/rocpd_stats.py $R/prof_fused/hl_results.db --csv $R/kernel_stats_fused.csv --top 14 > /dev/null
 python tools/pmc_summary.py $R/pmc_util8 > $R/pmc_util.txt
 python tools/pmc_summary.py $R/pmc_util0 > $R/factor0_pmc_util.txt
+python tools/pmc_summary.py $R/pmc_util_fused > $R/fused_pmc_util.txt
 python tools/pmc_to_traffic.py $R/pmc_traffic8 dust-devil-256-512x32-factor8 $R/roofline_traffic.json > $R/pmc_traffic.txt
 python tools/pmc_to_traffic.py $R/pmc_traffic0 dust-devil-256-512x32 $R/roofline_traffic.json > $R/pmc_traffic_factor0.txt
 python tools/pmc_to_traffic.py $R/pmc_traffic_env8 dust-devil-256-512x32-factor8-envmap2048 $R/roofline_traffic.json > $R/pmc_traffic_envmap8.txt
 python tools/pmc_to_traffic.py $R/pmc_traffic_fused fused-256-512x32 $R/roofline_traffic.json > $R/pmc_traffic_fused.txt
-python tools/pmc_to_util.py $R/pmc_util8 $R/kernel_stats.csv dust-devil-256-512x32-factor8 $R/roofline_traffic.json > $R/util.txt
-python tools/pmc_to_util.py $R/pmc_util0 $R/kernel_stats_factor0.csv dust-devil-256-512x32 $R/roofline_traffic.json > $R/util_factor0.txt
-python tools/pmc_to_util.py $R/pmc_util_fused $R/kernel_stats_fused.csv fused-256-512x32 $R/roofline_traffic.json > $R/util_fused.txt
+python tools/pmc_to_util.py $R/pmc_util.txt $R/kernel_stats.csv dust-devil-256-512x32-factor8 $R/roofline_traffic.json > $R/util.txt
+python tools/pmc_to_util.py $R/factor0_pmc_util.txt $R/kernel_stats_factor0.csv dust-devil-256-512x32 $R/roofline_traffic.json > $R/util_factor0.txt
+python tools/pmc_to_util.py $R/fused_pmc_util.txt $R/kernel_stats_fused.csv fused-256-512x32 $R/roofline_traffic.json > $R/util_fused.txt
 rm -rf $R/pmc_util0 $R/pmc_util8 $R/pmc_traffic0 $R/pmc_traffic8 $R/pmc_traffic_fused $R/pmc_traffic_env8 $R/pmc_util_fused $R/prof0 $R/prof8 $R/prof_fused
 cp $R/roofline_traffic.json profiles/roofline_traffic.json      # the bench lines below quote it (same kernel sources: hash checked)
 (timeout 1500 python bench.py > $R/bench.json 2>> $R/err.txt)

@@ -4,10 +4,11 @@ the SECONDARY ceilings SURVEY.md 8d asks for next to the HBM roofline, per kerne
 
   lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)      (share of the 64 lanes a vector instruction has work for)
   valu_busy    = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles)   (SQ_ACTIVE_INST_* count quad-cycles, MI355X_MICROARCH.md;
-                 kernel cycles = SQ_BUSY_CYCLES / 32 shader engines)
+                 kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs, or SQ_BUSY_CYCLES / 32 shader engines where that counter is missing)
   avg_ms       = the kernel's average duration in the rocprofv3 --kernel-trace --stats pass of the same command
+  ms_per_step  = avg_ms x (the kernel's launches per launch of a primal tracer kernel, i.e. per step of the command)
 
-    python tools/pmc_to_util.py <dir with *counter_collection.csv> <kernel_stats.csv> <workload key> [out.json]
+    python tools/pmc_to_util.py <dir with *counter_collection.csv | summary .txt of tools/pmc_summary.py> <kernel_stats.csv> <workload key> [out.json]
 
 Hash-gated like the traffic figures (bench.kernel_source_sha16): bench.py quotes them only for the sources they came from.
 """
@@ -24,24 +25,38 @@ def short(k):
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+if os.path.isfile(root):                               # a summary written by tools/pmc_summary.py: "kernel" lines, "   COUNTER  mean  (n=..)" lines
+    cur = None
+    for line in open(root):
+        if not line.startswith(" "):
+            cur = line.strip()
+        elif cur and line.split():
+            parts = line.split()
+            acc[cur][parts[0]].append(float(parts[1]))
+for f in ([] if os.path.isfile(root) else glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
     per = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         if "drt::" in r["Kernel_Name"]:
             per[(short(r["Kernel_Name"]), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (k, d, c), v in per.items():
         acc[k][c].append(v)
-ms = {}
+ms, calls = {}, {}
 for r in csv.DictReader(open(stats)):
     ms[short(r["Name"])] = float(r["AverageNs"]) / 1e6
+    calls[short(r["Name"])] = int(r["Calls"])
+# launches of a primal tracer kernel (counting instantiation included) = steps of the profiled command
+steps = sum(c for k, c in calls.items() if any(t in k for t in ("trace_sq_kernel<false", "trace_coop_kernel<false", "trace_super_kernel<false",
+                                                                "trace_wavefront_kernel<false", "fused_kernel<false")))
 util = {}
 for k in acc:
     m = lambda c: (sum(acc[k][c]) / len(acc[k][c])) if acc[k].get(c) else 0.0
-    a, t, b = m("SQ_ACTIVE_INST_VALU"), m("SQ_THREAD_CYCLES_VALU"), m("SQ_BUSY_CYCLES")
-    if a <= 0 or b <= 0:
+    a, t, b, g = m("SQ_ACTIVE_INST_VALU"), m("SQ_THREAD_CYCLES_VALU"), m("SQ_BUSY_CYCLES"), m("GRBM_GUI_ACTIVE")
+    cycles = g / 8.0 if g > 0 else b / 32.0
+    if a <= 0 or cycles <= 0:
         continue
-    util[k] = {"lanes_active": round(t / (64.0 * a), 4), "valu_busy": round(4.0 * a / (1024.0 * b / 32.0), 4),
-               "valu_insts": m("SQ_INSTS_VALU"), "salu_insts": m("SQ_INSTS_SALU"), "avg_ms": round(ms.get(k, 0.0), 4) or None}
+    util[k] = {"lanes_active": round(t / (64.0 * a), 4), "valu_busy": round(4.0 * a / (1024.0 * cycles), 4),
+               "valu_insts": m("SQ_INSTS_VALU"), "salu_insts": m("SQ_INSTS_SALU"), "avg_ms": round(ms.get(k, 0.0), 4) or None,
+               "ms_per_step": (round(ms[k] * calls[k] / steps, 4) if k in ms and steps else None)}
 sha = kernel_source_sha16()
 res = {}
 if os.path.exists(out):
