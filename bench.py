@@ -237,15 +237,18 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
         return r
 
     def cfg4():
+        # the reference's default majorant_resolution_factor 8 on a 512^3 grid: a 64^3 supergrid - its majorants do not fit LDS
+        # next to the ray records, the queued tracer's MG kernels keep one bit per cell there and read the majorants from L2
         sc = synthetic.dust_devil_scene(res=512, film=1024, device=dev)
+        sc.medium.majorant_resolution_factor = 8
         r = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 64, steps=3, warmup=1,
                     shard=u.ShardSpec(0, 8, 2048))
-        sc.medium.majorant_resolution_factor = 8
-        r["majorant_factor8"] = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 64, steps=3, warmup=1,
-                                        shard=u.ShardSpec(0, 8, 2048), roofline=False)
+        sc.medium.majorant_resolution_factor = 0
+        r["global_majorant"] = h1_rate(torch, u, sc, u.get_int_config(integ_name).create(max_depth=64), 64, steps=3, warmup=1,
+                                       shard=u.ShardSpec(0, 8, 2048), roofline=False)
         r["workload"] = ("config 4: 512^3 grid, rank 0's share (1/8, interleaved 2048-pixel chunks) of 1024x1024x64spp; "
-                         "per-GPU compute only, the 2 GiB gradient all-reduce is not included; global majorant (majorant_factor8: the "
-                         "same with a 64^3 supergrid, whose majorants do not fit LDS: drt_super.hip's bitmask instantiation)")
+                         "per-GPU compute only, the 2 GiB gradient all-reduce is not included; majorant_resolution_factor 8 "
+                         "(64^3 supergrid: drt_sq.hip, majorants from L2); global_majorant: the same with ONE majorant")
         return r
 
     def cfg5():

@@ -150,11 +150,14 @@ def test_headline_majorant_factor_8(uivr, oracle, gpu):
     _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, 256 * spp, min_lookups_per_ray=0.5)
 
 
-def test_config4_512_rank0_share_of_1024x64(uivr, oracle, gpu):
+@pytest.mark.parametrize("factor", [0, 8])
+def test_config4_512_rank0_share_of_1024x64(uivr, oracle, gpu, factor):
     """512^3 grid (16384 reduction tiles), rank 0 of 8 of a 1024^2 x 64 spp image: 8.4 M rays of the
-    interleaved chunk map, RNG keyed by the global ray index."""
+    interleaved chunk map, RNG keyed by the global ray index.  With ONE majorant and at the reference's default
+    majorant_resolution_factor 8: a 64^3 supergrid, whose majorants the queued tracer reads from L2 (drt_sq.hip, MG)."""
     from uivr_amd import synthetic
     sg = synthetic.dust_devil_scene(res=512, film=1024, device=gpu)
+    sg.medium.majorant_resolution_factor = factor
     props = props_for("drt")
     integ = _integrator(uivr, props)
     spp, seed = 64, 2005

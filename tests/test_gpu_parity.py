@@ -703,10 +703,13 @@ def _supergrid_case(uivr, oracle, gpu, flags, variant, density):
     _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], "grad albedo")
 
 
-def test_supergrid_too_large_for_lds_keeps_its_bitmask_there(uivr, oracle, gpu):
-    """A supergrid whose majorants do not fit the tracer's LDS next to the flight slots (160^3 voxels at factor 4 = 40^3
-    = 64000 cells: 125 KiB as bf16) runs the instantiation that keeps the non-empty-cell bitmask in LDS and loads the
-    majorants of non-empty cells from L2 (drt_super.hip, MGL = false).  A window of rays against the oracle."""
+@pytest.mark.parametrize("flags,variant", [(0, "drt"), (4096, "drt"), (0, "basic")])
+def test_supergrid_too_large_for_lds_keeps_its_bitmask_there(uivr, oracle, gpu, flags, variant):
+    """A supergrid whose majorants do not fit the tracer's LDS next to the ray records (160^3 voxels at factor 4 = 40^3
+    = 64000 cells: 125 KiB as bf16; the reference's default on a 512^3 grid gives 64^3) runs the instantiations that keep the
+    non-empty-cell bitmask in LDS and load the majorants of non-empty cells from L2: the queued tracer's (drt_sq.hip, MG:
+    flags 0) and the round-3 kernel's (drt_super.hip, MGL = false: test hook 4096).  A window of rays against the oracle;
+    counters in a counting launch."""
     rng = np.random.default_rng(3)
     res = 160
     lat = rng.random((20, 20, 20), dtype=np.float32)
@@ -718,14 +721,23 @@ def test_supergrid_too_large_for_lds_keeps_its_bitmask_there(uivr, oracle, gpu):
                              majorant_resolution_factor=4)
     sensor = uivr.PerspectiveSensor(origin=(3.0, 2.0, 4.0), target=(0, 0, 0), fov=30.0, width=32, height=32)
     scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter((1.0, 1.0, 1.0)), sensors=[sensor])
-    props, spp, seed = props_for("drt"), 4, 99
+    props, spp, seed = props_for(variant), 4, 99
     ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
+    _, c_primal = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)
     sg = uivr.scene_to(scene, gpu)
-    integ = _integrator(uivr, props)
+    integ = _integrator(uivr, props, hooks=True)
+    h = integ.native_handle(sg)
+    h.set_debug_flags(flags)
     batch = uivr.RayBatch(n_rays=32 * 32 * spp, spp=spp, sensor=sg.sensors[0])
     L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(seed, spp), batch)
     np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), ref["L"].view(np.uint32))
+    h.enable_counters(True)
+    h.reset_counters()
     img, grads = _h1_gpu(uivr, sg, integ, spp, seed)
+    cnt = {k: int(v) for k, v in h.get_counters().items()}
+    h.enable_counters(False)
+    h.set_debug_flags(0)
+    assert cnt == {k: ref["counters"][k] + c_primal[k] for k in ref["counters"]}
     g = grads[uivr.SIGMA_T_KEY].detach().cpu().numpy().astype(np.float64)
     tol = GRAD_RTOL * np.abs(ref["grad_sigma_t"]).max() + 1e-9
     assert np.abs(g - ref["grad_sigma_t"]).max() <= tol

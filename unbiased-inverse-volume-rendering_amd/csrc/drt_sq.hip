@@ -197,7 +197,11 @@ __device__ __forceinline__ void sq_push_all(unsigned long long *ctl, uint16_t *q
 
 }  // namespace
 
-template <bool ADJ, bool COUNT, bool ENV>
+// MG: the supergrid's majorants do not fit LDS next to the records (64^3 cells: a 512^3 grid at the reference's factor 8) - LDS
+// holds one BIT per cell (non-empty: two thirds of the cells a flight crosses answer without a load) and the majorants of the
+// others are read from global memory (1 MB, L2-resident); the cell steps are then unpredicated in both passes (the geometry of
+// the 8 steps first, their loads together) and a flight's first cells are not stepped by the lanes that set it up
+template <bool ADJ, bool COUNT, bool ENV, bool MG>
 __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P)
 {
     constexpr int NWV = DRT_SQ_THREADS / 64;
@@ -214,7 +218,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int NRAY = (int) P.sq_rays;                                        // records of this launch (a multiple of 64)
     const int n_cells = P.gx * P.gy * P.gz;
-    const int mg_words = (n_cells + 1) / 2;
+    const int mg_words = MG ? (n_cells + 31) / 32 : (n_cells + 1) / 2;
     uint4 *rec4 = (uint4 *) lds;
     uint32_t *mg_lds = lds + NRAY * R4 * 4;
     uint16_t *q_lds = (uint16_t *) (mg_lds + ((mg_words + 3) & ~3));
@@ -231,7 +235,14 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     if (threadIdx.x < 2) pool[threadIdx.x] = 0ull;
     for (int w = threadIdx.x; w < NWV * 8; w += blockDim.x) recst[w] = 0u;
     __syncthreads();
-    {                                                                        // (the grid's values are bf16-representable: exact)
+    if constexpr (MG) {
+        for (int w = threadIdx.x; w < mg_words; w += blockDim.x) mg_lds[w] = P.mocc[w];
+        // the largest cell majorant: every cell's is (scale x its largest sigma_t) rounded up to bf16 (majorant_grid_kernel), so
+        // the global majorant rounded up the same way bounds them all (the early-out below only needs a bound)
+        uint32_t b = __float_as_uint(P.majorant[0]);
+        if (b & 0xffffu) b = (b | 0xffffu) + 1u;
+        if (threadIdx.x == 0) misc[1] = b;
+    } else {                                                                 // (the grid's values are bf16-representable: exact)
         uint32_t top = 0u;                                                   // (non-negative floats order like their bit patterns)
         for (int w = threadIdx.x; w < mg_words; w += blockDim.x) {
             const uint32_t a = __float_as_uint(P.mgrid[2 * w]), b = 2 * w + 1 < n_cells ? __float_as_uint(P.mgrid[2 * w + 1]) : 0u;
@@ -348,7 +359,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 walked = true;
                 SQ_STAMP(1);
                 // (primal kernels: the steps are not predicated on `fly`, as in drt_super.hip)
-                constexpr bool kLoose = !ADJ;
+                constexpr bool kLoose = !ADJ || MG;
                 bool fin = false; float res_mc = 0.0f, res_t = 0.0f, res_acc = 0.0f;
 #pragma unroll
                 for (int k = 0; k < DRT_SQ_K; ++k) {
@@ -359,7 +370,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     const float tmin = fminf(fminf(tnx, tny), tnz);
                     const float texit = fminf(tmin, tmax);
                     const uint32_t ci = kLoose ? min((uint32_t) cell, (uint32_t) (n_cells - 1)) : (uint32_t) cell;
-                    const float mc = __uint_as_float((uint32_t) mg16[ci] << 16);
+                    float mc;
+                    if constexpr (MG) mc = ((mg_lds[ci >> 5] >> (ci & 31u)) & 1u) ? P.mgrid[ci] : 0.0f;
+                    else mc = __uint_as_float((uint32_t) mg16[ci] << 16);
                     const float nacc = acc + mc * (texit - t);                  // (an empty cell adds an exact zero)
                     const bool hit = mc > 0.0f && nacc >= tau;                  // the tentative collision lies in this cell
                     const bool isx = tnx == tmin, isy = !isx && tny == tmin;     // first axis with the earliest crossing
@@ -960,7 +973,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                             const int sx = sgx < 0 ? -1 : 1, sy = sgy < 0 ? -lin_y : lin_y, sz = sgz < 0 ? -lin_z : lin_z;
                             bool wfly = true;
 #pragma unroll
-                            for (int k = 0; k < DRT_SQ_INLINE_K; ++k) {
+                            for (int k = 0; k < (MG ? 0 : DRT_SQ_INLINE_K); ++k) {
                                 const float tmin = fminf(fminf(wnx, wny), wnz);
                                 const float texit = fminf(tmin, tmax);
                                 const float mc = __uint_as_float((uint32_t) mg16[wcell] << 16);
@@ -1062,18 +1075,25 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
 
 // Records per workgroup that fit LDS next to this supergrid's majorants (a multiple of 64); 0: this supergrid cannot be
 // served (the host keeps drt_super.hip).  *bytes: dynamic LDS of the launch
-static uint32_t sq_rays_for(const Params &P, size_t *bytes)
+// *global_majorants: the bf16 majorants do not fit (with at least DRT_SQ_MIN_RAYS records) but one bit per cell does - the MG kernels
+static uint32_t sq_rays_for(const Params &P, size_t *bytes, bool *global_majorants = nullptr)
 {
     const size_t cells = (size_t) P.gx * P.gy * P.gz;
     const size_t nwv = DRT_SQ_THREADS / 64;
-    const size_t fixed = (((((cells + 1) / 2) + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RING / 2 + 2 * SQ_KINDS + 4 + 4 + nwv * 8) * 4;
     const size_t cap = 160u * 1024u;
-    if (fixed >= cap) return 0;
-    size_t n = ((cap - fixed) / (7 * 16)) & ~(size_t) 63;
-    if (n > DRT_SQ_MAX_RAYS) n = DRT_SQ_MAX_RAYS;
-    if (n < DRT_SQ_MIN_RAYS) return 0;
-    if (bytes) *bytes = fixed + n * 7 * 16;
-    return (uint32_t) n;
+    for (int mg = 0; mg < 2; ++mg) {
+        if (mg && !(P.mocc && P.majorant)) break;
+        const size_t words = mg ? (cells + 31) / 32 : (cells + 1) / 2;
+        const size_t fixed = (((words + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RING / 2 + 2 * SQ_KINDS + 4 + 4 + nwv * 8) * 4;
+        if (fixed >= cap) continue;
+        size_t n = ((cap - fixed) / (7 * 16)) & ~(size_t) 63;
+        if (n > DRT_SQ_MAX_RAYS) n = DRT_SQ_MAX_RAYS;
+        if (n < DRT_SQ_MIN_RAYS) continue;
+        if (bytes) *bytes = fixed + n * 7 * 16;
+        if (global_majorants) *global_majorants = mg != 0;
+        return (uint32_t) n;
+    }
+    return 0;
 }
 
 size_t sq_cold_bytes(int n_cus) { return (size_t) n_cus * 9 * DRT_SQ_MAX_RAYS * sizeof(uint4); }
@@ -1087,7 +1107,8 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
 {
     if (Pin.n_rays <= Pin.ray_first) return hipSuccess;
     size_t lds = 0;
-    const uint32_t nray = sq_rays_for(Pin, &lds);
+    bool mg = false;
+    const uint32_t nray = sq_rays_for(Pin, &lds, &mg);
     if (!nray || !Pin.sq_cold) return hipErrorInvalidValue;
     Params P = Pin;
     P.sq_rays = nray;
@@ -1097,9 +1118,10 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
     dim3 block(DRT_SQ_THREADS), grid(blocks);
     const bool env = P.env_pix != nullptr;
     hipError_t e = hipSuccess;
-#define DRT_SQ_LAUNCH(A, C, E)                                                                                    \
+#define DRT_SQ_LAUNCH(A, C, E) do { if (mg) DRT_SQ_LAUNCH_(A, C, E, true); else DRT_SQ_LAUNCH_(A, C, E, false); } while (0)
+#define DRT_SQ_LAUNCH_(A, C, E, M)                                                                                \
     do {                                                                                                          \
-        auto kern = trace_sq_kernel<A, C, E>;                                                                     \
+        auto kern = trace_sq_kernel<A, C, E, M>;                                                                  \
         static std::atomic<size_t> lds_set[64];                                                                        \
         int dev_ = 0;                                                                                             \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 63;                               \
@@ -1122,6 +1144,7 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
         default: DRT_SQ_LAUNCH(true, true, true); break;
     }
 #undef DRT_SQ_LAUNCH
+#undef DRT_SQ_LAUNCH_
     return hipGetLastError();
 }
 
