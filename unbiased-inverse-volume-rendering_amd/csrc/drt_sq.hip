@@ -32,7 +32,9 @@
 #ifndef DRT_SQ_MAX_RAYS
 #define DRT_SQ_MAX_RAYS 1024       // most ray records per workgroup (a launch takes what fits LDS, a multiple of 64: Params::sq_rays)
 #endif
+#ifndef DRT_SQ_RING
 #define DRT_SQ_RING 1024           // entries per ring buffer of ids (a power of two >= DRT_SQ_MAX_RAYS)
+#endif
 #ifndef DRT_SQ_MIN_RAYS
 #define DRT_SQ_MIN_RAYS 256        // fewer records than this: the host keeps drt_super.hip
 #endif
@@ -1081,7 +1083,10 @@ static uint32_t sq_rays_for(const Params &P, size_t *bytes, bool *global_majoran
     const size_t cells = (size_t) P.gx * P.gy * P.gz;
     const size_t nwv = DRT_SQ_THREADS / 64;
     const size_t cap = 160u * 1024u;
-    for (int mg = 0; mg < 2; ++mg) {
+#ifndef DRT_SQ_FORCE_MG
+#define DRT_SQ_FORCE_MG 0          // experiment: 1 = majorants from L2 for every supergrid (more records fit LDS)
+#endif
+    for (int mg = DRT_SQ_FORCE_MG; mg < 2; ++mg) {
         if (mg && !(P.mocc && P.majorant)) break;
         const size_t words = mg ? (cells + 31) / 32 : (cells + 1) / 2;
         const size_t fixed = (((words + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RING / 2 + 2 * SQ_KINDS + 4 + 4 + nwv * 8) * 4;
