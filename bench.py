@@ -136,15 +136,21 @@ def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=Non
         step(i)
     torch.cuda.synchronize()
     h.enable_timing(True)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        sampler, state, dL = step(warmup + i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    # two timed blocks of `steps` steps; the entry reports the faster one (a side entry's few steps are short enough for one host
+    # hiccup - seen once after the CPU-baseline leg: 14.4 ms of wall clock per step around 6.5 ms of kernels - to halve its rate)
+    # and keeps both rates
+    blocks = []
+    for b in range(2):
+        t0 = time.perf_counter()
+        for i in range(steps):
+            sampler, state, dL = step(warmup + b * steps + i)
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / steps)
+    dt = min(blocks)
     t_p, t_a, t_r, t_pass = (h.read_timings(k) for k in range(4))
     h.enable_timing(False)
     out = {"value": round(n_local * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
-           "n_samples_per_step": n_local * spp}
+           "n_samples_per_step": n_local * spp, "blocks_msamples_per_s": [round(n_local * spp / b / 1e6, 2) for b in blocks]}
     if roofline:
         n = n_local * spp
         h.enable_counters(True)

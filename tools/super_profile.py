@@ -17,6 +17,9 @@ if os.environ.get("DRT_PROFILE_SCENE", "dust") == "smoke":
 else:
     scene = synthetic.dust_devil_scene(res=256, film=512, device=dev)
 scene.medium.majorant_resolution_factor = int(os.environ.get("DRT_PROFILE_FACTOR", "8"))
+if os.environ.get("DRT_PROFILE_ENV"):                    # lit by a 2048x1024 environment map (bench.py: headline_envmap_factor8)
+    g = torch.Generator().manual_seed(5)
+    scene.emitter = u.EnvmapEmitter(pixels=(torch.rand(1024, 2048, 3, generator=g) ** 4 * 3.0 + 0.2).to(dev), scale=1.0)
 spp = int(os.environ.get("DRT_PROFILE_SPP", "32"))
 sensor = scene.sensors[0]
 integ = u.get_int_config("volpathsimple-drt").create(max_depth=64)
