@@ -222,6 +222,11 @@ int drt_grad_block_mask(void *hip_stream, const float *buf, uint64_t n_blocks, u
  * bias corrections into lr_t = lr sqrt(1 - beta_2^t) / (1 - beta_1^t).  All four buffers: n floats, 16-byte aligned. */
 int drt_adam_step(void *hip_stream, float *p, const float *g, float *m, float *v, uint64_t n, double beta_1, double beta_2,
                   double epsilon, double lr_t);
+/* The same with the parameter's valid range applied to the updated value in the same pass: opt.step() followed by
+ * enforce_valid_params (python/optimize.py:169-179, 352-353: sigma_t >= 0, albedo in [0, 1]) - torch.clamp's semantics (a NaN
+ * stays a NaN); lo = -inf / hi = +inf: that side is open. */
+int drt_adam_step_clamped(void *hip_stream, float *p, const float *g, float *m, float *v, uint64_t n, double beta_1, double beta_2,
+                          double epsilon, double lr_t, float lo, float hi);
 
 /* Event counting (off by default; enabling selects a counting build of the kernels). */
 int drt_enable_counters(drt_handle h, int enable);

@@ -174,6 +174,44 @@ def test_fused_adam_step_equals_elementwise_sequence(uivr, gpu):
         native().adam_step(0, big.data_ptr() + 4, big.data_ptr(), big.data_ptr(), big.data_ptr(), 8, 0.9, 0.999, 1e-8, 1e-3)
 
 
+def test_clamped_adam_step_equals_step_then_clamp(uivr, gpu):
+    """drt_adam_step_clamped (opt.step + enforce_valid_params, optimize.py:352-353, in one pass) is bit-identical to
+    drt_adam_step followed by torch's clamp - NaNs stay NaNs, open sides stay open - and `Adam.step(bounds=...)` /
+    `run_optimization` use it: the parameters after a step equal the two-pass sequence."""
+    native = uivr._native.native
+    gen = torch.Generator().manual_seed(7)
+    for n, lo, hi in ((4099, 0.0, 1.0), (1023, 0.0, float("inf")), (64, float("-inf"), 0.3)):
+        p = (torch.rand(n, generator=gen) * 1.2 - 0.1).to(gpu); g = (torch.randn(n, generator=gen) * 30).to(gpu)
+        p[3] = float("nan")
+        m = (torch.randn(n, generator=gen) * 0.1).to(gpu); v = (torch.rand(n, generator=gen) * 0.01).to(gpu)
+        p2, m2, v2 = p.clone(), m.clone(), v.clone()
+        st = torch.cuda.current_stream().cuda_stream
+        native().adam_step(st, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 0.9, 0.999, 1e-8, 5e-2)
+        p.clamp_(None if lo == float("-inf") else lo, None if hi == float("inf") else hi)
+        native().adam_step_clamped(st, p2.data_ptr(), g.data_ptr(), m2.data_ptr(), v2.data_ptr(), n, 0.9, 0.999, 1e-8, 5e-2, lo, hi)
+        assert torch.equal(torch.nan_to_num(p, nan=-7.0), torch.nan_to_num(p2, nan=-7.0)) and bool(torch.isnan(p2[3]))
+        assert torch.equal(m, m2) and torch.equal(v, v2)
+        assert float(p2[~torch.isnan(p2)].min()) >= float(np.float32(lo)) and float(p2[~torch.isnan(p2)].max()) <= float(np.float32(hi))
+    with pytest.raises(RuntimeError):
+        native().adam_step_clamped(0, p2.data_ptr(), g.data_ptr(), m2.data_ptr(), v2.data_ptr(), 8, 0.9, 0.999, 1e-8, 1e-3, 1.0, 0.0)
+    # the optimizer: one step with bounds == step + enforce_valid_params
+    scene = uivr.scene_to(uivr.cube_test_scene(8, 8), gpu)
+    keys = (uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY)
+    sc = uivr.SceneConfig(name="c", scene=scene, param_keys=list(keys), sensors=[0], start_from_value={})
+    pa = {keys[0]: torch.rand(8, 8, 8, 1, device=gpu), keys[1]: torch.rand(8, 8, 8, 3, device=gpu)}
+    pb = {k: t.clone() for k, t in pa.items()}
+    grads = {k: torch.randn_like(t) * 50 for k, t in pa.items()}
+    oa, ob = uivr.Adam(lr=0.5, params=pa), uivr.Adam(lr=0.5, params=pb)
+    done = oa.step(grads, bounds=uivr.optimize.param_bounds(sc, keys))
+    assert done == set(keys)
+    uivr.enforce_valid_params(sc, oa, skip=done)
+    assert ob.step(grads) == set()
+    uivr.enforce_valid_params(sc, ob)
+    for k in keys:
+        assert torch.equal(pa[k], pb[k]) and float(pa[k].min()) >= 0.0
+    assert float(pa[keys[1]].max()) <= 1.0
+
+
 def test_adam_step_on_odd_sized_grids(uivr, gpu):
     """3^3 / 5^3 grids (the finite-difference fixtures): gradient views out of `alloc_grads` are 16-byte aligned, so the
     fused kernel takes them; a deliberately misaligned or mismatched gradient falls back to the torch ops - same result."""

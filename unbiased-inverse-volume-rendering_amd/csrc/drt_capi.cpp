@@ -753,10 +753,14 @@ int drt_params_changed(drt_handle h)
     if (!h->have_medium) return fail(h, DRT_ERR_NOT_CONFIGURED, "no medium set");
     DeviceGuard g(h->device);
     size_t n = (size_t) h->base.rx * h->base.ry * h->base.rz;
-    DRT_HIP_CHECK(h, drt::launch_majorant(h->base.sigma_t, n, h->base.scale, h->d_scratch, h->d_majorant, h->stream));
+    // (with a supergrid the global majorant comes out of the supergrid pass: its cells cover every voxel - one pass over the grid
+    //  less per optimisation step)
     if (h->base.mgrid)
         DRT_HIP_CHECK(h, drt::launch_majorant_grid(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.gx, h->base.gy,
-                                                   h->base.gz, h->base.scale, h->d_mgrid, (uint32_t *) h->base.mocc, h->stream));
+                                                   h->base.gz, h->base.scale, h->d_mgrid, (uint32_t *) h->base.mocc, h->stream,
+                                                   h->d_scratch, h->d_majorant));
+    else
+        DRT_HIP_CHECK(h, drt::launch_majorant(h->base.sigma_t, n, h->base.scale, h->d_scratch, h->d_majorant, h->stream));
     DRT_HIP_CHECK(h, drt::launch_occupancy(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.occ_shift, h->base.occ_x,
                                            h->base.occ_y, h->occ_z, h->d_occ, h->base.occ_words, h->stream));
     DRT_HIP_CHECK(h, drt::launch_brick_sigma(h->base.sigma_t, h->d_sigma_b, h->base.rx, h->base.ry, h->base.rz,
@@ -1204,6 +1208,16 @@ int drt_film_develop(drt_handle h, const float *L, uint64_t n_pixels, uint32_t s
     DeviceGuard g(h->device);
     DRT_HIP_CHECK(h, drt::launch_film_develop(L, n_pixels, spp, image, h->stream));
     return DRT_OK;
+}
+
+int drt_adam_step_clamped(void *hip_stream, float *p, const float *g, float *m, float *v, uint64_t n, double beta_1, double beta_2,
+                          double epsilon, double lr_t, float lo, float hi)
+{
+    if (!p || !g || !m || !v) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "drt_adam_step_clamped: null buffer");
+    if ((((uintptr_t) p) | ((uintptr_t) g) | ((uintptr_t) m) | ((uintptr_t) v)) & 15u)
+        return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "drt_adam_step_clamped: buffers must be 16-byte aligned");
+    if (!(lo <= hi)) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "drt_adam_step_clamped: lo > hi");
+    return drt::launch_adam_step(p, g, m, v, n, beta_1, beta_2, epsilon, lr_t, (hipStream_t) hip_stream, lo, hi) == hipSuccess ? DRT_OK : DRT_ERR_HIP;
 }
 
 int drt_adam_step(void *hip_stream, float *p, const float *g, float *m, float *v, uint64_t n, double beta_1, double beta_2,

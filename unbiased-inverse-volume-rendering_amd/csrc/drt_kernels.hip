@@ -630,8 +630,11 @@ __global__ void majorant_finalize_kernel(const uint32_t *max_bits, float scale, 
 // Majorant supergrid: cell (I,J,K) = scale * max over the voxels a trilinear lookup inside the
 // cell can touch, padded by one voxel: [floor(I*res/G) - 1, ceil((I+1)*res/G)] per axis, clamped; rounded up to bf16.
 // One wavefront per cell.
+// max_bits (optional): the cells cover every voxel, so the largest un-rounded cell maximum IS the grid's maximum - the global
+// majorant comes out of this pass and the separate reduction over the grid (majorant_reduce_kernel) is not launched.
 __global__ void __launch_bounds__(256) majorant_grid_kernel(const float *sigma_t, int rx, int ry, int rz,
-                                                            int gx, int gy, int gz, float scale, float *out, uint32_t *mask)
+                                                            int gx, int gy, int gz, float scale, float *out, uint32_t *mask,
+                                                            uint32_t *max_bits)
 {
     uint32_t cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (cell >= (uint32_t) gx * gy * gz) return;
@@ -650,6 +653,7 @@ __global__ void __launch_bounds__(256) majorant_grid_kernel(const float *sigma_t
     if (lane == 0) {
         // rounded UP to the next bf16-representable value (a majorant only has to bound; at most 0.8 % looser): the
         // supergrid tracer keeps the cells as 16-bit values in LDS (drt_super.hip) - as oracle/drt_oracle.c scene_init
+        if (max_bits && __float_as_uint(m) > *(volatile uint32_t *) max_bits) atomicMax(max_bits, __float_as_uint(m));   // (few cells get past the read)
         uint32_t b = __float_as_uint(m * scale);
         if (b & 0xffffu) b = (b | 0xffffu) + 1u;
         const float mm = __uint_as_float(b);
@@ -985,14 +989,19 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
 #endif  // DRT_TEST_HOOKS
 
 hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
-                                float *out, uint32_t *mask, hipStream_t stream)
+                                float *out, uint32_t *mask, hipStream_t stream, uint32_t *max_bits, float *majorant)
 {
     uint32_t cells = (uint32_t) gx * gy * gz;
+    if (max_bits) {
+        hipError_t e = hipMemsetAsync(max_bits, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
     if (mask) {
         hipError_t e = hipMemsetAsync(mask, 0, (size_t) ((cells + 31) / 32) * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(majorant_grid_kernel, dim3((cells * 64 + 255) / 256), dim3(256), 0, stream, sigma_t, rx, ry, rz, gx, gy, gz, scale, out, mask);
+    hipLaunchKernelGGL(majorant_grid_kernel, dim3((cells * 64 + 255) / 256), dim3(256), 0, stream, sigma_t, rx, ry, rz, gx, gy, gz, scale, out, mask, max_bits);
+    if (max_bits && majorant) hipLaunchKernelGGL(majorant_finalize_kernel, dim3(1), dim3(1), 0, stream, max_bits, scale, majorant);
     return hipGetLastError();
 }
 
@@ -1078,8 +1087,10 @@ hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, 
 // One Adam step in one pass over (p, g, m, v) (N2; mi.ad.Adam as optimize.py:329,352 uses it):
 //   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr_t m / (sqrt(v) + eps)      (lr_t carries the bias corrections)
 // instead of seven elementwise passes: 0.55 -> 0.2 ms per step for the 256^3 x (1 + 3) parameters.
+// lo / hi: the parameter's valid range applied to the updated value in the same pass (enforce_valid_params, python/optimize.py:169-179;
+// torch.clamp's semantics: a NaN stays a NaN); -inf / +inf: no clamp
 __global__ void __launch_bounds__(256) adam_step_kernel(float *p, const float *g, float *m, float *v, uint64_t n,
-                                                        float b1, float a1, float b2, float a2, float eps, float lr_t)
+                                                        float b1, float a1, float b2, float a2, float eps, float lr_t, float lo, float hi)
 {
     const uint64_t stride = (uint64_t) gridDim.x * 256;
     const uint64_t n4 = n / 4;
@@ -1089,6 +1100,7 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float *p, const float *g
         mm = mm * b1 + a1 * gg;
         vv = vv * b2 + a2 * (gg * gg);
         pp = pp - lr_t * (mm / (sqrtf(vv) + eps));
+        pp = pp < lo ? lo : (pp > hi ? hi : pp);
     };
     for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         float4 P = p4[i], M = m4[i], V = v4[i]; const float4 G = g4[i];
@@ -1099,7 +1111,7 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float *p, const float *g
 }
 
 hipError_t launch_adam_step(float *p, const float *g, float *m, float *v, uint64_t n, double b1, double b2, double eps, double lr_t,
-                            hipStream_t stream)
+                            hipStream_t stream, float lo, float hi)
 {
     if (n == 0) return hipSuccess;
     const uint64_t n4 = n / 4;
@@ -1107,7 +1119,7 @@ hipError_t launch_adam_step(float *p, const float *g, float *m, float *v, uint64
     if (blocks == 0) blocks = 1;
     // (1 - beta in double, THEN to float: 1.0f - 0.999f is off by 1.3e-5 relative)
     hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n, (float) b1, (float) (1.0 - b1), (float) b2,
-                       (float) (1.0 - b2), (float) eps, (float) lr_t);
+                       (float) (1.0 - b2), (float) eps, (float) lr_t, lo, hi);
     return hipGetLastError();
 }
 

@@ -9,7 +9,7 @@ namespace drt {
 
 hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
-                                float *out, uint32_t *mask, hipStream_t stream);
+                                float *out, uint32_t *mask, hipStream_t stream, uint32_t *max_bits = nullptr, float *majorant = nullptr);
 hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int shift, int ox, int oy, int oz,
                             uint32_t *occ, int words, hipStream_t stream);
 hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int nbx, int nby,
@@ -90,7 +90,7 @@ hipError_t launch_batch_raygen(const float *sensors, int n_sensors, uint32_t bat
                                uint32_t seed_pixels, uint32_t seed_rays, float *rays_o, float *rays_d, uint32_t *sensor_idx,
                                uint32_t *pixels, hipStream_t stream);
 hipError_t launch_adam_step(float *p, const float *g, float *m, float *v, uint64_t n, double b1, double b2, double eps, double lr_t,
-                            hipStream_t stream);
+                            hipStream_t stream, float lo = -__builtin_huge_valf(), float hi = __builtin_huge_valf());
 hipError_t launch_block_mask(const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask, hipStream_t stream);
 hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, float *image,
                                hipStream_t stream);

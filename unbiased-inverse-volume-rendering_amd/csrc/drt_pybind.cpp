@@ -265,6 +265,11 @@ PYBIND11_MODULE(DRT_PYBIND_NAME, m)
                                      reinterpret_cast<float *>(mm), reinterpret_cast<float *>(v), n, b1, b2, eps, lr_t);
         if (rc != DRT_OK) throw std::runtime_error("drt_adam_step failed (code " + std::to_string(rc) + ")");
     });
+    m.def("adam_step_clamped", [](uintptr_t stream, uintptr_t p, uintptr_t g, uintptr_t mm, uintptr_t v, uint64_t n, double b1, double b2, double eps, double lr_t, float lo, float hi) {
+        const int rc = drt_adam_step_clamped(reinterpret_cast<void *>(stream), reinterpret_cast<float *>(p), reinterpret_cast<const float *>(g),
+                                     reinterpret_cast<float *>(mm), reinterpret_cast<float *>(v), n, b1, b2, eps, lr_t, lo, hi);
+        if (rc != DRT_OK) throw std::runtime_error("drt_adam_step_clamped failed (code " + std::to_string(rc) + ")");
+    });
     m.def("grad_block_mask", [](uintptr_t stream, uintptr_t buf, uint64_t n_blocks, uint32_t block_floats, uintptr_t mask) {
         const int rc = drt_grad_block_mask(reinterpret_cast<void *>(stream), reinterpret_cast<const float *>(buf), n_blocks,
                                            block_floats, reinterpret_cast<uint8_t *>(mask));

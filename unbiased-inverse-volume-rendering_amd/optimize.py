@@ -154,7 +154,12 @@ class Adam:
             self.lr_default = lr
 
     @torch.no_grad()
-    def step(self, grads: Dict[str, torch.Tensor]):
+    def step(self, grads: Dict[str, torch.Tensor], bounds: Optional[Dict[str, tuple]] = None):
+        """`bounds` {key: (lo, hi)} (None = open): the parameter's valid range, applied to the updated value in the SAME device
+        pass where the fused kernel takes the parameter (drt_adam_step_clamped) - opt.step() + enforce_valid_params
+        (python/optimize.py:352-353) in one pass over p, g, m, v instead of that plus a clamp kernel per grid.  Returns the
+        keys whose bounds were applied here (the caller clamps the others)."""
+        clamped = set()
         for k, p in self.variables.items():
             g = grads.get(k)
             if g is None:
@@ -167,30 +172,54 @@ class Adam:
                 # one fused pass on the device (drt_adam_step) instead of seven elementwise kernels
                 from ._native import native
                 with torch.cuda.device(p.device):
-                    native().adam_step(torch.cuda.current_stream().cuda_stream, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                       p.numel(), self.beta_1, self.beta_2, self.epsilon, lr_t)
+                    if bounds and k in bounds:
+                        lo, hi = bounds[k]
+                        native().adam_step_clamped(torch.cuda.current_stream().cuda_stream, p.data_ptr(), g.data_ptr(), m.data_ptr(),
+                                                   v.data_ptr(), p.numel(), self.beta_1, self.beta_2, self.epsilon, lr_t,
+                                                   float("-inf") if lo is None else float(lo), float("inf") if hi is None else float(hi))
+                        clamped.add(k)
+                    else:
+                        native().adam_step(torch.cuda.current_stream().cuda_stream, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                           p.numel(), self.beta_1, self.beta_2, self.epsilon, lr_t)
                 p.view(-1)[:0].zero_()                                     # bumps the tensor version (the medium is re-bound), no work
             else:
                 m.mul_(self.beta_1).add_(g, alpha=1 - self.beta_1)
                 v.mul_(self.beta_2).addcmul_(g, g, value=1 - self.beta_2)
                 p.addcdiv_(m, v.sqrt().add_(self.epsilon), value=-lr_t)    # in place: bumps the tensor version
             self.state[k] = (t, m, v)
+        return clamped
 
 
 class SGD(Adam):
     """mi.ad.SGD without momentum."""
 
     @torch.no_grad()
-    def step(self, grads):
+    def step(self, grads, bounds=None):
         for k, p in self.variables.items():
             if grads.get(k) is not None:
                 p.add_(grads[k], alpha=-self.lr.get(k, self.lr_default))
+        return set()
+
+
+def param_bounds(scene_config: SceneConfig, keys) -> Dict[str, tuple]:
+    """The valid range of each parameter (optimize.py:169-179), (lo, hi) with None = open."""
+    out = {}
+    for k in keys:
+        if k.endswith('sigma_t.data'):
+            out[k] = (0.0, scene_config.max_density)
+        elif k.endswith('emission.data'):
+            out[k] = (0.0, None)
+        elif k.endswith('albedo.data'):
+            out[k] = (0.0, 1.0)
+    return out
 
 
 @torch.no_grad()
-def enforce_valid_params(scene_config: SceneConfig, opt) -> None:
-    """optimize.py:169-179."""
+def enforce_valid_params(scene_config: SceneConfig, opt, skip=()) -> None:
+    """optimize.py:169-179.  `skip`: keys whose range the optimizer step has applied already (Adam.step(bounds=...))."""
     for k, v in opt.items():
+        if k in skip:
+            continue
         if k.endswith('sigma_t.data'):
             v.clamp_(0, scene_config.max_density)
         elif k.endswith('emission.data'):
@@ -488,8 +517,9 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
         # the losses normalise by the local entry count: scale to this rank's share of the global loss
         loss_value = opt_config.loss(image, ref_values) * local_loss_scale(image.shape[0], n_global)
         loss_value.backward()                                          # dr.backward (:350)
-        opt.step({k: leaves[k].grad for k in keys if k in leaves and leaves[k].requires_grad})     # :352
-        enforce_valid_params(scene_config, opt)                        # :353
+        done = opt.step({k: leaves[k].grad for k in keys if k in leaves and leaves[k].requires_grad},    # :352
+                        bounds=param_bounds(scene_config, keys))
+        enforce_valid_params(scene_config, opt, skip=done or ())       # :353 (what the fused step did not clamp itself)
         total = allreduce_scalar(loss_value.detach()) if shard.partitioned else loss_value.detach()
         history.append(float(total))
         if writer and it_i > 0 and opt_config.checkpoint_stride and it_i % opt_config.checkpoint_stride == 0:
