@@ -197,7 +197,7 @@ def test_clamped_adam_step_equals_step_then_clamp(uivr, gpu):
     # the optimizer: one step with bounds == step + enforce_valid_params
     scene = uivr.scene_to(uivr.cube_test_scene(8, 8), gpu)
     keys = (uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY)
-    sc = uivr.SceneConfig(name="c", scene=scene, param_keys=list(keys), sensors=[0], start_from_value={})
+    sc = uivr.SceneConfig(name="c", scene=scene, param_keys=list(keys), sensors=[0], start_from_value={keys[0]: 0.1, keys[1]: 0.5})
     pa = {keys[0]: torch.rand(8, 8, 8, 1, device=gpu), keys[1]: torch.rand(8, 8, 8, 3, device=gpu)}
     pb = {k: t.clone() for k, t in pa.items()}
     grads = {k: torch.randn_like(t) * 50 for k, t in pa.items()}
