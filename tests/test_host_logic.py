@@ -433,3 +433,37 @@ def test_sharded_run_optimization_rejects_what_it_cannot_shard(uivr):
         uivr.run_optimization(None, oc2, sc, "volpathsimple-drt", ref_images=ref, shard=uivr.ShardSpec(0, 2, 16))
     with pytest.raises(ValueError, match="nerf-drt-fused"):
         uivr.run_optimization(None, oc, sc, "nerf-drt-fused", ref_images=ref)
+
+
+def test_gradient_support_matches_brute_force_dilation(uivr):
+    """distributed.gradient_support on the CPU: the sigma_t plane's blocks are all in the set, an albedo block is in it iff one of
+    its voxels lies within one step (3x3x3) of a non-zero sigma_t voxel - against a brute-force dilation; buffers that are too
+    small or not views of a flat buffer give None."""
+    from uivr_amd.distributed import COMPACT_BLOCK_FLOATS as B, gradient_support
+    g = torch.Generator().manual_seed(4)
+    scene = uivr.cube_test_scene(8, 8)
+    n = 20
+    st = torch.zeros(n, n, n, 1)
+    st[3, 4, 5, 0] = 1.0
+    st[15:18, 10, 2, 0] = torch.rand(3, generator=g) + 0.1
+    st[19, 19, 19, 0] = 2.0                                    # a corner voxel: the neighbourhood is clamped at the border
+    scene.medium.sigma_t = st
+    scene.medium.albedo = torch.rand(n, n, n, 3, generator=g)
+    grads = uivr.alloc_grads(scene)
+    sup = gradient_support(st, grads, sparse_keys=(uivr.ALBEDO_KEY,))
+    flat = grads["_flat"]
+    assert sup is not None and sup.mask.numel() == flat.numel() // B and sup.n_floats == flat.numel()
+    occ = torch.zeros(n, n, n, dtype=torch.bool)
+    for z, y, x in torch.nonzero(st[..., 0] != 0).tolist():
+        occ[max(z - 1, 0):z + 2, max(y - 1, 0):y + 2, max(x - 1, 0):x + 2] = True
+    may = torch.zeros(flat.numel(), dtype=torch.bool)
+    may[:n ** 3] = True                                          # sigma_t plane: dense
+    off = (grads[uivr.ALBEDO_KEY].data_ptr() - flat.data_ptr()) // 4
+    may[off:off + 3 * n ** 3] = occ.reshape(-1).repeat_interleave(3)
+    want = may[:(flat.numel() // B) * B].view(-1, B).any(dim=1)
+    assert torch.equal(sup.mask.bool(), want)
+    assert 0 < sup.count < sup.mask.numel() and sup.count == int(want.sum())
+    assert gradient_support(st, {k: v for k, v in grads.items() if k != "_flat"}) is None
+    tiny = uivr.cube_test_scene(4, 4)                            # 3^3 fixture: below 64 blocks
+    tiny.medium.sigma_t, tiny.medium.albedo = torch.ones(3, 3, 3, 1), torch.ones(3, 3, 3, 3)
+    assert gradient_support(torch.ones(3, 3, 3, 1), uivr.alloc_grads(tiny)) is None

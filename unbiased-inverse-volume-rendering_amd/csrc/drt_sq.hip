@@ -13,15 +13,23 @@
 // code needs: direction, moving origin, the active generator, flags) and 48 (adjoint: 144) bytes in global memory
 // (Params::sq_cold, per workgroup, L2-resident: what only the path transitions touch - throughput, radiance, reservoir, dL).
 // As many records as fit LDS next to the majorants (up to DRT_SQ_MAX_RAYS; 768 with a 32^3 supergrid): measured, the
-// number of rays a compute unit holds is what the speed of this tracer follows (256 / 512 records: 5.45 / 3.35 ms primal).  Four ring buffers of ray ids - flights to walk, collisions to evaluate, path transitions, free records - say
-// what is to be done; a wave takes up to 64 ids of ONE kind, loads those rays, runs that kind's code with all its lanes,
-// stores them and pushes their ids to the queues of what they need next.  A wave that finds no full batch walks flights
-// (as in drt_super.hip: DRT_SQ_K cells per look, lanes refilled from the flight queue).
+// number of rays a compute unit holds is what the speed of this tracer follows (256 / 512 / 768 records: 5.45 / 3.35 / 2.89 ms
+// primal).  Ring buffers of ray ids - flights to walk, collisions to evaluate, path transitions (two rings: rays that come
+// from a delta-tracking / DRT walk, rays that come from a transmittance walk; only the adjoint kernels use both), free
+// records - say what is to be done; a wave takes up to 64 ids of ONE kind, loads those rays, runs that kind's code with all
+// its lanes, stores them and pushes their ids to the queues of what they need next (one reserving LDS atomic for all kinds).
+// A wave that finds no full batch walks flights (as in drt_super.hip: DRT_SQ_K cells per look, lanes refilled from the
+// flight queue); the lanes that set a flight up step its first DRT_SQ_INLINE_K cells themselves.  A transition batch runs a
+// second pass only for >= DRT_SQ_T_PASS rays (the others are re-queued: a pass for a few lanes costs as much as one for 64),
+// and the adjoint kernels run the "NEE walk finished" block twice per pass so that a main path whose walks come out of the
+// path cache does a whole bounce in one pass.  Supergrids whose bf16 majorants do not fit LDS (64^3 cells: a 512^3 grid at
+// the reference's factor 8) run the MG instantiations: one bit per cell in LDS, the majorants of non-empty cells from L2.
 //
 // Arithmetic, random-number consumption and event counts are those of the scalar restatement (oracle/drt_oracle.c):
 // radiance is bit-exact per ray, counters are equal; gradients differ by summation order only.  A ray computes the same
 // numbers whichever lanes run its pieces.  Not handled here (the host keeps drt_super.hip / the one-ray-per-lane kernels):
-// supergrids whose bf16 majorants do not fit LDS next to the ray records, quadratic DRT, the atomic gradient path.
+// supergrids of more than 511 cells per axis or whose cell bitmask does not fit LDS either, quadratic DRT, the atomic gradient
+// path.  Design history, profiles and what was measured and not kept: DESIGN.md section 6.2, profiles/r04_sq_experiments.txt.
 #include <atomic>
 #include "drt_device.h"
 #include "drt_launch.h"
