@@ -642,8 +642,9 @@ def main():
             "value": round(n_pixels * cpu_spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores,
             "kind": "port",
             "sample": f"same workload, full {sensor.width}x{sensor.height} image at {cpu_spp} spp "
-                      f"({n_pixels * cpu_spp} samples, {dt:.1f} s); oracle/drt_oracle.c with OpenMP over rays, "
-                      f"gradients through a per-thread write-combining cache "
+                      f"({n_pixels * cpu_spp} samples, {dt:.1f} s); oracle/drt_oracle.c with OpenMP over rays, gradients "
+                      + ("through a per-thread write-combining cache " if dt_cached <= dt_atomic else "as atomic adds into the shared grids ") +
+                      f"(the better of the two, both reported) "
                       f"(the reference's llvm_ad_rgb needs Mitsuba 3 / Dr.Jit, absent here)",
             "value_shared_atomics": round(n_pixels * cpu_spp / dt_atomic / 1e6, 4),
             "value_thread_local_cache": round(n_pixels * cpu_spp / dt_cached / 1e6, 4),
