@@ -2,6 +2,8 @@
 
     tools/mk_variant.sh drain "-DDRT_SUPER_PROFILE=3"; LD_LIBRARY_PATH=variants/drain python tools/drain_profile.py
 
+    queued tracer (drt_sq.hip): tools/mk_variant.sh drain5 "-DDRT_SQ_PROFILE=5" drt_sq.hip; LD_LIBRARY_PATH=variants/drain5 python tools/drain_profile.py
+
 (headline scene at majorant_resolution_factor 8; times in microseconds from the first wave's start)
 """
 import os, sys

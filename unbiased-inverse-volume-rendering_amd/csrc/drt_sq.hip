@@ -313,6 +313,11 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     // to the next ones when that one is drained: every ray is traced whatever the placement of the workgroups.  The
     // positions a workgroup has reserved (DRT_SQ_CHUNK at a time) are handed out from LDS under a lock: any wave starts rays.
     int polls = 0;
+#if DRT_SQ_PROFILE == 5
+    // experiment build: when do the workgroups' ray queues run dry, when do their waves end (100 MHz clock; the counting kernels' slots:
+    // [0] 2^62 - first start, [1] 2^62 - first end, [2] last end, [3] sum of (end - start), [4] waves, [5] sum of (dry - start), [6] 2^62 - first dry)
+    const unsigned long long pt_start = __builtin_amdgcn_s_memrealtime(); unsigned long long pt_drained = 0;
+#endif
 
     for (;;) {
         // ---- what is there to do? ---------------------------------------------------------------------------
@@ -324,6 +329,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         const uint32_t dead = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[0]);
         if (dead >= (uint32_t) NRAY) break;
         const bool drained = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[3]) >= 8u;
+#if DRT_SQ_PROFILE == 5
+        if (drained && !pt_drained) pt_drained = __builtin_amdgcn_s_memrealtime();
+#endif
         int kind = -1; uint32_t min_n = DRT_SQ_BATCH;
         if (n_coll >= DRT_SQ_BATCH) kind = SQ_COLL;
         else if (n_ta >= DRT_SQ_BATCH) kind = SQ_TA;
@@ -1068,7 +1076,18 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     }
 
     if constexpr (ADJ) close_records(P, rec);
+#if DRT_SQ_PROFILE == 5
+    if (COUNT && lane == 0) {
+        const unsigned long long te = __builtin_amdgcn_s_memrealtime(), q62 = 1ull << 62;
+        if (!pt_drained) pt_drained = te;
+        atomicMax(P.counters + 0, q62 - pt_start); atomicMax(P.counters + 1, q62 - te); atomicMax(P.counters + 2, te);
+        atomicAdd(P.counters + 3, te - pt_start); atomicAdd(P.counters + 4, 1ull);
+        atomicAdd(P.counters + 5, pt_drained - pt_start); atomicMax(P.counters + 6, q62 - pt_drained);
+    }
+    if (false) {
+#else
     if (COUNT) {
+#endif
 #pragma unroll
         for (int s = 0; s < C_COUNT; ++s) {
             uint32_t v = cnt[s];
