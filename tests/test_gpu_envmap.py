@@ -70,7 +70,7 @@ def test_envmap_primitives_bit_exact(uivr, oracle, gpu):
 
 
 @pytest.mark.parametrize("flags,variant", [(0, "drt"), (0, "basic"), (0, "quadratic"), (8, "drt"), (32, "drt"), (32, "basic"),
-                                           (-3, "drt"), (-3, "basic")])
+                                           (-3, "drt"), (-3, "basic"), (-3, "quadratic")])
 def test_envmap_render_matches_oracle(uivr, oracle, gpu, flags, variant):
     """(flags -3: a majorant supergrid of factor 3 - the envmap instantiations of the supergrid tracer, drt_super.hip)"""
     props = props_for(variant)

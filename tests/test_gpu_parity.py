@@ -650,7 +650,8 @@ def test_heavy_tailed_ratio_tracking_splats_keep_ordinary_voxels_accurate(uivr, 
 
 @pytest.mark.parametrize("flags,variant", [(0, "drt"), (0, "drt-nomis"), (0, "basic"), (134217728, "drt"), (128, "drt"),
                                            (1048576, "drt"), (16384, "drt"), (1073741824, "drt"), (1073741824 | 16384, "drt"),
-                                           (1073741824, "basic"), (0, "quadratic")])
+                                           (1073741824, "basic"), (0, "quadratic"), (4096, "quadratic"), (1048576, "quadratic"),
+                                           (16384, "quadratic")])
 def test_supergrid_tracer_and_its_fallbacks_match_oracle(uivr, oracle, gpu, flags, variant):
     _supergrid_case(uivr, oracle, gpu, flags, variant, 7.0)
 
@@ -663,13 +664,24 @@ def test_supergrid_flights_that_cannot_collide_are_not_walked(uivr, oracle, gpu,
     _supergrid_case(uivr, oracle, gpu, 0, variant, density)
 
 
-def _supergrid_case(uivr, oracle, gpu, flags, variant, density):
+@pytest.mark.parametrize("max_depth,use_nee,flags", [(2, True, 0), (3, True, 0), (5, True, 0), (4, False, 0), (3, True, 4096)])
+def test_quadratic_drt_paths_cut_by_max_depth(uivr, oracle, gpu, max_depth, use_nee, flags):
+    """Quadratic DRT in the queued tracer (QUAD kernels): a recursive path that is killed by max_depth still makes its phase
+    draws (volpathsimple.py:221-222 run for every scatter), and here - unlike at the end of a subsampled path - the main
+    path's alt sampler continues behind them.  Short depth limits make every recursion end that way."""
+    _supergrid_case(uivr, oracle, gpu, flags, "quadratic", 7.0, max_depth=max_depth, use_nee=use_nee)
+
+
+def _supergrid_case(uivr, oracle, gpu, flags, variant, density, **over):
     """Scenes with a majorant supergrid run in the cell-stepping tracer (drt_super.hip): every estimator it takes
     (subsampled DRT with / without MIS, basic), with the path cache on and off (1048576), with the job cut into ray
     sub-batches (16384: launches with ray_first > 0), with its rays started thick pixels first as launches of millions of
     rays are (1073741824: from 4096 rays on; the at-size tests of test_gpu_configs.py run ordered by default, 536870912
     would keep index order); and what it hands back to the older kernels stays verified:
-    134217728 = the round-2 kernels for both passes, 128 = the atomic gradient path (no record streams), quadratic DRT.
+    134217728 = the round-2 kernels for both passes, 128 = the atomic gradient path (no record streams).  Quadratic DRT runs
+    in the queued tracer's QUAD adjoint kernels (drt_sq.hip: the main path suspended at every vertex for the DRT walk + the
+    recursive path; with and without the path cache, in ray sub-batches) and, with test hook 4096 (drt_super.hip does not
+    take it), in the round-2 kernels.
     Radiance bit-exact, counters equal, gradients close - against the oracle."""
     rng = np.random.default_rng(17)
     res = (24, 20, 28)                                   # X, Y, Z
@@ -681,7 +693,7 @@ def _supergrid_case(uivr, oracle, gpu, flags, variant, density):
                              majorant_resolution_factor=4)
     sensor = uivr.PerspectiveSensor(origin=(3.0, 2.0, 4.0), target=(0, 0, 0), fov=32.0, width=40, height=40)
     scene = uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter((0.9, 1.0, 1.1)), sensors=[sensor])
-    props, spp, seed = props_for(variant), 8, 515
+    props, spp, seed = props_for(variant, **over), 8, 515
     osc = oracle.OracleScene(scene)
     ref = oracle.h1_step(osc, props, spp, seed)
     _, c_primal = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)
@@ -703,7 +715,7 @@ def _supergrid_case(uivr, oracle, gpu, flags, variant, density):
     _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], "grad albedo")
 
 
-@pytest.mark.parametrize("flags,variant", [(0, "drt"), (4096, "drt"), (0, "basic")])
+@pytest.mark.parametrize("flags,variant", [(0, "drt"), (4096, "drt"), (0, "basic"), (4096, "quadratic"), (0, "quadratic")])
 def test_supergrid_too_large_for_lds_keeps_its_bitmask_there(uivr, oracle, gpu, flags, variant):
     """A supergrid whose majorants do not fit the tracer's LDS next to the ray records (160^3 voxels at factor 4 = 40^3
     = 64000 cells: 125 KiB as bf16; the reference's default on a 512^3 grid gives 64^3) runs the instantiations that keep the

@@ -280,8 +280,13 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
 #endif
     // supergrid scenes: the cell-stepping state machine (drt_super.hip) for both passes; bit 134217728 keeps the older
     // kernels (state machine of whole flights for the primal, one ray per lane for the adjoint) for the variant tests
-    const bool super = P.mgrid && !quadratic && !dbg(h->debug_flags, (134217728u | 8u | 32u | 32768u | 65536u)) &&
-                       (!adjoint || P.rec_buf[0] != nullptr) && drt::super_supported(P);
+    // (quadratic DRT: only the queued tracer takes it - its QUAD adjoint kernels; drt_super.hip hands it to the round-2 kernels)
+    bool sq_ok = P.mgrid && !dbg(h->debug_flags, 4096u) && drt::sq_supported(P);
+    if (sq_ok && !h->d_sq_cold && hipMalloc(&h->d_sq_cold, drt::sq_cold_bytes(h->n_cus)) != hipSuccess) {   // (the records' global halves)
+        (void) hipGetLastError(); h->d_sq_cold = nullptr; sq_ok = false;
+    }
+    const bool super = P.mgrid && (!quadratic || sq_ok) && !dbg(h->debug_flags, (134217728u | 8u | 32u | 32768u | 65536u)) &&
+                       (!adjoint || P.rec_buf[0] != nullptr) && (sq_ok || drt::super_supported(P));
     if (super) {
         drt::Params Q = P;
         Q.queues = h->d_queues;
@@ -314,10 +319,7 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         DRT_HIP_CHECK(h, hipMemsetAsync(h->d_queues, 0, 8 * sizeof(unsigned long long), h->stream));
         // round 4: the queued tracer (drt_sq.hip) where the ray records fit LDS next to the majorants; test hook 4096 keeps
         // the round-3 kernel (drt_super.hip), which also serves what the queued one does not take
-        bool queued = !dbg(h->debug_flags, 4096u) && drt::sq_supported(P);
-        if (queued && !h->d_sq_cold) {
-            if (hipMalloc(&h->d_sq_cold, drt::sq_cold_bytes(h->n_cus)) != hipSuccess) { (void) hipGetLastError(); h->d_sq_cold = nullptr; queued = false; }
-        }
+        const bool queued = sq_ok;
         if (queued) {
             Q.sq_cold = h->d_sq_cold;
             DRT_HIP_CHECK(h, drt::launch_trace_sq(Q, adjoint, h->counting, h->n_cus, h->stream));

@@ -28,8 +28,9 @@
 // Arithmetic, random-number consumption and event counts are those of the scalar restatement (oracle/drt_oracle.c):
 // radiance is bit-exact per ray, counters are equal; gradients differ by summation order only.  A ray computes the same
 // numbers whichever lanes run its pieces.  Not handled here (the host keeps drt_super.hip / the one-ray-per-lane kernels):
-// supergrids of more than 511 cells per axis or whose cell bitmask does not fit LDS either, quadratic DRT, the atomic gradient
-// path.  Design history, profiles and what was measured and not kept: DESIGN.md section 6.2, profiles/r04_sq_experiments.txt.
+// supergrids of more than 511 cells per axis or whose cell bitmask does not fit LDS either, the atomic gradient path.  Quadratic DRT
+// (the paper's comparison estimator) runs in the QUAD instantiations of the adjoint kernels: the main path is suspended at every
+// vertex for the DRT walk + recursive path the subsampled estimator runs once at the end of a path.  Design history, profiles and what was measured and not kept: DESIGN.md section 6.2, profiles/r04_sq_experiments.txt.
 #include <atomic>
 #include "drt_device.h"
 #include "drt_launch.h"
@@ -104,6 +105,7 @@ enum SqPhase : int {
     SP_DT = 0, SP_RT, SP_RTA, SP_DRT,
     // transition phases
     SP_HEAD, SP_SCAT, SP_ESC, SP_NEE, SP_RT_END, SP_RTA_END, SP_PHASE, SP_END, SP_DRT_END,
+    SP_QSCAT2,                     // quadratic DRT: the main path resumes behind the DRT detour of a vertex (second half of the collision block)
     SP_IDLE, SP_NONE
 };
 enum SqFlight : int { SF_NEW = 0, SF_NEXT = 1, SF_WAIT = 2 };   // first flight of a walk to set up | next flight to set up | posted
@@ -211,12 +213,20 @@ __device__ __forceinline__ void sq_push_all(unsigned long long *ctl, uint16_t *q
 // holds one BIT per cell (non-empty: two thirds of the cells a flight crosses answer without a load) and the majorants of the
 // others are read from global memory (1 MB, L2-resident); the cell steps are then unpredicated in both passes (the geometry of
 // the 8 steps first, their loads together) and a flight's first cells are not stepped by the lanes that set it up
-template <bool ADJ, bool COUNT, bool ENV, bool MG>
+// QUAD (adjoint kernels): quadratic DRT (use_drt without use_drt_subsampling, the paper's comparison estimator: volpathsimple.py:143-150
+// calls backpropagate_scattering_drt at EVERY vertex of the main path).  The main path is suspended in the middle of its collision
+// block: its state goes into the record's global half (the reservoir's slots, which this estimator does not use, + three more
+// quads), the record runs the DRT walk along the current segment and the recursive path from the selected vertex exactly as the
+// subsampled estimator does at the end of a path, and at the end of the recursion the main path is restored - with the alt sampler
+// advanced by the detour's draws - and resumes with the second half of the block (SP_QSCAT2).
+template <bool ADJ, bool COUNT, bool ENV, bool MG, bool QUAD = false>
 __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P)
 {
     constexpr int NWV = DRT_SQ_THREADS / 64;
     constexpr int R4 = 7;                                                    // uint4 per ray record in LDS
-    constexpr int NC = ADJ ? 9 : 3;                                          // uint4 per ray in global memory (Params::sq_cold)
+    static_assert(ADJ || !QUAD, "the primal pass of the quadratic estimator is the ordinary one");
+    constexpr int NB = QUAD ? 9 : 6;                                         // uint4 of part b of the global record (adjoint)
+    constexpr int NC = ADJ ? 3 + NB : 3;                                     // uint4 per ray in global memory (Params::sq_cold)
     // LDS record: [0] {tn.x, tn.y, tn.z, cell} [1] {td.x, td.y, td.z, steps left (9 bits per axis) + direction signs}
     // [2] {tau, tmax, t, acc} - the flight (a finished flight leaves its cell's majorant, 0: left the segment, in [0].x) -
     // [3] {rd, wmax} [4] {wo, wt} [5] {G.state, G.inc}: the generator the current walk draws from (the alt sampler in the main
@@ -304,7 +314,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
 
     uint32_t *rec = recst + wave * 8;                                          // record-stream state of this wave (emit_record)
     uint4 *cold_a = (uint4 *) P.sq_cold + (size_t) blockIdx.x * NC * NRAY;    // [NRAY][3] uint4 of this workgroup
-    uint4 *cold_b = cold_a + 3 * NRAY;                                        // [NRAY][6] (adjoint)
+    uint4 *cold_b = cold_a + 3 * NRAY;                                        // [NRAY][6] (adjoint; QUAD: [9], the last three: the suspended main path)
     const uint32_t xcc = sq_xcc_id();
     // (with a ray order the queue positions cover whole units: the last unit may reach past the launch's last ray)
     const uint64_t span = P.order ? (uint64_t) P.order_units * P.order_unit : P.n_rays - P.ray_first;
@@ -474,6 +484,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         int r_depth = -1; float r_si_t = kInf; V3 r_o = ro, r_d = rd;
         float r_wsum[3] = { 0, 0, 0 }, r_cw[3] = { 0, 0, 0 };
         bool b_live = true;                                                     // part b of the global record is in registers (adjoint)
+        // QUAD: the suspended main path {origin, segment end} {radiance, collision distance} {flags: scatter | escaped | has_scattered |
+        // scat_once | pc_on | pc_it << 8; the sampler's increment}
+        V3 q_ro = v3(0, 0, 0); float q_si_t = 0.0f, q_wt = 0.0f, q_result[3] = { 0, 0, 0 }; uint32_t q_flags = 0, q_sinc_lo = 1, q_sinc_hi = 0;
         bool walk_done = false;                                                 // the flight set up here ended within its first cells
         float c_lm = 0.0f, c_tau = 0.0f, c_t = 0.0f, c_acc = 0.0f;              // the finished flight (collision batches)
         float w_tdx = kInf, w_tdy = kInf, w_tdz = kInf; uint32_t w_rem = 0;      // the walk's direction share of the DDA
@@ -509,8 +522,14 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     if constexpr (ADJ) {
                       b_live = !rec_mode;
                       if (b_live) {
-                        const uint4 *cb = cold_b + 6 * id;
+                        const uint4 *cb = cold_b + NB * id;
                         const uint4 c3 = cb[0], c4 = cb[1], c5 = cb[2], c6 = cb[3], c7 = cb[4], c8 = cb[5];
+                        if constexpr (QUAD) {
+                            const uint4 c9 = cb[6], c10 = cb[7], c11 = cb[8];
+                            q_ro = v3(__uint_as_float(c9.x), __uint_as_float(c9.y), __uint_as_float(c9.z)); q_si_t = __uint_as_float(c9.w);
+                            q_result[0] = __uint_as_float(c10.x); q_result[1] = __uint_as_float(c10.y); q_result[2] = __uint_as_float(c10.z); q_wt = __uint_as_float(c10.w);
+                            q_flags = c11.x; q_sinc_lo = c11.y; q_sinc_hi = c11.z;
+                        }
                         dL[0] = __uint_as_float(c3.x); dL[1] = __uint_as_float(c3.y); dL[2] = __uint_as_float(c3.z); r_si_t = __uint_as_float(c3.w);
                         Cst = ((uint64_t) c4.y << 32) | c4.x; r_depth = (int) c4.z;
                         r_o = v3(__uint_as_float(c5.x), __uint_as_float(c5.y), __uint_as_float(c5.z)); r_wsum[0] = __uint_as_float(c5.w);
@@ -708,6 +727,21 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
             }
         };
+        // QUAD: the main path comes back from the DRT detour of a vertex (no vertex selected, or the recursive path has ended): the alt
+        // sampler continues where the detour left it, everything else is as it was in the middle of the collision block
+        auto quad_resume = [&](bool from_recursion) {
+            if constexpr (QUAD) {
+                if (from_recursion) { A.state = S.state; A.inc = S.inc; }       // (the recursion sampled with a copy of the alt sampler)
+                S.state = Cst; S.inc = ((uint64_t) q_sinc_hi << 32) | q_sinc_lo;
+                beta[0] = r_wsum[0]; beta[1] = r_wsum[1]; beta[2] = r_wsum[2];
+                result[0] = q_result[0]; result[1] = q_result[1]; result[2] = q_result[2];
+                depth = r_depth; ro = q_ro; rd = r_d; si_t = q_si_t; wt = q_wt;
+                escaped = (q_flags >> 1) & 1u; has_scattered = (q_flags >> 2) & 1u; scat_once = (q_flags >> 3) & 1u;
+                pc_on = (q_flags >> 4) & 1u; pc_it = (int) (q_flags >> 8);
+                rec_mode = false; rec_first = false;
+                ph = SP_QSCAT2;
+            }
+        };
         for (;;) {
             if (kind != SQ_COLL && __ballot(ph >= SP_HEAD && ph < SP_IDLE)) {
                 uint4 pce1 = make_uint4(0u, 0u, 0u, 0u); bool pce1_ok = false;   // this iteration's NEE entry of the path cache, read at the loop head
@@ -715,8 +749,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 // ---- DRT vertex selected: enter the detached recursive path (:553-575, :610-655) -----
                 if constexpr (ADJ) {
                     if (ph == SP_DRT_END) {
-                        if (!(wo.z < kInf)) ph = SP_IDLE;                       // no tentative collision (:558)
-                        else {
+                        if (!(wo.z < kInf)) {                                   // no tentative collision (:558)
+                            if constexpr (QUAD) quad_resume(false); else ph = SP_IDLE;
+                        } else {
                             const V3 xp = ray_at(ro, rd, wo.z);
                             r_o = xp; ro = xp;
                             const float sig = eval_sigma_t(P, xp, occ);         // :553-554
@@ -789,21 +824,40 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                             make_uint4(__float_as_uint(ph == SP_SCAT ? wt : kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
                 }
                 SQ_BLK(4, ph == SP_SCAT || ph == SP_ESC);
-                if (ph == SP_SCAT || ph == SP_ESC) {
-                    const bool scat = ph == SP_SCAT;
+                if (ph == SP_SCAT || ph == SP_ESC || (QUAD && ph == SP_QSCAT2)) {
+                    const bool resumed = QUAD && ph == SP_QSCAT2;               // (back from the detour: the lookups again, not counted again)
+                    const bool scat = resumed ? (q_flags & 1u) != 0u : ph == SP_SCAT;
                     const bool adj_lane = ADJ && !rec_mode;
                     float albedo[3] = { 1.0f, 1.0f, 1.0f }, mei_sig = 0.0f;
                     V3 mp = ro;
                     if (scat) {
                         mp = ray_at(ro, rd, wt);                                // :371
-                        if (adj_lane) { mei_sig = eval_sigma_t(P, mp, occ); SQ_COUNT(C_DT); }   // :373-375
+                        if (adj_lane) { mei_sig = eval_sigma_t(P, mp, occ); if (!resumed) SQ_COUNT(C_DT); }   // :373-375
                         has_scattered = true;
                         eval_albedo(P, mp, albedo);                             // :141
-                        SQ_COUNT(C_ALB);
+                        if (!resumed) SQ_COUNT(C_ALB);
+                    }
+                    bool detour = false;
+                    if constexpr (QUAD) {
+                        if (adj_lane && P.use_drt && !resumed) {
+                            // backpropagate_scattering_drt at this vertex (:143-150, :543-581): suspend the main path ...
+                            detour = true;
+                            q_flags = (scat ? 1u : 0u) | (escaped ? 2u : 0u) | (has_scattered ? 4u : 0u) | (scat_once ? 8u : 0u) | (pc_on ? 16u : 0u) |
+                                      ((uint32_t) pc_it << 8);
+                            q_ro = ro; q_si_t = si_t; q_wt = wt; q_sinc_lo = (uint32_t) S.inc; q_sinc_hi = (uint32_t) (S.inc >> 32);
+                            q_result[0] = result[0]; q_result[1] = result[1]; q_result[2] = result[2];
+                            Cst = S.state; r_depth = depth; r_d = rd;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) { r_wsum[k] = beta[k]; r_cw[k] = dL[k] * beta[k]; }   // adj (:146)
+                            // ... and walk the segment with sample_interaction_drt (:543-551), as the subsampled estimator does at the end of a path
+                            wmax = isfinite(si_t) ? si_t : kLargest;
+                            wt = 0.0f; wo = v3(1.0f, 0.0f, kInf);               // T, wsum, selected t
+                            ph = SP_DRT; fl = SF_NEW;
+                        }
                     }
                     if constexpr (ADJ) {
-                        if (adj_lane) {
-                            if (P.use_drt) {                                    // DRTReservoir.update :745-753
+                        if (adj_lane && !detour) {
+                            if (!QUAD && P.use_drt) {                           // DRTReservoir.update :745-753
                                 float u = A.next_1d();
                                 float m = 0.0f;
 #pragma unroll
@@ -841,12 +895,18 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                             if (tr_g != 0.0f) emit_records0<4>(P, pts, tr_g * P.scale, rec);
                         }
                     }
-                    if (scat) {
+                    if (detour) { }                                             // (the rest of the block when the main path is back)
+                    else if (scat) {
                         beta[0] *= albedo[0]; beta[1] *= albedo[1]; beta[2] *= albedo[2];   // :193
                         depth += 1;                                             // :199
                         ro = mp;
                         if (depth < P.max_depth) ph = P.use_nee ? SP_NEE : SP_PHASE;   // :200, :206-207
-                        else ph = SP_END;          // killed inside the medium; its phase draws are unobservable
+                        else {
+                            ph = SP_END;           // killed inside the medium; its phase draws (:221-222) are unobservable ...
+                            if constexpr (QUAD) {  // ... except on a recursive path of the quadratic estimator: the main path's alt sampler continues behind them
+                                if (rec_mode) { (void) S.next_1d(); (void) S.next_1d(); (void) S.next_1d(); }
+                            }
+                        }
                     } else {
                         escaped = true;                                         // :245
                         ph = SP_END;
@@ -898,11 +958,22 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                         if (rec_mode) {
                             // result = Li': gradient splat at x' (:577-581)
                             if (!b_live) {                                      // (a recursive path loaded without the main path's state)
-                                const uint4 *cb = cold_b + 6 * id;
+                                const uint4 *cb = cold_b + NB * id;
                                 const uint4 c3 = cb[0], c5 = cb[2], c7 = cb[4];
                                 r_si_t = __uint_as_float(c3.w);
                                 r_o = v3(__uint_as_float(c5.x), __uint_as_float(c5.y), __uint_as_float(c5.z));
                                 r_cw[0] = __uint_as_float(c7.x); r_cw[1] = __uint_as_float(c7.y); r_cw[2] = __uint_as_float(c7.z);
+                                if constexpr (QUAD) {                           // ... and everything of the suspended main path
+                                    const uint4 c4 = cb[1], c6 = cb[3], c9 = cb[6], c10 = cb[7], c11 = cb[8];
+                                    dL[0] = __uint_as_float(c3.x); dL[1] = __uint_as_float(c3.y); dL[2] = __uint_as_float(c3.z);
+                                    Cst = ((uint64_t) c4.y << 32) | c4.x; r_depth = (int) c4.z;
+                                    r_wsum[0] = __uint_as_float(c5.w); r_wsum[1] = __uint_as_float(c6.w); r_wsum[2] = __uint_as_float(c7.w);
+                                    r_d = v3(__uint_as_float(c6.x), __uint_as_float(c6.y), __uint_as_float(c6.z));
+                                    q_ro = v3(__uint_as_float(c9.x), __uint_as_float(c9.y), __uint_as_float(c9.z)); q_si_t = __uint_as_float(c9.w);
+                                    q_result[0] = __uint_as_float(c10.x); q_result[1] = __uint_as_float(c10.y); q_result[2] = __uint_as_float(c10.z); q_wt = __uint_as_float(c10.w);
+                                    q_flags = c11.x; q_sinc_lo = c11.y; q_sinc_hi = c11.z;
+                                    b_live = true;                              // (stored with the resumed main path)
+                                }
                             }
                             float alb[3];
                             eval_albedo(P, r_o, alb);                           // :578
@@ -915,8 +986,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                                 ga[k] = a * r_si_t;
                             }
                             splat_scatter<true>(P, r_o, gs, ga, rec); SQ_COUNT(C_SC); SQ_COUNT(C_SC_ALB);
-                            ph = SP_IDLE;
-                        } else if (P.use_drt && r_depth >= 0) {                 // :249-259, DRTReservoir.get :756-760
+                            if constexpr (QUAD) quad_resume(true); else ph = SP_IDLE;
+                        } else if (!QUAD && P.use_drt && r_depth >= 0) {        // :249-259, DRTReservoir.get :756-760
                             const float d = ((r_cw[0] + r_cw[1]) + r_cw[2]) / 3.0f;
                             const float ws = ((r_wsum[0] + r_wsum[1]) + r_wsum[2]) / 3.0f;
 #pragma unroll
@@ -1047,7 +1118,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 ca[2] = make_uint4(__float_as_uint(result[0]), __float_as_uint(result[1]), __float_as_uint(result[2]), li);
                 if constexpr (ADJ) {
                     if (b_live) {
-                        uint4 *cb = cold_b + 6 * id;
+                        uint4 *cb = cold_b + NB * id;
                         const uint64_t os = gA ? S.state : A.state, oi = gA ? S.inc : A.inc;
                         cb[0] = make_uint4(__float_as_uint(dL[0]), __float_as_uint(dL[1]), __float_as_uint(dL[2]), __float_as_uint(r_si_t));
                         cb[1] = make_uint4((uint32_t) Cst, (uint32_t) (Cst >> 32), (uint32_t) r_depth, 0u);
@@ -1055,6 +1126,11 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                         cb[3] = make_uint4(__float_as_uint(r_d.x), __float_as_uint(r_d.y), __float_as_uint(r_d.z), __float_as_uint(r_wsum[1]));
                         cb[4] = make_uint4(__float_as_uint(r_cw[0]), __float_as_uint(r_cw[1]), __float_as_uint(r_cw[2]), __float_as_uint(r_wsum[2]));
                         cb[5] = make_uint4((uint32_t) os, (uint32_t) (os >> 32), (uint32_t) oi, (uint32_t) (oi >> 32));
+                        if constexpr (QUAD) {
+                            cb[6] = make_uint4(__float_as_uint(q_ro.x), __float_as_uint(q_ro.y), __float_as_uint(q_ro.z), __float_as_uint(q_si_t));
+                            cb[7] = make_uint4(__float_as_uint(q_result[0]), __float_as_uint(q_result[1]), __float_as_uint(q_result[2]), __float_as_uint(q_wt));
+                            cb[8] = make_uint4(q_flags, q_sinc_lo, q_sinc_hi, 0u);
+                        }
                     }
                 }
             }
@@ -1128,7 +1204,7 @@ static uint32_t sq_rays_for(const Params &P, size_t *bytes, bool *global_majoran
     return 0;
 }
 
-size_t sq_cold_bytes(int n_cus) { return (size_t) n_cus * 9 * DRT_SQ_MAX_RAYS * sizeof(uint4); }
+size_t sq_cold_bytes(int n_cus) { return (size_t) n_cus * 12 * DRT_SQ_MAX_RAYS * sizeof(uint4); }   // (3 + 9: the quadratic estimator's adjoint records)
 
 bool sq_supported(const Params &P)
 {
@@ -1150,10 +1226,12 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
     dim3 block(DRT_SQ_THREADS), grid(blocks);
     const bool env = P.env_pix != nullptr;
     hipError_t e = hipSuccess;
-#define DRT_SQ_LAUNCH(A, C, E) do { if (mg) DRT_SQ_LAUNCH_(A, C, E, true); else DRT_SQ_LAUNCH_(A, C, E, false); } while (0)
-#define DRT_SQ_LAUNCH_(A, C, E, M)                                                                                \
+    const bool quad = adjoint && P.use_drt && !P.use_drt_subsampling;           // quadratic DRT: the QUAD instantiations of the adjoint kernels
+#define DRT_SQ_LAUNCH(A, C, E) do { if (A && quad) { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, A); else DRT_SQ_LAUNCH_(A, C, E, false, A); } \
+                                    else { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, false); else DRT_SQ_LAUNCH_(A, C, E, false, false); } } while (0)
+#define DRT_SQ_LAUNCH_(A, C, E, M, Q)                                                                             \
     do {                                                                                                          \
-        auto kern = trace_sq_kernel<A, C, E, M>;                                                                  \
+        auto kern = trace_sq_kernel<A, C, E, M, Q>;                                                               \
         static std::atomic<size_t> lds_set[64];                                                                        \
         int dev_ = 0;                                                                                             \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 63;                               \

@@ -60,12 +60,12 @@ add_int_config('fd-forward', pretty_name='Finite differences',
 add_int_config('volpathsimple-drt', pretty_name='Differential Ratio Tracking',
                params={'type': 'volpathsimple', 'use_drt': True,
                        'use_drt_subsampling': True, 'use_drt_mis': True})
-# SLOW PATH on purpose: the quadratic estimator (a DRT walk + recursive path at EVERY vertex of the main path, the paper's
-# comparison baseline, not its method) suspends the main path in the middle of a bounce.  The queued supergrid tracer
-# (csrc/drt_sq.hip) keeps ONE path per ray record and does not take it: with a majorant supergrid this configuration runs
-# the one-ray-per-lane kernel (CoopTracer<SUPER>, csrc/drt_coop_super.hip; oracle-checked like the others,
-# tests/test_gpu_parity.py::test_supergrid_tracer_and_its_fallbacks_match_oracle[0-quadratic]) at roughly a third of the
-# registered estimator's ray rate per event.
+# The quadratic estimator (a DRT walk + recursive path at EVERY vertex of the main path: the paper's comparison baseline, not its
+# method) suspends the main path in the middle of a bounce.  With a majorant supergrid it runs in the queued tracer's QUAD adjoint
+# kernels (csrc/drt_sq.hip: the suspended path is kept in the ray record's global half; headline scene at factor 8: 418 Msamples/s
+# against 128 in the one-ray-per-lane kernel it used before round 4), with ONE majorant in the one-ray-per-lane kernels; both are
+# oracle-checked (tests/test_gpu_parity.py::test_supergrid_tracer_and_its_fallbacks_match_oracle[*-quadratic],
+# ::test_quadratic_drt_paths_cut_by_max_depth).
 add_int_config('volpathsimple-drt-quadratic', pretty_name='Differential Ratio Tracking (quadratic)',
                params={'type': 'volpathsimple', 'use_drt': True,
                        'use_drt_subsampling': False, 'use_drt_mis': True})
