@@ -105,8 +105,9 @@ enum SqPhase : int {
     SP_DT = 0, SP_RT, SP_RTA, SP_DRT,
     // transition phases
     SP_HEAD, SP_SCAT, SP_ESC, SP_NEE, SP_RT_END, SP_RTA_END, SP_PHASE, SP_END, SP_DRT_END,
-    SP_QSCAT2,                     // quadratic DRT: the main path resumes behind the DRT detour of a vertex (second half of the collision block)
-    SP_IDLE, SP_NONE
+    SP_IDLE, SP_NONE,
+    SP_QSCAT2                      // quadratic DRT (QUAD kernels): the main path resumes behind the DRT detour of a vertex - a transition phase like
+                                   // SP_HEAD .. SP_DRT_END (sq_is_trans); numbered behind the others so that their constants are those of the other kernels
 };
 enum SqFlight : int { SF_NEW = 0, SF_NEXT = 1, SF_WAIT = 2 };   // first flight of a walk to set up | next flight to set up | posted
 #ifndef DRT_SQ_SPLIT
@@ -119,6 +120,8 @@ enum SqFlight : int { SF_NEW = 0, SF_NEXT = 1, SF_WAIT = 2 };   // first flight 
 // (One queue gave batches whose rays needed different blocks: each block ran with 14-27 of 64 lanes, profiles/r04_sq_experiments.txt.)
 enum SqKind : int { SQ_WALK = 0, SQ_COLL, SQ_TA, SQ_TB, SQ_REGEN, SQ_KINDS };
 constexpr uint32_t kSqEmpty = 0xffffu;
+template <bool QUAD>
+__device__ __forceinline__ bool sq_is_trans(int ph) { return (ph >= SP_HEAD && ph < SP_IDLE) || (QUAD && ph == SP_QSCAT2); }
 template <bool SPLIT>
 __device__ __forceinline__ int sq_trans_kind(int ph)
 {
@@ -743,9 +746,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             }
         };
         for (;;) {
-            if (kind != SQ_COLL && __ballot(ph >= SP_HEAD && ph < SP_IDLE)) {
+            if (kind != SQ_COLL && __ballot(sq_is_trans<QUAD>(ph))) {
                 uint4 pce1 = make_uint4(0u, 0u, 0u, 0u); bool pce1_ok = false;   // this iteration's NEE entry of the path cache, read at the loop head
-                SQ_BLK(8, ph >= SP_HEAD && ph < SP_IDLE); SQ_BLK(0, ph == SP_DRT_END); SQ_BLK(1, ph == SP_RT_END || ph == SP_RTA_END);
+                SQ_BLK(8, sq_is_trans<QUAD>(ph)); SQ_BLK(0, ph == SP_DRT_END); SQ_BLK(1, ph == SP_RT_END || ph == SP_RTA_END);
                 // ---- DRT vertex selected: enter the detached recursive path (:553-575, :610-655) -----
                 if constexpr (ADJ) {
                     if (ph == SP_DRT_END) {
@@ -1091,12 +1094,12 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
             }
             SQ_STAMP(6);
-            if (kind == SQ_COLL || __popcll(__ballot(ph >= SP_HEAD && ph < SP_IDLE)) < DRT_SQ_T_PASS) break;   // (what is left goes to the transition queue)
+            if (kind == SQ_COLL || __popcll(__ballot(sq_is_trans<QUAD>(ph))) < DRT_SQ_T_PASS) break;   // (what is left goes to the transition queue)
         }
 
         // ================= store the rays, hand them on ====================================================
         const bool go_walk = act && ph < SP_HEAD;                               // (posted: fl == SF_WAIT)
-        const bool go_trans = act && ph >= SP_HEAD && ph < SP_IDLE;            // (collision batches only: the walk ended)
+        const bool go_trans = act && sq_is_trans<QUAD>(ph);            // (collision batches only: the walk ended)
         const bool go_free = act && ph == SP_IDLE;
         if (go_walk || go_trans) {
             const bool drtw = ph == SP_DRT || ph == SP_DRT_END;
