@@ -217,6 +217,15 @@ int drt_film_backward(drt_handle h, const float *grad_image, uint64_t n_pixels, 
  * blocks that are non-zero on some rank - the reference is single-GPU, this replaces nothing in it. */
 int drt_grad_block_mask(void *hip_stream, const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask);
 
+/* The blocks of the flat gradient buffer that CAN be non-zero, from sigma_t alone (no handle; multi-GPU: the packing set of the ONE
+ * gradient all-reduce per backward, computed before the adjoint pass - distributed.gradient_support; the reference is single-GPU).
+ * sigma_t (Z,Y,X,1), res = {X,Y,Z}.  The buffer holds one per-voxel plane of `channels` floats per voxel (the albedo gradient)
+ * starting at float `sparse_offset_floats`: a block wholly inside it gets mask 1 iff one of its voxels lies within one step (3x3x3
+ * neighbourhood) of a non-zero sigma_t voxel - a scattering vertex has sigma_t(x) > 0 (volpathsimple.py:152-172, 577-581) and a
+ * trilinear footprint; every other block gets 1.  bits_scratch: ceil(X / 32) * Y * Z words of device scratch. */
+int drt_grad_support_mask(void *hip_stream, const float *sigma_t, const int32_t res[3], uint64_t sparse_offset_floats, uint32_t channels,
+                          uint64_t n_blocks, uint32_t block_floats, uint32_t *bits_scratch, uint8_t *mask);
+
 /* One Adam step on a parameter grid in a single pass (no handle; N2: mi.ad.Adam as python/optimize.py:329,352-354 uses it):
  * m = beta_1 m + (1 - beta_1) g;  v = beta_2 v + (1 - beta_2) g^2;  p -= lr_t m / (sqrt(v) + epsilon), where the caller folds the
  * bias corrections into lr_t = lr sqrt(1 - beta_2^t) / (1 - beta_1^t).  All four buffers: n floats, 16-byte aligned. */

@@ -210,6 +210,31 @@ def test_gradient_support_covers_every_nonzero_gradient_block(uivr, gpu, variant
         assert sup.count < 0.8 * sup.mask.numel()
 
 
+@pytest.mark.parametrize("shape", [(48, 48, 48), (50, 29, 37), (5, 70, 9), (33, 2, 1)])
+def test_device_gradient_support_equals_the_torch_formulation(uivr, gpu, shape):
+    """drt_grad_support_mask (two small kernels) gives exactly the mask of the torch formulation of distributed.gradient_support
+    (3 x 3 x 3 dilation of sigma_t != 0 over the albedo plane, every block of the sigma_t plane and of the padding) - grids whose
+    rows are not multiples of 32 voxels, blocks that span several rows, non-zero voxels on the borders."""
+    from uivr_amd.distributed import gradient_support
+    rz, ry, rx = shape
+    gen = torch.Generator().manual_seed(rx * 131 + ry)
+    st = torch.zeros(rz, ry, rx, 1)
+    idx = torch.randint(0, rz * ry * rx, (max(2, rz * ry * rx // 400),), generator=gen)
+    st.view(-1)[idx] = torch.rand(idx.numel(), generator=gen) + 0.1
+    st[0, 0, 0, 0] = 1.0; st[rz - 1, ry - 1, rx - 1, 0] = 1.0
+    scene = uivr.cube_test_scene(8, 8)
+    scene.medium.sigma_t, scene.medium.albedo = st, torch.rand(rz, ry, rx, 3, generator=gen)
+    cpu_grads = uivr.alloc_grads(scene)
+    ref = gradient_support(st, cpu_grads, sparse_keys=(uivr.ALBEDO_KEY,))
+    sg = uivr.scene_to(scene, gpu)
+    dev_grads = uivr.alloc_grads(sg)
+    got = gradient_support(sg.medium.sigma_t, dev_grads, sparse_keys=(uivr.ALBEDO_KEY,))
+    if ref is None:
+        assert got is None
+        return
+    assert got.mask.is_cuda and torch.equal(got.mask.cpu(), ref.mask) and got.count == ref.count
+
+
 @pytest.mark.parametrize("spp", [1, 7, 32, 128, 200, 1024])
 def test_film_develop_is_the_sample_mean(uivr, gpu, spp):
     """Box film (python/batched.py:176-197): image = mean over the pixel's samples - the thread-per-channel kernel

@@ -1230,6 +1230,15 @@ int drt_adam_step(void *hip_stream, float *p, const float *g, float *m, float *v
     return drt::launch_adam_step(p, g, m, v, n, beta_1, beta_2, epsilon, lr_t, (hipStream_t) hip_stream) == hipSuccess ? DRT_OK : DRT_ERR_HIP;
 }
 
+int drt_grad_support_mask(void *hip_stream, const float *sigma_t, const int32_t res[3], uint64_t sparse_offset_floats, uint32_t channels,
+                          uint64_t n_blocks, uint32_t block_floats, uint32_t *bits_scratch, uint8_t *mask)
+{
+    if (!sigma_t || !res || !bits_scratch || (n_blocks && !mask)) return DRT_ERR_INVALID_ARGUMENT;
+    if (res[0] <= 0 || res[1] <= 0 || res[2] <= 0 || channels == 0 || block_floats == 0) return DRT_ERR_INVALID_ARGUMENT;
+    return drt::launch_support_mask(sigma_t, res[0], res[1], res[2], sparse_offset_floats, channels, n_blocks, block_floats, bits_scratch, mask,
+                                    (hipStream_t) hip_stream) == hipSuccess ? DRT_OK : DRT_ERR_HIP;
+}
+
 int drt_grad_block_mask(void *hip_stream, const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask)
 {
     if (n_blocks && (!buf || !mask)) return DRT_ERR_INVALID_ARGUMENT;

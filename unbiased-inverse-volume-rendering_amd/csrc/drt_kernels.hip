@@ -1160,6 +1160,83 @@ hipError_t launch_block_mask(const float *buf, uint64_t n_blocks, uint32_t block
     return hipGetLastError();
 }
 
+// Which blocks of the flat gradient buffer CAN be non-zero, from sigma_t alone (distributed.gradient_support: the packing set of the
+// one-collective gradient all-reduce, known before the adjoint pass).  Pass 1: one bit per voxel, sigma_t != 0 (x fastest, rows padded
+// to whole words).  Pass 2: one thread per block; a block inside the per-voxel plane [sparse_off, sparse_off + V * ch) covers a run of
+// voxels in linear order - it is in the set iff some voxel of the run has a non-zero sigma_t voxel in its 3 x 3 x 3 neighbourhood
+// (a scattering vertex has sigma_t(x) > 0 and a trilinear footprint); every other block (the dense sigma_t plane, padding) is in the set.
+__global__ void __launch_bounds__(256) support_bits_kernel(const float *sigma_t, int rx, int ry, int rz, int row_words, uint32_t *bits)
+{
+    // one wave per 64 voxels of a row (coalesced), two words per ballot
+    const size_t wave = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int chunks = (rx + 63) / 64;
+    const size_t total = (size_t) chunks * ry * rz;
+    if (wave >= total) return;
+    const size_t row = wave / chunks; const int x = (int) (wave % chunks) * 64 + lane;
+    const bool nz = x < rx && sigma_t[row * rx + x] != 0.0f;
+    const uint64_t m = __ballot(nz);
+    const int w0 = (int) (wave % chunks) * 2;
+    if (lane == 0) bits[row * row_words + w0] = (uint32_t) m;
+    if (lane == 1 && w0 + 1 < row_words) bits[row * row_words + w0 + 1] = (uint32_t) (m >> 32);
+}
+
+__device__ __forceinline__ bool support_row_any(const uint32_t *bits, int row_words, int rx, size_t row, int xa, int xb)
+{
+    xa = xa < 0 ? 0 : xa; xb = xb > rx - 1 ? rx - 1 : xb;                 // voxels [xa, xb] of the row
+    if (xa > xb) return false;
+    const uint32_t *r = bits + row * row_words;
+    for (int w = xa >> 5; w <= (xb >> 5); ++w) {
+        uint32_t m = r[w];
+        const int lo = w * 32;
+        if (xa > lo) m &= ~0u << (xa - lo);
+        if (xb < lo + 31) m &= ~0u >> (lo + 31 - xb);
+        if (m) return true;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(256) support_mask_kernel(const uint32_t *bits, int rx, int ry, int rz, int row_words, uint64_t sparse_off,
+                                                           uint32_t ch, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask)
+{
+    const uint64_t b = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint64_t f0 = b * block_floats, f1 = f0 + block_floats - 1;                        // the block's floats [f0, f1]
+    const uint64_t V = (uint64_t) rx * ry * rz;
+    if (f0 < sparse_off || f1 >= sparse_off + V * ch) { mask[b] = 1; return; }              // (not wholly inside the per-voxel plane)
+    const uint64_t v0 = (f0 - sparse_off) / ch, v1 = (f1 - sparse_off) / ch;                 // voxels [v0, v1], linear (x fastest)
+    bool any = false;
+    uint64_t v = v0;
+    while (v <= v1 && !any) {                                                                // row by row (a block spans one or two rows)
+        const uint64_t row = v / rx; const int xa = (int) (v % rx);
+        const uint64_t row_end = row * rx + rx - 1;
+        const int xb = (int) ((v1 < row_end ? v1 : row_end) - row * rx);
+        const int y = (int) (row % ry), z = (int) (row / ry);
+        for (int dz = -1; dz <= 1 && !any; ++dz)
+            for (int dy = -1; dy <= 1 && !any; ++dy) {
+                const int yy = y + dy, zz = z + dz;
+                if (yy < 0 || yy >= ry || zz < 0 || zz >= rz) continue;
+                any = support_row_any(bits, row_words, rx, (size_t) zz * ry + yy, xa - 1, xb + 1);
+            }
+        v = row_end + 1;
+    }
+    mask[b] = any ? 1 : 0;
+}
+
+hipError_t launch_support_mask(const float *sigma_t, int rx, int ry, int rz, uint64_t sparse_off, uint32_t ch, uint64_t n_blocks,
+                               uint32_t block_floats, uint32_t *bits, uint8_t *mask, hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const int row_words = (rx + 31) / 32;
+    const size_t words = (size_t) row_words * ry * rz;
+    (void) words;
+    const size_t waves = (size_t) ((rx + 63) / 64) * ry * rz;
+    hipLaunchKernelGGL(support_bits_kernel, dim3((unsigned) ((waves * 64 + 255) / 256)), dim3(256), 0, stream, sigma_t, rx, ry, rz, row_words, bits);
+    hipLaunchKernelGGL(support_mask_kernel, dim3((unsigned) ((n_blocks + 255) / 256)), dim3(256), 0, stream, bits, rx, ry, rz, row_words,
+                       sparse_off, ch, n_blocks, block_floats, mask);
+    return hipGetLastError();
+}
+
 hipError_t launch_film_backward(const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL, hipStream_t stream)
 {
     uint64_t n = n_pixels * spp * 3;

@@ -91,6 +91,8 @@ hipError_t launch_batch_raygen(const float *sensors, int n_sensors, uint32_t bat
                                uint32_t *pixels, hipStream_t stream);
 hipError_t launch_adam_step(float *p, const float *g, float *m, float *v, uint64_t n, double b1, double b2, double eps, double lr_t,
                             hipStream_t stream, float lo = -__builtin_huge_valf(), float hi = __builtin_huge_valf());
+hipError_t launch_support_mask(const float *sigma_t, int rx, int ry, int rz, uint64_t sparse_off, uint32_t ch, uint64_t n_blocks,
+                               uint32_t block_floats, uint32_t *bits, uint8_t *mask, hipStream_t stream);
 hipError_t launch_block_mask(const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask, hipStream_t stream);
 hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, float *image,
                                hipStream_t stream);

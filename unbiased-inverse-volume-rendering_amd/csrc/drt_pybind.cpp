@@ -270,6 +270,13 @@ PYBIND11_MODULE(DRT_PYBIND_NAME, m)
                                      reinterpret_cast<float *>(mm), reinterpret_cast<float *>(v), n, b1, b2, eps, lr_t, lo, hi);
         if (rc != DRT_OK) throw std::runtime_error("drt_adam_step_clamped failed (code " + std::to_string(rc) + ")");
     });
+    m.def("grad_support_mask", [](uintptr_t stream, uintptr_t sigma_t, int rx, int ry, int rz, uint64_t sparse_off, uint32_t channels,
+                                  uint64_t n_blocks, uint32_t block_floats, uintptr_t bits, uintptr_t mask) {
+        const int32_t res[3] = { rx, ry, rz };
+        const int rc = drt_grad_support_mask(reinterpret_cast<void *>(stream), reinterpret_cast<const float *>(sigma_t), res, sparse_off, channels,
+                                             n_blocks, block_floats, reinterpret_cast<uint32_t *>(bits), reinterpret_cast<uint8_t *>(mask));
+        if (rc != DRT_OK) throw std::runtime_error("drt_grad_support_mask failed (code " + std::to_string(rc) + ")");
+    });
     m.def("grad_block_mask", [](uintptr_t stream, uintptr_t buf, uint64_t n_blocks, uint32_t block_floats, uintptr_t mask) {
         const int rc = drt_grad_block_mask(reinterpret_cast<void *>(stream), reinterpret_cast<const float *>(buf), n_blocks,
                                            block_floats, reinterpret_cast<uint8_t *>(mask));
