@@ -39,7 +39,10 @@
 #define DRT_SQ_THREADS 768         // threads per workgroup = per CU: 12 waves
 #endif
 #ifndef DRT_SQ_MAX_RAYS
-#define DRT_SQ_MAX_RAYS 1024       // most ray records per workgroup (a launch takes what fits LDS, a multiple of 64: Params::sq_rays)
+#define DRT_SQ_MAX_RAYS 896        // most ray records per workgroup (a launch takes what fits LDS, a multiple of 64: Params::sq_rays); measured on
+                                   // supergrids that leave room for more than the headline's 768 (config 2, 16^3 cells: 640 / 768 / 896 / 1024 records:
+                                   // 590 / 621 / 629-632 / 620-626 Msamples/s; config 4, majorants in L2: 896 / 1024: 631-634 / 628-631): beyond ~900
+                                   // the records' global halves outgrow the L2
 #endif
 #ifndef DRT_SQ_RING
 #define DRT_SQ_RING 1024           // entries per ring buffer of ids (a power of two >= DRT_SQ_MAX_RAYS)
