@@ -150,6 +150,21 @@ def test_headline_majorant_factor_8(uivr, oracle, gpu):
     _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, 256 * spp, min_lookups_per_ray=0.5)
 
 
+def test_headline_quadratic_drt_factor_8(uivr, oracle, gpu):
+    """`volpathsimple-drt-quadratic` (opt_config.py:123-169, the paper's comparison estimator) on the headline scene at the
+    reference's majorant_resolution_factor 8, at 8 spp: the queued tracer's QUAD adjoint kernels (drt_sq.hip) - determinism,
+    linearity of the adjoint, a window of rays against the oracle (radiance bit-exact, counters equal, gradients close)."""
+    from uivr_amd import synthetic
+    sg = synthetic.dust_devil_scene(res=256, film=512, device=gpu)
+    sg.medium.majorant_resolution_factor = 8
+    props = props_for("quadratic")
+    integ = _integrator(uivr, props)
+    spp, seed = 8, 2014
+    L, _ = _full_properties(uivr, sg, integ, spp, seed)
+    first = (380 * 512 + 200) * spp
+    _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, 256 * spp, min_lookups_per_ray=0.5)
+
+
 @pytest.mark.parametrize("factor", [0, 8])
 def test_config4_512_rank0_share_of_1024x64(uivr, oracle, gpu, factor):
     """512^3 grid (16384 reduction tiles), rank 0 of 8 of a 1024^2 x 64 spp image: 8.4 M rays of the
