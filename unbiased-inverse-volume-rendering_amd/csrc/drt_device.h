@@ -375,6 +375,9 @@ __device__ __forceinline__ float envmap_pdf_uv(const Params &P, int i, int j)
 // Emitter::eval for an escaped ray of direction d (volpathsimple.py:284)
 __device__ __forceinline__ void envmap_eval(const Params &P, V3 d, float out[3])
 {
+#if defined(DRT_ENV_EXP) && (DRT_ENV_EXP & 4)
+    out[0] = out[1] = out[2] = 0.5f + d.x * 0.1f; return;    // timing experiment only
+#endif
     float u, v, st;
     envmap_dir_to_uv(P, d, u, v, st);
     envmap_lookup(P, u, v, out);
@@ -383,6 +386,9 @@ __device__ __forceinline__ void envmap_eval(const Params &P, V3 d, float out[3])
 // Emitter::pdf_direction (volpathsimple.py:273)
 __device__ __forceinline__ float envmap_pdf(const Params &P, V3 d)
 {
+#if defined(DRT_ENV_EXP) && (DRT_ENV_EXP & 2)
+    return kInvFourPi + d.y * 1e-3f;                          // timing experiment only
+#endif
     float u, v, st;
     envmap_dir_to_uv(P, d, u, v, st);
     int i = min((int)(u * (float) P.env_w), P.env_w - 1), j = min((int)(v * (float) P.env_h), P.env_h - 1);
@@ -409,6 +415,12 @@ __device__ __forceinline__ int cdf_find_guided(const float *cdf, const uint32_t 
 {
     const int k = min((int) (x * (float) n), n - 1);
     int lo = (int) guide[max(k - 1, 0)], hi = min((int) guide[min(k + 1, n)] + 1, n);
+    if (hi - lo <= 4) {
+        // the usual bracket (two to four entries where the samples fall): its inner entries in ONE round of independent loads instead
+        // of two dependent bisection steps - the largest index of a non-decreasing table with cdf <= x is lo + (entries <= x behind lo)
+        const float c1 = cdf[min(lo + 1, n)], c2 = cdf[min(lo + 2, n)], c3 = cdf[min(lo + 3, n)];
+        return lo + ((lo + 1 < hi && c1 <= x) ? 1 : 0) + ((lo + 2 < hi && c2 <= x) ? 1 : 0) + ((lo + 3 < hi && c3 <= x) ? 1 : 0);
+    }
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (cdf[mid] <= x) lo = mid; else hi = mid;
@@ -421,6 +433,9 @@ __device__ __forceinline__ int cdf_find_guided(const float *cdf, const uint32_t 
 // MIS weight see the same density and the state machine only has to keep the direction.
 __device__ __forceinline__ V3 envmap_sample_dir(const Params &P, float u1, float u2)
 {
+#if defined(DRT_ENV_EXP) && (DRT_ENV_EXP & 1)
+    return square_to_uniform_sphere(u1, u2);                  // timing experiment only
+#endif
     const int w = P.env_w, h = P.env_h;
     int j = cdf_find_guided(P.env_marg, P.env_gmarg, h, u2);
     const float *c = P.env_cond + (size_t) j * (w + 1);
@@ -465,6 +480,19 @@ __device__ __forceinline__ float emitter_sample_value(const Params &P, V3 d, flo
         for (int k = 0; k < 3; ++k) val[k] = P.Le[k] * kFourPi;
         return kInvFourPi;
     }
+}
+
+// the same with the direction's density already known (the NEE block of the same pass evaluated it for this very direction)
+template <bool ENV>
+__device__ __forceinline__ float emitter_sample_value_with_pdf(const Params &P, V3 d, float p, float val[3])
+{
+    if constexpr (ENV) {
+        float Le[3];
+        envmap_eval(P, d, Le);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) val[k] = p > 0.0f ? Le[k] / p : 0.0f;
+        return p;
+    } else return emitter_sample_value<ENV>(P, d, val);
 }
 
 template <bool ENV>

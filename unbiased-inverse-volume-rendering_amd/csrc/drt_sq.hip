@@ -706,7 +706,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         // ---- NEE walk finished (:388-403): at the head of a pass and, in the adjoint kernels, once more behind the emitter direction
         // block - a main path whose walks come out of the path cache then does a whole bounce (phase sampling, loop head, collision,
         // emitter direction, this block) in ONE pass
-        auto rt_end_block = [&]() {
+        float nee_pdf = 0.0f; bool nee_pdf_ok = false;                          // ENV: the emitter density of the direction the NEE block of THIS pass sampled
+        auto rt_end_block = [&](bool behind_nee) {
             if constexpr (!ADJ) {
                 if (ph == SP_RT_END && pc_on && pc_it < (int) P.path_cache_cap)
                     P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1] =
@@ -714,7 +715,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             }
             if (ph == SP_RT_END) {
                 float val[3], contrib[3];
-                const float ds_pdf = emitter_sample_value<ENV>(P, rd, val);      // recomputed from the direction
+                // (recomputed from the direction; behind the NEE block of the same pass the density is the one it just evaluated)
+                const float ds_pdf = (ENV && behind_nee && nee_pdf_ok) ? emitter_sample_value_with_pdf<ENV>(P, rd, nee_pdf, val)
+                                                                       : emitter_sample_value<ENV>(P, rd, val);
                 const float w = mis_weight(ds_pdf, kInvFourPi);             // :391
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -777,7 +780,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     }
                 }
 
-                rt_end_block();
+                nee_pdf_ok = false;
+                rt_end_block(false);
                 if constexpr (ADJ) {
                     if (ph == SP_RTA_END) { S.state = Cst; ph = SP_PHASE; }     // back to the primary stream
                 }
@@ -926,7 +930,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     float ux = S.next_1d(), uy = S.next_1d();                   // :418
                     rd = emitter_sample_dir<ENV>(P, ux, uy);
                     Hit h = box_hit(P, ro, rd);                                 // :427-428
-                    if constexpr (ENV) { if (envmap_pdf(P, rd) == 0.0f) h.valid = false; }   // sampling_worked :421-423
+                    if constexpr (ENV) { nee_pdf = envmap_pdf(P, rd); nee_pdf_ok = true; if (nee_pdf == 0.0f) h.valid = false; }   // sampling_worked :421-423
                     pc_steps = 0;
                     nt0 = h.valid ? h.t : kInf;
                     if (ADJ && !rec_mode && pc_on && pc_it < (int) P.path_cache_cap) {
@@ -942,7 +946,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
                 // ---- end of a path (:249-287) -----------------------------------------------------
                 if constexpr (ADJ && DRT_SQ_RT2) {
-                    if (__ballot(ph == SP_RT_END)) rt_end_block();              // (the value walk came out of the path cache)
+                    if (__ballot(ph == SP_RT_END)) rt_end_block(true);          // (the value walk came out of the path cache)
                 }
                 SQ_BLK(6, ph == SP_END);
                 if (ph == SP_END) {
