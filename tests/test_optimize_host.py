@@ -156,3 +156,32 @@ def test_gradient_views_are_aligned_and_fused_adam_gate(uivr):
     opt.step({"a": flat[:27].view(3, 3, 3, 1), "b": flat[28:28 + 81].view(3, 3, 3, 3)})
     assert torch.isfinite(params["a"]).all() and torch.isfinite(params["b"]).all()
     assert float((params["b"] - 1).abs().max()) > 0
+
+
+def test_adam_bounds_on_host_tensors_fall_back_to_the_clamp(uivr):
+    """`Adam.step(bounds=...)` applies a parameter's valid range inside the fused device pass only (drt_adam_step_clamped); for host
+    tensors it returns no key and `enforce_valid_params(skip=...)` clamps as python/optimize.py:169-179 does - the parameters end up the
+    same either way."""
+    import torch
+    scene = uivr.cube_test_scene(8, 8)
+    keys = [uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY]
+    sc = uivr.SceneConfig(name="c", scene=scene, param_keys=keys, sensors=[0], start_from_value={keys[0]: 0.1, keys[1]: 0.5})
+    g = torch.Generator().manual_seed(0)
+    pa = {keys[0]: torch.rand(4, 4, 4, 1, generator=g), keys[1]: torch.rand(4, 4, 4, 3, generator=g)}
+    pb = {k: v.clone() for k, v in pa.items()}
+    grads = {k: torch.randn(v.shape, generator=g) * 50 for k, v in pa.items()}
+    bounds = uivr.optimize.param_bounds(sc, keys)
+    assert bounds == {keys[0]: (0.0, sc.max_density), keys[1]: (0.0, 1.0)}
+    oa, ob = uivr.Adam(lr=0.5, params=pa), uivr.Adam(lr=0.5, params=pb)
+    done = oa.step(grads, bounds=bounds)
+    assert done == set()                                        # host tensors: the torch path, nothing clamped in the step
+    uivr.enforce_valid_params(sc, oa, skip=done)
+    ob.step(grads)
+    uivr.enforce_valid_params(sc, ob)
+    for k in keys:
+        assert torch.equal(pa[k], pb[k]) and float(pa[k].min()) >= 0.0
+    assert float(pa[keys[1]].max()) <= 1.0
+    # a key the step did clamp is left alone by enforce_valid_params
+    pa[keys[1]][0, 0, 0, 0] = 7.0
+    uivr.enforce_valid_params(sc, oa, skip={keys[1]})
+    assert float(pa[keys[1]][0, 0, 0, 0]) == 7.0
