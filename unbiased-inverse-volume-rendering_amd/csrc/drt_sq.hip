@@ -57,7 +57,8 @@
 #define DRT_SQ_REFILL_MIN 16       // free walker lanes before more flights are taken
 #endif
 #ifndef DRT_SQ_BATCH
-#define DRT_SQ_BATCH 64            // entries of a heavy queue that make a batch worth taking at once
+#define DRT_SQ_BATCH 56            // entries of a heavy queue that make a batch worth taking at once (48 / 56 / 64, alternating runs on one box:
+                                   // headline 876 / 874 / 868 Msamples/s, config 2 628 / 633 / 626, envmap + factor 8 - / 711 / 702, config 3 the same)
 #endif
 #ifndef DRT_SQ_REGEN_MIN
 #define DRT_SQ_REGEN_MIN 48        // free records before new rays are started (the prologue is long)
