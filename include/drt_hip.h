@@ -226,6 +226,17 @@ int drt_grad_block_mask(void *hip_stream, const float *buf, uint64_t n_blocks, u
 int drt_grad_support_mask(void *hip_stream, const float *sigma_t, const int32_t res[3], uint64_t sparse_offset_floats, uint32_t channels,
                           uint64_t n_blocks, uint32_t block_floats, uint32_t *bits_scratch, uint8_t *mask);
 
+/* Packing of that ONE all-reduce (no handle; distributed._allreduce_flat - the reference is single-GPU).
+ * drt_grad_block_positions: pos[b] = rank of block b among the blocks with mask[b] != 0, -1 for the others; *count (device) = their
+ * number.  scratch: ceil(n_blocks / 1024) words.
+ * drt_grad_pack: one pass over the flat buffer - block b of the set is copied to packed[pos[b] * block_floats ...]; every block outside
+ * the set is tested and the number of those that hold anything but zeros is ADDED to *check (the float that rides at the end of the
+ * packed buffer: a non-zero sum over the ranks says the set was too small).  drt_grad_unpack: the summed blocks back to their places.
+ * flat / packed 16-byte aligned, block_floats = 64 | 128 | 256. */
+int drt_grad_block_positions(void *hip_stream, const uint8_t *mask, uint64_t n_blocks, int32_t *pos, int32_t *count, uint32_t *scratch);
+int drt_grad_pack(void *hip_stream, const float *flat, const int32_t *pos, uint64_t n_blocks, uint32_t block_floats, float *packed, float *check);
+int drt_grad_unpack(void *hip_stream, const float *packed, const int32_t *pos, uint64_t n_blocks, uint32_t block_floats, float *flat);
+
 /* One Adam step on a parameter grid in a single pass (no handle; N2: mi.ad.Adam as python/optimize.py:329,352-354 uses it):
  * m = beta_1 m + (1 - beta_1) g;  v = beta_2 v + (1 - beta_2) g^2;  p -= lr_t m / (sqrt(v) + epsilon), where the caller folds the
  * bias corrections into lr_t = lr sqrt(1 - beta_2^t) / (1 - beta_1^t).  All four buffers: n floats, 16-byte aligned. */
@@ -286,7 +297,8 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
  * the older kernels instead of drt_super.hip; bit 28 (268435456): no early histogram pass beside the adjoint's tail launch;
  * bit 29 (536870912): the supergrid tracer takes its rays in index order (production: thick pixels first); bit 30
  * (1073741824): launches of fewer than 1.5 M rays are scheduled like large ones (ray order, tail launch) - the small scenes
- * of the tests then cover those schedules. */
+ * of the tests then cover those schedules; bit 31 (2147483648): the queued supergrid tracer walks every flight (production: the
+ * primary-segment flights of pixels whose rays cross only empty supergrid cells are ended at their set-up). */
 int drt_set_debug_flags(drt_handle h, uint32_t flags);
 
 const char *drt_version(void);

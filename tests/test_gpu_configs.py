@@ -7,8 +7,13 @@ ray's radiance depends only on (seed, global ray index, scene).  So each configu
       is compared with the oracle: radiance BIT-EXACT;
   (2) the same window traced alone (primal + adjoint): event counters EQUAL, gradients within
       2e-4 * max|oracle| (fp32 sums in a different order; the oracle accumulates in fp64);
-  (3) size-independent properties of the full launch: determinism (bitwise), linearity of the adjoint in dL,
-      gradient support inside the sensor frustum (energy bound), window gradients contained in the full ones.
+  (3) size-independent properties of the full launch: determinism (bitwise), linearity of the adjoint in dL, energy bound (the mean
+      radiance does not exceed the emitter's), every non-zero 256-byte block of the gradient inside `gradient_support(sigma_t)`, and
+      "window gradients contained in the full ones": the FULL launch with dL zeroed outside a window gives the gradient of that window
+      traced alone;
+  (4) a SECOND window per configuration chosen by a seeded draw among the stretches of a row that hold rays that miss the medium's
+      box, rays through its thin edge AND rays through thicker parts (round-4 review: no configuration's window is one hand-picked
+      row through the dense part).
 Workloads (python/reproduce.py:45-59, python/scene_config.py:108-170):
   config 2  smoke plume 128^3 (janga-smoke stand-in), 512^2 x 16 spp
   config 3  dust devil 256^3, 63 sensors, render_batch(32768 px, spp 1024 / spp_grad 16), 3 optimiser iterations
@@ -59,7 +64,7 @@ def _window_check(uivr, oracle, sg, integ, props, spp, seed, L_full, local_first
     osc = oracle.OracleScene(_cpu_scene(uivr, sg))
     Lr, c_primal = oracle.render_primal(osc, props, spp, seed, n_rays=n, ray_offset=global_first)
     np.testing.assert_array_equal(L_full[local_first:local_first + n].cpu().numpy().view(np.uint32), Lr.view(np.uint32))
-    assert c_primal["n_dt"] >= min_lookups_per_ray * n, "the window misses the dense part of the volume"
+    assert c_primal["n_dt"] >= min_lookups_per_ray * n and c_primal["n_dt"] > 0, "the window misses the volume"
     rng = np.random.default_rng(5)
     dL = ((rng.random((n, 3), dtype=np.float32) - 0.5) * 1e-3).astype(np.float32)
     gs, ga, c_adj = oracle.render_backward(osc, props, spp, seed, dL, Lr, n_rays=n, ray_offset=global_first)
@@ -80,7 +85,80 @@ def _window_check(uivr, oracle, sg, integ, props, spp, seed, L_full, local_first
     assert ca == c_adj
     _close_on_device(grads[uivr.SIGMA_T_KEY], gs, "window grad sigma_t")
     _close_on_device(grads[uivr.ALBEDO_KEY], ga, "window grad albedo")
+    grads["_dL"] = dL
     return grads
+
+
+def _pixel_classes(sg, n_samples=48):
+    """Per pixel of sensor 0 (centre ray): 0 = misses the medium's box, 1 = crosses it with optical depth < 0.05 (thin edge),
+    2 = thicker.  Nearest-voxel samples of sigma_t along the chord: a classification for choosing windows, it enters no result."""
+    s = sg.sensors[0]
+    dev = sg.medium.sigma_t.device
+    f = s.frame()
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)
+    py, px = torch.meshgrid(torch.arange(s.height, device=dev), torch.arange(s.width, device=dev), indexing="ij")
+    cx = (1.0 - 2.0 * (px.double() + 0.5) / s.width) * float(f["tan_x"])
+    cy = (1.0 - 2.0 * (py.double() + 0.5) / s.height) * float(f["tan_y"])
+    d = cx[..., None] * t(f["left"]) + cy[..., None] * t(f["up"]) + t(f["dir"])
+    d = d / d.norm(dim=-1, keepdim=True)
+    o = t(f["origin"])
+    bmin, bmax = t(sg.medium.bbox_min), t(sg.medium.bbox_max)
+    inv = 1.0 / torch.where(d.abs() < 1e-30, torch.full_like(d, 1e-30), d)
+    ta, tb = (bmin - o) * inv, (bmax - o) * inv
+    t0 = torch.minimum(ta, tb).amax(dim=-1).clamp_min(0.0)
+    t1 = torch.maximum(ta, tb).amin(dim=-1)
+    hit = t1 > t0
+    grid = sg.medium.sigma_t.reshape(sg.medium.sigma_t.shape[:3]).double() * float(sg.medium.scale)
+    rz, ry, rx = grid.shape
+    od = torch.zeros_like(t0)
+    for j in range(n_samples):
+        tt = t0 + (t1 - t0) * ((j + 0.5) / n_samples)
+        p = (o + tt[..., None] * d - bmin) / (bmax - bmin)
+        ix = (p[..., 0] * rx).long().clamp(0, rx - 1); iy = (p[..., 1] * ry).long().clamp(0, ry - 1); iz = (p[..., 2] * rz).long().clamp(0, rz - 1)
+        od += grid[iz, iy, ix]
+    od = od * (t1 - t0).clamp_min(0.0) / n_samples
+    cls = torch.where(hit, torch.where(od < 0.05, 1, 2), 0)
+    return cls.reshape(-1)                                                   # row-major pixels
+
+
+def _seeded_window(sg, n_pix, draw_seed, ranges=None):
+    """First pixel of a window of `n_pix` consecutive pixels (inside one row, inside one of the pixel `ranges`) drawn - seeded - among
+    the windows that hold at least n_pix / 8 rays of each kind: missing the box, through the thin edge, through thicker parts (if no
+    window holds all three: thin edge + thicker, else missing + thicker)."""
+    s = sg.sensors[0]
+    cls = _pixel_classes(sg).cpu().numpy()
+    ranges = ranges or [(0, cls.size)]
+    need = max(1, n_pix // 8)
+    cs = [np.concatenate([[0], np.cumsum(cls == k)]) for k in range(3)]
+    starts = np.concatenate([np.arange(lo, hi - n_pix + 1, 8) for lo, hi in ranges])
+    starts = starts[(starts % s.width) + n_pix <= s.width]
+    cands = np.zeros(0, dtype=np.int64)
+    for kinds in ((0, 1, 2), (1, 2), (0, 2)):                   # (a scene whose box fills the image has no missing rays: the thin edge then)
+        ok = np.ones(starts.size, dtype=bool)
+        for k in kinds:
+            ok &= (cs[k][starts + n_pix] - cs[k][starts]) >= need
+        cands = starts[ok]
+        if cands.size:
+            break
+    assert cands.size > 0, "no window holds rays of different kinds: the scene's silhouette is not in this pixel range"
+    return int(cands[np.random.default_rng(draw_seed).integers(cands.size)])
+
+
+def _masked_full_equals_window(uivr, sg, integ, spp, seed, batch, local_first, n, grads_window, dLw, L_full_state):
+    """ "Window gradients contained in the full ones": the FULL launch (its ray order, batches, record streams and tile partition)
+    with dL = 0 outside the window's rays gives the gradient of the window traced alone (same dL) - gradients within 2e-4 max."""
+    dev = sg.medium.sigma_t.device
+    dL = torch.zeros((batch.n_rays, 3), device=dev)
+    dL[local_first:local_first + n] = torch.from_numpy(dLw).to(dev)
+    samp = uivr.IndependentSampler(seed, spp)
+    L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    grads = uivr.alloc_grads(sg)
+    integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=dL, state_in=st, grads=grads)
+    for k in (uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY):
+        ref = grads_window[k]
+        tol = GRAD_RTOL * float(ref.abs().max()) + 1e-12
+        err = float((grads[k] - ref).abs().max())
+        assert float(ref.abs().max()) > 0 and err <= tol, f"masked full launch vs window, {k}: {err:.3e} > {tol:.3e}"
 
 
 def _full_properties(uivr, sg, integ, spp, seed, shard=None):
@@ -109,6 +187,15 @@ def _full_properties(uivr, sg, integ, spp, seed, shard=None):
     scale = float(g1.abs().max())
     assert scale > 0
     assert float((g2 - 2.0 * g1).abs().max()) <= 1e-3 * scale             # linear in dL
+    # energy bound: no emitter but the constant environment (radiance Le) and albedo <= 1 - the mean radiance cannot exceed it
+    if isinstance(sg.emitter, uivr.ConstantEmitter):
+        assert float(L1.double().mean()) <= 1.001 * float(max(sg.emitter.radiance))
+    # every non-zero block of the gradient lies inside the support derived from sigma_t alone (the packing set of the multi-GPU all-reduce)
+    from uivr_amd.distributed import COMPACT_BLOCK_FLOATS as B, _block_mask, gradient_support
+    sup = gradient_support(sg.medium.sigma_t, grads)
+    if sup is not None:
+        n_full = (g1.numel() // B) * B
+        assert int((_block_mask(g1[:n_full].view(-1, B)) & (1 - sup.mask)).sum()) == 0
     return L1, batch
 
 
@@ -119,11 +206,16 @@ def test_config2_smoke_128_512x16(uivr, oracle, gpu):
     props = props_for("drt")
     integ = _integrator(uivr, props)
     spp, seed = 16, 2002
-    L, _ = _full_properties(uivr, sg, integ, spp, seed)
+    L, batch = _full_properties(uivr, sg, integ, spp, seed)
     assert L.shape[0] == 512 * 512 * 16
     # 1024 pixels of row 300, columns 192..: through the plume
     first = (300 * 512 + 192) * spp
     _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, 1024 * spp)
+    # ... and a seeded window across the plume's silhouette: rays that miss the box, thin-edge rays, thicker ones
+    n_pix = 256
+    first = _seeded_window(sg, n_pix, 20021) * spp
+    gw = _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, n_pix * spp, min_lookups_per_ray=0.0)
+    _masked_full_equals_window(uivr, sg, integ, spp, seed, batch, first, n_pix * spp, gw, gw["_dL"], None)
 
 
 def test_headline_dust_devil_256_512x32(uivr, oracle, gpu):
@@ -132,9 +224,13 @@ def test_headline_dust_devil_256_512x32(uivr, oracle, gpu):
     props = props_for("drt")
     integ = _integrator(uivr, props)
     spp, seed = 32, 2003
-    L, _ = _full_properties(uivr, sg, integ, spp, seed)
+    L, batch = _full_properties(uivr, sg, integ, spp, seed)
     first = (380 * 512 + 200) * spp
     _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, 512 * spp)
+    n_pix = 128
+    first = _seeded_window(sg, n_pix, 20031) * spp
+    gw = _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, n_pix * spp, min_lookups_per_ray=0.0)
+    _masked_full_equals_window(uivr, sg, integ, spp, seed, batch, first, n_pix * spp, gw, gw["_dL"], None)
 
 
 def test_headline_majorant_factor_8(uivr, oracle, gpu):
@@ -145,9 +241,13 @@ def test_headline_majorant_factor_8(uivr, oracle, gpu):
     props = props_for("drt")
     integ = _integrator(uivr, props)
     spp, seed = 32, 2004
-    L, _ = _full_properties(uivr, sg, integ, spp, seed)
+    L, batch = _full_properties(uivr, sg, integ, spp, seed)
     first = (380 * 512 + 200) * spp
     _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, 256 * spp, min_lookups_per_ray=0.5)
+    n_pix = 128
+    first = _seeded_window(sg, n_pix, 20041) * spp
+    gw = _window_check(uivr, oracle, sg, integ, props, spp, seed, L, first, first, n_pix * spp, min_lookups_per_ray=0.0)
+    _masked_full_equals_window(uivr, sg, integ, spp, seed, batch, first, n_pix * spp, gw, gw["_dL"], None)
 
 
 def test_headline_quadratic_drt_factor_8(uivr, oracle, gpu):
@@ -187,6 +287,14 @@ def test_config4_512_rank0_share_of_1024x64(uivr, oracle, gpu, factor):
     n = 128 * spp
     # the window alone is traced UNSHARDED at the global offset: same rays, same streams
     _window_check(uivr, oracle, sg, integ, props, spp, seed, L, local_first, global_first, n)
+    # a seeded window on the silhouette, inside one of rank 0's chunks (chunk c = pixels [2048 c, 2048 (c + 1)), c % 8 == 0)
+    n_pix = 64
+    p0 = _seeded_window(sg, n_pix, 20051 + factor, ranges=[(2048 * c, 2048 * (c + 1)) for c in range(0, 512, 8)])
+    c, within = divmod(p0, 2048)
+    assert c % 8 == 0
+    local_first, global_first = (c // 8) * chunk_rays + within * spp, p0 * spp
+    gw = _window_check(uivr, oracle, sg, integ, props, spp, seed, L, local_first, global_first, n_pix * spp, min_lookups_per_ray=0.0)
+    _masked_full_equals_window(uivr, sg, integ, spp, seed, batch, local_first, n_pix * spp, gw, gw["_dL"], None)
 
 
 def test_config3_optimize_loop_256_63_sensors(uivr, oracle, gpu):

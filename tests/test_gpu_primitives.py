@@ -235,6 +235,79 @@ def test_device_gradient_support_equals_the_torch_formulation(uivr, gpu, shape):
     assert got.mask.is_cuda and torch.equal(got.mask.cpu(), ref.mask) and got.count == ref.count
 
 
+@pytest.mark.parametrize("block", [64, 128, 256])
+def test_grad_pack_kernels_equal_the_torch_formulation(uivr, gpu, block):
+    """drt_grad_block_positions / drt_grad_pack / drt_grad_unpack (the packing of the one-collective gradient all-reduce):
+    positions = exclusive rank among the set's blocks (block counts that are no multiple of the kernels' 1024-block groups, empty and
+    full sets), the packed buffer = index_select of the set's blocks, the check = the number of blocks OUTSIDE the set that hold
+    anything but zeros (NaN and denormals count, -0.0 does not), unpack puts the blocks back and touches nothing else."""
+    from uivr_amd.distributed import _positions
+    native = uivr._native.native
+    gen = torch.Generator().manual_seed(5 * block)
+    stream = torch.cuda.current_stream().cuda_stream
+    for n_blocks, density in ((1, 1.0), (5, 0.5), (1024, 0.3), (1025, 0.0), (3071, 1.0), (8195, 0.4)):
+        mask = (torch.rand(n_blocks, generator=gen) < density).to(torch.uint8)
+        body = torch.randn(n_blocks, block, generator=gen)
+        outside = torch.nonzero(mask == 0).reshape(-1)
+        body[outside] = 0                                              # a proper support ...
+        extra = 0
+        if outside.numel() >= 4:                                       # ... violated in three blocks
+            body[outside[0], block - 1] = 1e-42
+            body[outside[1], 3] = float("nan")
+            body[outside[2], 0] = -0.0
+            body[outside[3], block // 2] = -2.5
+            extra = 3
+        want_pos_cpu, want_cnt = _positions(mask)
+        dmask, dbody = mask.to(gpu), body.to(gpu)
+        pos, cnt = _positions(dmask)
+        assert torch.equal(pos.cpu(), want_pos_cpu) and int(cnt) == int(want_cnt) == int(mask.sum())
+        count = int(cnt)
+        packed = torch.full((count * block + 1 + 4,), 7.0, device=gpu)             # [blocks | check | guard]
+        packed[count * block] = 0.0
+        native().grad_pack(stream, dbody.data_ptr(), pos.data_ptr(), n_blocks, block, packed.data_ptr(), packed.data_ptr() + 4 * count * block)
+        src = torch.nonzero(mask).reshape(-1)
+        assert torch.equal(packed[:count * block].cpu().view(-1, block), body.index_select(0, src))
+        assert float(packed[count * block]) == float(extra)
+        assert bool((packed[count * block + 1:] == 7.0).all())
+        summed = packed.clone(); summed[:count * block] *= 2.0                     # "the all-reduce"
+        flat = dbody.clone()
+        native().grad_unpack(stream, summed.data_ptr(), pos.data_ptr(), n_blocks, block, flat.data_ptr())
+        want = body.clone(); want[src] *= 2.0
+        got = flat.cpu()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))           # bit for bit (NaN and -0.0 outside the set untouched)
+    with pytest.raises(RuntimeError):
+        native().grad_pack(stream, dbody.data_ptr(), pos.data_ptr(), 1, 96, packed.data_ptr(), packed.data_ptr())
+
+
+def test_grad_pack_and_unpack_time_at_256(uivr, gpu):
+    """The packing passes of a 256^3 gradient buffer (256 MiB, the headline's support: 44 % of the blocks) are two streaming kernels:
+    pack reads the whole buffer once (the set's blocks are copied, the others checked), unpack writes the set's blocks back."""
+    from uivr_amd import synthetic
+    from uivr_amd.distributed import COMPACT_BLOCK_FLOATS as B, gradient_support
+    native = uivr._native.native
+    scene = synthetic.dust_devil_scene(res=256, film=64, device=gpu)
+    grads = uivr.alloc_grads(scene)
+    sup = gradient_support(scene.medium.sigma_t, grads)
+    flat = grads["_flat"]
+    n_blocks = flat.numel() // B
+    count = sup.count
+    assert 0.2 < count / n_blocks < 0.7
+    packed = torch.zeros(count * B + 1, device=gpu)
+    stream = torch.cuda.current_stream().cuda_stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    best = [1e9, 1e9]
+    for _ in range(5):
+        ev[0].record()
+        native().grad_pack(stream, flat.data_ptr(), sup.pos.data_ptr(), n_blocks, B, packed.data_ptr(), packed.data_ptr() + 4 * count * B)
+        ev[1].record()
+        native().grad_unpack(stream, packed.data_ptr(), sup.pos.data_ptr(), n_blocks, B, flat.data_ptr())
+        ev[2].record()
+        torch.cuda.synchronize()
+        best = [min(best[0], ev[0].elapsed_time(ev[1])), min(best[1], ev[1].elapsed_time(ev[2]))]
+    print(f"grad_pack {best[0]:.3f} ms, grad_unpack {best[1]:.3f} ms at 256^3 ({count} of {n_blocks} blocks)")
+    assert best[0] + best[1] < 0.4                                   # (measured 0.1 - 0.15 ms; the torch formulation: ~1 ms)
+
+
 @pytest.mark.parametrize("spp", [1, 7, 32, 128, 200, 1024])
 def test_film_develop_is_the_sample_mean(uivr, gpu, spp):
     """Box film (python/batched.py:176-197): image = mean over the pixel's samples - the thread-per-channel kernel

@@ -30,10 +30,13 @@ struct drt_handle_s {
     float *d_gt = nullptr;         // gradient scratch, 4 planes (always zero between launches)
     unsigned long long *d_queues = nullptr;   // 8 per-XCD ray queue heads (wavefront kernel)
     void *d_sq_cold = nullptr;                // queued supergrid tracer: adjoint path state kept in global memory (drt_sq.hip)
+    void *d_uempty = nullptr;                 // per pixel: its rays cross only empty supergrid cells (build_unit_empty; queued supergrid tracer)
+    size_t uempty_bytes = 0;
     void *d_order = nullptr;                  // ray order of the supergrid tracer's current launch (build_super_order)
     size_t order_bytes = 0;
     uint64_t order_first = 0, order_end = 0;  // ... made by the primal launch over these rays of the job the path cache describes:
     uint32_t order_unit = 0;                  //     the adjoint launch over the same rays takes it as it is (0: none)
+    bool order_triv = false;                  // the stored order has the trivial units sorted to its end (it is not reused: its count belongs to that launch)
     void *d_tail = nullptr;                   // tail pool of the cooperative kernels: [counter, pad to 256 B][entries x 128 B]
     size_t tail_entries = 0;
     int n_cus = 256;
@@ -163,7 +166,8 @@ void fill_job(drt_handle h, drt::Params &P, const float *rays_o, const float *ra
     P.alt_seed = drt::host_alt_seed(seed, rays_o == nullptr);
     P.counters = h->counting ? h->d_counters : nullptr;
     P.debug_flags = h->debug_flags;
-    P.order = nullptr; P.order_unit = 1; P.order_units = 0;
+    P.order = nullptr; P.order_unit = 1; P.order_units = 0; P.order_count = nullptr;
+    P.unit_empty = nullptr; P.empty_unit = 0;
 }
 
 void clear_timings(drt_handle h)
@@ -175,7 +179,13 @@ void clear_timings(drt_handle h)
 }
 
 // launch bracketed by an event pair on the handle's stream when timing is enabled
-constexpr uint32_t kPathCacheCap = 16;                 // bounce-loop iterations cached per ray (headline: 2.4 on average)
+#ifndef DRT_PATH_CACHE_CAP
+#define DRT_PATH_CACHE_CAP 16
+#endif
+#ifndef DRT_ORDER_ITERS
+#define DRT_ORDER_ITERS 1           // adjoint launches of the supergrid tracer: units ordered by the primal pass's iteration counts too (0: as the primal launch)
+#endif
+constexpr uint32_t kPathCacheCap = DRT_PATH_CACHE_CAP;  // bounce-loop iterations cached per ray (headline: 2.4 on average)
 constexpr uint64_t kHeavyFirstMaxBlocks = 12288;       // launches up to this many 256-ray blocks run heavy blocks first
 constexpr uint64_t kPathCacheMaxRays = 1ull << 24;     // larger primal launches (reference renders) skip the cache
 
@@ -237,6 +247,11 @@ void bind_path_cache_read(drt_handle h, drt::Params &P, uint64_t job_rays)
     if (!no_lpt && P.ray_first == 0 && P.n_rays == job_rays && h->order_valid)
         P.block_order = P.ray_hash + job_rays + (job_rays + 255) / 256;
     if (h->perm_valid && !dbg(h->debug_flags, 4194304u)) P.ray_perm = perm_base(P.ray_hash, job_rays);
+    // (the iteration counts of the primal pass: the supergrid tracer's adjoint launches order their rays by them)
+    if (!dbg(h->debug_flags, 4194304u)) {
+        const size_t perm_slots = ((size_t) job_rays + drt::kPermGroup - 1) / drt::kPermGroup * drt::kPermGroup;
+        P.ray_iters = (uint8_t *) (perm_base(P.ray_hash, job_rays) + perm_slots);
+    }
 }
 
 struct EarlyCtx { drt_handle h; const drt::Params *P; };
@@ -290,9 +305,31 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     if (super) {
         drt::Params Q = P;
         Q.queues = h->d_queues;
+        const uint64_t span = P.n_rays - P.ray_first;
+        // round 4: the queued tracer (drt_sq.hip) where the ray records fit LDS next to the majorants; test hook 4096 keeps
+        // the round-3 kernel (drt_super.hip), which also serves what the queued one does not take
+        const bool queued = sq_ok;
+#ifndef DRT_SQ_TRIVIAL
+#define DRT_SQ_TRIVIAL 1            // the flagged pixels' rays are sorted to the end of the order and traced by trivial_rays_kernel, one thread per ray
+#endif
+#ifndef DRT_SQ_UNIT_EMPTY
+#define DRT_SQ_UNIT_EMPTY 1         // pixels whose rays cross only empty supergrid cells are flagged: their primary-segment flights are not walked
+#endif
+        // (sensor rays whose units are whole pixels: sub-batches, interleaved chunks and offsets that cut a pixel's rays get no flags)
+        if (DRT_SQ_UNIT_EMPTY && queued && P.sensor_flow && P.mocc && P.spp && span < (1ull << 31) && P.ray_first % P.spp == 0 &&
+            P.ray_offset % P.spp == 0 && P.chunk % P.spp == 0 && P.stride % P.spp == 0 && !dbg(h->debug_flags, 2147483648u)) {
+            const uint32_t eunits = (uint32_t) ((span + P.spp - 1) / P.spp);
+            if (eunits > h->uempty_bytes) {
+                if (h->d_uempty) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_uempty); h->d_uempty = nullptr; h->uempty_bytes = 0; }
+                if (hipMalloc(&h->d_uempty, eunits) == hipSuccess) h->uempty_bytes = eunits; else { (void) hipGetLastError(); h->d_uempty = nullptr; }
+            }
+            if (h->d_uempty) {
+                DRT_HIP_CHECK(h, drt::build_unit_empty(P, P.spp, eunits, (uint8_t *) h->d_uempty, h->stream));
+                Q.unit_empty = (const uint8_t *) h->d_uempty; Q.empty_unit = P.spp;
+            }
+        }
         // Ray order: the longest paths first - units of one pixel's rays by the majorant optical depth along the pixel's ray
         // (drt_super.hip).  Best effort (no memory: index order); test hook 536870912: index order.
-        const uint64_t span = P.n_rays - P.ray_first;
         const uint32_t unit = P.spp >= 4u ? P.spp : 16u;
         // (units of more rays than a CU traces at a time - the optimisation loop's primal launches, 1024 rays per pixel -
         //  are too coarse to be scheduled: measured 3-5 % slower in that order than in index order)
@@ -308,21 +345,27 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
                 if (hipMalloc(&h->d_order, need) == hipSuccess) h->order_bytes = need; else { (void) hipGetLastError(); h->d_order = nullptr; }
             }
             if (h->d_order) {
-                const bool reuse = adjoint && P.path_cache_mode == 2 && h->order_unit == unit && h->order_first == P.ray_first && h->order_end == P.n_rays;
-                if (!reuse) DRT_HIP_CHECK(h, drt::build_super_order(P, unit, units, h->d_order, h->stream));
+                // (adjoint launches behind the primal pass of the same job: the primal pass counted every ray's bounce-loop iterations -
+                //  units with a long main path start first, whatever the optical depth along their pixel's ray says)
+                const uint8_t *iters = (DRT_ORDER_ITERS && adjoint && P.path_cache_mode == 2 && sq_ok) ? P.ray_iters : nullptr;
+                // (the flagged pixels - a unit is one pixel's rays - go to the end of the order, for trivial_rays_kernel: no Russian roulette at depth 0)
+                const uint8_t *triv = (DRT_SQ_TRIVIAL && Q.unit_empty && Q.empty_unit == unit && P.rr_depth >= 0) ? Q.unit_empty : nullptr;
+                const bool reuse = !iters && !triv && !h->order_triv && adjoint && P.path_cache_mode == 2 && h->order_unit == unit && h->order_first == P.ray_first &&
+                                   h->order_end == P.n_rays;
+                if (!reuse) DRT_HIP_CHECK(h, drt::build_super_order(P, unit, units, h->d_order, h->stream, iters, triv));
                 h->order_unit = (!adjoint && P.path_cache_mode == 1) || reuse ? unit : 0u;
                 h->order_first = P.ray_first; h->order_end = P.n_rays;
+                if (!reuse) h->order_triv = triv != nullptr;
                 Q.order = (const uint32_t *) h->d_order; Q.order_unit = unit; Q.order_units = units;
+                if (triv) Q.order_count = drt::super_order_count(h->d_order, units);
             }
         }
         Q.ray_perm = nullptr; Q.block_order = nullptr;
         DRT_HIP_CHECK(h, hipMemsetAsync(h->d_queues, 0, 8 * sizeof(unsigned long long), h->stream));
-        // round 4: the queued tracer (drt_sq.hip) where the ray records fit LDS next to the majorants; test hook 4096 keeps
-        // the round-3 kernel (drt_super.hip), which also serves what the queued one does not take
-        const bool queued = sq_ok;
         if (queued) {
             Q.sq_cold = h->d_sq_cold;
             DRT_HIP_CHECK(h, drt::launch_trace_sq(Q, adjoint, h->counting, h->n_cus, h->stream));
+            if (Q.order_count) DRT_HIP_CHECK(h, drt::launch_trivial_rays(Q, adjoint, h->counting, h->stream));
         } else
         DRT_HIP_CHECK(h, drt::launch_trace_super(Q, adjoint, h->counting, h->n_cus, h->stream));
         if (h->timing) {
@@ -686,6 +729,7 @@ int drt_destroy(drt_handle h)
     if (h->d_gt) (void) hipFree(h->d_gt);
     if (h->d_queues) (void) hipFree(h->d_queues);
     if (h->d_order) (void) hipFree(h->d_order);
+    if (h->d_uempty) (void) hipFree(h->d_uempty);
     if (h->d_sq_cold) (void) hipFree(h->d_sq_cold);
     if (h->d_tail) (void) hipFree(h->d_tail);
     if (h->d_sigma_b) (void) hipFree(h->d_sigma_b);
@@ -760,7 +804,7 @@ int drt_params_changed(drt_handle h)
     if (h->base.mgrid)
         DRT_HIP_CHECK(h, drt::launch_majorant_grid(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.gx, h->base.gy,
                                                    h->base.gz, h->base.scale, h->d_mgrid, (uint32_t *) h->base.mocc, h->stream,
-                                                   h->d_scratch, h->d_majorant));
+                                                   h->d_scratch, h->d_majorant, (uint32_t *) h->base.mocc_dil));
     else
         DRT_HIP_CHECK(h, drt::launch_majorant(h->base.sigma_t, n, h->base.scale, h->d_scratch, h->d_majorant, h->stream));
     DRT_HIP_CHECK(h, drt::launch_occupancy(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.occ_shift, h->base.occ_x,
@@ -815,13 +859,14 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         if (cells != h->mgrid_cells) {
             DeviceGuard g(h->device);
             if (h->d_mgrid) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_mgrid); h->d_mgrid = nullptr; h->mgrid_cells = 0; }
-            DRT_HIP_CHECK(h, hipMalloc(&h->d_mgrid, (cells + (cells + 31) / 32) * sizeof(float)));   // majorants | non-empty bitmask
+            DRT_HIP_CHECK(h, hipMalloc(&h->d_mgrid, (cells + 2 * ((cells + 31) / 32)) * sizeof(float)));   // majorants | non-empty bitmask | the same, dilated by one cell
             h->mgrid_cells = cells;
         }
         B.mgrid = h->d_mgrid; B.gx = G[0]; B.gy = G[1]; B.gz = G[2];
         B.mocc = (const uint32_t *) (h->d_mgrid + cells); B.mocc_words = (int) ((cells + 31) / 32);
+        B.mocc_dil = B.mocc + B.mocc_words;
     } else {
-        B.mgrid = nullptr; B.gx = B.gy = B.gz = 0; B.mocc = nullptr; B.mocc_words = 0;
+        B.mgrid = nullptr; B.gx = B.gy = B.gz = 0; B.mocc = nullptr; B.mocc_words = 0; B.mocc_dil = nullptr;
     }
     // empty-space bitmask: cells of 2^shift voxels, at most kOccWords*32 cells
     {
@@ -977,6 +1022,11 @@ int drt_set_sensor_perspective(drt_handle h, const float origin[3], const float 
     return DRT_OK;
 }
 
+#ifndef DRT_ALBEDO_GRID4
+#define DRT_ALBEDO_GRID4 0          // 1: the volpathsimple kernels read the albedo (and the attached sigma_t of a scattering vertex) from the four-channel copy
+#endif
+static int ensure_grid4(drt_handle h, drt::Params &P);
+
 int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
                       uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_out)
 {
@@ -988,6 +1038,7 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     drt::Params P;
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
     P.L_out = L_out;
+    if (DRT_ALBEDO_GRID4 && h->base.albedo && h->base.mgrid) { rc = ensure_grid4(h, P); if (rc) return rc; }
     h->pcache_sig.valid = false;
     bind_path_cache_write(h, P);                                 // every primal kernel records its walks
     {   // the block order left by the previous primal launch of the same shape predicts this one's heavy blocks
@@ -1031,6 +1082,7 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     drt::Params P;
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
+    if (DRT_ALBEDO_GRID4 && h->base.albedo && h->base.mgrid) { rc = ensure_grid4(h, P); if (rc) return rc; }
     // capacity: 48 sigma_t and 6 colour records per ray (headline workload: 12.3 and 1.4); beyond it the
     // tracer falls back to direct atomics (emit_record), so this is a performance choice only
     const uint64_t job_rays = n_rays;
@@ -1089,11 +1141,9 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
 }
 
 // ---- fused nerf + volpathsimple pass (BASELINE config 5; drt_fused.hip) ---------------------------------------------
-static int fused_prepare(drt_handle h, drt::Params &P, const drt_nerf_config *cfg)
+// the interleaved four-channel apron-brick copy [sigma_t, r, g, b] (eval4): (re)built when the parameter grids changed since the last copy
+static int ensure_grid4(drt_handle h, drt::Params &P)
 {
-    if (!cfg) return fail(h, DRT_ERR_INVALID_ARGUMENT, "fused: null nerf config");
-    if (cfg->queries_per_ray < 2) return fail(h, DRT_ERR_INVALID_ARGUMENT, "queries_per_ray must be >= 2");
-    // (either emitter, either kind of majorant: drt_fused.hip and its three sibling translation units)
     const drt::Params &B = h->base;
     const size_t nbx = ((size_t) B.rx + 2) / 3, quads = nbx * (size_t) B.ry * (size_t) B.rz * 16;
     if (quads > 0x7fffffffull) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the four-channel copy");
@@ -1107,6 +1157,16 @@ static int fused_prepare(drt_handle h, drt::Params &P, const drt_nerf_config *cf
         h->grid4_version = h->medium_version;
     }
     P.grid4 = h->d_grid4; P.g4_nbx = (int) nbx;
+    return DRT_OK;
+}
+
+static int fused_prepare(drt_handle h, drt::Params &P, const drt_nerf_config *cfg)
+{
+    if (!cfg) return fail(h, DRT_ERR_INVALID_ARGUMENT, "fused: null nerf config");
+    if (cfg->queries_per_ray < 2) return fail(h, DRT_ERR_INVALID_ARGUMENT, "queries_per_ray must be >= 2");
+    // (either emitter, either kind of majorant: drt_fused.hip and its three sibling translation units)
+    const int rc = ensure_grid4(h, P);
+    if (rc) return rc;
     P.nerf_queries = cfg->queries_per_ray; P.nerf_jitter = cfg->jittering_enabled ? 1 : 0;
     P.nerf_relu = cfg->activation_relu ? 1 : 0; P.hide_emitters_nerf = cfg->hide_emitters ? 1 : 0;
     return DRT_OK;
@@ -1247,6 +1307,30 @@ int drt_grad_block_mask(void *hip_stream, const float *buf, uint64_t n_blocks, u
     if (block_floats != 64 && block_floats != 128 && block_floats != 256) return DRT_ERR_INVALID_ARGUMENT;
     if ((uintptr_t) buf % 16) return DRT_ERR_INVALID_ARGUMENT;
     return drt::launch_block_mask(buf, n_blocks, block_floats, mask, (hipStream_t) hip_stream) == hipSuccess ? DRT_OK : DRT_ERR_HIP;
+}
+
+int drt_grad_block_positions(void *hip_stream, const uint8_t *mask, uint64_t n_blocks, int32_t *pos, int32_t *count, uint32_t *scratch)
+{
+    if (n_blocks && (!mask || !pos || !scratch)) return DRT_ERR_INVALID_ARGUMENT;
+    return drt::launch_block_positions(mask, n_blocks, pos, count, scratch, (hipStream_t) hip_stream) == hipSuccess ? DRT_OK : DRT_ERR_HIP;
+}
+
+int drt_grad_pack(void *hip_stream, const float *flat, const int32_t *pos, uint64_t n_blocks, uint32_t block_floats, float *packed, float *check)
+{
+    if (n_blocks && (!flat || !pos || !packed || !check)) return DRT_ERR_INVALID_ARGUMENT;
+    if (block_floats != 64 && block_floats != 128 && block_floats != 256) return DRT_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t) flat | (uintptr_t) packed) % 16) return DRT_ERR_INVALID_ARGUMENT;
+    return drt::launch_grad_pack(const_cast<float *>(flat), pos, n_blocks, block_floats, packed, check, false, (hipStream_t) hip_stream) == hipSuccess
+               ? DRT_OK : DRT_ERR_HIP;
+}
+
+int drt_grad_unpack(void *hip_stream, const float *packed, const int32_t *pos, uint64_t n_blocks, uint32_t block_floats, float *flat)
+{
+    if (n_blocks && (!flat || !pos || !packed)) return DRT_ERR_INVALID_ARGUMENT;
+    if (block_floats != 64 && block_floats != 128 && block_floats != 256) return DRT_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t) flat | (uintptr_t) packed) % 16) return DRT_ERR_INVALID_ARGUMENT;
+    return drt::launch_grad_pack(flat, pos, n_blocks, block_floats, const_cast<float *>(packed), nullptr, true, (hipStream_t) hip_stream) == hipSuccess
+               ? DRT_OK : DRT_ERR_HIP;
 }
 
 int drt_film_backward(drt_handle h, const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL)

@@ -34,6 +34,40 @@ constexpr bool kTestHooks = false;
 #endif
 __host__ __device__ __forceinline__ constexpr bool dbg(uint32_t flags, uint32_t bits) { return kTestHooks && (flags & bits) != 0u; }
 
+// Experiment switches (timing / profiling builds made by tools/mk_variant.sh; several of them give WRONG results on purpose)
+// must never leak into a shipped library: they only compile with -DDRT_EXPERIMENT_BUILD.
+#if !defined(DRT_EXPERIMENT_BUILD) && (defined(DRT_FAST_MATH) || defined(DRT_ENV_EXP) || defined(DRT_EXP_ALB) || defined(DRT_EXP_NT) || \
+                                       (defined(DRT_SQ_PROFILE) && DRT_SQ_PROFILE != 0))
+#error "experiment switch without -DDRT_EXPERIMENT_BUILD (tools/mk_variant.sh adds it): not for a shipped library"
+#endif
+#ifndef DRT_GRID4_ALBEDO
+#define DRT_GRID4_ALBEDO 0         // 1: the tracing kernels hold the code that reads albedo lookups from Params::grid4 when it is bound (measured round 5:
+                                   // the eight float4 loads cost the queued adjoint kernel 60 B more scratch - 877 -> 810 Msamples/s with the copy NOT bound, 799 with it)
+#endif
+#ifndef DRT_EXP_NT
+#define DRT_EXP_NT 0               // bits: 1 splat records, 2 path cache, 4 L / dL / L_in, 8 sigma_t bricks, 16 albedo go through nontemporal accesses
+#endif
+typedef uint32_t __attribute__((ext_vector_type(4))) nt_u4;
+__device__ __forceinline__ void st_stream(float4 *p, float4 v, int bit)
+{
+    if (DRT_EXP_NT & bit) {
+        nt_u4 w; w.x = __float_as_uint(v.x); w.y = __float_as_uint(v.y); w.z = __float_as_uint(v.z); w.w = __float_as_uint(v.w);
+        __builtin_nontemporal_store(w, (nt_u4 *) p);
+    } else *p = v;
+}
+__device__ __forceinline__ void st_stream(uint4 *p, uint4 v, int bit)
+{
+    if (DRT_EXP_NT & bit) { nt_u4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, (nt_u4 *) p); }
+    else *p = v;
+}
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p, int bit)
+{
+    if (DRT_EXP_NT & bit) { const nt_u4 w = __builtin_nontemporal_load((const nt_u4 *) p); return make_uint4(w.x, w.y, w.z, w.w); }
+    return *p;
+}
+__device__ __forceinline__ void st_stream(float *p, float v, int bit) { if (DRT_EXP_NT & bit) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ float ld_stream(const float *p, int bit) { if (DRT_EXP_NT & bit) return __builtin_nontemporal_load(p); return *p; }
+
 constexpr float kInvFourPi = 0.07957747154594767f;
 constexpr float kFourPi    = 12.566370614359172f;
 constexpr float kHalfPi    = 1.5707963267948966f;
@@ -222,6 +256,7 @@ struct Params {
     const float *majorant;     // device: [0] = scale*max(sigma_t), [1] = 1/[0] (0 if [0]==0)
     const float *mgrid;        // majorant supergrid, one majorant per cell (x fastest), or nullptr
     const uint32_t *mocc;      // bit c = supergrid cell c has a non-zero majorant (the DDA skips the others without a load)
+    const uint32_t *mocc_dil;  // bit c = cell c or one of its 26 neighbours has (build_unit_empty)
     int mocc_words;
     int gx, gy, gz;
     int rx, ry, rz;
@@ -307,6 +342,13 @@ struct Params {
     // only: every ray's result is independent of when it is traced).  nullptr: rays in index order
     const uint32_t *order;
     uint32_t order_unit, order_units;
+    // queued supergrid tracer: *order_count (device) = the first order_count units of the order are traced by the queued kernel, the rest -
+    // units whose rays cross only empty supergrid cells, sorted to the end - by trivial_rays_kernel.  nullptr: all of them by the queued kernel
+    const uint32_t *order_count;
+    // queued supergrid tracer: unit_empty[(i - ray_first) / empty_unit] != 0 - every ray of that unit (one pixel's sensor rays) crosses only
+    // supergrid cells whose majorant is 0 (build_unit_empty): the flights along its primary segment are not walked.  nullptr: no flags
+    const uint8_t *unit_empty;
+    uint32_t empty_unit;
     // queued supergrid tracer (drt_sq.hip): per workgroup [3 | 9][sq_rays] uint4 of path state that only the path
     // transitions use (throughput, radiance; adjoint: dL, the sampler clone, the DRT reservoir); library-owned, L2-resident.
     // sq_rays: ray records per workgroup (set by launch_trace_sq: what fits LDS next to the majorants)
@@ -664,7 +706,8 @@ __device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p, const uint3
     const float *g = P.sigma_b + ((size_t) (__umul24((uint32_t) s.z0, (uint32_t) P.sb_zstride) + __umul24(by, (uint32_t) P.sb_ystride) + bx) << 5)
                    + (oy << 2) + ox;
     // the line stores clamped neighbours itself, so +1 / +4 / +16 are always the right corners
-    float d0 = g[0], d1 = g[1], d2 = g[4], d3 = g[5], d4 = g[16], d5 = g[17], d6 = g[20], d7 = g[21];
+    float d0 = ld_stream(g, 8), d1 = ld_stream(g + 1, 8), d2 = ld_stream(g + 4, 8), d3 = ld_stream(g + 5, 8), d4 = ld_stream(g + 16, 8),
+          d5 = ld_stream(g + 17, 8), d6 = ld_stream(g + 20, 8), d7 = ld_stream(g + 21, 8);
     // lower clamp (floor(q) = -1): both corners of that axis are voxel 0 (axis_setup), not 0 and 1.  Only lookups
     // within half a voxel of the box surface get here: one wave-level test keeps the 15 selects out of the common path
     const bool border = s.x1 == s.x0 || s.y1 == s.y0 || s.z1 == s.z0;
@@ -724,11 +767,30 @@ __device__ __forceinline__ void eval_rgb(const Params &P, const float *g, V3 p, 
     int i4 = 3 * (c + s.x0), i5 = 3 * (c + s.x1), i6 = 3 * (d + s.x0), i7 = 3 * (d + s.x1);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
-        out[ch] = trilerp8(s, g[i0 + ch], g[i1 + ch], g[i2 + ch], g[i3 + ch],
-                           g[i4 + ch], g[i5 + ch], g[i6 + ch], g[i7 + ch]);
+        out[ch] = trilerp8(s, ld_stream(g + i0 + ch, 16), ld_stream(g + i1 + ch, 16), ld_stream(g + i2 + ch, 16), ld_stream(g + i3 + ch, 16),
+                           ld_stream(g + i4 + ch, 16), ld_stream(g + i5 + ch, 16), ld_stream(g + i6 + ch, 16), ld_stream(g + i7 + ch, 16));
 }
 
-__device__ __forceinline__ void eval_albedo(const Params &P, V3 p, float out[3]) { eval_rgb(P, P.albedo, p, out); }
+__device__ __forceinline__ void eval_albedo(const Params &P, V3 p, float out[3])
+{
+#if defined(DRT_EXP_ALB) && DRT_EXP_ALB == 1       // timing experiment: no albedo loads at all (results are wrong)
+    out[0] = 0.8f; out[1] = 0.65f; out[2] = 0.45f + 1e-9f * p.x; return;
+#endif
+    // with the four-channel apron-brick copy bound (Params::grid4: copies of the same values, the same stencil and interpolation -
+    // bit-identical) the footprint is two 128-byte lines instead of the 4..8 lines of the caller's (Z,Y,X,3) rows
+    if (DRT_GRID4_ALBEDO && P.grid4) { float s; eval4(P, p, s, out); return; }
+    eval_rgb(P, P.albedo, p, out);
+}
+
+// sigma_t AND the albedo at a scattering vertex of the adjoint's main path (volpathsimple.py:141 and :373-375: the attached lookup at the
+// same point): ONE footprint of the four-channel copy when it is bound
+__device__ __forceinline__ float eval_sigma_t_albedo(const Params &P, V3 p, const uint32_t *occ, float out[3])
+{
+    if (DRT_GRID4_ALBEDO && P.grid4) { float s; eval4(P, p, s, out); return s; }
+    const float s = eval_sigma_t(P, p, occ);
+    eval_albedo(P, p, out);
+    return s;
+}
 
 // Reverse mode of the trilinear gather = 8-corner scatter-add.  gfx950 has a
 // hardware fp32 global atomic add (global_atomic_add_f32, device scope); the
@@ -871,11 +933,11 @@ __device__ __forceinline__ void emit_record(const Params &P, V3 p, float v0, con
     if (rank < split) slot = base0 + rank;
     else if (base1 != 0xffffffffu) slot = base1 + (rank - split);
     if (slot != 0xffffffffu) {
-        if constexpr (S == 0) P.rec_buf[0][slot] = make_float4(p.x, p.y, p.z, v0);
+        if constexpr (S == 0) st_stream(P.rec_buf[0] + slot, make_float4(p.x, p.y, p.z, v0), 1);
         else {
             float4 *dst = P.rec_buf[1] + 2 * (size_t) slot;
-            dst[0] = make_float4(p.x, p.y, p.z, v0);
-            dst[1] = make_float4(c[0], c[1], c[2], 0.0f);
+            st_stream(dst, make_float4(p.x, p.y, p.z, v0), 1);
+            st_stream(dst + 1, make_float4(c[0], c[1], c[2], 0.0f), 1);
         }
     } else {
         if (v0 != 0.0f) splat_direct(P, 0, p, v0);
@@ -929,7 +991,7 @@ __device__ __forceinline__ void emit_records0(const Params &P, const V3 (&p)[N],
         uint32_t slot = 0xffffffffu;
         if (r < split) slot = base0 + r;
         else if (base1 != 0xffffffffu) slot = base1 + (r - split);
-        if (slot != 0xffffffffu) P.rec_buf[0][slot] = make_float4(p[j].x, p[j].y, p[j].z, v0);
+        if (slot != 0xffffffffu) st_stream(P.rec_buf[0] + slot, make_float4(p[j].x, p[j].y, p[j].z, v0), 1);
         else splat_direct(P, 0, p[j], v0);
     }
 }

@@ -988,8 +988,32 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
 }
 #endif  // DRT_TEST_HOOKS
 
+// bit c of `dil`: supergrid cell c or one of its 26 neighbours has a non-zero majorant (Params::mocc_dil: the per-pixel emptiness proof of
+// build_unit_empty tests ONE bit per sample of the pixel's centre ray).  One thread per word of 32 cells.
+__global__ void __launch_bounds__(256) dilate_mask_kernel(const uint32_t *mask, int gx, int gy, int gz, uint32_t *dil)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x, cells = (uint32_t) gx * gy * gz;
+    if (w >= (cells + 31u) / 32u) return;
+    uint32_t out = 0;
+    for (uint32_t b = 0; b < 32u && w * 32u + b < cells; ++b) {
+        const uint32_t c = w * 32u + b;
+        const int x = (int) (c % (uint32_t) gx), y = (int) ((c / (uint32_t) gx) % (uint32_t) gy), z = (int) (c / ((uint32_t) gx * (uint32_t) gy));
+        bool any = false;
+        for (int dz = -1; dz <= 1 && !any; ++dz)
+            for (int dy = -1; dy <= 1 && !any; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx, yy = y + dy, zz = z + dz;
+                    if (xx < 0 || yy < 0 || zz < 0 || xx >= gx || yy >= gy || zz >= gz) continue;
+                    const uint32_t cc = (uint32_t) ((zz * gy + yy) * gx + xx);
+                    if ((mask[cc >> 5] >> (cc & 31u)) & 1u) { any = true; break; }
+                }
+        out |= any ? 1u << b : 0u;
+    }
+    dil[w] = out;
+}
+
 hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
-                                float *out, uint32_t *mask, hipStream_t stream, uint32_t *max_bits, float *majorant)
+                                float *out, uint32_t *mask, hipStream_t stream, uint32_t *max_bits, float *majorant, uint32_t *mask_dil)
 {
     uint32_t cells = (uint32_t) gx * gy * gz;
     if (max_bits) {
@@ -1002,6 +1026,7 @@ hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, in
     }
     hipLaunchKernelGGL(majorant_grid_kernel, dim3((cells * 64 + 255) / 256), dim3(256), 0, stream, sigma_t, rx, ry, rz, gx, gy, gz, scale, out, mask, max_bits);
     if (max_bits && majorant) hipLaunchKernelGGL(majorant_finalize_kernel, dim3(1), dim3(1), 0, stream, max_bits, scale, majorant);
+    if (mask && mask_dil) hipLaunchKernelGGL(dilate_mask_kernel, dim3(((cells + 31) / 32 + 255) / 256), dim3(256), 0, stream, mask, gx, gy, gz, mask_dil);
     return hipGetLastError();
 }
 
@@ -1234,6 +1259,122 @@ hipError_t launch_support_mask(const float *sigma_t, int rx, int ry, int rz, uin
     hipLaunchKernelGGL(support_bits_kernel, dim3((unsigned) ((waves * 64 + 255) / 256)), dim3(256), 0, stream, sigma_t, rx, ry, rz, row_words, bits);
     hipLaunchKernelGGL(support_mask_kernel, dim3((unsigned) ((n_blocks + 255) / 256)), dim3(256), 0, stream, bits, rx, ry, rz, row_words,
                        sparse_off, ch, n_blocks, block_floats, mask);
+    return hipGetLastError();
+}
+
+
+// ---- packing of the one-collective gradient all-reduce (distributed._allreduce_flat, round 5) ------------------------------------
+// The packing set is a byte per 256-byte block (gradient_support / the agreed history set).  block_positions: pos[b] = rank of block b
+// among the set's blocks (-1: not in the set) - counts per group of 1024 blocks, then every workgroup sums the counts of the groups
+// before its own and ranks its own 1024 bytes with wave ballots.  grad_pack: ONE pass over the flat buffer - blocks of the set are copied
+// to their place in the packed buffer, the others are tested and the number of non-zero ones is added to *check (the float that rides
+// at the end of the packed buffer: a non-zero sum over the ranks says the set was too small).  grad_unpack: the reverse copy.
+// (torch formulation before: cumsum + searchsorted + index_select + cat + a mask pass + three mask ops, index_copy_.)
+constexpr int kPosGroup = 1024;
+
+__global__ void __launch_bounds__(256) block_count_kernel(const uint8_t *mask, uint64_t n_blocks, uint32_t *group_count)
+{
+    __shared__ uint32_t part[4];
+    const uint64_t first = (uint64_t) blockIdx.x * kPosGroup;
+    uint32_t c = 0;
+    for (int k = threadIdx.x; k < kPosGroup; k += 256) c += (first + k < n_blocks && mask[first + k]) ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) group_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void __launch_bounds__(256) block_pos_kernel(const uint8_t *mask, uint64_t n_blocks, const uint32_t *group_count, uint32_t n_groups,
+                                                        int32_t *pos, int32_t *count_out)
+{
+    __shared__ uint32_t part[4], wbase[4];
+    uint32_t c = 0;
+    const uint32_t upto = count_out && blockIdx.x == 0 ? n_groups : blockIdx.x;            // (workgroup 0 also writes the total)
+    for (uint32_t g = threadIdx.x; g < upto; g += 256) c += group_count[g];
+    uint32_t mine = 0;                                                                     // groups before this one
+    for (uint32_t g = threadIdx.x; g < blockIdx.x; g += 256) mine += group_count[g];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); mine += __shfl_down(mine, off, 64); }
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = c; wbase[threadIdx.x >> 6] = mine; }
+    __syncthreads();
+    if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = (int32_t) (part[0] + part[1] + part[2] + part[3]);
+    uint32_t base = wbase[0] + wbase[1] + wbase[2] + wbase[3];
+    __syncthreads();
+    const uint64_t first = (uint64_t) blockIdx.x * kPosGroup;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int round = 0; round < kPosGroup / 256; ++round) {
+        const uint64_t b = first + (uint64_t) round * 256 + threadIdx.x;
+        const bool in = b < n_blocks && mask[b] != 0;
+        const uint64_t m = __ballot(in);
+        if (lane == 0) part[wave] = (uint32_t) __popcll(m);
+        __syncthreads();
+        uint32_t before = 0;
+        for (unsigned w = 0; w < wave; ++w) before += part[w];
+        const uint32_t total = part[0] + part[1] + part[2] + part[3];
+        if (b < n_blocks) pos[b] = in ? (int32_t) (base + before + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))) : -1;
+        base += total;
+        __syncthreads();
+    }
+}
+
+template <int BLOCK, bool UNPACK>
+__global__ void __launch_bounds__(256) grad_pack_kernel(float4 *flat, const int32_t *pos, uint64_t n_vec, float4 *packed, float *check)
+{
+    constexpr int kLanes = BLOCK / 4;                       // lanes (float4s) per block
+    const uint64_t stride = (uint64_t) gridDim.x * 256;
+    const unsigned lane = threadIdx.x & 63u;
+    uint32_t outside = 0;
+    for (uint64_t v = (uint64_t) blockIdx.x * 256 + threadIdx.x; v < (n_vec + 63) / 64 * 64; v += stride) {
+        bool nz = false;
+        if (v < n_vec) {
+            const int32_t p = pos[v / kLanes];
+            if constexpr (UNPACK) {
+                if (p >= 0) flat[v] = packed[(uint64_t) p * kLanes + v % kLanes];
+            } else {
+                const float4 f = flat[v];
+                if (p >= 0) packed[(uint64_t) p * kLanes + v % kLanes] = f;
+                else nz = !(f.x == 0.f && f.y == 0.f && f.z == 0.f && f.w == 0.f);
+            }
+        }
+        if constexpr (!UNPACK) {
+            const uint64_t b = __ballot(nz);
+            if (lane % kLanes == 0 && ((b >> lane) & (kLanes == 64 ? ~0ull : ((1ull << (kLanes & 63)) - 1ull)))) ++outside;
+        }
+    }
+    if constexpr (!UNPACK) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) outside += __shfl_down(outside, off, 64);
+        if (lane == 0 && outside) atomicAdd(check, (float) outside);
+    }
+}
+
+hipError_t launch_block_positions(const uint8_t *mask, uint64_t n_blocks, int32_t *pos, int32_t *count, uint32_t *group_count, hipStream_t stream)
+{
+    if (n_blocks == 0) return count ? hipMemsetAsync(count, 0, sizeof(int32_t), stream) : hipSuccess;
+    const uint64_t n_groups = (n_blocks + kPosGroup - 1) / kPosGroup;
+    if (n_groups > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(block_count_kernel, dim3((unsigned) n_groups), dim3(256), 0, stream, mask, n_blocks, group_count);
+    hipLaunchKernelGGL(block_pos_kernel, dim3((unsigned) n_groups), dim3(256), 0, stream, mask, n_blocks, group_count, (uint32_t) n_groups, pos, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_grad_pack(float *flat, const int32_t *pos, uint64_t n_blocks, uint32_t block_floats, float *packed, float *check, bool unpack,
+                            hipStream_t stream)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const uint64_t n_vec = n_blocks * (block_floats / 4);
+    unsigned blocks = (unsigned) ((n_vec + 255) / 256 < 16384 ? (n_vec + 255) / 256 : 16384);
+    float4 *f4 = reinterpret_cast<float4 *>(flat), *p4 = reinterpret_cast<float4 *>(packed);
+#define DRT_PACK(B) do { if (unpack) hipLaunchKernelGGL((grad_pack_kernel<B, true>), dim3(blocks), dim3(256), 0, stream, f4, pos, n_vec, p4, check); \
+                         else hipLaunchKernelGGL((grad_pack_kernel<B, false>), dim3(blocks), dim3(256), 0, stream, f4, pos, n_vec, p4, check); } while (0)
+    switch (block_floats) {
+    case 64:  DRT_PACK(64); break;
+    case 128: DRT_PACK(128); break;
+    case 256: DRT_PACK(256); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef DRT_PACK
     return hipGetLastError();
 }
 

@@ -9,7 +9,8 @@ namespace drt {
 
 hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t stream);
 hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
-                                float *out, uint32_t *mask, hipStream_t stream, uint32_t *max_bits = nullptr, float *majorant = nullptr);
+                                float *out, uint32_t *mask, hipStream_t stream, uint32_t *max_bits = nullptr, float *majorant = nullptr,
+                                uint32_t *mask_dil = nullptr);
 hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int shift, int ox, int oy, int oz,
                             uint32_t *occ, int words, hipStream_t stream);
 hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int nbx, int nby,
@@ -29,8 +30,14 @@ hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_c
 bool sq_supported(const Params &P);
 size_t sq_cold_bytes(int n_cus);
 hipError_t launch_trace_sq(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
+// the units at the end of the order (Params::order_count ..): rays that cross only empty supergrid cells, one thread per ray
+hipError_t launch_trivial_rays(const Params &P, bool adjoint, bool count, hipStream_t stream);
 size_t super_order_bytes(uint32_t units);
-hipError_t build_super_order(const Params &P, uint32_t unit, uint32_t units, void *work, hipStream_t stream);
+// flags[u] = 1: every ray of unit u (the `unit` = spp rays of one pixel, sensor rays only) crosses only empty supergrid cells (Params::unit_empty)
+hipError_t build_unit_empty(const Params &P, uint32_t unit, uint32_t units, uint8_t *flags, hipStream_t stream);
+hipError_t build_super_order(const Params &P, uint32_t unit, uint32_t units, void *work, hipStream_t stream, const uint8_t *iters = nullptr,
+                             const uint8_t *triv = nullptr);
+const uint32_t *super_order_count(const void *work, uint32_t units);   // device word: units in front of the trivial ones (triv)
 // one ray per lane with wave-cooperative tracking loops (drt_coop.hip); global majorant only (P.mgrid == nullptr)
 hipError_t launch_trace_coop_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
 // `between` (optional): called on the host after the main launch has been enqueued and before the tail launch (adjoint of the
@@ -94,6 +101,11 @@ hipError_t launch_adam_step(float *p, const float *g, float *m, float *v, uint64
 hipError_t launch_support_mask(const float *sigma_t, int rx, int ry, int rz, uint64_t sparse_off, uint32_t ch, uint64_t n_blocks,
                                uint32_t block_floats, uint32_t *bits, uint8_t *mask, hipStream_t stream);
 hipError_t launch_block_mask(const float *buf, uint64_t n_blocks, uint32_t block_floats, uint8_t *mask, hipStream_t stream);
+// packing of the one-collective gradient all-reduce: ranks of the set's blocks (group_count: ceil(n_blocks / 1024) words of scratch), the
+// gather into the packed buffer fused with the check of the blocks outside the set, and the scatter back
+hipError_t launch_block_positions(const uint8_t *mask, uint64_t n_blocks, int32_t *pos, int32_t *count, uint32_t *group_count, hipStream_t stream);
+hipError_t launch_grad_pack(float *flat, const int32_t *pos, uint64_t n_blocks, uint32_t block_floats, float *packed, float *check, bool unpack,
+                            hipStream_t stream);
 hipError_t launch_film_develop(const float *L, uint64_t n_pixels, uint32_t spp, float *image,
                                hipStream_t stream);
 hipError_t launch_film_backward(const float *grad_image, uint64_t n_pixels, uint32_t spp, float *dL,

@@ -282,6 +282,21 @@ PYBIND11_MODULE(DRT_PYBIND_NAME, m)
                                            block_floats, reinterpret_cast<uint8_t *>(mask));
         if (rc != DRT_OK) throw std::runtime_error("drt_grad_block_mask failed (code " + std::to_string(rc) + ")");
     });
+    m.def("grad_block_positions", [](uintptr_t stream, uintptr_t mask, uint64_t n_blocks, uintptr_t pos, uintptr_t count, uintptr_t scratch) {
+        const int rc = drt_grad_block_positions(reinterpret_cast<void *>(stream), reinterpret_cast<const uint8_t *>(mask), n_blocks,
+                                                reinterpret_cast<int32_t *>(pos), reinterpret_cast<int32_t *>(count), reinterpret_cast<uint32_t *>(scratch));
+        if (rc != DRT_OK) throw std::runtime_error("drt_grad_block_positions failed (code " + std::to_string(rc) + ")");
+    });
+    m.def("grad_pack", [](uintptr_t stream, uintptr_t flat, uintptr_t pos, uint64_t n_blocks, uint32_t block_floats, uintptr_t packed, uintptr_t check) {
+        const int rc = drt_grad_pack(reinterpret_cast<void *>(stream), reinterpret_cast<const float *>(flat), reinterpret_cast<const int32_t *>(pos), n_blocks,
+                                     block_floats, reinterpret_cast<float *>(packed), reinterpret_cast<float *>(check));
+        if (rc != DRT_OK) throw std::runtime_error("drt_grad_pack failed (code " + std::to_string(rc) + ")");
+    });
+    m.def("grad_unpack", [](uintptr_t stream, uintptr_t packed, uintptr_t pos, uint64_t n_blocks, uint32_t block_floats, uintptr_t flat) {
+        const int rc = drt_grad_unpack(reinterpret_cast<void *>(stream), reinterpret_cast<const float *>(packed), reinterpret_cast<const int32_t *>(pos), n_blocks,
+                                       block_floats, reinterpret_cast<float *>(flat));
+        if (rc != DRT_OK) throw std::runtime_error("drt_grad_unpack failed (code " + std::to_string(rc) + ")");
+    });
     py::class_<Integrator>(m, "Integrator", py::module_local())   // (two flavours of this module can live in one process)
         .def(py::init<const py::dict &, int>(), py::arg("props"), py::arg("device") = 0)
         .def("set_stream", &Integrator::set_stream)

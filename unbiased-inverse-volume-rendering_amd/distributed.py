@@ -107,13 +107,34 @@ def _block_mask(body: torch.Tensor) -> torch.Tensor:
 _PINNED = {"buf": None, "next": 0}
 
 
-def _pinned_slot() -> torch.Tensor:
-    """One int32 of a small ring of pinned host memory (a slot is read long before the ring comes round again)."""
+def _pinned_slot(dtype=torch.int32) -> torch.Tensor:
+    """One 4-byte word (int32 or float32) of a small ring of pinned host memory (a slot is read long before the ring comes
+    round again; a pinned allocation per step would cost more than the kernels it serves)."""
     if _PINNED["buf"] is None:
         _PINNED["buf"] = torch.empty(256, dtype=torch.int32, pin_memory=True)
     i = _PINNED["next"]
     _PINNED["next"] = (i + 1) % 256
-    return _PINNED["buf"][i:i + 1]
+    slot = _PINNED["buf"][i:i + 1]
+    return slot if dtype == torch.int32 else slot.view(dtype)
+
+
+def _positions(mask: torch.Tensor):
+    """(pos, count): pos[b] = rank of block b among the blocks of the set `mask` (uint8), -1 outside it; count = their number, a
+    one-element int32 tensor on the mask's device.  Device masks: drt_grad_block_positions (two small kernels)."""
+    n = mask.numel()
+    if mask.is_cuda:
+        from ._native import native
+        pos = torch.empty(n, dtype=torch.int32, device=mask.device)
+        cnt = torch.empty(1, dtype=torch.int32, device=mask.device)
+        scratch = torch.empty((n + 1023) // 1024 + 1, dtype=torch.int32, device=mask.device)
+        with torch.cuda.device(mask.device):
+            native().grad_block_positions(torch.cuda.current_stream().cuda_stream, mask.data_ptr(), n, pos.data_ptr(), cnt.data_ptr(),
+                                          scratch.data_ptr())
+        return pos, cnt
+    m = mask.to(torch.int32)
+    pos = torch.cumsum(m, dim=0, dtype=torch.int32) - 1
+    pos = torch.where(m != 0, pos, torch.full_like(pos, -1))
+    return pos, m.sum(dtype=torch.int32).reshape(1)
 
 
 class GradientSupport:
@@ -129,7 +150,7 @@ class GradientSupport:
         self.n_floats = int(n_floats)
         self._count = None
         self._host, self._ready = None, None
-        cnt = self.mask.sum(dtype=torch.int32).reshape(1)
+        self.pos, cnt = _positions(self.mask)               # where each block of the set goes in the packed buffer
         if self.mask.is_cuda:
             with torch.cuda.device(self.mask.device):
                 self._host = _pinned_slot()                          # (a pinned allocation per step would cost more than the kernels)
@@ -163,6 +184,8 @@ def gradient_support(sigma_t: torch.Tensor, grads: Dict[str, torch.Tensor], spar
         return None
     n_floats = flat.numel()
     n_blocks = n_floats // block_floats
+    if sigma_t.device != flat.device:                               # (a replica on another device: the mask belongs next to the buffer)
+        sigma_t = sigma_t.to(flat.device)
     # device buffers with ONE per-voxel plane (volpathsimple's albedo): two small kernels (a non-zero bit per voxel, then one thread
     # per block: drt_grad_support_mask, 0.05 ms at 256^3 - the torch formulation below takes 0.86 ms, a fifth of a rank's step at 8 GPUs)
     sparse = [(k, g) for k, g in grads.items() if k != "_flat" and k in sparse_keys]
@@ -206,11 +229,12 @@ def gradient_support(sigma_t: torch.Tensor, grads: Dict[str, torch.Tensor], spar
 
 class _ReduceState:
     """What one (process group, buffer) remembers between backward passes."""
-    __slots__ = ("in_set", "src", "count", "calls", "pending")
+    __slots__ = ("in_set", "src", "pos", "count", "calls", "pending")
 
     def __init__(self):
         self.in_set = None          # uint8 [n_blocks]: the packing set grown from the gradients seen so far
-        self.src = None             # int64 [count]: its block indices
+        self.src = None             # int64 [count]: its block indices (host tensors: the torch formulation of the packing)
+        self.pos = None             # int32 [n_blocks]: rank of every block in the set, -1 outside (device buffers: the packing kernels)
         self.count = 0
         self.calls = 0
         self.pending = None         # (pinned host float, event): blocks found outside a GradientSupport, not looked at yet
@@ -304,38 +328,46 @@ def _allreduce_flat_body(flat, group, compact, stats, support, strict, dist, n, 
         raise ValueError("allreduce_gradients: `support` was built for another buffer")
 
     # ---- the packing set ------------------------------------------------------------------------------------------------
+    dev_path = flat.is_cuda and flat.dtype == torch.float32 and flat.data_ptr() % 16 == 0          # the packing kernels
     if support is not None:
-        in_set, count = support.mask, support.count
+        in_set, count, pos = support.mask, support.count, support.pos
         src = None
     else:
         if st.in_set is None or st.calls % HISTORY_RESET_CALLS == 0:
             mask = _block_mask(body)                               # agree on the set: one byte per block, MAX
             dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
             n_coll += 1
-            st.in_set = mask
-            st.src = torch.nonzero(mask).reshape(-1)               # (host wait: first call and resets only)
-            st.count = int(st.src.numel())
-        in_set, count, src = st.in_set, st.count, st.src
+            _set_history(st, mask, dev_path)                       # (host wait: first call and resets only)
+        in_set, count, src, pos = st.in_set, st.count, st.src, st.pos
     frac = count / n_blocks
     if compact != "always" and frac > COMPACT_MAX_ACTIVE:          # (known before anything is packed)
         return dense(frac)
-    if src is None:
-        cs = torch.cumsum(in_set, dim=0, dtype=torch.int32)
-        src = torch.searchsorted(cs, torch.arange(1, count + 1, dtype=torch.int32, device=flat.device)).to(torch.int64)
 
     # ---- one collective: the set's blocks + the ragged tail + the check ---------------------------------------------------
-    local = _block_mask(body)
-    outside = (local & (1 - in_set)).sum(dtype=torch.float32).reshape(1)
     if count == 0 and tail.numel() == 0 and support is None and n_coll:
         if stats is not None:                                      # (the mask collective just said: zeros on every rank)
             stats.update(mode="compact", floats=0, active_fraction=0.0, collectives=n_coll)
         return
-    packed = _pack(body, tail, src, outside)
+    if dev_path:
+        # one pass over the buffer: the set's blocks to their places, the others tested for the check (drt_grad_pack)
+        from ._native import native
+        packed = torch.empty(count * B + tail.numel() + 1, dtype=torch.float32, device=flat.device)
+        packed[count * B:].zero_()
+        if tail.numel():
+            packed[count * B:count * B + tail.numel()].copy_(tail)
+        native().grad_pack(torch.cuda.current_stream().cuda_stream, flat.data_ptr(), pos.data_ptr(), n_blocks, B, packed.data_ptr(),
+                           packed.data_ptr() + 4 * (packed.numel() - 1))
+    else:
+        if src is None:
+            src = torch.nonzero(in_set).reshape(-1)
+        local = _block_mask(body)
+        outside = (local & (1 - in_set)).sum(dtype=torch.float32).reshape(1)
+        packed = _pack(body, tail, src, outside)
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     n_coll += 1
     lazy = support is not None and flat.is_cuda and not strict
     if lazy:
-        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        host = _pinned_slot(torch.float32)
         host.copy_(packed[-1:], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(flat.device))
@@ -347,18 +379,32 @@ def _allreduce_flat_body(flat, group, compact, stats, support, strict, dist, n, 
         # the set was outgrown: nothing has been scattered yet, `flat` still holds this rank's gradient
         dense(frac)
         if support is None:                                        # grow the set by what the dense sum shows
-            st.in_set = torch.maximum(st.in_set, _block_mask(body))
-            st.src = torch.nonzero(st.in_set).reshape(-1)
-            st.count = int(st.src.numel())
+            _set_history(st, torch.maximum(st.in_set, _block_mask(body)), dev_path)
         if stats is not None:
             stats.update(outgrown=True)
         return
-    body.index_copy_(0, src, packed[:count * B].view(-1, B))
+    if dev_path:
+        native().grad_unpack(torch.cuda.current_stream().cuda_stream, packed.data_ptr(), pos.data_ptr(), n_blocks, B, flat.data_ptr())
+    else:
+        body.index_copy_(0, src, packed[:count * B].view(-1, B))
     if tail.numel():
         tail.copy_(packed[count * B:count * B + tail.numel()])
     if stats is not None:
         stats.update(mode="compact", floats=count * B + tail.numel(), sent_floats=packed.numel(), active_fraction=frac,
                      collectives=n_coll)
+
+
+def _set_history(st: _ReduceState, mask: torch.Tensor, dev_path: bool) -> None:
+    """The packing set grown from the sums seen so far (no `GradientSupport`): its size is needed on the host."""
+    st.in_set = mask
+    if dev_path:
+        st.pos, cnt = _positions(mask)
+        st.src = None
+        st.count = int(cnt)
+    else:
+        st.src = torch.nonzero(mask).reshape(-1)
+        st.pos = None
+        st.count = int(st.src.numel())
 
 
 def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None, shard: Optional[ShardSpec] = None,

@@ -377,7 +377,7 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
     iteration are dealt across the ranks, the local loss is scaled to its share of the global loss and the
     gradient grids are summed with one all-reduce per backward; every rank then takes the identical
     optimizer step."""
-    from .distributed import ShardSpec, allreduce_scalar, local_loss_scale
+    from .distributed import ShardSpec, allreduce_scalar, local_loss_scale, verify_pending
     from . import losses as _losses
     shard = shard or ShardSpec()
     if shard.partitioned:
@@ -522,12 +522,17 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
         enforce_valid_params(scene_config, opt, skip=done or ())       # :353 (what the fused step did not clamp itself)
         total = allreduce_scalar(loss_value.detach()) if shard.partitioned else loss_value.detach()
         history.append(float(total))
+        if shard.partitioned and opt_config.checkpoint_stride and it_i > 0 and it_i % opt_config.checkpoint_stride == 0:
+            verify_pending()                                           # (no checkpoint of parameters that took an unsummed gradient)
         if writer and it_i > 0 and opt_config.checkpoint_stride and it_i % opt_config.checkpoint_stride == 0:
             save_params(os.path.join(output_dir, 'params'), scene_config, params, f'{it_i:08d}', scene.medium)
         if writer and it_i > 0 and opt_config.preview_stride and it_i % opt_config.preview_stride == 0:   # :357-358
             render_previews(output_dir, opt_config, scene_config, scene, integrator, it_i)
         if progress:
             progress(it_i, history[-1])
+    if shard.partitioned:
+        # the packed all-reduce of the last backward pass left its check to "the next call": this is it (raised, never silent)
+        verify_pending()
     if writer and opt_config.checkpoint_final:
         save_params(os.path.join(output_dir, 'params'), scene_config, params, 'final', scene.medium)
     if writer:

@@ -89,13 +89,15 @@ def render_primal(scene: Scene, integrator, sensor: int = 0, spp: int = 1, seed:
 def render_backward(scene: Scene, integrator, grad_image: torch.Tensor, sensor: int = 0,
                     spp: int = 1, seed: int = 0, shard: Optional[ShardSpec] = None,
                     grads: Optional[Dict[str, torch.Tensor]] = None,
-                    allreduce: bool = True) -> Dict[str, torch.Tensor]:
+                    allreduce: bool = True, strict: Optional[bool] = True) -> Dict[str, torch.Tensor]:
     """The H1 sequence (batched.py:212-326) for the local pixels; returns the
     gradient grids - summed over all ranks when the pixels were dealt across a process group
     (`shard.world > 1`); an unsharded call never communicates.  For the sum to be the gradient of
     the GLOBAL loss, `grad_image` must be the derivative of the global loss with respect to the local
     pixels (a mean over the local pixels only over-scales it by `world`: use
-    `distributed.local_loss_scale`)."""
+    `distributed.local_loss_scale`).  `strict` (sharded calls): True - the check of the packed all-reduce is looked at before this
+    call returns (a one-off call has no next call that would look); False / None - it is left to the next backward pass or
+    `distributed.verify_pending()` (the autograd ops inside an optimisation loop, which ends with `verify_pending`)."""
     batch = _sensor_batch(scene, sensor, spp, shard)
     sampler = IndependentSampler(seed, spp)
     L, _, state_out = integrator.sample(ADMode.Primal, scene, sampler.clone(), batch)     # :255-264
@@ -106,7 +108,7 @@ def render_backward(scene: Scene, integrator, grad_image: torch.Tensor, sensor: 
     integrator.sample(ADMode.Backward, scene, sampler, batch, δL=dL, state_in=state_out,  # :309-318
                       grads=grads)
     if allreduce:
-        allreduce_gradients(grads, shard=shard or ShardSpec(), support=support)
+        allreduce_gradients(grads, shard=shard or ShardSpec(), support=support, strict=strict)
     return grads
 
 
@@ -123,7 +125,7 @@ class _RenderOp(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_image):
         g = render_backward(ctx.scene, ctx.integrator, grad_image.contiguous(), ctx.sensor,
-                            ctx.spp_grad, ctx.seed_grad, ctx.shard)
+                            ctx.spp_grad, ctx.seed_grad, ctx.shard, strict=False)   # (run_optimization ends with verify_pending)
         k0, k1 = ctx.integrator.param_keys
         return g[k0], g[k1], None, None, None, None, None, None, None, None
 
