@@ -316,6 +316,49 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
         out3["msamples_per_s"] = round(out3["value"] * 32768 * (1024 + 2 * 16) / 1e6, 1)
         return out3
 
+    def cfg3_reproduce():
+        # The dust-devil DRT run as python/reproduce.py sets it up (:48-59, :108-110): Adam lr 3e-4 with the Last25 schedule, l1, batch 32768 px,
+        # spp_grad 16, spp_primal 1024, constant init sigma_t 0.04 / 100, albedo 0.6 (scene_config.py:166-169) on a grid 2^4 times coarser than
+        # the target, upsampled x2 at 4 / 16 / 36 / 64 % of the run (optimize.py:134-166, 228-252), majorant_resolution_factor 8 reduced on the
+        # coarse grids as adjust_majorant_res_factor does (optimize.py:182-199), lit by a 4096 x 2048 environment map (scene_config.py:152).
+        # The reference runs 6000 iterations; the bench runs 250 with the same fractions: iterations/s per resolution level.
+        target = synthetic.dust_devil_scene(res=256, film=512, device=dev, n_sensors=63)
+        target.medium.majorant_resolution_factor = 8
+        target.emitter = u.EnvmapEmitter(pixels=envmap_pixels(4096, 2048), scale=1.0)
+        scfg = u.SceneConfig(name="dust-devil", scene=target, param_keys=[u.SIGMA_T_KEY, u.ALBEDO_KEY], sensors=list(range(63)),
+                             start_from_value={u.SIGMA_T_KEY: 0.04 / 100, u.ALBEDO_KEY: 0.6}, majorant_resolution_factor=8, ref_spp=64)
+        rendered = u.render_reference_image(scfg, {s_: None for s_ in scfg.sensors})
+        ref = torch.stack([rendered[s_] for s_ in scfg.sensors])
+        out = {}
+        for n_iter in (25, 250):                                   # warm-up run (every level once), then the timed one
+            oc = u.OptimizationConfig(name="r", spp=16, n_iter=n_iter, lr=3e-4, primal_spp_factor=64, batch_size=32768,
+                                      lr_schedule=u.Schedule.Last25, upsample=[0.04, 0.16, 0.36, 0.64])
+            stamps = []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, params, _, hist = u.run_optimization(None, oc, scfg, integ_name, ref_images=ref,
+                                                    progress=lambda i, l: stamps.append(time.perf_counter()))
+            torch.cuda.synchronize()
+            total = time.perf_counter() - t0
+            bounds = [0] + sorted(oc.upsample_at) + [n_iter]
+            levels = []
+            for lv in range(len(bounds) - 1):
+                a, b = bounds[lv], bounds[lv + 1]
+                # (the first iteration of a level pays the upsampling and the scene rebuild: counted with its level)
+                # (... except the run's very first iteration, which pays allocations and the first launches of every kernel)
+                t_a = stamps[0] if a == 0 else stamps[a - 1]
+                n_lv = b - a - (1 if a == 0 else 0)
+                res = 256 >> (len(bounds) - 2 - lv)
+                levels.append({"grid": f"{res}^3", "iterations": b - a, "iterations_per_s": round(n_lv / (stamps[b - 1] - t_a), 2)})
+            out = {"value": round(n_iter / total, 2), "unit": "iterations/s", "n_iter": n_iter, "levels": levels,
+                   "loss_first20_mean": round(sum(hist[:20]) / 20, 6), "loss_last20_mean": round(sum(hist[-20:]) / 20, 6),
+                   "final_grid": list(params[u.SIGMA_T_KEY].shape)}
+        out["slowest_level"] = min(out["levels"], key=lambda l: l["iterations_per_s"])["grid"]
+        out["workload"] = ("config 3 as python/reproduce.py runs dust-devil DRT: Adam lr 3e-4 (Last25), l1, batch 32768 px, spp 1024 / 16, init "
+                           "sigma_t 0.04/100 and albedo 0.6 on 16^3, x2 upsampling at 4/16/36/64 % of the run, majorant_resolution_factor 8 "
+                           "(adjusted on the coarse grids), 4096x2048 environment map, 63 sensors 512^2; 250 iterations instead of 6000")
+        return out
+
     def cfg5_fused(env=False, factor=0):
         sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
         sc.medium.majorant_resolution_factor = factor
@@ -421,6 +464,7 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
     guarded("headline_envmap_factor8", envmap8)
     guarded("headline_envmap", envmap)
     guarded("config3_optimize_loop", cfg3)
+    guarded("config3_as_reproduce", cfg3_reproduce)
     guarded("config4_512_rank_share_1024x64", cfg4)
     guarded("config5_nerf_256_512x32", cfg5)
     def cfg5_fused_both():

@@ -179,8 +179,11 @@ void clear_timings(drt_handle h)
 }
 
 // launch bracketed by an event pair on the handle's stream when timing is enabled
+#ifndef DRT_ORDER_NEAR
+#define DRT_ORDER_NEAR 0            // > 0: the ray order's cost key integrates the largest majorant within this many supergrid cells of the pixel's ray
+#endif
 #ifndef DRT_PATH_CACHE_CAP
-#define DRT_PATH_CACHE_CAP 16
+#define DRT_PATH_CACHE_CAP 64
 #endif
 #ifndef DRT_ORDER_ITERS
 #define DRT_ORDER_ITERS 1           // adjoint launches of the supergrid tracer: units ordered by the primal pass's iteration counts too (0: as the primal launch)
@@ -310,7 +313,7 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         // the round-3 kernel (drt_super.hip), which also serves what the queued one does not take
         const bool queued = sq_ok;
 #ifndef DRT_SQ_TRIVIAL
-#define DRT_SQ_TRIVIAL 1            // the flagged pixels' rays are sorted to the end of the order and traced by trivial_rays_kernel, one thread per ray
+#define DRT_SQ_TRIVIAL 0            // 1: the flagged pixels' rays are sorted to the end of the order and traced by trivial_rays_kernel, one thread per ray
 #endif
 #ifndef DRT_SQ_UNIT_EMPTY
 #define DRT_SQ_UNIT_EMPTY 1         // pixels whose rays cross only empty supergrid cells are flagged: their primary-segment flights are not walked
@@ -805,6 +808,8 @@ int drt_params_changed(drt_handle h)
         DRT_HIP_CHECK(h, drt::launch_majorant_grid(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.gx, h->base.gy,
                                                    h->base.gz, h->base.scale, h->d_mgrid, (uint32_t *) h->base.mocc, h->stream,
                                                    h->d_scratch, h->d_majorant, (uint32_t *) h->base.mocc_dil));
+    if (h->base.mgrid && h->base.mgrid_near)
+        DRT_HIP_CHECK(h, drt::launch_majorant_near(h->d_mgrid, h->base.gx, h->base.gy, h->base.gz, DRT_ORDER_NEAR, (float *) h->base.mgrid_near, h->stream));
     else
         DRT_HIP_CHECK(h, drt::launch_majorant(h->base.sigma_t, n, h->base.scale, h->d_scratch, h->d_majorant, h->stream));
     DRT_HIP_CHECK(h, drt::launch_occupancy(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.occ_shift, h->base.occ_x,
@@ -859,14 +864,15 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         if (cells != h->mgrid_cells) {
             DeviceGuard g(h->device);
             if (h->d_mgrid) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_mgrid); h->d_mgrid = nullptr; h->mgrid_cells = 0; }
-            DRT_HIP_CHECK(h, hipMalloc(&h->d_mgrid, (cells + 2 * ((cells + 31) / 32)) * sizeof(float)));   // majorants | non-empty bitmask | the same, dilated by one cell
+            DRT_HIP_CHECK(h, hipMalloc(&h->d_mgrid, (2 * cells + 2 * ((cells + 31) / 32)) * sizeof(float)));   // majorants | non-empty bitmask | the same, dilated by one cell | majorants nearby
             h->mgrid_cells = cells;
         }
         B.mgrid = h->d_mgrid; B.gx = G[0]; B.gy = G[1]; B.gz = G[2];
         B.mocc = (const uint32_t *) (h->d_mgrid + cells); B.mocc_words = (int) ((cells + 31) / 32);
         B.mocc_dil = B.mocc + B.mocc_words;
+        B.mgrid_near = DRT_ORDER_NEAR ? (const float *) (B.mocc_dil + B.mocc_words) : nullptr;
     } else {
-        B.mgrid = nullptr; B.gx = B.gy = B.gz = 0; B.mocc = nullptr; B.mocc_words = 0; B.mocc_dil = nullptr;
+        B.mgrid = nullptr; B.gx = B.gy = B.gz = 0; B.mocc = nullptr; B.mocc_words = 0; B.mocc_dil = nullptr; B.mgrid_near = nullptr;
     }
     // empty-space bitmask: cells of 2^shift voxels, at most kOccWords*32 cells
     {
@@ -907,7 +913,7 @@ int drt_set_emitter_constant(drt_handle h, const float radiance[3])
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
     if (!radiance) return fail(h, DRT_ERR_INVALID_ARGUMENT, "null radiance");
     for (int k = 0; k < 3; ++k) h->base.Le[k] = radiance[k];
-    h->base.env_pix = h->base.env_marg = h->base.env_cond = nullptr; h->base.env_gmarg = h->base.env_gcond = nullptr;
+    h->base.env_pix = nullptr; h->base.env_marg = h->base.env_cond = nullptr; h->base.env_gmarg = h->base.env_gcond = nullptr;
     h->have_emitter = true; h->scene_version++;
     return DRT_OK;
 }
@@ -981,20 +987,41 @@ int drt_set_emitter_envmap(drt_handle h, const float *pixels, int32_t width, int
     make_guide(marg.data(), hh, gmarg.data());
     for (size_t j = 0; j < hh; ++j) make_guide(cond.data() + j * (w + 1), w, gcond.data() + j * (w + 1));
 
+    // device layout: float4 texels {r, g, b, density} | conditional CDF rows | their guide rows | marginal CDF | its guide; the rows of the
+    // two [h][w + 1] tables are padded to whole 128-byte lines (a guided search touches neighbouring entries of ONE row)
+    const size_t cstride = ((w + 1) + 31) & ~(size_t) 31;
+    std::vector<float> pix4(4 * w * hh), condp(hh * cstride, 1.0f);
+    std::vector<uint32_t> gcondp(hh * cstride, 0u);
+    for (size_t j = 0; j < hh; ++j) {
+        const float *c = cond.data() + j * (w + 1);
+        // the texel's density in uv space, with the float operations the device lookup made per query before round 5 (drt_device.h):
+        // (pmf(row) * pmf(col | row)) * (w * h), each difference and product rounded to float
+        const float pm = marg[j + 1] - marg[j];
+        for (size_t i = 0; i < w; ++i) {
+            const float pc = c[i + 1] - c[i];
+            float *t = pix4.data() + 4 * (j * w + i);
+            t[0] = pix[3 * (j * w + i)]; t[1] = pix[3 * (j * w + i) + 1]; t[2] = pix[3 * (j * w + i) + 2];
+            t[3] = (pm * pc) * ((float) width * (float) height);
+        }
+        std::copy(c, c + w + 1, condp.begin() + j * cstride);
+        std::copy(gcond.begin() + j * (w + 1), gcond.begin() + (j + 1) * (w + 1), gcondp.begin() + j * cstride);
+    }
     if (h->d_env) { (void) hipFree(h->d_env); h->d_env = nullptr; }
-    const size_t n_tab = marg.size() + cond.size();
-    const size_t n_all = n_pix + 2 * n_tab;
+    auto pad32 = [](size_t n) { return (n + 31) & ~(size_t) 31; };
+    const size_t o_cond = pad32(pix4.size()), o_gcond = o_cond + condp.size(), o_marg = o_gcond + gcondp.size(), o_gmarg = o_marg + pad32(marg.size());
+    const size_t n_all = o_gmarg + pad32(gmarg.size());
     DRT_HIP_CHECK(h, hipMalloc(&h->d_env, n_all * sizeof(float)));
-    DRT_HIP_CHECK(h, hipMemcpy(h->d_env, pix.data(), n_pix * sizeof(float), hipMemcpyHostToDevice));
-    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + n_pix, marg.data(), marg.size() * sizeof(float), hipMemcpyHostToDevice));
-    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + n_pix + marg.size(), cond.data(), cond.size() * sizeof(float), hipMemcpyHostToDevice));
-    h->base.env_pix = h->d_env;
-    h->base.env_marg = h->d_env + n_pix;
-    h->base.env_cond = h->d_env + n_pix + marg.size();
-    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + n_pix + n_tab, gmarg.data(), gmarg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + n_pix + n_tab + gmarg.size(), gcond.data(), gcond.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    h->base.env_gmarg = (const uint32_t *) (h->d_env + n_pix + n_tab);
-    h->base.env_gcond = (const uint32_t *) (h->d_env + n_pix + n_tab + gmarg.size());
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env, pix4.data(), pix4.size() * sizeof(float), hipMemcpyHostToDevice));
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + o_cond, condp.data(), condp.size() * sizeof(float), hipMemcpyHostToDevice));
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + o_gcond, gcondp.data(), gcondp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + o_marg, marg.data(), marg.size() * sizeof(float), hipMemcpyHostToDevice));
+    DRT_HIP_CHECK(h, hipMemcpy(h->d_env + o_gmarg, gmarg.data(), gmarg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->base.env_pix = (const float4 *) h->d_env;
+    h->base.env_cond = h->d_env + o_cond;
+    h->base.env_gcond = (const uint32_t *) (h->d_env + o_gcond);
+    h->base.env_marg = h->d_env + o_marg;
+    h->base.env_gmarg = (const uint32_t *) (h->d_env + o_gmarg);
+    h->base.env_cstride = (int) cstride;
     h->base.env_w = width; h->base.env_h = height; h->base.env_scale = scale;
     for (int k = 0; k < 9; ++k) h->base.env_R[k] = to_world[k];
     for (int k = 0; k < 3; ++k) h->base.Le[k] = 0.0f;

@@ -594,12 +594,8 @@ struct CoopTracer {
     {
         if (escaped && !(depth <= 0 && P.hide_emitters)) {
             float w = 1.0f, Le[3];
-            if (use_nee()) {
-                float epdf = 0.0f;                                              // :273-277
-                if (has_scattered) epdf = emitter_pdf<ENV>(P, d);
-                w = mis_weight(last_pdf, epdf);
-            }
-            emitter_eval<ENV>(P, d, Le);                                        // :284
+            const float e_pdf = emitter_eval_pdf<ENV>(P, d, Le);                // :284 and :273: the same taps of the map
+            if (use_nee()) w = mis_weight(last_pdf, has_scattered ? e_pdf : 0.0f);   // :273-277
 #pragma unroll
             for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
         }

@@ -257,6 +257,7 @@ struct Params {
     const float *mgrid;        // majorant supergrid, one majorant per cell (x fastest), or nullptr
     const uint32_t *mocc;      // bit c = supergrid cell c has a non-zero majorant (the DDA skips the others without a load)
     const uint32_t *mocc_dil;  // bit c = cell c or one of its 26 neighbours has (build_unit_empty)
+    const float *mgrid_near;   // the largest majorant within a few cells of every cell (the ray order's cost key), or nullptr
     int mocc_words;
     int gx, gy, gz;
     int rx, ry, rz;
@@ -266,9 +267,10 @@ struct Params {
     // `envmap` emitter (env_pix != nullptr) instead of the constant Le: lat-long RGB bitmap
     // [env_h][env_w][3] (library-owned device copy), row-major to_world rotation, scale, and the
     // importance-sampling tables (marginal CDF over rows [h+1], conditional CDFs [h][w+1])
-    const float *env_pix, *env_marg, *env_cond;
-    const uint32_t *env_gmarg, *env_gcond;   // guide tables of the two CDF families (cdf_find_guided): [h + 1], [h][w + 1]
-    int env_w, env_h;
+    const float4 *env_pix;                   // [env_h][env_w] texels {r, g, b, density in uv space} (envmap_taps)
+    const float *env_marg, *env_cond;
+    const uint32_t *env_gmarg, *env_gcond;   // guide tables of the two CDF families (cdf_find_guided): [h + 1], [h][env_cstride]
+    int env_w, env_h, env_cstride;           // env_cstride: floats per row of env_cond / env_gcond (w + 1 rounded up to whole 128-byte lines)
     float env_R[9], env_scale;
     // nerf integrator (python/integrators/nerf.py): emission grid (Z,Y,X,3) and properties
     const float *emission;
@@ -367,22 +369,38 @@ constexpr float kInvPi = 0.31830988618379069f;
 constexpr float kTwoPiSq = 19.739208802178716f;
 constexpr float kOneMinusEps = 0.99999994f;
 
-// bilinear lookup at uv in [0,1)^2: texel centres at ((i+.5)/w, (j+.5)/h), wrap in u, clamp in v
-__device__ __forceinline__ void envmap_lookup(const Params &P, float u, float v, float out[3])
+// The map is ONE table of float4 texels {r, g, b, density}: `density` = the texel's probability density in uv space, pmf(row) * pmf(col | row)
+// * w * h - the float product of the table differences, computed once per texel on the host with the very operations the lookup used to
+// make (drt_set_emitter_envmap) - so that Emitter::eval (bilinear, :284) and Emitter::pdf_direction (piecewise constant, :273) of ONE direction
+// come from the same four taps: the density's texel (floor(u w), floor(v h)) is always one of the bilinear footprint's four (round 4 read the
+// radiance from an RGB table and the density from two CDF tables: 16 scalar loads over three tables, and the direction -> uv conversion twice).
+struct EnvTaps { float4 t00, t01, t10, t11; float fx, fy; int i0, i1, j0, j1; };
+
+// bilinear footprint at uv in [0,1)^2: texel centres at ((i+.5)/w, (j+.5)/h), wrap in u, clamp in v
+__device__ __forceinline__ EnvTaps envmap_taps(const Params &P, float u, float v)
 {
     const int w = P.env_w, h = P.env_h;
     float px = fmaf(u, (float) w, -0.5f), py = fmaf(v, (float) h, -0.5f);
     float fx0 = floorf(px), fy0 = floorf(py);
-    float fx = px - fx0, fy = py - fy0;
+    EnvTaps T;
+    T.fx = px - fx0; T.fy = py - fy0;
     int i0 = (int) fx0, j0 = (int) fy0;
     int i1 = i0 + 1, j1 = j0 + 1;
     if (i0 < 0) i0 += w;
     if (i1 >= w) i1 -= w;
     j0 = min(max(j0, 0), h - 1);
     j1 = min(max(j1, 0), h - 1);
-    const float *p00 = P.env_pix + 3 * ((size_t) j0 * w + i0), *p01 = P.env_pix + 3 * ((size_t) j0 * w + i1);
-    const float *p10 = P.env_pix + 3 * ((size_t) j1 * w + i0), *p11 = P.env_pix + 3 * ((size_t) j1 * w + i1);
-    float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+    T.i0 = i0; T.i1 = i1; T.j0 = j0; T.j1 = j1;
+    T.t00 = P.env_pix[(size_t) j0 * w + i0]; T.t01 = P.env_pix[(size_t) j0 * w + i1];
+    T.t10 = P.env_pix[(size_t) j1 * w + i0]; T.t11 = P.env_pix[(size_t) j1 * w + i1];
+    return T;
+}
+
+__device__ __forceinline__ void envmap_bilinear(const Params &P, const EnvTaps &T, float out[3])
+{
+    const float wx0 = 1.0f - T.fx, wy0 = 1.0f - T.fy, fx = T.fx, fy = T.fy;
+    const float p00[3] = { T.t00.x, T.t00.y, T.t00.z }, p01[3] = { T.t01.x, T.t01.y, T.t01.z };
+    const float p10[3] = { T.t10.x, T.t10.y, T.t10.z }, p11[3] = { T.t11.x, T.t11.y, T.t11.z };
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float a = fmaf(wx0, p00[k], fx * p01[k]);
@@ -406,14 +424,6 @@ __device__ __forceinline__ void envmap_dir_to_uv(const Params &P, V3 d, float &u
     u = uu; v = vv; sin_theta = st;
 }
 
-// texel probability density in uv space: pmf(row) * pmf(col | row) * w * h
-__device__ __forceinline__ float envmap_pdf_uv(const Params &P, int i, int j)
-{
-    const float *c = P.env_cond + (size_t) j * (P.env_w + 1);
-    float pm = P.env_marg[j + 1] - P.env_marg[j], pc = c[i + 1] - c[i];
-    return (pm * pc) * ((float) P.env_w * (float) P.env_h);
-}
-
 // Emitter::eval for an escaped ray of direction d (volpathsimple.py:284)
 __device__ __forceinline__ void envmap_eval(const Params &P, V3 d, float out[3])
 {
@@ -422,10 +432,11 @@ __device__ __forceinline__ void envmap_eval(const Params &P, V3 d, float out[3])
 #endif
     float u, v, st;
     envmap_dir_to_uv(P, d, u, v, st);
-    envmap_lookup(P, u, v, out);
+    const EnvTaps T = envmap_taps(P, u, v);
+    envmap_bilinear(P, T, out);
 }
 
-// Emitter::pdf_direction (volpathsimple.py:273)
+// Emitter::pdf_direction (volpathsimple.py:273): the density texel alone (one 16-byte load)
 __device__ __forceinline__ float envmap_pdf(const Params &P, V3 d)
 {
 #if defined(DRT_ENV_EXP) && (DRT_ENV_EXP & 2)
@@ -435,7 +446,23 @@ __device__ __forceinline__ float envmap_pdf(const Params &P, V3 d)
     envmap_dir_to_uv(P, d, u, v, st);
     int i = min((int)(u * (float) P.env_w), P.env_w - 1), j = min((int)(v * (float) P.env_h), P.env_h - 1);
     float den = kTwoPiSq * st;
-    return den > 0.0f ? envmap_pdf_uv(P, i, j) / den : 0.0f;
+    return den > 0.0f ? P.env_pix[(size_t) j * P.env_w + i].w / den : 0.0f;
+}
+
+// both of ONE direction: one direction -> uv conversion, the four taps of the bilinear footprint (the density's texel is one of them)
+__device__ __forceinline__ float envmap_eval_pdf(const Params &P, V3 d, float out[3])
+{
+    float u, v, st;
+    envmap_dir_to_uv(P, d, u, v, st);
+    const EnvTaps T = envmap_taps(P, u, v);
+    envmap_bilinear(P, T, out);
+    const int i = min((int)(u * (float) P.env_w), P.env_w - 1), j = min((int)(v * (float) P.env_h), P.env_h - 1);
+    float dens;
+    if ((i == T.i0 || i == T.i1) && (j == T.j0 || j == T.j1))
+        dens = i == T.i0 ? (j == T.j0 ? T.t00.w : T.t10.w) : (j == T.j0 ? T.t01.w : T.t11.w);
+    else dens = P.env_pix[(size_t) j * P.env_w + i].w;        // (cannot happen: floor(u w) lies in the footprint; kept for safety)
+    const float den = kTwoPiSq * st;
+    return den > 0.0f ? dens / den : 0.0f;
 }
 
 // largest k in [0, n-1] with cdf[k] <= x (cdf[0] = 0, cdf[n] = 1, x in [0,1))
@@ -480,8 +507,8 @@ __device__ __forceinline__ V3 envmap_sample_dir(const Params &P, float u1, float
 #endif
     const int w = P.env_w, h = P.env_h;
     int j = cdf_find_guided(P.env_marg, P.env_gmarg, h, u2);
-    const float *c = P.env_cond + (size_t) j * (w + 1);
-    int i = cdf_find_guided(c, P.env_gcond + (size_t) j * (w + 1), w, u1);
+    const float *c = P.env_cond + (size_t) j * P.env_cstride;          // (rows padded to whole 128-byte lines)
+    int i = cdf_find_guided(c, P.env_gcond + (size_t) j * P.env_cstride, w, u1);
     float dv = fminf((u2 - P.env_marg[j]) / (P.env_marg[j + 1] - P.env_marg[j]), kOneMinusEps);
     float du = fminf((u1 - c[i]) / (c[i + 1] - c[i]), kOneMinusEps);
     float u = ((float) i + du) / (float) w, v = ((float) j + dv) / (float) h;
@@ -512,8 +539,8 @@ template <bool ENV>
 __device__ __forceinline__ float emitter_sample_value(const Params &P, V3 d, float val[3])
 {
     if constexpr (ENV) {
-        float p = envmap_pdf(P, d), Le[3];
-        envmap_eval(P, d, Le);
+        float Le[3];
+        const float p = envmap_eval_pdf(P, d, Le);
 #pragma unroll
         for (int k = 0; k < 3; ++k) val[k] = p > 0.0f ? Le[k] / p : 0.0f;
         return p;
@@ -542,6 +569,14 @@ __device__ __forceinline__ float emitter_pdf(const Params &P, V3 d)
 {
     if constexpr (ENV) return envmap_pdf(P, d);
     else return kInvFourPi;
+}
+
+// radiance towards an escaped ray AND the emitter's density of its direction (the escape side of the MIS weight, :273-284)
+template <bool ENV>
+__device__ __forceinline__ float emitter_eval_pdf(const Params &P, V3 d, float Le[3])
+{
+    if constexpr (ENV) return envmap_eval_pdf(P, d, Le);
+    else { Le[0] = P.Le[0]; Le[1] = P.Le[1]; Le[2] = P.Le[2]; return kInvFourPi; }
 }
 
 // emitter radiance towards an escaped ray
@@ -759,10 +794,34 @@ __device__ __forceinline__ void eval4(const Params &P, V3 p, float &sigma_t, flo
     rgb[2] = trilerp8(s, d0.w, d1.w, d2.w, d3.w, d4.w, d5.w, d6.w, d7.w);
 }
 
+#ifndef DRT_RGB_WIDE
+#define DRT_RGB_WIDE 0             // 1: eval_rgb reads the two x-neighbours of a row as ONE run of six floats (two 12-byte loads) instead of six scalar loads
+#endif
 __device__ __forceinline__ void eval_rgb(const Params &P, const float *g, V3 p, float out[3])
 {
     Stencil s = make_stencil(P, p);
     int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
+    if (DRT_RGB_WIDE && P.rx >= 2) {
+        // the voxels x0 and x1 of a row are neighbours in memory (x1 = x0 + 1) except at the clamped ends (x1 = x0): the run [xb, xb + 1] with
+        // xb = min(x0, rx - 2) holds both in every case and never leaves the row.  The same values as the scalar loads: bit-identical.
+        typedef float __attribute__((ext_vector_type(3))) f3;
+        const int xb = min(s.x0, P.rx - 2);
+        const bool lo0 = s.x0 == xb, lo1 = s.x1 == xb;
+        const int rows[4] = { a, b, c, d };
+        float v[4][2][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float *q = g + 3 * (size_t) (rows[r] + xb);
+            f3 lo, hi;
+            __builtin_memcpy(&lo, q, 12); __builtin_memcpy(&hi, q + 3, 12);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { v[r][0][ch] = lo0 ? lo[ch] : hi[ch]; v[r][1][ch] = lo1 ? lo[ch] : hi[ch]; }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            out[ch] = trilerp8(s, v[0][0][ch], v[0][1][ch], v[1][0][ch], v[1][1][ch], v[2][0][ch], v[2][1][ch], v[3][0][ch], v[3][1][ch]);
+        return;
+    }
     int i0 = 3 * (a + s.x0), i1 = 3 * (a + s.x1), i2 = 3 * (b + s.x0), i3 = 3 * (b + s.x1);
     int i4 = 3 * (c + s.x0), i5 = 3 * (c + s.x1), i6 = 3 * (d + s.x0), i7 = 3 * (d + s.x1);
 #pragma unroll

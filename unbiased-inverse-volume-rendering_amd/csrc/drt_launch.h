@@ -11,6 +11,7 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
 hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
                                 float *out, uint32_t *mask, hipStream_t stream, uint32_t *max_bits = nullptr, float *majorant = nullptr,
                                 uint32_t *mask_dil = nullptr);
+hipError_t launch_majorant_near(const float *mg, int gx, int gy, int gz, int radius, float *out, hipStream_t stream);
 hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int shift, int ox, int oy, int oz,
                             uint32_t *occ, int words, hipStream_t stream);
 hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int nbx, int nby,

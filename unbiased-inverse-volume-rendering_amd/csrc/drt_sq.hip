@@ -96,6 +96,13 @@
 #ifndef DRT_SQ_INLINE_K
 #define DRT_SQ_INLINE_K 4          // cells a flight is stepped by the lanes that set it up, before it is posted for the walkers
 #endif
+#ifndef DRT_SQ_DRAIN_INLINE
+#define DRT_SQ_DRAIN_INLINE 0      // > 0: in a workgroup whose ray queues are drained the lanes that set a flight up walk it themselves, up to this many rounds of
+                                   // DRT_SQ_INLINE_K cells (the walkers' queue hop costs a lone ray more than the cells do)
+#endif
+#ifndef DRT_SQ_DRAIN_K
+#define DRT_SQ_DRAIN_K 1           // walkers of a drained workgroup step this many rounds of DRT_SQ_K cells between two looks at the queues
+#endif
 #ifndef DRT_SQ_URGENT
 #define DRT_SQ_URGENT 0            // > 0: a record with at least this many bounce-loop iterations behind it is URGENT once the workgroup has started
                                    // DRT_SQ_URGENT_FROM percent of its XCD's rays: a heavy queue that holds one is taken at once (a partial batch), by a wave
@@ -437,6 +444,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 // (primal kernels: the steps are not predicated on `fly`, as in drt_super.hip)
                 constexpr bool kLoose = !ADJ || MG;
                 bool fin = false; float res_mc = 0.0f, res_t = 0.0f, res_acc = 0.0f;
+                for (int wrep = 0; wrep < (drained ? DRT_SQ_DRAIN_K : 1); ++wrep) {
 #pragma unroll
                 for (int k = 0; k < DRT_SQ_K; ++k) {
 #if DRT_SQ_PROFILE == 1
@@ -472,6 +480,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                         cell += go ? (isx ? sx : isy ? sy : sz) : 0;
                         tnx = (go && isx) ? tnn : tnx; tny = (go && isy) ? tnn : tny; tnz = (go && !isx && !isy) ? tnn : tnz;
                     }
+                }
+                if (DRT_SQ_DRAIN_K > 1 && __ballot(fin)) break;
                 }
                 SQ_STAMP(0);
                 if (__ballot(fin)) {
@@ -1019,8 +1029,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     if (!ADJ || rec_mode) {                                     // envmap block, primal only
                         if (escaped && !(depth <= 0 && P.hide_emitters)) {
                             float w = 1.0f, Le[3];
-                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? emitter_pdf<ENV>(P, rd) : 0.0f);
-                            emitter_eval<ENV>(P, rd, Le);
+                            // (radiance and density of the direction from the same taps of the map: emitter_eval_pdf)
+                            const float e_pdf = emitter_eval_pdf<ENV>(P, rd, Le);
+                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? e_pdf : 0.0f);
 #pragma unroll
                             for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
                         }
@@ -1143,6 +1154,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                             uint32_t wrem = rem;
                             const int sx = sgx < 0 ? -1 : 1, sy = sgy < 0 ? -lin_y : lin_y, sz = sgz < 0 ? -lin_z : lin_z;
                             bool wfly = true;
+                            int inl_rounds = 0;
+                            do {
 #pragma unroll
                             for (int k = 0; k < (MG ? 0 : DRT_SQ_INLINE_K); ++k) {
                                 const float tmin = fminf(fminf(wnx, wny), wnz);
@@ -1162,6 +1175,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                                 wcell += go ? (isx ? sx : isy ? sy : sz) : 0;
                                 wnx = (go && isx) ? tnn : wnx; wny = (go && isy) ? tnn : wny; wnz = (go && !isx && !isy) ? tnn : wnz;
                             }
+                            // (a workgroup whose ray queues are drained: its last paths are latency - the flight is walked to its end right here,
+                            //  it never waits for a walker)
+                            } while (DRT_SQ_DRAIN_INLINE && !MG && drained && wfly && ++inl_rounds < DRT_SQ_DRAIN_INLINE);
                             R[0] = make_uint4(wfly ? __float_as_uint(wnx) : __float_as_uint(res_mc), __float_as_uint(wny), __float_as_uint(wnz), (uint32_t) wcell);
                             R[1] = make_uint4(__float_as_uint(tdx), __float_as_uint(tdy), __float_as_uint(tdz), wrem);
                             R[2] = make_uint4(__float_as_uint(tau), __float_as_uint(tmax), __float_as_uint(wt_), __float_as_uint(wacc));

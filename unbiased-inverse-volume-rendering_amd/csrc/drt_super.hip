@@ -753,8 +753,9 @@ __global__ void __launch_bounds__(ADJ ? DRT_SUPER_THREADS_ADJ : DRT_SUPER_THREAD
                     if (!ADJ || rec_mode) {                                     // envmap block, primal only
                         if (escaped && !(depth <= 0 && P.hide_emitters)) {
                             float w = 1.0f, Le[3];
-                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? emitter_pdf<ENV>(P, rd) : 0.0f);
-                            emitter_eval<ENV>(P, rd, Le);
+                            // (radiance and density of the direction from the same taps of the map: emitter_eval_pdf)
+                            const float e_pdf = emitter_eval_pdf<ENV>(P, rd, Le);
+                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? e_pdf : 0.0f);
 #pragma unroll
                             for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
                         }
@@ -971,7 +972,7 @@ __global__ void __launch_bounds__(kOrderThreads) order_keys_depth_kernel(const P
                 const float gf = ((fmaf(dd[a], t, oo[a]) - P.bmin[a]) * P.inv_ext[a]) * (float) gn[a];
                 c[a] = (int) fminf(fmaxf(floorf(gf), 0.0f), (float) (gn[a] - 1));
             }
-            m[j] = P.mgrid[((size_t) c[2] * P.gy + c[1]) * P.gx + c[0]];
+            m[j] = (P.mgrid_near ? P.mgrid_near : P.mgrid)[((size_t) c[2] * P.gy + c[1]) * P.gx + c[0]];
         }
 #pragma unroll
         for (int j = 0; j < kSamples; ++j) od += m[j];

@@ -270,8 +270,9 @@ __global__ void __launch_bounds__(256, DRT_WF_WAVES) trace_wavefront_kernel(cons
                     if (!ADJ || rec_mode) {                                     // envmap block, primal only
                         if (escaped && !(depth <= 0 && P.hide_emitters)) {
                             float w = 1.0f, Le[3];
-                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? emitter_pdf<ENV>(P, rd) : 0.0f);
-                            emitter_eval<ENV>(P, rd, Le);
+                            // (radiance and density of the direction from the same taps of the map: emitter_eval_pdf)
+                            const float e_pdf = emitter_eval_pdf<ENV>(P, rd, Le);
+                            if (P.use_nee) w = mis_weight(scat_once ? kInvFourPi : 1.0f, has_scattered ? e_pdf : 0.0f);
 #pragma unroll
                             for (int k = 0; k < 3; ++k) result[k] += (beta[k] * w) * Le[k];
                         }
