@@ -36,7 +36,6 @@ struct drt_handle_s {
     size_t order_bytes = 0;
     uint64_t order_first = 0, order_end = 0;  // ... made by the primal launch over these rays of the job the path cache describes:
     uint32_t order_unit = 0;                  //     the adjoint launch over the same rays takes it as it is (0: none)
-    bool order_triv = false;                  // the stored order has the trivial units sorted to its end (it is not reused: its count belongs to that launch)
     void *d_tail = nullptr;                   // tail pool of the cooperative kernels: [counter, pad to 256 B][entries x 128 B]
     size_t tail_entries = 0;
     int n_cus = 256;
@@ -166,7 +165,7 @@ void fill_job(drt_handle h, drt::Params &P, const float *rays_o, const float *ra
     P.alt_seed = drt::host_alt_seed(seed, rays_o == nullptr);
     P.counters = h->counting ? h->d_counters : nullptr;
     P.debug_flags = h->debug_flags;
-    P.order = nullptr; P.order_unit = 1; P.order_units = 0; P.order_count = nullptr;
+    P.order = nullptr; P.order_unit = 1; P.order_units = 0;
     P.unit_empty = nullptr; P.empty_unit = 0;
 }
 
@@ -179,9 +178,6 @@ void clear_timings(drt_handle h)
 }
 
 // launch bracketed by an event pair on the handle's stream when timing is enabled
-#ifndef DRT_ORDER_NEAR
-#define DRT_ORDER_NEAR 0            // > 0: the ray order's cost key integrates the largest majorant within this many supergrid cells of the pixel's ray
-#endif
 #ifndef DRT_PATH_CACHE_CAP
 #define DRT_PATH_CACHE_CAP 64
 #endif
@@ -299,12 +295,14 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     // supergrid scenes: the cell-stepping state machine (drt_super.hip) for both passes; bit 134217728 keeps the older
     // kernels (state machine of whole flights for the primal, one ray per lane for the adjoint) for the variant tests
     // (quadratic DRT: only the queued tracer takes it - its QUAD adjoint kernels; drt_super.hip hands it to the round-2 kernels)
-    bool sq_ok = P.mgrid && !dbg(h->debug_flags, 4096u) && drt::sq_supported(P);
-    if (sq_ok && !h->d_sq_cold && hipMalloc(&h->d_sq_cold, drt::sq_cold_bytes(h->n_cus)) != hipSuccess) {   // (the records' global halves)
+    // (the records' global halves, ~44 MB, are allocated only by a launch that will run the queued kernel: not when a test hook or the atomic
+    //  gradient path routes this launch to the older kernels)
+    const bool super_path = P.mgrid && !dbg(h->debug_flags, (134217728u | 8u | 32u | 32768u | 65536u)) && (!adjoint || P.rec_buf[0] != nullptr);
+    bool sq_ok = super_path && !dbg(h->debug_flags, 4096u) && drt::sq_supported(P);
+    if (sq_ok && !h->d_sq_cold && hipMalloc(&h->d_sq_cold, drt::sq_cold_bytes(h->n_cus)) != hipSuccess) {
         (void) hipGetLastError(); h->d_sq_cold = nullptr; sq_ok = false;
     }
-    const bool super = P.mgrid && (!quadratic || sq_ok) && !dbg(h->debug_flags, (134217728u | 8u | 32u | 32768u | 65536u)) &&
-                       (!adjoint || P.rec_buf[0] != nullptr) && (sq_ok || drt::super_supported(P));
+    const bool super = super_path && (!quadratic || sq_ok) && (sq_ok || drt::super_supported(P));
     if (super) {
         drt::Params Q = P;
         Q.queues = h->d_queues;
@@ -312,9 +310,6 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         // round 4: the queued tracer (drt_sq.hip) where the ray records fit LDS next to the majorants; test hook 4096 keeps
         // the round-3 kernel (drt_super.hip), which also serves what the queued one does not take
         const bool queued = sq_ok;
-#ifndef DRT_SQ_TRIVIAL
-#define DRT_SQ_TRIVIAL 0            // 1: the flagged pixels' rays are sorted to the end of the order and traced by trivial_rays_kernel, one thread per ray
-#endif
 #ifndef DRT_SQ_UNIT_EMPTY
 #define DRT_SQ_UNIT_EMPTY 1         // pixels whose rays cross only empty supergrid cells are flagged: their primary-segment flights are not walked
 #endif
@@ -351,16 +346,11 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
                 // (adjoint launches behind the primal pass of the same job: the primal pass counted every ray's bounce-loop iterations -
                 //  units with a long main path start first, whatever the optical depth along their pixel's ray says)
                 const uint8_t *iters = (DRT_ORDER_ITERS && adjoint && P.path_cache_mode == 2 && sq_ok) ? P.ray_iters : nullptr;
-                // (the flagged pixels - a unit is one pixel's rays - go to the end of the order, for trivial_rays_kernel: no Russian roulette at depth 0)
-                const uint8_t *triv = (DRT_SQ_TRIVIAL && Q.unit_empty && Q.empty_unit == unit && P.rr_depth >= 0) ? Q.unit_empty : nullptr;
-                const bool reuse = !iters && !triv && !h->order_triv && adjoint && P.path_cache_mode == 2 && h->order_unit == unit && h->order_first == P.ray_first &&
-                                   h->order_end == P.n_rays;
-                if (!reuse) DRT_HIP_CHECK(h, drt::build_super_order(P, unit, units, h->d_order, h->stream, iters, triv));
+                const bool reuse = !iters && adjoint && P.path_cache_mode == 2 && h->order_unit == unit && h->order_first == P.ray_first && h->order_end == P.n_rays;
+                if (!reuse) DRT_HIP_CHECK(h, drt::build_super_order(P, unit, units, h->d_order, h->stream, iters));
                 h->order_unit = (!adjoint && P.path_cache_mode == 1) || reuse ? unit : 0u;
                 h->order_first = P.ray_first; h->order_end = P.n_rays;
-                if (!reuse) h->order_triv = triv != nullptr;
                 Q.order = (const uint32_t *) h->d_order; Q.order_unit = unit; Q.order_units = units;
-                if (triv) Q.order_count = drt::super_order_count(h->d_order, units);
             }
         }
         Q.ray_perm = nullptr; Q.block_order = nullptr;
@@ -368,7 +358,6 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         if (queued) {
             Q.sq_cold = h->d_sq_cold;
             DRT_HIP_CHECK(h, drt::launch_trace_sq(Q, adjoint, h->counting, h->n_cus, h->stream));
-            if (Q.order_count) DRT_HIP_CHECK(h, drt::launch_trivial_rays(Q, adjoint, h->counting, h->stream));
         } else
         DRT_HIP_CHECK(h, drt::launch_trace_super(Q, adjoint, h->counting, h->n_cus, h->stream));
         if (h->timing) {
@@ -808,8 +797,6 @@ int drt_params_changed(drt_handle h)
         DRT_HIP_CHECK(h, drt::launch_majorant_grid(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.gx, h->base.gy,
                                                    h->base.gz, h->base.scale, h->d_mgrid, (uint32_t *) h->base.mocc, h->stream,
                                                    h->d_scratch, h->d_majorant, (uint32_t *) h->base.mocc_dil));
-    if (h->base.mgrid && h->base.mgrid_near)
-        DRT_HIP_CHECK(h, drt::launch_majorant_near(h->d_mgrid, h->base.gx, h->base.gy, h->base.gz, DRT_ORDER_NEAR, (float *) h->base.mgrid_near, h->stream));
     else
         DRT_HIP_CHECK(h, drt::launch_majorant(h->base.sigma_t, n, h->base.scale, h->d_scratch, h->d_majorant, h->stream));
     DRT_HIP_CHECK(h, drt::launch_occupancy(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.occ_shift, h->base.occ_x,
@@ -864,15 +851,14 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
         if (cells != h->mgrid_cells) {
             DeviceGuard g(h->device);
             if (h->d_mgrid) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_mgrid); h->d_mgrid = nullptr; h->mgrid_cells = 0; }
-            DRT_HIP_CHECK(h, hipMalloc(&h->d_mgrid, (2 * cells + 2 * ((cells + 31) / 32)) * sizeof(float)));   // majorants | non-empty bitmask | the same, dilated by one cell | majorants nearby
+            DRT_HIP_CHECK(h, hipMalloc(&h->d_mgrid, (cells + 2 * ((cells + 31) / 32)) * sizeof(float)));   // majorants | non-empty bitmask | the same, dilated by one cell
             h->mgrid_cells = cells;
         }
         B.mgrid = h->d_mgrid; B.gx = G[0]; B.gy = G[1]; B.gz = G[2];
         B.mocc = (const uint32_t *) (h->d_mgrid + cells); B.mocc_words = (int) ((cells + 31) / 32);
         B.mocc_dil = B.mocc + B.mocc_words;
-        B.mgrid_near = DRT_ORDER_NEAR ? (const float *) (B.mocc_dil + B.mocc_words) : nullptr;
     } else {
-        B.mgrid = nullptr; B.gx = B.gy = B.gz = 0; B.mocc = nullptr; B.mocc_words = 0; B.mocc_dil = nullptr; B.mgrid_near = nullptr;
+        B.mgrid = nullptr; B.gx = B.gy = B.gz = 0; B.mocc = nullptr; B.mocc_words = 0; B.mocc_dil = nullptr;
     }
     // empty-space bitmask: cells of 2^shift voxels, at most kOccWords*32 cells
     {
@@ -1049,11 +1035,6 @@ int drt_set_sensor_perspective(drt_handle h, const float origin[3], const float 
     return DRT_OK;
 }
 
-#ifndef DRT_ALBEDO_GRID4
-#define DRT_ALBEDO_GRID4 0          // 1: the volpathsimple kernels read the albedo (and the attached sigma_t of a scattering vertex) from the four-channel copy
-#endif
-static int ensure_grid4(drt_handle h, drt::Params &P);
-
 int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, uint64_t n_rays,
                       uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_out)
 {
@@ -1065,7 +1046,6 @@ int drt_render_primal(drt_handle h, const float *rays_o, const float *rays_d, ui
     drt::Params P;
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
     P.L_out = L_out;
-    if (DRT_ALBEDO_GRID4 && h->base.albedo && h->base.mgrid) { rc = ensure_grid4(h, P); if (rc) return rc; }
     h->pcache_sig.valid = false;
     bind_path_cache_write(h, P);                                 // every primal kernel records its walks
     {   // the block order left by the previous primal launch of the same shape predicts this one's heavy blocks
@@ -1109,7 +1089,6 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     drt::Params P;
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_albedo;
-    if (DRT_ALBEDO_GRID4 && h->base.albedo && h->base.mgrid) { rc = ensure_grid4(h, P); if (rc) return rc; }
     // capacity: 48 sigma_t and 6 colour records per ray (headline workload: 12.3 and 1.4); beyond it the
     // tracer falls back to direct atomics (emit_record), so this is a performance choice only
     const uint64_t job_rays = n_rays;

@@ -36,38 +36,10 @@ __host__ __device__ __forceinline__ constexpr bool dbg(uint32_t flags, uint32_t 
 
 // Experiment switches (timing / profiling builds made by tools/mk_variant.sh; several of them give WRONG results on purpose)
 // must never leak into a shipped library: they only compile with -DDRT_EXPERIMENT_BUILD.
-#if !defined(DRT_EXPERIMENT_BUILD) && (defined(DRT_FAST_MATH) || defined(DRT_ENV_EXP) || defined(DRT_EXP_ALB) || defined(DRT_EXP_NT) || \
+#if !defined(DRT_EXPERIMENT_BUILD) && (defined(DRT_FAST_MATH) || defined(DRT_ENV_EXP) || defined(DRT_EXP_ALB) || \
                                        (defined(DRT_SQ_PROFILE) && DRT_SQ_PROFILE != 0))
 #error "experiment switch without -DDRT_EXPERIMENT_BUILD (tools/mk_variant.sh adds it): not for a shipped library"
 #endif
-#ifndef DRT_GRID4_ALBEDO
-#define DRT_GRID4_ALBEDO 0         // 1: the tracing kernels hold the code that reads albedo lookups from Params::grid4 when it is bound (measured round 5:
-                                   // the eight float4 loads cost the queued adjoint kernel 60 B more scratch - 877 -> 810 Msamples/s with the copy NOT bound, 799 with it)
-#endif
-#ifndef DRT_EXP_NT
-#define DRT_EXP_NT 0               // bits: 1 splat records, 2 path cache, 4 L / dL / L_in, 8 sigma_t bricks, 16 albedo go through nontemporal accesses
-#endif
-typedef uint32_t __attribute__((ext_vector_type(4))) nt_u4;
-__device__ __forceinline__ void st_stream(float4 *p, float4 v, int bit)
-{
-    if (DRT_EXP_NT & bit) {
-        nt_u4 w; w.x = __float_as_uint(v.x); w.y = __float_as_uint(v.y); w.z = __float_as_uint(v.z); w.w = __float_as_uint(v.w);
-        __builtin_nontemporal_store(w, (nt_u4 *) p);
-    } else *p = v;
-}
-__device__ __forceinline__ void st_stream(uint4 *p, uint4 v, int bit)
-{
-    if (DRT_EXP_NT & bit) { nt_u4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, (nt_u4 *) p); }
-    else *p = v;
-}
-__device__ __forceinline__ uint4 ld_stream(const uint4 *p, int bit)
-{
-    if (DRT_EXP_NT & bit) { const nt_u4 w = __builtin_nontemporal_load((const nt_u4 *) p); return make_uint4(w.x, w.y, w.z, w.w); }
-    return *p;
-}
-__device__ __forceinline__ void st_stream(float *p, float v, int bit) { if (DRT_EXP_NT & bit) __builtin_nontemporal_store(v, p); else *p = v; }
-__device__ __forceinline__ float ld_stream(const float *p, int bit) { if (DRT_EXP_NT & bit) return __builtin_nontemporal_load(p); return *p; }
-
 constexpr float kInvFourPi = 0.07957747154594767f;
 constexpr float kFourPi    = 12.566370614359172f;
 constexpr float kHalfPi    = 1.5707963267948966f;
@@ -257,7 +229,6 @@ struct Params {
     const float *mgrid;        // majorant supergrid, one majorant per cell (x fastest), or nullptr
     const uint32_t *mocc;      // bit c = supergrid cell c has a non-zero majorant (the DDA skips the others without a load)
     const uint32_t *mocc_dil;  // bit c = cell c or one of its 26 neighbours has (build_unit_empty)
-    const float *mgrid_near;   // the largest majorant within a few cells of every cell (the ray order's cost key), or nullptr
     int mocc_words;
     int gx, gy, gz;
     int rx, ry, rz;
@@ -344,9 +315,6 @@ struct Params {
     // only: every ray's result is independent of when it is traced).  nullptr: rays in index order
     const uint32_t *order;
     uint32_t order_unit, order_units;
-    // queued supergrid tracer: *order_count (device) = the first order_count units of the order are traced by the queued kernel, the rest -
-    // units whose rays cross only empty supergrid cells, sorted to the end - by trivial_rays_kernel.  nullptr: all of them by the queued kernel
-    const uint32_t *order_count;
     // queued supergrid tracer: unit_empty[(i - ray_first) / empty_unit] != 0 - every ray of that unit (one pixel's sensor rays) crosses only
     // supergrid cells whose majorant is 0 (build_unit_empty): the flights along its primary segment are not walked.  nullptr: no flags
     const uint8_t *unit_empty;
@@ -741,8 +709,7 @@ __device__ __forceinline__ float eval_sigma_t(const Params &P, V3 p, const uint3
     const float *g = P.sigma_b + ((size_t) (__umul24((uint32_t) s.z0, (uint32_t) P.sb_zstride) + __umul24(by, (uint32_t) P.sb_ystride) + bx) << 5)
                    + (oy << 2) + ox;
     // the line stores clamped neighbours itself, so +1 / +4 / +16 are always the right corners
-    float d0 = ld_stream(g, 8), d1 = ld_stream(g + 1, 8), d2 = ld_stream(g + 4, 8), d3 = ld_stream(g + 5, 8), d4 = ld_stream(g + 16, 8),
-          d5 = ld_stream(g + 17, 8), d6 = ld_stream(g + 20, 8), d7 = ld_stream(g + 21, 8);
+    float d0 = g[0], d1 = g[1], d2 = g[4], d3 = g[5], d4 = g[16], d5 = g[17], d6 = g[20], d7 = g[21];
     // lower clamp (floor(q) = -1): both corners of that axis are voxel 0 (axis_setup), not 0 and 1.  Only lookups
     // within half a voxel of the box surface get here: one wave-level test keeps the 15 selects out of the common path
     const bool border = s.x1 == s.x0 || s.y1 == s.y0 || s.z1 == s.z0;
@@ -794,40 +761,16 @@ __device__ __forceinline__ void eval4(const Params &P, V3 p, float &sigma_t, flo
     rgb[2] = trilerp8(s, d0.w, d1.w, d2.w, d3.w, d4.w, d5.w, d6.w, d7.w);
 }
 
-#ifndef DRT_RGB_WIDE
-#define DRT_RGB_WIDE 0             // 1: eval_rgb reads the two x-neighbours of a row as ONE run of six floats (two 12-byte loads) instead of six scalar loads
-#endif
 __device__ __forceinline__ void eval_rgb(const Params &P, const float *g, V3 p, float out[3])
 {
     Stencil s = make_stencil(P, p);
     int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
-    if (DRT_RGB_WIDE && P.rx >= 2) {
-        // the voxels x0 and x1 of a row are neighbours in memory (x1 = x0 + 1) except at the clamped ends (x1 = x0): the run [xb, xb + 1] with
-        // xb = min(x0, rx - 2) holds both in every case and never leaves the row.  The same values as the scalar loads: bit-identical.
-        typedef float __attribute__((ext_vector_type(3))) f3;
-        const int xb = min(s.x0, P.rx - 2);
-        const bool lo0 = s.x0 == xb, lo1 = s.x1 == xb;
-        const int rows[4] = { a, b, c, d };
-        float v[4][2][3];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float *q = g + 3 * (size_t) (rows[r] + xb);
-            f3 lo, hi;
-            __builtin_memcpy(&lo, q, 12); __builtin_memcpy(&hi, q + 3, 12);
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) { v[r][0][ch] = lo0 ? lo[ch] : hi[ch]; v[r][1][ch] = lo1 ? lo[ch] : hi[ch]; }
-        }
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-            out[ch] = trilerp8(s, v[0][0][ch], v[0][1][ch], v[1][0][ch], v[1][1][ch], v[2][0][ch], v[2][1][ch], v[3][0][ch], v[3][1][ch]);
-        return;
-    }
     int i0 = 3 * (a + s.x0), i1 = 3 * (a + s.x1), i2 = 3 * (b + s.x0), i3 = 3 * (b + s.x1);
     int i4 = 3 * (c + s.x0), i5 = 3 * (c + s.x1), i6 = 3 * (d + s.x0), i7 = 3 * (d + s.x1);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
-        out[ch] = trilerp8(s, ld_stream(g + i0 + ch, 16), ld_stream(g + i1 + ch, 16), ld_stream(g + i2 + ch, 16), ld_stream(g + i3 + ch, 16),
-                           ld_stream(g + i4 + ch, 16), ld_stream(g + i5 + ch, 16), ld_stream(g + i6 + ch, 16), ld_stream(g + i7 + ch, 16));
+        out[ch] = trilerp8(s, g[i0 + ch], g[i1 + ch], g[i2 + ch], g[i3 + ch],
+                           g[i4 + ch], g[i5 + ch], g[i6 + ch], g[i7 + ch]);
 }
 
 __device__ __forceinline__ void eval_albedo(const Params &P, V3 p, float out[3])
@@ -835,20 +778,7 @@ __device__ __forceinline__ void eval_albedo(const Params &P, V3 p, float out[3])
 #if defined(DRT_EXP_ALB) && DRT_EXP_ALB == 1       // timing experiment: no albedo loads at all (results are wrong)
     out[0] = 0.8f; out[1] = 0.65f; out[2] = 0.45f + 1e-9f * p.x; return;
 #endif
-    // with the four-channel apron-brick copy bound (Params::grid4: copies of the same values, the same stencil and interpolation -
-    // bit-identical) the footprint is two 128-byte lines instead of the 4..8 lines of the caller's (Z,Y,X,3) rows
-    if (DRT_GRID4_ALBEDO && P.grid4) { float s; eval4(P, p, s, out); return; }
     eval_rgb(P, P.albedo, p, out);
-}
-
-// sigma_t AND the albedo at a scattering vertex of the adjoint's main path (volpathsimple.py:141 and :373-375: the attached lookup at the
-// same point): ONE footprint of the four-channel copy when it is bound
-__device__ __forceinline__ float eval_sigma_t_albedo(const Params &P, V3 p, const uint32_t *occ, float out[3])
-{
-    if (DRT_GRID4_ALBEDO && P.grid4) { float s; eval4(P, p, s, out); return s; }
-    const float s = eval_sigma_t(P, p, occ);
-    eval_albedo(P, p, out);
-    return s;
 }
 
 // Reverse mode of the trilinear gather = 8-corner scatter-add.  gfx950 has a
@@ -992,11 +922,11 @@ __device__ __forceinline__ void emit_record(const Params &P, V3 p, float v0, con
     if (rank < split) slot = base0 + rank;
     else if (base1 != 0xffffffffu) slot = base1 + (rank - split);
     if (slot != 0xffffffffu) {
-        if constexpr (S == 0) st_stream(P.rec_buf[0] + slot, make_float4(p.x, p.y, p.z, v0), 1);
+        if constexpr (S == 0) P.rec_buf[0][slot] = make_float4(p.x, p.y, p.z, v0);
         else {
             float4 *dst = P.rec_buf[1] + 2 * (size_t) slot;
-            st_stream(dst, make_float4(p.x, p.y, p.z, v0), 1);
-            st_stream(dst + 1, make_float4(c[0], c[1], c[2], 0.0f), 1);
+            dst[0] = make_float4(p.x, p.y, p.z, v0);
+            dst[1] = make_float4(c[0], c[1], c[2], 0.0f);
         }
     } else {
         if (v0 != 0.0f) splat_direct(P, 0, p, v0);
@@ -1050,7 +980,7 @@ __device__ __forceinline__ void emit_records0(const Params &P, const V3 (&p)[N],
         uint32_t slot = 0xffffffffu;
         if (r < split) slot = base0 + r;
         else if (base1 != 0xffffffffu) slot = base1 + (r - split);
-        if (slot != 0xffffffffu) st_stream(P.rec_buf[0] + slot, make_float4(p[j].x, p[j].y, p[j].z, v0), 1);
+        if (slot != 0xffffffffu) P.rec_buf[0][slot] = make_float4(p[j].x, p[j].y, p[j].z, v0);
         else splat_direct(P, 0, p[j], v0);
     }
 }

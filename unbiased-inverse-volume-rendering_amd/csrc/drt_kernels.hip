@@ -1012,28 +1012,6 @@ __global__ void __launch_bounds__(256) dilate_mask_kernel(const uint32_t *mask, 
     dil[w] = out;
 }
 
-// out[c] = the largest majorant within `radius` cells of cell c (Params::mgrid_near: the ray order's cost key reads it - a pixel whose ray
-// passes NEAR thick medium starts early, its paths can wander into it; build_super_order)
-__global__ void __launch_bounds__(256) majorant_near_kernel(const float *mg, int gx, int gy, int gz, int radius, float *out)
-{
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (uint32_t) gx * gy * gz) return;
-    const int x = (int) (c % (uint32_t) gx), y = (int) ((c / (uint32_t) gx) % (uint32_t) gy), z = (int) (c / ((uint32_t) gx * (uint32_t) gy));
-    float m = 0.0f;
-    for (int zz = max(z - radius, 0); zz <= min(z + radius, gz - 1); ++zz)
-        for (int yy = max(y - radius, 0); yy <= min(y + radius, gy - 1); ++yy)
-            for (int xx = max(x - radius, 0); xx <= min(x + radius, gx - 1); ++xx)
-                m = fmaxf(m, mg[(zz * gy + yy) * gx + xx]);
-    out[c] = m;
-}
-
-hipError_t launch_majorant_near(const float *mg, int gx, int gy, int gz, int radius, float *out, hipStream_t stream)
-{
-    const uint32_t cells = (uint32_t) gx * gy * gz;
-    hipLaunchKernelGGL(majorant_near_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, mg, gx, gy, gz, radius, out);
-    return hipGetLastError();
-}
-
 hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
                                 float *out, uint32_t *mask, hipStream_t stream, uint32_t *max_bits, float *majorant, uint32_t *mask_dil)
 {

@@ -11,7 +11,6 @@ hipError_t launch_trace(const Params &P, bool adjoint, bool count, hipStream_t s
 hipError_t launch_majorant_grid(const float *sigma_t, int rx, int ry, int rz, int gx, int gy, int gz, float scale,
                                 float *out, uint32_t *mask, hipStream_t stream, uint32_t *max_bits = nullptr, float *majorant = nullptr,
                                 uint32_t *mask_dil = nullptr);
-hipError_t launch_majorant_near(const float *mg, int gx, int gy, int gz, int radius, float *out, hipStream_t stream);
 hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int shift, int ox, int oy, int oz,
                             uint32_t *occ, int words, hipStream_t stream);
 hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int nbx, int nby,
@@ -31,14 +30,10 @@ hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_c
 bool sq_supported(const Params &P);
 size_t sq_cold_bytes(int n_cus);
 hipError_t launch_trace_sq(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
-// the units at the end of the order (Params::order_count ..): rays that cross only empty supergrid cells, one thread per ray
-hipError_t launch_trivial_rays(const Params &P, bool adjoint, bool count, hipStream_t stream);
 size_t super_order_bytes(uint32_t units);
 // flags[u] = 1: every ray of unit u (the `unit` = spp rays of one pixel, sensor rays only) crosses only empty supergrid cells (Params::unit_empty)
 hipError_t build_unit_empty(const Params &P, uint32_t unit, uint32_t units, uint8_t *flags, hipStream_t stream);
-hipError_t build_super_order(const Params &P, uint32_t unit, uint32_t units, void *work, hipStream_t stream, const uint8_t *iters = nullptr,
-                             const uint8_t *triv = nullptr);
-const uint32_t *super_order_count(const void *work, uint32_t units);   // device word: units in front of the trivial ones (triv)
+hipError_t build_super_order(const Params &P, uint32_t unit, uint32_t units, void *work, hipStream_t stream, const uint8_t *iters = nullptr);
 // one ray per lane with wave-cooperative tracking loops (drt_coop.hip); global majorant only (P.mgrid == nullptr)
 hipError_t launch_trace_coop_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
 // `between` (optional): called on the host after the main launch has been enqueued and before the tail launch (adjoint of the

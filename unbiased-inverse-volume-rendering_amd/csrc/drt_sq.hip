@@ -96,24 +96,6 @@
 #ifndef DRT_SQ_INLINE_K
 #define DRT_SQ_INLINE_K 4          // cells a flight is stepped by the lanes that set it up, before it is posted for the walkers
 #endif
-#ifndef DRT_SQ_DRAIN_INLINE
-#define DRT_SQ_DRAIN_INLINE 0      // > 0: in a workgroup whose ray queues are drained the lanes that set a flight up walk it themselves, up to this many rounds of
-                                   // DRT_SQ_INLINE_K cells (the walkers' queue hop costs a lone ray more than the cells do)
-#endif
-#ifndef DRT_SQ_DRAIN_K
-#define DRT_SQ_DRAIN_K 1           // walkers of a drained workgroup step this many rounds of DRT_SQ_K cells between two looks at the queues
-#endif
-#ifndef DRT_SQ_URGENT
-#define DRT_SQ_URGENT 0            // > 0: a record with at least this many bounce-loop iterations behind it is URGENT once the workgroup has started
-                                   // DRT_SQ_URGENT_FROM percent of its XCD's rays: a heavy queue that holds one is taken at once (a partial batch), by a wave
-                                   // that runs at raised priority - the launch's last paths are long paths that started late (tools/finish_age_profile.py)
-#endif
-#ifndef DRT_SQ_URGENT_FROM
-#define DRT_SQ_URGENT_FROM 50
-#endif
-#ifndef DRT_SQ_URGENT_PRIO
-#define DRT_SQ_URGENT_PRIO 1
-#endif
 #ifndef DRT_SQ_PROFILE
 #define DRT_SQ_PROFILE 0
 #endif
@@ -283,9 +265,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     uint16_t *q_lds = (uint16_t *) (mg_lds + ((mg_words + 3) & ~3));
     unsigned long long *ctl = (unsigned long long *) (q_lds + SQ_KINDS * DRT_SQ_RING);
     unsigned long long *pool = ctl + SQ_KINDS;                                // [0] next, [1] end of the workgroup's reserved positions of the ray queues
-    uint32_t *misc = (uint32_t *) (pool + 2);                                 // [0] dead records, [1] bits of the largest majorant, [2] lock of the pool, [3] ray queues tried,
-                                                                             // [4] heavy queues that hold an urgent record (bit per kind), [5] urgency is on
-    uint32_t *recst = misc + 8;                                              // record-stream state per wave (emit_record)
+    uint32_t *misc = (uint32_t *) (pool + 2);                                 // [0] dead records, [1] bits of the largest majorant, [2] lock of the pool, [3] ray queues tried
+    uint32_t *recst = misc + 4;                                              // record-stream state per wave (emit_record)
 #if DRT_SQ_PROFILE == 6
     uint32_t *pdbg = recst + NWV * 8;
     for (int w = threadIdx.x; w < 160; w += blockDim.x) pdbg[w] = 0u;
@@ -295,7 +276,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         q_lds[i] = (uint16_t) (k >= 0 && k < NRAY ? k : (int) kSqEmpty);
     }
     if (threadIdx.x < SQ_KINDS) ctl[threadIdx.x] = threadIdx.x == SQ_REGEN ? ((unsigned long long) NRAY << 32) : 0ull;
-    if (threadIdx.x < 8) misc[threadIdx.x] = 0u;
+    if (threadIdx.x < 4) misc[threadIdx.x] = 0u;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0ull;
     for (int w = threadIdx.x; w < NWV * 8; w += blockDim.x) recst[w] = 0u;
     __syncthreads();
@@ -361,10 +342,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     uint4 *cold_b = cold_a + 3 * NRAY;                                        // [NRAY][6] (adjoint; QUAD: [9], the last three: the suspended main path)
     const uint32_t xcc = sq_xcc_id();
     // (with a ray order the queue positions cover whole units: the last unit may reach past the launch's last ray)
-    // (units whose rays all cross only empty supergrid cells are at the end of the order and traced by trivial_rays_kernel: the number of the
-    //  others comes out of the order's counting sort, from device memory)
-    const uint64_t span = P.order ? (uint64_t) (P.order_count ? (uint32_t) __builtin_amdgcn_readfirstlane((int) *P.order_count) : P.order_units) * P.order_unit
-                                  : P.n_rays - P.ray_first;
+    const uint64_t span = P.order ? (uint64_t) P.order_units * P.order_unit : P.n_rays - P.ray_first;
     const uint64_t n_runs = (span + DRT_SQ_RUN - 1) / DRT_SQ_RUN;
     // queue x serves the runs x, x + 8, ...; a workgroup starts on the queue of the XCD it runs on (L2 locality) and moves on
     // to the next ones when that one is drained: every ray is traced whatever the placement of the workgroups.  The
@@ -393,14 +371,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         if (drained && !pt_drained) pt_drained = __builtin_amdgcn_s_memrealtime();
 #endif
         int kind = -1; uint32_t min_n = DRT_SQ_BATCH;
-        uint32_t urg_bits = 0;
-        if (DRT_SQ_URGENT) urg_bits = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[4]);
         if (n_coll >= DRT_SQ_BATCH) kind = SQ_COLL;
         else if (n_ta >= DRT_SQ_BATCH) kind = SQ_TA;
         else if (n_tb >= DRT_SQ_BATCH) kind = SQ_TB;
-        else if (DRT_SQ_URGENT && (urg_bits & (1u << SQ_COLL)) && n_coll) { kind = SQ_COLL; min_n = 1; }
-        else if (DRT_SQ_URGENT && (urg_bits & (1u << SQ_TA)) && n_ta) { kind = SQ_TA; min_n = 1; }
-        else if (DRT_SQ_URGENT && (urg_bits & (1u << SQ_TB)) && n_tb) { kind = SQ_TB; min_n = 1; }
         else if (n_regen >= DRT_SQ_REGEN_MIN || (drained && n_regen)) { kind = SQ_REGEN; min_n = 1; }
         else if (n_walk) kind = SQ_WALK;
         else if (n_coll | n_ta | n_tb | n_regen) {
@@ -444,7 +417,6 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 // (primal kernels: the steps are not predicated on `fly`, as in drt_super.hip)
                 constexpr bool kLoose = !ADJ || MG;
                 bool fin = false; float res_mc = 0.0f, res_t = 0.0f, res_acc = 0.0f;
-                for (int wrep = 0; wrep < (drained ? DRT_SQ_DRAIN_K : 1); ++wrep) {
 #pragma unroll
                 for (int k = 0; k < DRT_SQ_K; ++k) {
 #if DRT_SQ_PROFILE == 1
@@ -481,8 +453,6 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                         tnx = (go && isx) ? tnn : tnx; tny = (go && isy) ? tnn : tny; tnz = (go && !isx && !isy) ? tnn : tnz;
                     }
                 }
-                if (DRT_SQ_DRAIN_K > 1 && __ballot(fin)) break;
-                }
                 SQ_STAMP(0);
                 if (__ballot(fin)) {
                     // result: where the last cell was entered, the optical depth up to there, its majorant (0: left the segment)
@@ -500,7 +470,6 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     uint32_t hn = 0;
                     if (lane >= (uint32_t) SQ_COLL && lane < (uint32_t) SQ_KINDS) { const unsigned long long c = ((sq_vu64 *) ctl)[lane]; hn = (uint32_t) (c >> 32) - (uint32_t) c; }
                     if (__ballot(hn >= DRT_SQ_BATCH)) break;
-                    if (DRT_SQ_URGENT && __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[4]) != 0) break;   // (an urgent record waits in a heavy queue)
                 }
             }
             if (__ballot(fly)) {                                                 // flights still under way: back to their records
@@ -520,14 +489,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
 
         // ================= a heavy batch: up to 64 rays of one kind ==========================================
         uint32_t h0;
-        bool urgent_batch = false;
-        if (DRT_SQ_URGENT && kind != SQ_REGEN && (urg_bits & (1u << kind))) {
-            if (lane == 0) atomicAnd(misc + 4, ~(1u << kind));                     // (a push behind this pop sets it again)
-            urgent_batch = true;
-        }
         const uint32_t nb = sq_pop(ctl, kind, 64u, min_n, lane, h0);
         if (!nb) continue;                                                       // (another wave was faster)
-        if (DRT_SQ_URGENT && DRT_SQ_URGENT_PRIO && urgent_batch) __builtin_amdgcn_s_setprio(3);
         polls = 0;
         const bool act = lane < nb;
         uint32_t id = 0;
@@ -681,11 +644,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     const uint32_t x = (xcc + qs) & 7u;
                     const uint64_t len = (n_runs > x ? (n_runs - x + 7) / 8 : 0) * DRT_SQ_RUN;
                     const unsigned long long base = atomicAdd(P.queues + x, (unsigned long long) DRT_SQ_CHUNK);
-                    if (base < len) {
-                        pn = base; pe = base + DRT_SQ_CHUNK < len ? base + DRT_SQ_CHUNK : len;
-                        if (DRT_SQ_URGENT && base * 100ull >= len * (unsigned long long) DRT_SQ_URGENT_FROM) ((sq_vu32 *) misc)[5] = 1u;
-                    }
-                    else { ++qs; if (DRT_SQ_URGENT) ((sq_vu32 *) misc)[5] = 1u; }   // this queue is drained: next one
+                    if (base < len) { pn = base; pe = base + DRT_SQ_CHUNK < len ? base + DRT_SQ_CHUNK : len; }
+                    else ++qs;                                               // this queue is drained: next one
                 }
                 qx = (xcc + qs) & 7u; qs_ = qs;
                 const uint64_t want = (uint64_t) __popcll(wmask);
@@ -749,8 +709,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     beta[0] = beta[1] = beta[2] = 1.0f;
                     result[0] = result[1] = result[2] = 0.0f;
                     if constexpr (ADJ) {
-                        dL[0] = ld_stream(P.dL + 3 * i, 4); dL[1] = ld_stream(P.dL + 3 * i + 1, 4); dL[2] = ld_stream(P.dL + 3 * i + 2, 4);
-                        result[0] = ld_stream(P.L_in + 3 * i, 4); result[1] = ld_stream(P.L_in + 3 * i + 1, 4); result[2] = ld_stream(P.L_in + 3 * i + 2, 4);
+                        dL[0] = P.dL[3 * i]; dL[1] = P.dL[3 * i + 1]; dL[2] = P.dL[3 * i + 2];
+                        result[0] = P.L_in[3 * i]; result[1] = P.L_in[3 * i + 1]; result[2] = P.L_in[3 * i + 2];
                     }
                     depth = 0; escaped = false; has_scattered = false; scat_once = false;
                     rec_mode = false; rec_first = false;
@@ -786,8 +746,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         auto rt_end_block = [&](bool behind_nee) {
             if constexpr (!ADJ) {
                 if (ph == SP_RT_END && pc_on && pc_it < (int) P.path_cache_cap)
-                    st_stream(P.path_cache + ((size_t) li * P.path_cache_cap + pc_it) * 2 + 1,
-                              make_uint4(__float_as_uint(wt), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps), 2);
+                    P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1] =
+                        make_uint4(__float_as_uint(wt), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
             }
             if (ph == SP_RT_END) {
                 float val[3], contrib[3];
@@ -894,8 +854,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     else if (ADJ && !rec_mode && pc_on && pc_it < (int) P.path_cache_cap) {
                         // the adjoint takes this iteration's delta-tracking walk from the primal pass of the same job
                         const uint4 *pce = P.path_cache + ((size_t) li * P.path_cache_cap + pc_it) * 2;
-                        const uint4 e = ld_stream(pce, 2);
-                        pce1 = ld_stream(pce + 1, 2); pce1_ok = true;                          // (adjacent: one round trip for both)
+                        const uint4 e = pce[0];
+                        pce1 = pce[1]; pce1_ok = true;                          // (adjacent: one round trip for both)
                         wt = __uint_as_float(e.x);                              // mei.t
                         S.state = ((uint64_t) e.z << 32) | e.y;
                         if (COUNT && !DRT_SQ_PROFILE) cnt[C_DT] += e.w;
@@ -906,8 +866,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 // ---- the walk found a real collision (wt = mei.t) or left the medium (:130-215, :244-245) -----------
                 if constexpr (!ADJ) {                                           // path cache: what this iteration's walk returned
                     if ((ph == SP_SCAT || ph == SP_ESC) && pc_on && pc_it < (int) P.path_cache_cap)
-                        st_stream(P.path_cache + ((size_t) li * P.path_cache_cap + pc_it) * 2,
-                                  make_uint4(__float_as_uint(ph == SP_SCAT ? wt : kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps), 2);
+                        P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2] =
+                            make_uint4(__float_as_uint(ph == SP_SCAT ? wt : kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), pc_steps);
                 }
                 SQ_BLK(4, ph == SP_SCAT || ph == SP_ESC);
                 if (ph == SP_SCAT || ph == SP_ESC || (QUAD && ph == SP_QSCAT2)) {
@@ -919,8 +879,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     if (scat) {
                         mp = ray_at(ro, rd, wt);                                // :371
                         has_scattered = true;
-                        if (adj_lane) { mei_sig = eval_sigma_t_albedo(P, mp, occ, albedo); if (!resumed) SQ_COUNT(C_DT); }   // :373-375, :141
-                        else eval_albedo(P, mp, albedo);                        // :141
+                        if (adj_lane) { mei_sig = eval_sigma_t(P, mp, occ); if (!resumed) SQ_COUNT(C_DT); }   // :373-375
+                        eval_albedo(P, mp, albedo);                             // :141
                         if (!resumed) SQ_COUNT(C_ALB);
                     }
                     bool detour = false;
@@ -929,7 +889,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                             // backpropagate_scattering_drt at this vertex (:143-150, :543-581): suspend the main path ...
                             detour = true;
                             q_flags = (scat ? 1u : 0u) | (escaped ? 2u : 0u) | (has_scattered ? 4u : 0u) | (scat_once ? 8u : 0u) | (pc_on ? 16u : 0u) |
-                                      ((uint32_t) pc_it << 8);
+                                      ((uint32_t) min(pc_it, 1023) << 8);      // (the width of the record's field, below)
                             q_ro = ro; q_si_t = si_t; q_wt = wt; q_sinc_lo = (uint32_t) S.inc; q_sinc_hi = (uint32_t) (S.inc >> 32);
                             q_result[0] = result[0]; q_result[1] = result[1]; q_result[2] = result[2];
                             Cst = S.state; r_depth = depth; r_d = rd;
@@ -1012,7 +972,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     if (ADJ && !rec_mode && pc_on && pc_it < (int) P.path_cache_cap) {
                         // the value walk of the main path comes out of the path cache: transmittance, stream, steps
                         uint4 e = pce1;
-                        if (!pce1_ok) e = ld_stream(P.path_cache + ((size_t) li * P.path_cache_cap + pc_it) * 2 + 1, 2);
+                        if (!pce1_ok) e = P.path_cache[((size_t) li * P.path_cache_cap + pc_it) * 2 + 1];
                         wt = __uint_as_float(e.x);
                         S.state = ((uint64_t) e.z << 32) | e.y;
                         if (COUNT && !DRT_SQ_PROFILE) cnt[C_RT] += e.w;
@@ -1038,7 +998,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     }
                     if constexpr (!ADJ) {
                         const size_t o3 = 3 * (size_t) li;
-                        st_stream(P.L_out + o3, result[0], 4); st_stream(P.L_out + o3 + 1, result[1], 4); st_stream(P.L_out + o3 + 2, result[2], 4);
+                        P.L_out[o3] = result[0]; P.L_out[o3 + 1] = result[1]; P.L_out[o3 + 2] = result[2];
                         if (P.ray_iters) P.ray_iters[li] = (uint8_t) (pc_it < 255 ? pc_it : 255);
                         ph = SP_IDLE;
                     } else {
@@ -1154,8 +1114,6 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                             uint32_t wrem = rem;
                             const int sx = sgx < 0 ? -1 : 1, sy = sgy < 0 ? -lin_y : lin_y, sz = sgz < 0 ? -lin_z : lin_z;
                             bool wfly = true;
-                            int inl_rounds = 0;
-                            do {
 #pragma unroll
                             for (int k = 0; k < (MG ? 0 : DRT_SQ_INLINE_K); ++k) {
                                 const float tmin = fminf(fminf(wnx, wny), wnz);
@@ -1175,9 +1133,6 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                                 wcell += go ? (isx ? sx : isy ? sy : sz) : 0;
                                 wnx = (go && isx) ? tnn : wnx; wny = (go && isy) ? tnn : wny; wnz = (go && !isx && !isy) ? tnn : wnz;
                             }
-                            // (a workgroup whose ray queues are drained: its last paths are latency - the flight is walked to its end right here,
-                            //  it never waits for a walker)
-                            } while (DRT_SQ_DRAIN_INLINE && !MG && drained && wfly && ++inl_rounds < DRT_SQ_DRAIN_INLINE);
                             R[0] = make_uint4(wfly ? __float_as_uint(wnx) : __float_as_uint(res_mc), __float_as_uint(wny), __float_as_uint(wnz), (uint32_t) wcell);
                             R[1] = make_uint4(__float_as_uint(tdx), __float_as_uint(tdy), __float_as_uint(tdz), wrem);
                             R[2] = make_uint4(__float_as_uint(tau), __float_as_uint(tmax), __float_as_uint(wt_), __float_as_uint(wacc));
@@ -1212,6 +1167,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             R[3] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), __float_as_uint(wmax));
             R[4] = make_uint4(__float_as_uint(wo.x), __float_as_uint(wo.y), __float_as_uint(wo.z), __float_as_uint(wt));
             R[5] = make_uint4((uint32_t) gs, (uint32_t) (gs >> 32), (uint32_t) gi, (uint32_t) (gi >> 32));
+            // (depth and pc_it have 10 bits each: sq_supported bounds max_depth by 1000; pc_it - the bounce-loop iteration, i.e. the path cache index
+            //  of the MAIN path, used while pc_it < path_cache_cap <= 64 - keeps counting on recursive and quadratic-detour paths, where nothing reads
+            //  it, and saturates at 1023; the main path's value comes back from q_flags when a detour ends)
             const uint32_t f = (uint32_t) ph | ((uint32_t) fl << 4) | (rec_mode ? 1u << 6 : 0u) | (rec_first ? 1u << 7 : 0u) | (escaped ? 1u << 8 : 0u) |
                                (has_scattered ? 1u << 9 : 0u) | (scat_once ? 1u << 10 : 0u) | (pc_on ? 1u << 11 : 0u) |
                                ((uint32_t) min(depth, 1023) << 12) | ((uint32_t) min(pc_it, 1023) << 22);
@@ -1264,12 +1222,6 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         sq_push(ctl, q_lds, SQ_TB, go_trans && tk == SQ_TB, id, lane);
         sq_push(ctl, q_lds, SQ_REGEN, go_free, id, lane);
 #endif
-        if (DRT_SQ_URGENT) {
-            const int dk = go_walk ? (walk_done ? SQ_COLL : SQ_KINDS) : go_trans ? tk : SQ_KINDS;
-            const bool on = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[5]) != 0u;
-            if (on && dk < SQ_KINDS && pc_it >= DRT_SQ_URGENT) atomicOr(misc + 4, 1u << dk);
-            if (DRT_SQ_URGENT_PRIO && urgent_batch) __builtin_amdgcn_s_setprio(0);
-        }
         SQ_STAMP(7);
     }
 
@@ -1308,119 +1260,6 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
 #undef SQ_BLK
 }
 
-// ---- rays of pixels that cross only EMPTY supergrid cells (build_unit_empty): one thread per ray (round 5) -------------------------------
-// Such a ray cannot collide: VolpathSimpleIntegrator.sample (volpathsimple.py:38-290) runs its prologue, the loop head of iteration 0, a
-// free flight that leaves the medium (or the ray misses the box altogether) and the escape block.  The primal pass writes the emitter's
-// radiance (:262-287, MIS weight of an unscattered path), the path-cache entry of iteration 0 and the schedule key; the adjoint pass
-// emits the four transmittance splats of backpropagate_transmittance along the primary segment (:181-189, :584-607) - whose value does not
-// depend on any walk - and consumes the alt sampler as sample() does (the reservoir's draw, :745-753, or - quadratic DRT - the draw of the
-// DRT sampler's flight, which ends at its set-up).  The units come from the END of the ray order (positions [*order_count, order_units)):
-// the queued kernel never sees them.  Same draws, same arithmetic (the prologue of trace_sq_kernel's regeneration block): bit-exact.
-template <bool ADJ, bool COUNT, bool ENV>
-__global__ void __launch_bounds__(256) trivial_rays_kernel(const Params P)
-{
-    __shared__ uint32_t recst[4 * 8];
-    if (threadIdx.x < 32) recst[threadIdx.x] = 0u;
-    __syncthreads();
-    uint32_t *rec = recst + (threadIdx.x >> 6) * 8;
-    const uint32_t n_active = *P.order_count;
-    const uint64_t pos = (uint64_t) n_active * P.order_unit + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t span = P.n_rays - P.ray_first;
-    bool job = pos < (uint64_t) P.order_units * P.order_unit;
-    uint64_t i = 0;
-    if (job) {
-        const uint32_t u = (uint32_t) (pos / P.order_unit);
-        i = (uint64_t) P.order[u] * P.order_unit + (pos - (uint64_t) u * P.order_unit);
-        job = i < span;
-        i += P.ray_first;
-    }
-    uint32_t n_rays = 0, n_tr = 0;
-    if (job) {
-        // ---- sample() prologue (:51-108) + reach_medium (:292-319), as the regeneration block of trace_sq_kernel ----
-        const uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
-        const uint32_t gi = (uint32_t) g64;
-        Pcg32 S; S.seed(P.seed, gi);
-        V3 ro, rd;
-        { float ux = S.next_1d(), uy = S.next_1d(); sensor_ray(P, gi / P.spp, ux, uy, ro, rd); }
-        ++n_rays;
-        (void) S.next_1d();                                                     // :71
-        bool active = true;
-        float si_t = kInf;
-        Hit si = box_hit(P, ro, rd);
-        if (!si.valid) active = false;
-        else {
-            ro = offset_p(si, rd);
-            Hit sn = box_hit(P, ro, rd);
-            if (!sn.valid) active = false; else si_t = sn.t;
-        }
-        // (a ray that misses the box is `escaped`; one that enters it but has no exit (:307-318) ends without having escaped)
-        const bool escaped = !si.valid || active;
-        if (active) (void) S.next_1d();                                         // :99
-        if constexpr (!ADJ) {
-            if (P.path_cache_mode == 1) P.ray_hash[i] = 0x9e3779b9u ^ gi;        // (sensor rays: the job signature ties the entries to the ray)
-            if (active) {
-                (void) S.next_1d();                                             // loop head: Russian roulette draw (:120)
-                (void) S.next_1d();                                             // the free flight's draw; the flight leaves the segment
-                if (P.path_cache_mode == 1 && P.path_cache_cap > 0)
-                    P.path_cache[(size_t) i * P.path_cache_cap * 2] = make_uint4(__float_as_uint(kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), 0u);
-            }
-            float result[3] = { 0.0f, 0.0f, 0.0f };
-            if (escaped && !P.hide_emitters) {                                  // :262-287 at depth 0, nothing scattered
-                float w = 1.0f, Le[3];
-                if (P.use_nee) w = mis_weight(1.0f, 0.0f);
-                emitter_eval<ENV>(P, rd, Le);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) result[k] += (1.0f * w) * Le[k];
-            }
-            const size_t o3 = 3 * (size_t) i;
-            P.L_out[o3] = result[0]; P.L_out[o3 + 1] = result[1]; P.L_out[o3 + 2] = result[2];
-            if (P.ray_iters) P.ray_iters[i] = 0;
-        } else if (active) {
-            Pcg32 A; A.seed(P.alt_seed, gi);                                     // :100-107
-            if (P.use_drt) (void) A.next_1d();                                  // DRTReservoir.update (:745-753) / the DRT flight of the quadratic estimator
-            const float dL0 = P.dL[3 * i], dL1 = P.dL[3 * i + 1], dL2 = P.dL[3 * i + 2];
-            const float r0 = P.L_in[3 * i], r1 = P.L_in[3 * i + 1], r2 = P.L_in[3 * i + 2];
-            // backpropagate_transmittance: 4 resampled points on the segment (:181-189, :584-607)
-            const float tr_g = -(((dL0 * r0 + dL1 * r1) + dL2 * r2) * (si_t / 4.0f));
-            V3 pts[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float u = A.next_1d(); pts[j] = ray_at(ro, rd, u * si_t); }
-            n_tr += 4;
-            if (tr_g != 0.0f) emit_records0<4>(P, pts, tr_g * P.scale, rec);
-        }
-    }
-    if constexpr (ADJ) close_records(P, rec);
-    if (COUNT) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { n_rays += __shfl_down(n_rays, off, 64); n_tr += __shfl_down(n_tr, off, 64); }
-        if ((threadIdx.x & 63u) == 0u) {
-            if (n_rays) atomicAdd(P.counters + C_RAYS, (unsigned long long) n_rays);
-            if (n_tr) atomicAdd(P.counters + C_TR, (unsigned long long) n_tr);
-        }
-    }
-}
-
-// trivial_rays_kernel over the tail of the order (at most `units` units: the grid covers them all, the kernel reads how many there are)
-hipError_t launch_trivial_rays(const Params &P, bool adjoint, bool count, hipStream_t stream)
-{
-    if (!P.order || !P.order_count || !P.order_units) return hipSuccess;
-    const uint64_t threads = (uint64_t) P.order_units * P.order_unit;
-    dim3 block(256), grid((unsigned) ((threads + 255) / 256));
-    const bool env = P.env_pix != nullptr;
-    const int variant = (adjoint ? 4 : 0) | (count ? 2 : 0) | (env ? 1 : 0);
-    switch (variant) {
-        case 0: hipLaunchKernelGGL((trivial_rays_kernel<false, false, false>), grid, block, 0, stream, P); break;
-        case 1: hipLaunchKernelGGL((trivial_rays_kernel<false, false, true>), grid, block, 0, stream, P); break;
-        case 2: hipLaunchKernelGGL((trivial_rays_kernel<false, true, false>), grid, block, 0, stream, P); break;
-        case 3: hipLaunchKernelGGL((trivial_rays_kernel<false, true, true>), grid, block, 0, stream, P); break;
-        case 4: hipLaunchKernelGGL((trivial_rays_kernel<true, false, false>), grid, block, 0, stream, P); break;
-        case 5: hipLaunchKernelGGL((trivial_rays_kernel<true, false, true>), grid, block, 0, stream, P); break;
-        case 6: hipLaunchKernelGGL((trivial_rays_kernel<true, true, false>), grid, block, 0, stream, P); break;
-        default: hipLaunchKernelGGL((trivial_rays_kernel<true, true, true>), grid, block, 0, stream, P); break;
-    }
-    return hipGetLastError();
-}
-
 // Records per workgroup that fit LDS next to this supergrid's majorants (a multiple of 64); 0: this supergrid cannot be
 // served (the host keeps drt_super.hip).  *bytes: dynamic LDS of the launch
 // *global_majorants: the bf16 majorants do not fit (with at least DRT_SQ_MIN_RAYS records) but one bit per cell does - the MG kernels
@@ -1435,7 +1274,7 @@ static uint32_t sq_rays_for(const Params &P, size_t *bytes, bool *global_majoran
     for (int mg = DRT_SQ_FORCE_MG; mg < 2; ++mg) {
         if (mg && !(P.mocc && P.majorant)) break;
         const size_t words = mg ? (cells + 31) / 32 : (cells + 1) / 2;
-        const size_t fixed = (((words + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RING / 2 + 2 * SQ_KINDS + 4 + 8 + nwv * 8 + (DRT_SQ_PROFILE == 6 ? 160 : 0)) * 4;
+        const size_t fixed = (((words + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RING / 2 + 2 * SQ_KINDS + 4 + 4 + nwv * 8 + (DRT_SQ_PROFILE == 6 ? 160 : 0)) * 4;
         if (fixed >= cap) continue;
         size_t n = ((cap - fixed) / (7 * 16)) & ~(size_t) 63;
         if (n > DRT_SQ_MAX_RAYS) n = DRT_SQ_MAX_RAYS;

@@ -925,14 +925,10 @@ constexpr int kOrderKeys = 64, kOrderBlock = DRT_ORDER_BLOCK, kOrderThreads = 25
 // pass counted for every ray.  A unit's key is then at least twice the count of its longest main path: measured with the queued tracer
 // (tools/finish_age_profile.py, profiles/r05_finish_age.txt) the launch's last paths are paths of 15 - 40 iterations whose rays were
 // started in its last fifth - the optical depth along the pixel's ray does not see them coming, the primal pass did.
-// `triv` (queued tracer, sensor rays; build_unit_empty): units whose rays cross only empty supergrid cells get the key kOrderKeys - they are
-// sorted behind everything else and counted apart: trivial_rays_kernel (drt_sq.hip) traces them, the queued kernel never starts them.
-__global__ void __launch_bounds__(kOrderThreads) order_keys_depth_kernel(const Params P, uint32_t unit, uint32_t units, uint8_t *keys, const uint8_t *iters,
-                                                                         const uint8_t *triv)
+__global__ void __launch_bounds__(kOrderThreads) order_keys_depth_kernel(const Params P, uint32_t unit, uint32_t units, uint8_t *keys, const uint8_t *iters)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= units) return;
-    if (triv && triv[u]) { keys[u] = (uint8_t) kOrderKeys; return; }
     const uint64_t i = P.ray_first + (uint64_t) u * unit;
     V3 o, d;
     if (P.sensor_flow) {
@@ -972,7 +968,7 @@ __global__ void __launch_bounds__(kOrderThreads) order_keys_depth_kernel(const P
                 const float gf = ((fmaf(dd[a], t, oo[a]) - P.bmin[a]) * P.inv_ext[a]) * (float) gn[a];
                 c[a] = (int) fminf(fmaxf(floorf(gf), 0.0f), (float) (gn[a] - 1));
             }
-            m[j] = (P.mgrid_near ? P.mgrid_near : P.mgrid)[((size_t) c[2] * P.gy + c[1]) * P.gx + c[0]];
+            m[j] = P.mgrid[((size_t) c[2] * P.gy + c[1]) * P.gx + c[0]];
         }
 #pragma unroll
         for (int j = 0; j < kSamples; ++j) od += m[j];
@@ -989,17 +985,16 @@ __global__ void __launch_bounds__(kOrderThreads) order_keys_depth_kernel(const P
     keys[u] = (uint8_t) k;
 }
 
-// counts per (key, block), keys by descending cost: hist[(63 - key) * n_blocks + block]; the trivial units (key 64) in row 64, behind all
-__device__ __forceinline__ uint32_t order_row(uint32_t key) { return key >= (uint32_t) kOrderKeys ? (uint32_t) kOrderKeys : (uint32_t) kOrderKeys - 1u - key; }
+// counts per (key, block), keys by descending cost: hist[(63 - key) * n_blocks + block]
 __global__ void __launch_bounds__(kOrderThreads) order_hist_kernel(const uint8_t *keys, uint32_t units, uint32_t n_blocks, uint32_t *hist)
 {
-    __shared__ uint32_t h[kOrderKeys + 1];
-    if (threadIdx.x <= kOrderKeys) h[threadIdx.x] = 0u;
+    __shared__ uint32_t h[kOrderKeys];
+    if (threadIdx.x < kOrderKeys) h[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t first = blockIdx.x * kOrderBlock;
     for (uint32_t k = threadIdx.x; k < kOrderBlock && first + k < units; k += kOrderThreads) atomicAdd(&h[keys[first + k]], 1u);
     __syncthreads();
-    if (threadIdx.x <= kOrderKeys) hist[(size_t) order_row(threadIdx.x) * n_blocks + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < kOrderKeys) hist[(size_t) (kOrderKeys - 1 - threadIdx.x) * n_blocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // exclusive scan of the n counts in place (one workgroup: n = 64 x blocks <= a few hundred thousand)
@@ -1022,18 +1017,15 @@ __global__ void __launch_bounds__(1024) order_scan_kernel(uint32_t *hist, uint32
 }
 
 // units -> their places (inside a block of 2048 units and one key in any order: neighbours stay neighbours)
-__global__ void __launch_bounds__(kOrderThreads) order_scatter_kernel(const uint8_t *keys, uint32_t units, uint32_t n_blocks, const uint32_t *offs, uint32_t *order,
-                                                                      uint32_t *meta)
+__global__ void __launch_bounds__(kOrderThreads) order_scatter_kernel(const uint8_t *keys, uint32_t units, uint32_t n_blocks, const uint32_t *offs, uint32_t *order)
 {
-    __shared__ uint32_t cur[kOrderKeys + 1];
-    if (threadIdx.x <= kOrderKeys) cur[threadIdx.x] = offs[(size_t) order_row(threadIdx.x) * n_blocks + blockIdx.x];
+    __shared__ uint32_t cur[kOrderKeys];
+    if (threadIdx.x < kOrderKeys) cur[threadIdx.x] = offs[(size_t) (kOrderKeys - 1 - threadIdx.x) * n_blocks + blockIdx.x];
     __syncthreads();
     const uint32_t first = blockIdx.x * kOrderBlock;
     // no unit reaches optical depth 1 (key 8): paths are short everywhere, nothing to bring forward - index order (an
-    // order by chord length made the optimisation loop's launches over its thin starting medium 9 % slower); the trivial units then stay
-    // where they are too (the queued kernel ends their flights at the set-up)
+    // order by chord length made the optimisation loop's launches over its thin starting medium 9 % slower)
     const bool flat = offs[(size_t) (kOrderKeys - kOrderFlatBelow) * n_blocks] == 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) meta[0] = flat ? units : offs[(size_t) kOrderKeys * n_blocks];   // units the queued kernel traces
     for (uint32_t k = threadIdx.x; k < kOrderBlock && first + k < units; k += kOrderThreads) {
         const uint32_t place = atomicAdd(&cur[keys[first + k]], 1u);
         order[flat ? first + k : place] = first + k;
@@ -1043,18 +1035,16 @@ __global__ void __launch_bounds__(kOrderThreads) order_scatter_kernel(const uint
 // launches of up to kOrderSmall units (the optimisation loop's: 10^4 pixels of 1024 rays): the three passes in ONE workgroup
 // (every launch of the tracer pays for its order: 4 kernels were 3 % of the loop's iteration)
 constexpr uint32_t kOrderSmall = 65536;
-__global__ void __launch_bounds__(1024) order_small_kernel(const uint8_t *keys, uint32_t units, uint32_t *order, uint32_t *meta)
+__global__ void __launch_bounds__(1024) order_small_kernel(const uint8_t *keys, uint32_t units, uint32_t *order)
 {
-    __shared__ uint32_t h[kOrderKeys + 1], cur[kOrderKeys + 1];
-    if (threadIdx.x <= kOrderKeys) h[threadIdx.x] = 0u;
+    __shared__ uint32_t h[kOrderKeys], cur[kOrderKeys];
+    if (threadIdx.x < kOrderKeys) h[threadIdx.x] = 0u;
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < units; k += 1024u) atomicAdd(&h[keys[k]], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (int key = kOrderKeys - 1; key >= 0; --key) { cur[key] = run; run += h[key]; }
-        cur[kOrderKeys] = run;                                    // the trivial units, behind all
-        meta[0] = cur[kOrderFlatBelow - 1] == 0u ? units : run;
     }
     __syncthreads();
     const bool flat = cur[kOrderFlatBelow - 1] == 0u;            // = units with key >= kOrderFlatBelow
@@ -1149,33 +1139,25 @@ static inline size_t order_align(size_t n) { return (n + 255) & ~(size_t) 255; }
 size_t super_order_bytes(uint32_t units)
 {
     const size_t n_blocks = ((size_t) units + kOrderBlock - 1) / kOrderBlock;
-    return order_align((size_t) units * 4) + order_align((size_t) units) + order_align(n_blocks * (kOrderKeys + 1) * 4) + 256;
+    return order_align((size_t) units * 4) + order_align((size_t) units) + order_align(n_blocks * kOrderKeys * 4);
 }
 
-// *: the word of the work buffer that holds the number of units the queued kernel traces (the others are the trivial units at the end)
-const uint32_t *super_order_count(const void *work, uint32_t units)
-{
-    const size_t n_blocks = ((size_t) units + kOrderBlock - 1) / kOrderBlock;
-    return (const uint32_t *) ((const char *) work + order_align((size_t) units * 4) + order_align((size_t) units) + order_align(n_blocks * (kOrderKeys + 1) * 4));
-}
-
-hipError_t build_super_order(const Params &P, uint32_t unit, uint32_t units, void *work, hipStream_t stream, const uint8_t *iters, const uint8_t *triv)
+hipError_t build_super_order(const Params &P, uint32_t unit, uint32_t units, void *work, hipStream_t stream, const uint8_t *iters)
 {
     if (!units) return hipSuccess;
     const uint32_t n_blocks = (units + kOrderBlock - 1) / kOrderBlock;
     uint32_t *order = (uint32_t *) work;
     uint8_t *keys = (uint8_t *) work + order_align((size_t) units * 4);
     uint32_t *hist = (uint32_t *) (keys + order_align((size_t) units));
-    uint32_t *meta = const_cast<uint32_t *>(super_order_count(work, units));
     const unsigned key_blocks = (units + kOrderThreads - 1) / kOrderThreads;
-    hipLaunchKernelGGL(order_keys_depth_kernel, dim3(key_blocks), dim3(kOrderThreads), 0, stream, P, unit, units, keys, iters, triv);
+    hipLaunchKernelGGL(order_keys_depth_kernel, dim3(key_blocks), dim3(kOrderThreads), 0, stream, P, unit, units, keys, iters);
     if (units <= kOrderSmall) {
-        hipLaunchKernelGGL(order_small_kernel, dim3(1), dim3(1024), 0, stream, keys, units, order, meta);
+        hipLaunchKernelGGL(order_small_kernel, dim3(1), dim3(1024), 0, stream, keys, units, order);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(order_hist_kernel, dim3(n_blocks), dim3(kOrderThreads), 0, stream, keys, units, n_blocks, hist);
-    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, n_blocks * (uint32_t) (kOrderKeys + 1));
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(kOrderThreads), 0, stream, keys, units, n_blocks, hist, order, meta);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, n_blocks * (uint32_t) kOrderKeys);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(n_blocks), dim3(kOrderThreads), 0, stream, keys, units, n_blocks, hist, order);
     return hipGetLastError();
 }
 
