@@ -136,9 +136,10 @@ def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=Non
         step(i)
     torch.cuda.synchronize()
     h.enable_timing(True)
-    # two timed blocks of `steps` steps; the entry reports the faster one (a side entry's few steps are short enough for one host
-    # hiccup - seen once after the CPU-baseline leg: 14.4 ms of wall clock per step around 6.5 ms of kernels - to halve its rate)
-    # and keeps both rates
+    # two timed blocks of `steps` steps; `value` is the MEAN over both (as rounds 1-3 reported it; round 4's entries quoted the faster block,
+    # which biased every side entry upward - advisor r4); the faster block stays as `best_block_msamples_per_s` (a side entry's few steps
+    # are short enough for one host hiccup - seen once after the CPU-baseline leg: 14.4 ms of wall clock per step around 6.5 ms of
+    # kernels - to halve a block's rate).  The HIP-event kernel times below are sums over BOTH blocks divided by their launch counts.
     blocks = []
     for b in range(2):
         t0 = time.perf_counter()
@@ -146,11 +147,12 @@ def h1_rate(torch, u, scene, integ, spp, steps=5, warmup=2, shard=None, keys=Non
             sampler, state, dL = step(warmup + b * steps + i)
         torch.cuda.synchronize()
         blocks.append((time.perf_counter() - t0) / steps)
-    dt = min(blocks)
+    dt = sum(blocks) / len(blocks)
     t_p, t_a, t_r, t_pass = (h.read_timings(k) for k in range(4))
     h.enable_timing(False)
     out = {"value": round(n_local * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
-           "n_samples_per_step": n_local * spp, "blocks_msamples_per_s": [round(n_local * spp / b / 1e6, 2) for b in blocks]}
+           "n_samples_per_step": n_local * spp, "blocks_msamples_per_s": [round(n_local * spp / b / 1e6, 2) for b in blocks],
+           "best_block_msamples_per_s": round(n_local * spp / min(blocks) / 1e6, 2)}
     if roofline:
         n = n_local * spp
         h.enable_counters(True)
@@ -316,6 +318,25 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
         out3["msamples_per_s"] = round(out3["value"] * 32768 * (1024 + 2 * 16) / 1e6, 1)
         return out3
 
+    def rank_share():
+        # what ONE rank of a G-GPU run of the headline computes per step (rank 0's interleaved pixel chunks, majorant_resolution_factor 8), timed
+        # on this one GPU: the per-rank compute column of DESIGN.md section 7's projection (the all-reduce needs G GPUs).  A small launch is
+        # bound by the latency of its longest paths, not by its work: G = 8 is an eighth of the rays and a third of the time.
+        sc = synthetic.dust_devil_scene(res=256, film=512, device=dev)
+        sc.medium.majorant_resolution_factor = 8
+        integ = u.get_int_config(integ_name).create(max_depth=64)
+        res = {}
+        for w in (1, 2, 4, 8):
+            sh = u.ShardSpec(0, w, u.ShardSpec.default_chunk(512 * 512, w)) if w > 1 else None
+            r = h1_rate(torch, u, sc, integ, 32, steps=8, warmup=3, shard=sh, roofline=False)
+            res[f"G{w}"] = {"ms_per_step": r["ms_per_step"], "rays_per_rank": r["n_samples_per_step"],
+                            "msamples_per_s_per_rank": r["value"], "best_block_ms_per_step": round(r["n_samples_per_step"] / r["best_block_msamples_per_s"] / 1e3, 3)}
+        res["G8_over_ideal"] = round(res["G8"]["ms_per_step"] / (res["G1"]["ms_per_step"] / 8), 2)
+        res["workload"] = ("headline (dust devil 256^3, 512x512x32spp, factor 8): rank 0's share of G = 1 / 2 / 4 / 8 ranks, per-GPU compute only "
+                           "(no all-reduce); UNMEASURED ON MULTI-GPU HARDWARE")
+        res["value"], res["unit"] = res["G8"]["ms_per_step"], "ms per step of a rank's share at G = 8"
+        return res
+
     def cfg3_reproduce():
         # The dust-devil DRT run as python/reproduce.py sets it up (:48-59, :108-110): Adam lr 3e-4 with the Last25 schedule, l1, batch 32768 px,
         # spp_grad 16, spp_primal 1024, constant init sigma_t 0.04 / 100, albedo 0.6 (scene_config.py:166-169) on a grid 2^4 times coarser than
@@ -465,6 +486,7 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
     guarded("headline_envmap", envmap)
     guarded("config3_optimize_loop", cfg3)
     guarded("config3_as_reproduce", cfg3_reproduce)
+    guarded("headline_rank_share", rank_share)
     guarded("config4_512_rank_share_1024x64", cfg4)
     guarded("config5_nerf_256_512x32", cfg5)
     def cfg5_fused_both():

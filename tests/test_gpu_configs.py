@@ -371,6 +371,86 @@ def test_config3_optimize_loop_256_63_sensors(uivr, oracle, gpu):
     assert float((p[uivr.SIGMA_T_KEY] - 0.04).abs().max()) > 0                  # the parameters moved
 
 
+def test_config3_as_reproduce_every_resolution_level(uivr, oracle, gpu):
+    """The dust-devil DRT run as python/reproduce.py sets it up (:48-59, :108-110; bench.py config3_as_reproduce): the parameters start on a
+    16^3 grid and are upsampled x2 four times (optimize.py:134-166, 228-252), the majorant supergrid follows (adjust_majorant_res_factor,
+    optimize.py:182-199: factor 4 on 16^3, 8 from 32^3 on), the scene is lit by a 4096 x 2048 environment map (scene_config.py:152).  At EVERY
+    level - a thin medium on that level's grid, as the optimisation sees it early on -: one batched iteration's rays and radiance bit-exact
+    against the oracle for a window of batch entries, event counters equal, window gradients close; then the loop itself through all five
+    levels (25 iterations, the reference's learning rate, schedule and upsampling fractions)."""
+    from uivr_amd import synthetic
+    target = synthetic.dust_devil_scene(res=256, film=512, device=gpu, n_sensors=63)
+    g = torch.Generator().manual_seed(5)
+    env = (torch.rand(2048, 4096, 3, generator=g) ** 4 * 3.0 + 0.2).to(gpu)
+    target.emitter = uivr.EnvmapEmitter(pixels=env, scale=1.0)
+    props = props_for("drt")
+    integ = _integrator(uivr, props)
+    table = uivr.sensors_to_device(target.sensors, gpu)
+    B, spp, spp_grad, seed, seed_grad = 4096, 1024, 16, 3101, 3102
+    full = target.medium.sigma_t
+    for res in (16, 32, 64, 128, 256):
+        # the level's grid: the target downsampled (max over the block: the structure survives) and thinned, albedo at its initial 0.6
+        k = 256 // res
+        st = full.reshape(res, k, res, k, res, k, 1).amax(dim=(1, 3, 5)) * 0.05 + 0.04 / 100
+        factor = uivr.adjusted_majorant_res_factor(8, st.shape)
+        assert factor == (4 if res == 16 else 8)
+        medium = uivr.GridMedium(sigma_t=st.contiguous(), albedo=torch.full((res, res, res, 3), 0.6, device=gpu), bbox_min=target.medium.bbox_min,
+                                 bbox_max=target.medium.bbox_max, scale=target.medium.scale, majorant_resolution_factor=factor)
+        sg = uivr.Scene(medium=medium, emitter=target.emitter, sensors=target.sensors)
+        params = {kk: v.clone().requires_grad_(True) for kk, v in sg.params().items() if kk in integ.param_keys}
+        image, _, _, sidx, pix = uivr.render_batch(B, sg, params=params, integrator=integ, seed=seed + res, seed_grad=seed_grad + res,
+                                                   spp=spp, spp_grad=spp_grad, sensor_table=table)
+        assert image.shape == (B, 3) and torch.isfinite(image).all()
+        W = 6
+        sub0, sub1, sub2 = (uivr.sample_tea_32(seed + res, 17 * kq + 5)[0] for kq in (0, 1, 2))
+        ro, rd, si_r, px_r = oracle.batch_sample_rays(sg.sensors, W, spp, sub0, sub1)
+        np.testing.assert_array_equal(sidx[:W].cpu().numpy().astype(np.uint32), si_r)
+        np.testing.assert_array_equal(pix[:W].cpu().numpy().astype(np.uint32), px_r)
+        osc = oracle.OracleScene(_cpu_scene(uivr, sg), sensor_index=None)
+        Lr, _ = oracle.render_primal(osc, props, spp, seed + res, rays_o=ro, rays_d=rd)
+        np.testing.assert_allclose(image[:W].detach().cpu().numpy(), oracle.develop(Lr, spp), rtol=0, atol=1e-6)
+        Wg = 192
+        ro2, rd2, _, _ = oracle.batch_sample_rays(sg.sensors, Wg, spp_grad, sub0, sub2)
+        L2, c_p = oracle.render_primal(osc, props, spp_grad, seed_grad + res, rays_o=ro2, rays_d=rd2)
+        rng = np.random.default_rng(res)
+        dLw = ((rng.random((Wg * spp_grad, 3), dtype=np.float32) - 0.5) * 1e-3).astype(np.float32)
+        gs, ga, c_adj = oracle.render_backward(osc, props, spp_grad, seed_grad + res, dLw, L2, rays_o=ro2, rays_d=rd2)
+        tro, trd, _, _ = uivr.sample_batch(integ, sg, table, Wg, spp_grad, seed + res, 2)
+        np.testing.assert_array_equal(tro.cpu().numpy().view(np.uint32), ro2.view(np.uint32))
+        batch = uivr.RayBatch(n_rays=Wg * spp_grad, spp=spp_grad, o=tro, d=trd)
+        samp = uivr.IndependentSampler(seed_grad + res, spp_grad)
+        h = integ.native_handle(sg)
+        h.enable_counters(True)
+        h.reset_counters()
+        Lw, _, stt = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+        cp = {kk: int(v) for kk, v in h.get_counters().items()}
+        np.testing.assert_array_equal(Lw.cpu().numpy().view(np.uint32), L2.view(np.uint32))
+        assert cp == c_p
+        h.reset_counters()
+        grads = uivr.alloc_grads(sg)
+        integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dLw).to(gpu), state_in=stt, grads=grads)
+        ca = {kk: int(v) for kk, v in h.get_counters().items()}
+        h.enable_counters(False)
+        assert ca == c_adj
+        _close_on_device(grads[uivr.SIGMA_T_KEY], gs, f"level {res}^3 window grad sigma_t")
+        _close_on_device(grads[uivr.ALBEDO_KEY], ga, f"level {res}^3 window grad albedo")
+        del params, image, grads, osc
+    # the loop through all five levels as reproduce.py configures it
+    target.medium.majorant_resolution_factor = 8
+    sc = uivr.SceneConfig(name="dust-devil", scene=target, param_keys=[uivr.SIGMA_T_KEY, uivr.ALBEDO_KEY], sensors=list(range(63)),
+                          start_from_value={uivr.SIGMA_T_KEY: 0.04 / 100, uivr.ALBEDO_KEY: 0.6}, majorant_resolution_factor=8, ref_spp=16)
+    rendered = uivr.render_reference_image(sc, {s_: None for s_ in sc.sensors})
+    ref = torch.stack([rendered[s_] for s_ in sc.sensors])
+    oc = uivr.OptimizationConfig(name="r", spp=16, n_iter=25, lr=3e-4, primal_spp_factor=64, batch_size=32768,
+                                 lr_schedule=uivr.Schedule.Last25, upsample=[0.04, 0.16, 0.36, 0.64])
+    assert sorted(oc.upsample_at) == [1, 4, 9, 16]
+    _, p, _, hist = uivr.run_optimization(None, oc, sc, "volpathsimple-drt", ref_images=ref)
+    assert len(hist) == 25 and all(np.isfinite(hist))
+    assert tuple(p[uivr.SIGMA_T_KEY].shape) == (256, 256, 256, 1) and tuple(p[uivr.ALBEDO_KEY].shape) == (256, 256, 256, 3)
+    assert float(p[uivr.SIGMA_T_KEY].min()) >= 0 and float(p[uivr.ALBEDO_KEY].min()) >= 0 and float(p[uivr.ALBEDO_KEY].max()) <= 1
+    assert float((p[uivr.SIGMA_T_KEY] - 0.04 / 100).abs().max()) > 0
+
+
 def test_config5_nerf_256_512x32_128_queries(uivr, oracle, gpu):
     """The registered `nerf` IntegratorConfig (128 queries, opt_config.py:162-169) on the 256^3 density + emission
     grids (emission = the albedo grid, scene_config.py:109-110) at 512^2 x 32 spp."""

@@ -129,6 +129,19 @@ def test_c_abi_library_exports_every_declared_symbol(uivr):
         assert "gfx950" in native(hooks).version()   # the pybind11 shims load too
 
 
+def test_production_library_holds_no_older_tracer_generation(uivr):
+    """a production call reaches CoopTracer (global majorant), the queued tracer (supergrid) or CoopTracer<SUPER>
+    (supergrids beyond it, the atomic gradient path) - the round-2 state machine (drt_wavefront.hip), the round-3 supergrid kernel
+    (drt_super.hip) and the plain per-lane Tracer are compiled only into the flavour with test hooks."""
+    from uivr_amd import _build
+    prod, hooks = (open(p, "rb").read() for p in (_build.LIB_PATH, _build.HOOKS_LIB_PATH))
+    for name in (b"trace_wavefront_kernel", b"trace_super_kernel", b"trace_kernelILb"):
+        assert name not in prod, name
+        assert name in hooks, name
+    for name in (b"trace_sq_kernel", b"trace_coop_kernel", b"fused_kernel", b"tile_reduce_kernel"):
+        assert name in prod, name
+
+
 def test_c_abi_argument_errors_without_gpu(uivr):
     """Error convention: negative status + message, no exceptions, no crash (no compute)."""
     from uivr_amd._native import library_path

@@ -5,7 +5,7 @@
 # (the pybind shim finds libdrt_hip.so through RUNPATH, which LD_LIBRARY_PATH precedes).  variants/ is git-ignored.
 set -e
 name=$1; defs=$2; shift 2 || true
-srcs=("$@"); [ ${#srcs[@]} -eq 0 ] && srcs=(drt_super.hip)
+srcs=("$@"); [ ${#srcs[@]} -eq 0 ] && srcs=(drt_sq.hip)
 root=$(cd "$(dirname "$0")/.." && pwd)
 csrc=$root/unbiased-inverse-volume-rendering_amd/csrc
 out=$root/variants/$name

@@ -281,20 +281,16 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         DRT_HIP_CHECK(h, hipEventCreate(&b));
         DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
     }
-    // Kernel choice (measured on MI355X, headline workload; DESIGN.md sections 6.1, 9):
-    //   global majorant: the one-ray-per-lane kernels of drt_coop.hip (CoopTracer: wave-cooperative tracking rounds) for both
-    //   passes; majorant supergrid: the cell-stepping state machine of drt_super.hip for both passes (quadratic DRT, a
-    //   supergrid beyond its limits and the variant tests: the round-2 kernels - state machine of whole flights,
-    //   drt_wavefront.hip, for the primal pass, CoopTracer<SUPER> for the adjoint).  Every primal kernel writes the path
-    //   cache the adjoint pass of the job reads.  The plain per-lane Tracer (drt_kernels.hip; bits 8 / 32768) exists only in
-    //   the library flavour with test hooks, where the variant tests keep it in lock-step with the rest.
+    // Kernel choice - which call reaches which kernel (DESIGN.md section 1 has the table):
+    //   global majorant (majorant_resolution_factor 0): CoopTracer (drt_coop.hip: one ray per lane, wave-cooperative tracking rounds), both passes;
+    //   majorant supergrid (the reference's default 8): the queued tracer (drt_sq.hip: rays are records, waves take batches of one kind of work),
+    //   both passes, every estimator - where its records fit LDS next to the supergrid's majorants or cell bitmask (sq_supported: up to ~99^3 cells,
+    //   max_depth <= 1000) and the adjoint's splats travel as records; otherwise (larger supergrids, the atomic gradient path of grids beyond 16384
+    //   reduction tiles or without record memory): CoopTracer<SUPER> (drt_coop_super.hip: own-lane tracking steps through the supergrid).
+    //   Every primal kernel writes the path cache the adjoint pass of the job reads.  Only the library flavour with test hooks also holds the older
+    //   generations - the round-3 supergrid kernel (drt_super.hip; hook 4096), the round-2 state machine of whole flights (drt_wavefront.hip; hooks
+    //   32 / 65536 / 134217728) and the plain per-lane Tracer (drt_kernels.hip; hooks 8 / 32768) - where the variant tests keep them in lock-step.
     const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
-#ifndef DRT_SUPER_COOP_PRIMAL
-#define DRT_SUPER_COOP_PRIMAL 0     // experiment: 1 = the supergrid primal runs in CoopTracer<SUPER> too (measured slower)
-#endif
-    // supergrid scenes: the cell-stepping state machine (drt_super.hip) for both passes; bit 134217728 keeps the older
-    // kernels (state machine of whole flights for the primal, one ray per lane for the adjoint) for the variant tests
-    // (quadratic DRT: only the queued tracer takes it - its QUAD adjoint kernels; drt_super.hip hands it to the round-2 kernels)
     // (the records' global halves, ~44 MB, are allocated only by a launch that will run the queued kernel: not when a test hook or the atomic
     //  gradient path routes this launch to the older kernels)
     const bool super_path = P.mgrid && !dbg(h->debug_flags, (134217728u | 8u | 32u | 32768u | 65536u)) && (!adjoint || P.rec_buf[0] != nullptr);
@@ -302,7 +298,14 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     if (sq_ok && !h->d_sq_cold && hipMalloc(&h->d_sq_cold, drt::sq_cold_bytes(h->n_cus)) != hipSuccess) {
         (void) hipGetLastError(); h->d_sq_cold = nullptr; sq_ok = false;
     }
-    const bool super = super_path && (!quadratic || sq_ok) && (sq_ok || drt::super_supported(P));
+    // Production: the queued tracer or - supergrids it does not take, the atomic gradient path - CoopTracer<SUPER> below.  The flavour with test
+    // hooks also keeps the round-3 kernel (drt_super.hip; hook 4096) and the round-2 state machine (drt_wavefront.hip; hooks 32 / 65536 / 134217728).
+#ifdef DRT_TEST_HOOKS
+    const bool super3 = super_path && !sq_ok && !quadratic && dbg(h->debug_flags, 4096u) && drt::super_supported(P);
+#else
+    const bool super3 = false;
+#endif
+    const bool super = (super_path && sq_ok) || super3;
     if (super) {
         drt::Params Q = P;
         Q.queues = h->d_queues;
@@ -358,16 +361,20 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         if (queued) {
             Q.sq_cold = h->d_sq_cold;
             DRT_HIP_CHECK(h, drt::launch_trace_sq(Q, adjoint, h->counting, h->n_cus, h->stream));
-        } else
-        DRT_HIP_CHECK(h, drt::launch_trace_super(Q, adjoint, h->counting, h->n_cus, h->stream));
+        }
+#ifdef DRT_TEST_HOOKS
+        else DRT_HIP_CHECK(h, drt::launch_trace_super(Q, adjoint, h->counting, h->n_cus, h->stream));
+#endif
         if (h->timing) {
             DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
             h->timed[which].emplace_back(a, b);
         }
         return DRT_OK;
     }
-    const bool sm_primal = !adjoint && ((P.mgrid != nullptr && !DRT_SUPER_COOP_PRIMAL) || dbg(h->debug_flags, 65536u)) && !dbg(h->debug_flags, 8u);
-    const bool sm_adjoint = adjoint && dbg(h->debug_flags, 32u) && !quadratic && !dbg(h->debug_flags, 8u);
+    // (hooks only: 134217728 = supergrid scenes in the round-2 kernels - the state machine of whole flights for the primal pass, 65536 = that
+    //  kernel for any primal pass, 32 = for the adjoint too)
+    const bool sm_primal = drt::kTestHooks && !adjoint && ((P.mgrid != nullptr && dbg(h->debug_flags, 134217728u)) || dbg(h->debug_flags, 65536u)) && !dbg(h->debug_flags, 8u);
+    const bool sm_adjoint = drt::kTestHooks && adjoint && dbg(h->debug_flags, 32u) && !quadratic && !dbg(h->debug_flags, 8u);
     const bool wavefront = sm_primal || sm_adjoint;
     const bool coop = !wavefront && !dbg(h->debug_flags, (adjoint ? 32768u : 8u));
     if (coop) {
@@ -419,13 +426,13 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         Q.ray_perm = nullptr;
         DRT_HIP_CHECK(h, drt::launch_trace(Q, adjoint, h->counting, h->stream));
     }
-#endif
     else {
         drt::Params Q = P;
         Q.queues = h->d_queues;
         DRT_HIP_CHECK(h, hipMemsetAsync(h->d_queues, 0, 8 * sizeof(unsigned long long), h->stream));
         DRT_HIP_CHECK(h, drt::launch_trace_wavefront(Q, adjoint, h->counting, h->n_cus, h->stream));
     }
+#endif
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
         h->timed[which].emplace_back(a, b);
