@@ -370,11 +370,12 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
                 t_a = stamps[0] if a == 0 else stamps[a - 1]
                 n_lv = b - a - (1 if a == 0 else 0)
                 res = 256 >> (len(bounds) - 2 - lv)
-                levels.append({"grid": f"{res}^3", "iterations": b - a, "iterations_per_s": round(n_lv / (stamps[b - 1] - t_a), 2)})
+                t_lv = stamps[b - 1] - t_a                           # (the warm-up run's first level is that one iteration: no rate)
+                levels.append({"grid": f"{res}^3", "iterations": b - a, "iterations_per_s": round(n_lv / t_lv, 2) if n_lv > 0 and t_lv > 0 else None})
             out = {"value": round(n_iter / total, 2), "unit": "iterations/s", "n_iter": n_iter, "levels": levels,
                    "loss_first20_mean": round(sum(hist[:20]) / 20, 6), "loss_last20_mean": round(sum(hist[-20:]) / 20, 6),
                    "final_grid": list(params[u.SIGMA_T_KEY].shape)}
-        out["slowest_level"] = min(out["levels"], key=lambda l: l["iterations_per_s"])["grid"]
+        out["slowest_level"] = min((l for l in out["levels"] if l["iterations_per_s"]), key=lambda l: l["iterations_per_s"])["grid"]
         out["workload"] = ("config 3 as python/reproduce.py runs dust-devil DRT: Adam lr 3e-4 (Last25), l1, batch 32768 px, spp 1024 / 16, init "
                            "sigma_t 0.04/100 and albedo 0.6 on 16^3, x2 upsampling at 4/16/36/64 % of the run, majorant_resolution_factor 8 "
                            "(adjusted on the coarse grids), 4096x2048 environment map, 63 sensors 512^2; 250 iterations instead of 6000")

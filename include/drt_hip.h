@@ -294,7 +294,7 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
  * the atomic path); bit 21 (2097152): generic tracing kernels instead of the ones specialised for the registered
  * `volpathsimple-drt` estimator; bit 25 (33554432): no workgroup hand-off of sparse waves' paths (every wave runs
  * its own paths to the end); bit 26 (67108864): none in the primal pass only; bit 27 (134217728): supergrid scenes in
- * the older kernels instead of drt_super.hip; bit 28 (268435456): no early histogram pass beside the adjoint's tail launch;
+ * the older kernels instead of drt_super.hip; bit 28 (268435456): no early histogram pass beside the adjoint's tail launch (queued tracer: no tail pool);
  * bit 29 (536870912): the supergrid tracer takes its rays in index order (production: thick pixels first); bit 30
  * (1073741824): launches of fewer than 1.5 M rays are scheduled like large ones (ray order, tail launch) - the small scenes
  * of the tests then cover those schedules; bit 31 (2147483648): the queued supergrid tracer walks every flight (production: the

@@ -70,12 +70,13 @@ def test_envmap_primitives_bit_exact(uivr, oracle, gpu):
 
 
 @pytest.mark.parametrize("flags,variant", [(0, "drt"), (0, "basic"), (0, "quadratic"), (8, "drt"), (32, "drt"), (32, "basic"),
-                                           (-3, "drt"), (-3, "basic"), (-3, "quadratic")])
+                                           (-3, "drt"), (-3, "basic"), (-3, "quadratic"), (-3 - 1073741824, "drt"), (-3 - 1073741824, "quadratic")])
 def test_envmap_render_matches_oracle(uivr, oracle, gpu, flags, variant):
-    """(flags -3: a majorant supergrid of factor 3 - the envmap instantiations of the supergrid tracer, drt_super.hip)"""
+    """(flags -3: a majorant supergrid of factor 3 - the envmap instantiations of the queued supergrid tracer, drt_sq.hip; -3 - f: with test
+    hooks f - 1073741824: a launch this small scheduled like the large ones, i.e. with the adjoint's tail pool and tail launch)"""
     props = props_for(variant)
     scene = _env_scene(uivr, factor=3 if flags < 0 else 0)
-    flags = max(flags, 0)
+    flags = -flags - 3 if flags < 0 else flags
     spp, seed = 8, 4242
     ref = oracle.h1_step(oracle.OracleScene(scene), props, spp, seed)
     _, c_primal = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)

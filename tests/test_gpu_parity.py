@@ -651,7 +651,8 @@ def test_heavy_tailed_ratio_tracking_splats_keep_ordinary_voxels_accurate(uivr, 
 @pytest.mark.parametrize("flags,variant", [(0, "drt"), (0, "drt-nomis"), (0, "basic"), (134217728, "drt"), (128, "drt"),
                                            (1048576, "drt"), (16384, "drt"), (1073741824, "drt"), (1073741824 | 16384, "drt"),
                                            (1073741824, "basic"), (0, "quadratic"), (4096, "quadratic"), (1048576, "quadratic"),
-                                           (16384, "quadratic")])
+                                           (16384, "quadratic"), (1073741824, "quadratic"), (1073741824, "drt-nomis"),
+                                           (1073741824 | 268435456, "drt"), (1073741824 | 1048576, "drt")])
 def test_supergrid_tracer_and_its_fallbacks_match_oracle(uivr, oracle, gpu, flags, variant):
     _supergrid_case(uivr, oracle, gpu, flags, variant, 7.0)
 
@@ -677,7 +678,9 @@ def _supergrid_case(uivr, oracle, gpu, flags, variant, density, **over):
     (subsampled DRT with / without MIS, basic), with the path cache on and off (1048576), with the job cut into ray
     sub-batches (16384: launches with ray_first > 0), with its rays started thick pixels first as launches of millions of
     rays are (1073741824: from 4096 rays on; the at-size tests of test_gpu_configs.py run ordered by default, 536870912
-    would keep index order); and what it hands back to the older kernels stays verified:
+    would keep index order) - and, in the adjoint launches of the queued tracer, with the drained workgroups' last records handed
+    to the tail pool and finished by the tail launch beside the partition passes of the gradient reduction (round 5; with
+    268435456: without the pool); and what it hands back to the older kernels stays verified:
     134217728 = the round-2 kernels for both passes, 128 = the atomic gradient path (no record streams).  Quadratic DRT runs
     in the queued tracer's QUAD adjoint kernels (drt_sq.hip: the main path suspended at every vertex for the DRT walk + the
     recursive path; with and without the path cache, in ray sub-batches) and, with test hook 4096 (drt_super.hip does not
@@ -715,7 +718,7 @@ def _supergrid_case(uivr, oracle, gpu, flags, variant, density, **over):
     _assert_grads_close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], "grad albedo")
 
 
-@pytest.mark.parametrize("flags,variant", [(0, "drt"), (4096, "drt"), (0, "basic"), (4096, "quadratic"), (0, "quadratic")])
+@pytest.mark.parametrize("flags,variant", [(0, "drt"), (4096, "drt"), (0, "basic"), (4096, "quadratic"), (0, "quadratic"), (1073741824, "drt")])
 def test_supergrid_too_large_for_lds_keeps_its_bitmask_there(uivr, oracle, gpu, flags, variant):
     """A supergrid whose majorants do not fit the tracer's LDS next to the ray records (160^3 voxels at factor 4 = 40^3
     = 64000 cells: 125 KiB as bf16; the reference's default on a 512^3 grid gives 64^3) runs the instantiations that keep the

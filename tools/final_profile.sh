@@ -17,6 +17,8 @@ for f in 8 0; do
   (timeout 600 rocprofv3 -i /root/repo/tools/pmc_util.txt --kernel-trace --output-format csv -d $R/pmc_util$f -- $B --steps 3 --warmup 1 --majorant-factor $f > /dev/null 2>> $R/err.txt)
   (timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic$f -- $B --steps 3 --warmup 1 --majorant-factor $f > /dev/null 2>> $R/err.txt)
 done
+# (traffic by buffer: the same pass over the build whose albedo lookups load nothing - tools/mk_variant.sh alb0 "-DDRT_EXP_ALB=1" drt_sq.hip, built before the call)
+[ -f /root/repo/variants/alb0/libdrt_hip.so ] && (LD_LIBRARY_PATH=/root/repo/variants/alb0 timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic_alb0 -- $B --steps 3 --warmup 1 --majorant-factor 8 > /dev/null 2>> $R/err.txt)
 (timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic_env8 -- python /root/repo/bench.py --only-config headline_envmap_factor8 > /dev/null 2>> $R/err.txt)
 (timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic_fused -- python /root/repo/bench.py --only-config config5_fused_nerf_drt_256_512x32 > /dev/null 2>> $R/err.txt)
 (timeout 900 rocprofv3 -i /root/repo/tools/pmc_util.txt --kernel-trace --output-format csv -d $R/pmc_util_fused -- python /root/repo/bench.py --only-config config5_fused_nerf_drt_256_512x32 > /dev/null 2>> $R/err.txt)
@@ -36,10 +38,13 @@ python tools/pmc_to_traffic.py $R/pmc_traffic_fused fused-256-512x32 $R/roofline
 python tools/pmc_to_util.py $R/pmc_util.txt $R/kernel_stats.csv dust-devil-256-512x32-factor8 $R/roofline_traffic.json > $R/util.txt
 python tools/pmc_to_util.py $R/factor0_pmc_util.txt $R/kernel_stats_factor0.csv dust-devil-256-512x32 $R/roofline_traffic.json > $R/util_factor0.txt
 python tools/pmc_to_util.py $R/fused_pmc_util.txt $R/kernel_stats_fused.csv fused-256-512x32 $R/roofline_traffic.json > $R/util_fused.txt
+[ -d $R/pmc_traffic_alb0 ] && python tools/pmc_to_traffic.py $R/pmc_traffic_alb0 dust-devil-256-512x32-factor8 $R/traffic_alb0.json > /dev/null
+rm -rf $R/pmc_traffic_alb0
 rm -rf $R/pmc_util0 $R/pmc_util8 $R/pmc_traffic0 $R/pmc_traffic8 $R/pmc_traffic_fused $R/pmc_traffic_env8 $R/pmc_util_fused $R/prof0 $R/prof8 $R/prof_fused
 cp $R/roofline_traffic.json profiles/roofline_traffic.json      # the bench lines below quote it (same kernel sources: hash checked)
 (timeout 1500 python bench.py > $R/bench.json 2>> $R/err.txt)
 (timeout 600 python bench.py --majorant-factor 0 --no-extra-configs --no-cpu-baseline > $R/bench_factor0.json 2>> $R/err.txt)
+[ -f $R/traffic_alb0.json ] && python tools/traffic_by_buffer.py $R/roofline_traffic.json $R/traffic_alb0.json $R/bench.json dust-devil-256-512x32-factor8 > $R/traffic_by_buffer.txt
 python - <<P
 import json
 for f in ("bench.json", "bench_factor0.json"):

@@ -66,6 +66,9 @@ struct drt_handle_s {
     // follows; the adjoint launcher takes the histogram of the main launch's records on `side` next to the tail launch
     const drt::DeferredPlan *early_plan = nullptr;
     bool early_done = false;
+    bool early_partition = false;             // ... and it was the whole partition (histogram .. scatter: the queued tracer's tail launch), not just the histogram
+    void *d_sq_tail = nullptr;                // tail pool of the queued tracer's adjoint launches: 256-byte header {count, .., dummy cursors} + entries
+    size_t sq_tail_bytes = 0;
     hipEvent_t ev_split = nullptr, ev_hist = nullptr;
     // path cache (drt_coop.hip): written by the primal launch of an H1 step, read by the adjoint launch of the
     // same job if nothing happened to the handle in between
@@ -360,7 +363,59 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
         DRT_HIP_CHECK(h, hipMemsetAsync(h->d_queues, 0, 8 * sizeof(unsigned long long), h->stream));
         if (queued) {
             Q.sq_cold = h->d_sq_cold;
+#ifndef DRT_SQ_TAIL
+#define DRT_SQ_TAIL 1               // adjoint launches of the queued tracer: drained workgroups hand their last records to a tail pool; 0: they finish them
+#endif
+            // Tail pool (adjoint, deferred splats, the reduction of this very launch follows on h->stream): the last paths of a launch are latency - a
+            // few records per CU, 0.45 ms of the headline's adjoint launch.  Drained workgroups write them to the pool and end; the partition
+            // passes of the gradient reduction (histogram, offsets, scan, scatter: they do not touch the gradient grids) run on a side stream
+            // BESIDE the tail launch, which finishes the pooled records with its splats as direct atomics; tile_reduce follows both.
+            // Launches of fewer than 2 M rays keep their last paths (a rank's share of the headline at 8 GPUs, 1 M rays: 3.19 ms per step without
+            // the pool, 3.31 with it - such a launch IS its longest path, a second launch only adds its own start; at 4 GPUs, 2 M rays: 4.00 / 4.07 ms).
+            // (test hooks: 268435456 no tail pool, 1073741824 launches from 4096 rays on have one)
+            const uint64_t tail_min = dbg(h->debug_flags, 1073741824u) ? 4096u : (1u << 21);
+            const bool tail = DRT_SQ_TAIL && adjoint && h->early_plan && Q.rec_buf[0] && span >= tail_min && !dbg(h->debug_flags, 268435456u);
+            if (tail) {
+                const size_t cap = (size_t) h->n_cus * drt::sq_tail_push();
+                const size_t need_b = 256 + cap * drt::sq_tail_entry_quads() * sizeof(uint4);
+                if (need_b > h->sq_tail_bytes) {
+                    if (h->d_sq_tail) { DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream)); (void) hipFree(h->d_sq_tail); h->d_sq_tail = nullptr; h->sq_tail_bytes = 0; }
+                    if (hipMalloc(&h->d_sq_tail, need_b) == hipSuccess) h->sq_tail_bytes = need_b; else { (void) hipGetLastError(); h->d_sq_tail = nullptr; }
+                }
+                if (h->d_sq_tail) {
+                    DRT_HIP_CHECK(h, hipMemsetAsync(h->d_sq_tail, 0, 256, h->stream));
+                    Q.tail_count = (uint32_t *) h->d_sq_tail; Q.tail_pool = (uint4 *) ((char *) h->d_sq_tail + 256); Q.tail_cap = (uint32_t) cap; Q.tail_mode = 0;
+                }
+            }
             DRT_HIP_CHECK(h, drt::launch_trace_sq(Q, adjoint, h->counting, h->n_cus, h->stream));
+            if (tail && Q.tail_pool) {
+                if (!h->side) {
+                    int lo = 0, hi = 0;
+                    DRT_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                    DRT_HIP_CHECK(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
+                }
+                if (!h->ev_split) {
+                    DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_split, hipEventDisableTiming));
+                    DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_hist, hipEventDisableTiming));
+                }
+                // the main launch's records are complete (the tail launch emits none): partition them on the side stream ...
+                DRT_HIP_CHECK(h, hipEventRecord(h->ev_split, h->stream));
+                DRT_HIP_CHECK(h, hipStreamWaitEvent(h->side, h->ev_split, 0));
+                hipEvent_t ta = nullptr, tb = nullptr;
+                if (h->timing) { DRT_HIP_CHECK(h, hipEventCreate(&ta)); DRT_HIP_CHECK(h, hipEventCreate(&tb)); DRT_HIP_CHECK(h, hipEventRecord(ta, h->side)); }
+                DRT_HIP_CHECK(h, drt::launch_deferred_reduce(Q, *h->early_plan, h->side, nullptr, false, 1));
+                if (h->timing) { DRT_HIP_CHECK(h, hipEventRecord(tb, h->side)); h->timed[2].emplace_back(ta, tb); }
+                DRT_HIP_CHECK(h, hipEventRecord(h->ev_hist, h->side));
+                // ... beside the tail launch: the pool's records to their ends, splats as direct atomics into the caller's grids (no chunk is
+                // handed out: the cursors it touches are dummies in the pool's header)
+                drt::Params T = Q;
+                T.tail_mode = 1;
+                T.rec_cursor = (uint32_t *) h->d_sq_tail + 8;
+                T.rec_cap_chunks[0] = T.rec_cap_chunks[1] = 0;
+                T.order = nullptr; T.unit_empty = nullptr;
+                DRT_HIP_CHECK(h, drt::launch_trace_sq(T, adjoint, h->counting, h->n_cus, h->stream));
+                h->early_done = true; h->early_partition = true;
+            }
         }
 #ifdef DRT_TEST_HOOKS
         else DRT_HIP_CHECK(h, drt::launch_trace_super(Q, adjoint, h->counting, h->n_cus, h->stream));
@@ -521,7 +576,7 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
     return DRT_OK;
 }
 
-int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream, bool early_hist = false);
+int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream, bool early_hist = false, int phase = 0);
 int timed_untile(drt_handle h, const drt::Params &P);
 
 // Adjoint launch + gradient reduction of one job.  Deferred path: the job is cut into sub-batches of rays
@@ -596,14 +651,14 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
             }
             if (rc) return rc;
             P.ray_first = first; P.n_rays = first + count;
-            h->early_plan = overlap ? nullptr : &R.plan; h->early_done = false;
+            h->early_plan = overlap ? nullptr : &R.plan; h->early_done = false; h->early_partition = false;
             rc = launch(P);
             if (rc) { h->early_plan = nullptr; return rc; }
             if (!overlap) {
-                const bool early = h->early_done;
-                h->early_plan = nullptr; h->early_done = false;
+                const bool early = h->early_done, part = h->early_partition;
+                h->early_plan = nullptr; h->early_done = false; h->early_partition = false;
                 if (early) DRT_HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_hist, 0));
-                rc = timed_reduce(h, P, R.plan, h->stream, early);
+                rc = timed_reduce(h, P, R.plan, h->stream, early && !part, part ? 2 : 0);
                 if (rc) return rc;
                 continue;
             }
@@ -626,7 +681,7 @@ int run_backward(drt_handle h, drt::Params &P, uint32_t per_ray_sigma, uint32_t 
     return DRT_OK;
 }
 
-int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream, bool early_hist)
+int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D, hipStream_t stream, bool early_hist, int phase)
 {
     hipEvent_t a = nullptr, b = nullptr;
     if (h->timing) {
@@ -634,7 +689,7 @@ int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D,
         DRT_HIP_CHECK(h, hipEventCreate(&b));
         DRT_HIP_CHECK(h, hipEventRecord(a, stream));
     }
-    DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, D, stream, nullptr, early_hist));
+    DRT_HIP_CHECK(h, drt::launch_deferred_reduce(P, D, stream, nullptr, early_hist, phase));
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventRecord(b, stream));
         h->timed[2].emplace_back(a, b);
@@ -729,6 +784,7 @@ int drt_destroy(drt_handle h)
     if (h->d_queues) (void) hipFree(h->d_queues);
     if (h->d_order) (void) hipFree(h->d_order);
     if (h->d_uempty) (void) hipFree(h->d_uempty);
+    if (h->d_sq_tail) (void) hipFree(h->d_sq_tail);
     if (h->d_sq_cold) (void) hipFree(h->d_sq_cold);
     if (h->d_tail) (void) hipFree(h->d_tail);
     if (h->d_sigma_b) (void) hipFree(h->d_sigma_b);

@@ -431,18 +431,23 @@ hipError_t launch_deferred_early_histogram(const Params &P, const DeferredPlan &
     return hipGetLastError();
 }
 
-hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev, bool early_hist)
+// phase 0: everything; 1: the partition only (histogram, offsets, scan, scatter: the passes that do not touch the caller's gradient grids - the
+// queued tracer runs them on a side stream beside its tail launch); 2: tile_reduce only (the partition has been made)
+hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev, bool early_hist, int phase)
 {
     const size_t lds = (size_t) D.n_bins * sizeof(uint32_t);
     auto mark = [&](int k) { if (ev) (void) hipEventRecord(ev[k], stream); };
     mark(0);
-    hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D, early_hist ? 2 : 0);
-    mark(1);
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3((D.n_bins + 3) / 4, kRecStreams), dim3(256), 0, stream, D, kPartWGs);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(kRecStreams), dim3(1024), 0, stream, D);
-    mark(2);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D);
-    mark(3);
+    if (phase != 2) {
+        hipLaunchKernelGGL(bin_histogram_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D, early_hist ? 2 : 0);
+        mark(1);
+        hipLaunchKernelGGL(bin_offsets_kernel, dim3((D.n_bins + 3) / 4, kRecStreams), dim3(256), 0, stream, D, kPartWGs);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(kRecStreams), dim3(1024), 0, stream, D);
+        mark(2);
+        hipLaunchKernelGGL(bin_scatter_kernel, dim3(kPartWGs, kRecStreams), dim3(kPartThreads), lds, stream, P, D);
+        mark(3);
+    }
+    if (phase == 1) return hipGetLastError();
     {   // (the attribute belongs to the function on a device: set once per device)
         static std::atomic<bool> attr_set[64];                   // (zero-initialised; handles may be driven from several host threads)
         int dev = 0;

@@ -36,7 +36,7 @@ __host__ __device__ __forceinline__ constexpr bool dbg(uint32_t flags, uint32_t 
 
 // Experiment switches (timing / profiling builds made by tools/mk_variant.sh; several of them give WRONG results on purpose)
 // must never leak into a shipped library: they only compile with -DDRT_EXPERIMENT_BUILD.
-#if !defined(DRT_EXPERIMENT_BUILD) && (defined(DRT_FAST_MATH) || defined(DRT_ENV_EXP) || defined(DRT_EXP_ALB) || \
+#if !defined(DRT_EXPERIMENT_BUILD) && (defined(DRT_FAST_MATH) || defined(DRT_ENV_EXP) || defined(DRT_EXP_ALB) || defined(DRT_EXP_DROP_TAIL) || \
                                        (defined(DRT_SQ_PROFILE) && DRT_SQ_PROFILE != 0))
 #error "experiment switch without -DDRT_EXPERIMENT_BUILD (tools/mk_variant.sh adds it): not for a shipped library"
 #endif

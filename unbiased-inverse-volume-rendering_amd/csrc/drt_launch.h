@@ -30,6 +30,10 @@ hipError_t launch_trace_super(const Params &P, bool adjoint, bool count, int n_c
 bool sq_supported(const Params &P);
 size_t sq_cold_bytes(int n_cus);
 hipError_t launch_trace_sq(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
+// tail pool of the queued tracer's adjoint launches (Params::tail_pool / tail_count / tail_cap / tail_mode): a drained workgroup writes its last
+// <= sq_tail_push() records to the pool and ends; launch_trace_sq with tail_mode = 1 finishes them (its splats as direct atomics)
+uint32_t sq_tail_push();
+size_t sq_tail_entry_quads();
 size_t super_order_bytes(uint32_t units);
 // flags[u] = 1: every ray of unit u (the `unit` = spp rays of one pixel, sensor rays only) crosses only empty supergrid cells (Params::unit_empty)
 hipError_t build_unit_empty(const Params &P, uint32_t unit, uint32_t units, uint8_t *flags, hipStream_t stream);
@@ -81,7 +85,7 @@ struct DeferredPlan {
 };
 // ev: optional 5 events recorded before/after the stages (histogram | offsets+scan | scatter | reduce)
 // early_hist: the histogram of the chunks below the split (launch_deferred_early_histogram) has been taken already
-hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev = nullptr, bool early_hist = false);
+hipError_t launch_deferred_reduce(const Params &P, const DeferredPlan &D, hipStream_t stream, hipEvent_t *ev = nullptr, bool early_hist = false, int phase = 0);
 // The adjoint tracer's tail launch keeps few workgroups busy for as long as the job's longest path: between the main and
 // the tail launch the record streams' chunk cursors are snapshot (`split`, on `stream`), and the histogram pass over the
 // chunks below the split - everything the main launch wrote - runs on `side` next to the tail launch.

@@ -96,6 +96,15 @@
 #ifndef DRT_SQ_INLINE_K
 #define DRT_SQ_INLINE_K 4          // cells a flight is stepped by the lanes that set it up, before it is posted for the walkers
 #endif
+#ifndef DRT_SQ_TAIL_PUSH
+#define DRT_SQ_TAIL_PUSH 64        // adjoint launches with a tail pool (Params::tail_pool): a workgroup whose ray queues are drained and that holds at most
+                                   // this many live records writes them to the pool and ends; a second launch (tail_mode) finishes them beside the
+                                   // partition passes of the gradient reduction (measured: a drained workgroup's last paths are 0.45 ms of the launch)
+#endif
+#ifndef DRT_SQ_TAIL_BLOCKS
+#define DRT_SQ_TAIL_BLOCKS 64      // workgroups of the tail launch (the partition passes of the reduction run on the other compute units)
+#endif
+constexpr int kSqTailQuads = 20;   // uint4 per pool entry: 7 (the LDS record) + 1 {queue kind} + 3 (global part a) + up to 9 (part b)
 #ifndef DRT_SQ_PROFILE
 #define DRT_SQ_PROFILE 0
 #endif
@@ -240,12 +249,15 @@ __device__ __forceinline__ void sq_push_all(unsigned long long *ctl, uint16_t *q
 // quads), the record runs the DRT walk along the current segment and the recursive path from the selected vertex exactly as the
 // subsampled estimator does at the end of a path, and at the end of the recursion the main path is restored - with the alt sampler
 // advanced by the detour's draws - and resumes with the second half of the block (SP_QSCAT2).
-template <bool ADJ, bool COUNT, bool ENV, bool MG, bool QUAD = false>
+// TAILM (adjoint kernels): the tail launch (Params::tail_mode) - it starts from the records of the tail pool instead of the ray queues.  An instantiation of
+// its own: with the pool's prologue compiled into the main kernels those came out 3 KB larger and 8 % slower (instruction cache; profiles/r05_sq_experiments.txt)
+template <bool ADJ, bool COUNT, bool ENV, bool MG, bool QUAD = false, bool TAILM = false>
 __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P)
 {
     constexpr int NWV = DRT_SQ_THREADS / 64;
     constexpr int R4 = 7;                                                    // uint4 per ray record in LDS
     static_assert(ADJ || !QUAD, "the primal pass of the quadratic estimator is the ordinary one");
+    static_assert(ADJ || !TAILM, "only adjoint launches have a tail pool");
     constexpr int NB = QUAD ? 9 : 6;                                         // uint4 of part b of the global record (adjoint)
     constexpr int NC = ADJ ? 3 + NB : 3;                                     // uint4 per ray in global memory (Params::sq_cold)
     // LDS record: [0] {tn.x, tn.y, tn.z, cell} [1] {td.x, td.y, td.z, steps left (9 bits per axis) + direction signs}
@@ -265,8 +277,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     uint16_t *q_lds = (uint16_t *) (mg_lds + ((mg_words + 3) & ~3));
     unsigned long long *ctl = (unsigned long long *) (q_lds + SQ_KINDS * DRT_SQ_RING);
     unsigned long long *pool = ctl + SQ_KINDS;                                // [0] next, [1] end of the workgroup's reserved positions of the ray queues
-    uint32_t *misc = (uint32_t *) (pool + 2);                                 // [0] dead records, [1] bits of the largest majorant, [2] lock of the pool, [3] ray queues tried
-    uint32_t *recst = misc + 4;                                              // record-stream state per wave (emit_record)
+    uint32_t *misc = (uint32_t *) (pool + 2);                                 // [0] dead records, [1] bits of the largest majorant, [2] lock of the pool, [3] ray queues tried,
+                                                                             // [4] the workgroup hands its last records to the tail pool, [5] waves that have left for it
+    uint32_t *recst = misc + 8;                                              // record-stream state per wave (emit_record)
 #if DRT_SQ_PROFILE == 6
     uint32_t *pdbg = recst + NWV * 8;
     for (int w = threadIdx.x; w < 160; w += blockDim.x) pdbg[w] = 0u;
@@ -276,7 +289,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         q_lds[i] = (uint16_t) (k >= 0 && k < NRAY ? k : (int) kSqEmpty);
     }
     if (threadIdx.x < SQ_KINDS) ctl[threadIdx.x] = threadIdx.x == SQ_REGEN ? ((unsigned long long) NRAY << 32) : 0ull;
-    if (threadIdx.x < 4) misc[threadIdx.x] = 0u;
+    if (threadIdx.x < 8) misc[threadIdx.x] = (threadIdx.x == 3 && TAILM) ? 8u                // (tail mode: the ray queues count as drained)
+                                           : (threadIdx.x == 4 && ADJ && !TAILM && P.tail_pool) ? (uint32_t) DRT_SQ_TAIL_PUSH : 0u;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0ull;
     for (int w = threadIdx.x; w < NWV * 8; w += blockDim.x) recst[w] = 0u;
     __syncthreads();
@@ -348,6 +362,34 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     // to the next ones when that one is drained: every ray is traced whatever the placement of the workgroups.  The
     // positions a workgroup has reserved (DRT_SQ_CHUNK at a time) are handed out from LDS under a lock: any wave starts rays.
     int polls = 0;
+    if constexpr (TAILM) {
+        // tail mode (Params::tail_mode): this launch finishes the records the main launch's drained workgroups wrote to the pool - workgroup b takes
+        // the entries b, b + gridDim.x, ... into free records, each into the queue it was taken from; no ray is started (the ray queues count as drained)
+        {
+            const uint32_t n_pool = min(*P.tail_count, P.tail_cap);
+            const uint32_t n_tail = n_pool > blockIdx.x ? min((uint32_t) NRAY, (n_pool - blockIdx.x + gridDim.x - 1u) / gridDim.x) : 0u;
+#pragma unroll 1
+            for (uint32_t k = (uint32_t) wave; k < n_tail; k += NWV) {
+                uint32_t hq;
+                if (!sq_pop(ctl, SQ_REGEN, 1u, 1u, lane, hq)) break;
+                uint32_t id_k = 0;
+                if (lane == 0u) id_k = sq_take(q_lds, SQ_REGEN, hq);
+                id_k = (uint32_t) __builtin_amdgcn_readfirstlane((int) id_k);
+                const uint4 *src = P.tail_pool + ((size_t) blockIdx.x + (size_t) k * gridDim.x) * kSqTailQuads;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (lane < 11u + NB) v = src[lane];
+                if (lane < 7u) rec4[R4 * id_k + lane] = v;
+                else if (lane >= 8u && lane < 11u) cold_a[3 * id_k + (lane - 8u)] = v;
+                else if (lane >= 11u && lane < 11u + NB) cold_b[NB * id_k + (lane - 11u)] = v;
+                const int kd = __builtin_amdgcn_readlane((int) v.x, 7);
+                __threadfence_block();
+                sq_fence();
+                sq_push(ctl, q_lds, kd, lane == 0u, id_k, lane);
+            }
+        }
+        // (every entry has its record before any wave enters the loop: there the free records are retired at once - the ray queues count as drained)
+        __syncthreads();
+    }
 #if DRT_SQ_PROFILE == 6
     const unsigned long long pt_start6 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -367,6 +409,21 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         const uint32_t dead = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[0]);
         if (dead >= (uint32_t) NRAY) break;
         const bool drained = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[3]) >= 8u;
+        if constexpr (ADJ && !TAILM) {
+            // a drained workgroup's last paths are latency: nothing on this CU can hide them.  Their records go to the tail pool (behind the loop) and
+            // the workgroup ends; the tail launch finishes them while the partition passes of the gradient reduction run on the CUs this frees.
+            // (`live` counts the records in the queues or in a wave's registers; the two LDS reads are not one snapshot: it may be low by one batch)
+            // (the hand-over flag is the top bit of the dead-record count: every wave leaves through the check above)
+            if (drained && ((uint32_t) NRAY - dead - n_regen) - 1u < (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[4])) {
+                if (lane == 0u) atomicOr(misc, 0x80000000u);
+                continue;
+            }
+        }
+#ifdef DRT_EXP_DROP_TAIL
+        // timing experiment (wrong results): a drained workgroup with at most DRT_EXP_DROP_TAIL live records ends at once - what a launch costs
+        // WITHOUT the latency of its last paths (the upper bound of what a tail pool can hide behind the reductions)
+        if (drained && (uint32_t) NRAY - dead - n_regen <= (uint32_t) DRT_EXP_DROP_TAIL) break;
+#endif
 #if DRT_SQ_PROFILE == 5
         if (drained && !pt_drained) pt_drained = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1225,7 +1282,34 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         SQ_STAMP(7);
     }
 
-    if constexpr (ADJ) close_records(P, rec);
+    if constexpr (ADJ) {
+        if (!TAILM && P.tail_pool) {
+            // hand-over: every wave is out of the loop with no record in its registers (a batch is stored and queued before the loop head is seen again):
+            // what the queues hold goes to the pool - wave k the entries of queue kind k, three records per round (lane = 20 x record + quad)
+            __syncthreads();
+            if ((((sq_vu32 *) misc)[0] & 0x80000000u) != 0u && wave <= SQ_TB) {
+                const unsigned long long c = ((sq_vu64 *) ctl)[wave];
+                const uint32_t head = (uint32_t) c, nq = (uint32_t) (c >> 32) - head;
+                uint32_t base = 0;
+                if (lane == 0u && nq) base = atomicAdd(P.tail_count, nq);
+                base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                const uint32_t sub = lane / (uint32_t) kSqTailQuads, quad = lane - sub * (uint32_t) kSqTailQuads;
+#pragma unroll 1
+                for (uint32_t r = sub; r < nq; r += 3u) {
+                    if (sub < 3u && base + r < P.tail_cap && quad < 11u + NB) {
+                        const uint32_t id_r = q_lds[wave * DRT_SQ_RING + ((head + r) & (DRT_SQ_RING - 1u))];
+                        uint4 v;
+                        if (quad < 7u) v = rec4[R4 * id_r + quad];
+                        else if (quad == 7u) v = make_uint4((uint32_t) wave, 0u, 0u, 0u);
+                        else if (quad < 11u) v = cold_a[3 * id_r + (quad - 8u)];
+                        else v = cold_b[NB * id_r + (quad - 11u)];
+                        P.tail_pool[(size_t) (base + r) * kSqTailQuads + quad] = v;
+                    }
+                }
+            }
+        }
+        close_records(P, rec);
+    }
 #if DRT_SQ_PROFILE == 6
     __syncthreads();
     if (COUNT && threadIdx.x < 160) {
@@ -1274,7 +1358,7 @@ static uint32_t sq_rays_for(const Params &P, size_t *bytes, bool *global_majoran
     for (int mg = DRT_SQ_FORCE_MG; mg < 2; ++mg) {
         if (mg && !(P.mocc && P.majorant)) break;
         const size_t words = mg ? (cells + 31) / 32 : (cells + 1) / 2;
-        const size_t fixed = (((words + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RING / 2 + 2 * SQ_KINDS + 4 + 4 + nwv * 8 + (DRT_SQ_PROFILE == 6 ? 160 : 0)) * 4;
+        const size_t fixed = (((words + 3) & ~(size_t) 3) + (size_t) SQ_KINDS * DRT_SQ_RING / 2 + 2 * SQ_KINDS + 4 + 8 + nwv * 8 + (DRT_SQ_PROFILE == 6 ? 160 : 0)) * 4;
         if (fixed >= cap) continue;
         size_t n = ((cap - fixed) / (7 * 16)) & ~(size_t) 63;
         if (n > DRT_SQ_MAX_RAYS) n = DRT_SQ_MAX_RAYS;
@@ -1285,6 +1369,9 @@ static uint32_t sq_rays_for(const Params &P, size_t *bytes, bool *global_majoran
     }
     return 0;
 }
+
+uint32_t sq_tail_push() { return DRT_SQ_TAIL_PUSH + 64; }   // (the hand-over's count of live records may be low by one batch)
+size_t sq_tail_entry_quads() { return kSqTailQuads; }
 
 size_t sq_cold_bytes(int n_cus) { return (size_t) n_cus * 12 * DRT_SQ_MAX_RAYS * sizeof(uint4); }   // (3 + 9: the quadratic estimator's adjoint records)
 
@@ -1305,15 +1392,19 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
     unsigned blocks = (unsigned) n_cus;                                         // one workgroup per CU
     const uint64_t need = (P.n_rays - P.ray_first + nray - 1) / nray;           // no more workgroups than groups of records
     if (need < blocks) blocks = (unsigned) need;
+    if (adjoint && P.tail_mode) blocks = blocks < (unsigned) DRT_SQ_TAIL_BLOCKS ? blocks : (unsigned) DRT_SQ_TAIL_BLOCKS;   // the tail launch: the pool's (few thousand) records over a few workgroups
+    else if (adjoint && P.tail_pool && (uint64_t) P.tail_cap < (uint64_t) blocks * (DRT_SQ_TAIL_PUSH + 64)) P.tail_pool = nullptr;   // (capacity invariant of the hand-over)
     dim3 block(DRT_SQ_THREADS), grid(blocks);
     const bool env = P.env_pix != nullptr;
     hipError_t e = hipSuccess;
     const bool quad = adjoint && P.use_drt && !P.use_drt_subsampling;           // quadratic DRT: the QUAD instantiations of the adjoint kernels
-#define DRT_SQ_LAUNCH(A, C, E) do { if (A && quad) { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, A); else DRT_SQ_LAUNCH_(A, C, E, false, A); } \
-                                    else { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, false); else DRT_SQ_LAUNCH_(A, C, E, false, false); } } while (0)
-#define DRT_SQ_LAUNCH_(A, C, E, M, Q)                                                                             \
+    const bool tailm = adjoint && P.tail_mode != 0u;
+#define DRT_SQ_LAUNCH(A, C, E) do { if (A && tailm) DRT_SQ_LAUNCH_Q(A, C, E, A); else DRT_SQ_LAUNCH_Q(A, C, E, false); } while (0)
+#define DRT_SQ_LAUNCH_Q(A, C, E, T) do { if (A && quad) { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, A, T); else DRT_SQ_LAUNCH_(A, C, E, false, A, T); } \
+                                    else { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, false, T); else DRT_SQ_LAUNCH_(A, C, E, false, false, T); } } while (0)
+#define DRT_SQ_LAUNCH_(A, C, E, M, Q, T)                                                                             \
     do {                                                                                                          \
-        auto kern = trace_sq_kernel<A, C, E, M, Q>;                                                               \
+        auto kern = trace_sq_kernel<A, C, E, M, Q, T>;                                                            \
         static std::atomic<size_t> lds_set[64];                                                                        \
         int dev_ = 0;                                                                                             \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 63;                               \
@@ -1336,6 +1427,7 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
         default: DRT_SQ_LAUNCH(true, true, true); break;
     }
 #undef DRT_SQ_LAUNCH
+#undef DRT_SQ_LAUNCH_Q
 #undef DRT_SQ_LAUNCH_
     return hipGetLastError();
 }
