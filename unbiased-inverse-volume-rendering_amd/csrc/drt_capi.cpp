@@ -1163,8 +1163,9 @@ int drt_render_backward(drt_handle h, const float *rays_o, const float *rays_d, 
     return rc;
 }
 
-static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, const float *emission)
+static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, const float *emission, bool fused_half = false)
 {
+    P.nerf_fused_half = fused_half ? 1 : 0;
     if (!cfg || !emission) return fail(h, DRT_ERR_INVALID_ARGUMENT, "nerf: null config / emission grid");
     if (cfg->queries_per_ray < 2) return fail(h, DRT_ERR_INVALID_ARGUMENT, "queries_per_ray must be >= 2");
     P.emission = emission; P.nerf_queries = cfg->queries_per_ray; P.nerf_jitter = cfg->jittering_enabled ? 1 : 0;
@@ -1172,9 +1173,34 @@ static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, c
     return DRT_OK;
 }
 
-int drt_nerf_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
-                           const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
-                           float *L_out)
+// The nerf adjoint of a filled job.  Sensor rays: drt_nerf_tile.hip (a workgroup per pixel tile, the splats pre-reduced in an LDS window and
+// flushed with atomics into the caller's grids: no records, no sub-batches); explicit ray batches - the optimisation loop's random pixels -
+// and test hook 512: the record path (nerf_kernel + drt_deferred.hip).  g4: lookups from the four-channel copy (the fused pass).
+static int nerf_backward(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, bool g4)
+{
+    if (drt::nerf_tile_supported(P) && !dbg(h->debug_flags, 512u)) {
+        hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };   // (tracer slot and whole-pass slot: the pass is this launch)
+        if (h->timing) {
+            for (auto &e : ev) DRT_HIP_CHECK(h, hipEventCreate(&e));
+            DRT_HIP_CHECK(h, hipEventRecord(ev[0], h->stream));
+            DRT_HIP_CHECK(h, hipEventRecord(ev[2], h->stream));
+        }
+        DRT_HIP_CHECK(h, drt::launch_nerf_tile_adjoint(P, g4, h->counting, (uint32_t *) h->d_queues, h->stream));
+        if (h->timing) {
+            DRT_HIP_CHECK(h, hipEventRecord(ev[1], h->stream));
+            DRT_HIP_CHECK(h, hipEventRecord(ev[3], h->stream));
+            h->timed[1].emplace_back(ev[0], ev[1]);
+            h->timed[3].emplace_back(ev[2], ev[3]);
+        }
+        return DRT_OK;
+    }
+    const uint32_t q = (uint32_t) cfg->queries_per_ray;          // at most one splat per query and plane
+    return run_backward(h, P, q, q, [&](drt::Params &Q) { return timed_nerf(h, 1, Q, true); });
+}
+
+static int nerf_primal(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
+                       const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
+                       float *L_out, bool fused_half)
 {
     if (h && n_rays == 0) return DRT_OK;
     int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp, false);
@@ -1183,11 +1209,18 @@ int drt_nerf_render_primal(drt_handle h, const drt_nerf_config *cfg, const float
     DeviceGuard g(h->device);
     drt::Params P;
     fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
-    rc = nerf_fill(h, P, cfg, emission);
+    rc = nerf_fill(h, P, cfg, emission, fused_half);
     if (rc) return rc;
     P.L_out = L_out;
     h->pcache_sig.valid = false;
     return timed_nerf(h, 0, P, false);
+}
+
+int drt_nerf_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
+                           const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
+                           float *L_out)
+{
+    return nerf_primal(h, cfg, emission, rays_o, rays_d, n_rays, ray_offset, spp, seed, L_out, false);
 }
 
 int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
@@ -1205,8 +1238,7 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
     rc = nerf_fill(h, P, cfg, emission);
     if (rc) return rc;
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_emission;
-    const uint32_t q = (uint32_t) cfg->queries_per_ray;          // at most one splat per query and plane
-    return run_backward(h, P, q, q, [&](drt::Params &Q) { return timed_nerf(h, 1, Q, true); });
+    return nerf_backward(h, P, cfg, false);
 }
 
 // ---- fused nerf + volpathsimple pass (BASELINE config 5; drt_fused.hip) ---------------------------------------------
@@ -1229,34 +1261,13 @@ static int ensure_grid4(drt_handle h, drt::Params &P)
     return DRT_OK;
 }
 
-static int fused_prepare(drt_handle h, drt::Params &P, const drt_nerf_config *cfg)
-{
-    if (!cfg) return fail(h, DRT_ERR_INVALID_ARGUMENT, "fused: null nerf config");
-    if (cfg->queries_per_ray < 2) return fail(h, DRT_ERR_INVALID_ARGUMENT, "queries_per_ray must be >= 2");
-    // (either emitter, either kind of majorant: drt_fused.hip and its three sibling translation units)
-    const int rc = ensure_grid4(h, P);
-    if (rc) return rc;
-    P.nerf_queries = cfg->queries_per_ray; P.nerf_jitter = cfg->jittering_enabled ? 1 : 0;
-    P.nerf_relu = cfg->activation_relu ? 1 : 0; P.hide_emitters_nerf = cfg->hide_emitters ? 1 : 0;
-    return DRT_OK;
-}
-
-static int timed_fused(drt_handle h, int which, const drt::Params &P, bool adjoint)
-{
-    hipEvent_t a = nullptr, b = nullptr;
-    if (h->timing) {
-        DRT_HIP_CHECK(h, hipEventCreate(&a));
-        DRT_HIP_CHECK(h, hipEventCreate(&b));
-        DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
-    }
-    DRT_HIP_CHECK(h, drt::launch_fused(P, adjoint, h->counting, h->stream));
-    if (h->timing) {
-        DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
-        h->timed[which].emplace_back(a, b);
-    }
-    return DRT_OK;
-}
-
+// The fused pass = the two integrators over the SAME rays and the same four grids, each on its own copy of the sampler stream (round 5: as two
+// dense passes - rounds 3/4 ran both halves in one kernel, drt_fused*.hip, whose nerf half emitted one gradient record per query: 907 M
+// records per step of config 5, 25 of the adjoint pass's 46 ms in the reduction; and whose volpathsimple half ran one path per lane at a third
+// of the lanes).  Now: the nerf march as the stand-alone integrator with emission = the medium's albedo grid (primal: nerf_kernel; adjoint for
+// sensor rays: drt_nerf_tile.hip, lookups from the four-channel copy, splats pre-reduced in LDS), and the volpathsimple half through
+// drt_render_primal / drt_render_backward - i.e. the queued supergrid tracer or the wave-cooperative tracer, path cache, record streams and
+// ONE tile_reduce.  Results: radiance of both halves bit-exact as before (the same statements per ray), gradients up to summation order.
 int drt_fused_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
                             uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_nerf_out, float *L_drt_out)
 {
@@ -1264,17 +1275,10 @@ int drt_fused_render_primal(drt_handle h, const drt_nerf_config *cfg, const floa
     int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp);
     if (rc) return rc;
     if (!L_nerf_out || !L_drt_out) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_fused_render_primal: null output buffer");
-    DeviceGuard g(h->device);
-    drt::Params P;
-    fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
-    rc = fused_prepare(h, P, cfg);
+    if (!cfg) return fail(h, DRT_ERR_INVALID_ARGUMENT, "fused: null nerf config");
+    rc = nerf_primal(h, cfg, h->base.albedo, rays_o, rays_d, n_rays, ray_offset, spp, seed, L_nerf_out, true);
     if (rc) return rc;
-    P.L_out = L_drt_out; P.L_out2 = L_nerf_out;
-    h->pcache_sig.valid = false;
-    bind_path_cache_write(h, P);
-    P.block_cost = nullptr;                                      // (the fused kernel keeps the plain XCD block map)
-    h->order_valid = false;
-    return timed_fused(h, 0, P, false);
+    return drt_render_primal(h, rays_o, rays_d, n_rays, ray_offset, spp, seed, L_drt_out);      // (last: its path cache serves the backward pass)
 }
 
 int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
@@ -1286,29 +1290,19 @@ int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const fl
     if (rc) return rc;
     if (!dL_nerf || !L_nerf_in || !dL_drt || !L_drt_in || !grad_sigma_t || !grad_rgb)
         return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_fused_render_backward: null dL / L_in / gradient buffer");
-    DeviceGuard g(h->device);
-    drt::Params P;
-    fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
-    rc = fused_prepare(h, P, cfg);
-    if (rc) return rc;
-    P.dL = dL_drt; P.L_in = L_drt_in; P.dL2 = dL_nerf; P.L_in2 = L_nerf_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_rgb;
-    {   // the fused adjoint only exists on the deferred path: grids beyond kMaxBins tiles are not supported
-        const int ntx = (P.rx + drt::kTileX - 1) / drt::kTileX, nty = (P.ry + drt::kTileY - 1) / drt::kTileY, ntz = (P.rz + drt::kTileZ - 1) / drt::kTileZ;
-        if ((int64_t) ntx * nty * ntz > drt::kMaxBins) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the fused adjoint pass");
+    {
+        DeviceGuard g(h->device);
+        drt::Params P;
+        fill_job(h, P, rays_o, rays_d, n_rays, ray_offset, spp, seed);
+        rc = nerf_fill(h, P, cfg, h->base.albedo, true);
+        if (rc) return rc;
+        P.dL = dL_nerf; P.L_in = L_nerf_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_rgb;
+        const bool tile = drt::nerf_tile_supported(P) && !dbg(h->debug_flags, 512u);
+        if (tile) { rc = ensure_grid4(h, P); if (rc) return rc; }   // (sigma_t and the colour of a query from ONE 256-byte block)
+        rc = nerf_backward(h, P, cfg, tile);
+        if (rc) return rc;
     }
-    const uint64_t job_rays = n_rays;
-    const uint32_t q = (uint32_t) cfg->queries_per_ray;
-    const uint32_t saved = h->debug_flags;
-    h->debug_flags &= ~(128u | 2u | 32u);                         // (the atomic-path test hooks do not apply here)
-    rc = run_backward(h, P, 48 + q, 6 + q, [&](drt::Params &Q) {
-        if (!Q.rec_buf[0]) return fail(h, DRT_ERR_HIP, "not enough device memory for the record streams of the fused adjoint pass");
-        bind_path_cache_read(h, Q, job_rays);
-        Q.block_order = nullptr;
-        return timed_fused(h, 1, Q, true);
-    });
-    h->debug_flags = saved;
-    h->pcache_sig.valid = false;
-    return rc;
+    return drt_render_backward(h, rays_o, rays_d, n_rays, ray_offset, spp, seed, dL_drt, L_drt_in, grad_sigma_t, grad_rgb);
 }
 
 int drt_batch_sample_rays_range(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_first,

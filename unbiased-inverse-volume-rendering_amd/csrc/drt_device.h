@@ -36,7 +36,7 @@ __host__ __device__ __forceinline__ constexpr bool dbg(uint32_t flags, uint32_t 
 
 // Experiment switches (timing / profiling builds made by tools/mk_variant.sh; several of them give WRONG results on purpose)
 // must never leak into a shipped library: they only compile with -DDRT_EXPERIMENT_BUILD.
-#if !defined(DRT_EXPERIMENT_BUILD) && (defined(DRT_FAST_MATH) || defined(DRT_ENV_EXP) || defined(DRT_EXP_ALB) || defined(DRT_EXP_DROP_TAIL) || \
+#if !defined(DRT_EXPERIMENT_BUILD) && (defined(DRT_FAST_MATH) || defined(DRT_ENV_EXP) || defined(DRT_EXP_ALB) || defined(DRT_EXP_DROP_TAIL) || defined(DRT_NT_STATS) || \
                                        (defined(DRT_SQ_PROFILE) && DRT_SQ_PROFILE != 0))
 #error "experiment switch without -DDRT_EXPERIMENT_BUILD (tools/mk_variant.sh adds it): not for a shipped library"
 #endif
@@ -246,10 +246,8 @@ struct Params {
     // nerf integrator (python/integrators/nerf.py): emission grid (Z,Y,X,3) and properties
     const float *emission;
     int nerf_queries, nerf_jitter, nerf_relu;
-    // fused nerf + volpathsimple pass (drt_fused.hip): the nerf half's own outputs / adjoint inputs and hide_emitters
-    float *L_out2;
-    const float *dL2, *L_in2;
-    int hide_emitters_nerf;
+    // 1: this nerf march is one half of the fused nerf + volpathsimple pass (drt_fused_render_*): its rays are counted by the other half
+    int nerf_fused_half;
     // integrator flags
     int hide_emitters, use_nee, use_drt, use_drt_subsampling, use_drt_mis, max_depth, rr_depth;
     // sensor (mi.render flow)

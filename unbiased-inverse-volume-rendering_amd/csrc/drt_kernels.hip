@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(256) nerf_kernel(const Params P)
     }
     if constexpr (ADJ && DEFER) close_records(P, rec);
     if (COUNT) {
-        uint32_t vals[C_COUNT] = { n_rays, n_q, 0, 0, n_q, 0, 0, ADJ ? n_q : 0u, ADJ ? n_q : 0u };
+        uint32_t vals[C_COUNT] = { P.nerf_fused_half ? 0u : n_rays, n_q, 0, 0, n_q, 0, 0, ADJ ? n_q : 0u, ADJ ? n_q : 0u };
 #pragma unroll
         for (int s = 0; s < C_COUNT; ++s) {
             uint32_t v = vals[s];

@@ -16,6 +16,11 @@ hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int sh
 hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int nbx, int nby,
                               hipStream_t stream);
 hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream);
+// drt_nerf_tile.hip: the nerf adjoint for sensor rays - a workgroup per pixel tile, its splats pre-reduced in an LDS window of 16^3 voxels, no records
+// (g4: lookups from Params::grid4 - the fused pass, emission = the medium's albedo grid - instead of sigma_b + Params::emission)
+bool nerf_tile_supported(const Params &P);
+// bounds: 16 bytes of device scratch (the fixed-point units of the LDS window follow from max |dL|, max |L_in|, max |emission|, reduced there first)
+hipError_t launch_nerf_tile_adjoint(const Params &P, bool g4, bool count, uint32_t *bounds, hipStream_t stream);
 hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
 // supergrid scenes (majorant_resolution_factor > 0): lane-level state machine stepping one supergrid cell at a time, the
 // majorant grid in LDS (drt_super.hip); the adjoint needs the record streams (deferred splatting)
@@ -48,12 +53,8 @@ hipError_t launch_trace_coop(const Params &P, bool adjoint, bool count, hipStrea
 hipError_t launch_ray_perm(const uint8_t *iters, uint64_t n_rays, uint16_t *perm, uint32_t *block_cost, hipStream_t stream);
 hipError_t launch_block_order(const uint32_t *cost, uint32_t n_blocks, uint32_t *order, bool heavy_first, hipStream_t stream);
 hipError_t launch_untile(const Params &P, hipStream_t stream);
-// fused nerf + volpathsimple pass over the interleaved four-channel grid (drt_fused.hip)
+// the interleaved four-channel apron-brick copy [sigma_t, r, g, b] of the medium (eval4; drt_nerf_tile.hip)
 hipError_t launch_brick_grid4(const float *sigma_t, const float *rgb, float4 *dst, int rx, int ry, int rz, int nbx, hipStream_t stream);
-hipError_t launch_fused(const Params &P, bool adjoint, bool count, hipStream_t stream);   // picks one of the four below
-hipError_t launch_fused_env(const Params &P, bool adjoint, bool count, hipStream_t stream);
-hipError_t launch_fused_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
-hipError_t launch_fused_env_super(const Params &P, bool adjoint, bool count, hipStream_t stream);
 
 // Deferred splatting (drt_deferred.hip): record streams -> tile partition -> LDS reduction.
 constexpr int kTileX = 32, kTileY = 16, kTileZ = 16;   // base-corner cells per tile; LDS tile = 33 x 17 x 17 floats
