@@ -476,10 +476,11 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
                                     "algorithmic_bytes": b_p},
                 "roofline_note": "SURVEY 8d convention (every lookup / splat priced as an independent 8-corner access); "
                                  "consecutive march steps of one ray share cache lines, so lookup_rate_* is a lookup rate served "
-                                 "mostly by L2 and can exceed 1 - `frac` is the counter traffic; the pass is bound by tile_reduce's "
-                                 "LDS adds (secondary.tile_reduce)",
-                "workload": "config 5 as BASELINE states it: nerf (128 queries) FUSED with volpathsimple-drt in one pass over the "
-                            "interleaved [sigma_t,r,g,b] grid, 256^3, 512x512x32spp"}
+                                 "mostly by L2 and can exceed 1 - `frac` is the counter traffic.  Round 5: the nerf half's splats are "
+                                 "pre-reduced in an LDS window (drt_nerf_tile.hip, ds_add_u64 fixed point) and reach the grids as ~1e8 "
+                                 "atomics per step instead of 907 M records; the volpathsimple half runs through the production tracers",
+                "workload": "config 5 as BASELINE states it: nerf (128 queries) together with volpathsimple-drt over ONE set of grids "
+                            "[sigma_t,r,g,b] (emission = albedo), one call per pass, gradients of both into one pair of grids; 256^3, 512x512x32spp"}
 
     guarded("config2_smoke128_512x16", cfg2)
     guarded("headline_global_majorant" if main_factor else "headline_majorant_factor8", other_factor)

@@ -168,17 +168,17 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
                              const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
                              const float *dL, const float *L_in, float *grad_sigma_t, float *grad_emission);
 
-/* BASELINE config 5: the `nerf` march and volpathsimple scattering FUSED in one pass over one interleaved
- * four-channel [sigma_t, r, g, b] grid.  The reference's scenes bind ONE asset as the medium's albedo and emission
- * grid (python/scene_config.py:109-110), so the colour grid given to drt_set_medium as `albedo` is both: the library
- * keeps an interleaved 16-byte-voxel apron-brick copy of sigma_t + colour (rebuilt after drt_set_medium /
- * drt_params_changed).  Per ray, the pass computes NeRFIntegrator.sample (nerf.py:47-148; `cfg`) and
- * VolpathSimpleIntegrator.sample (volpathsimple.py:38-290; the handle's drt_config) from the same camera ray and the
- * same PCG32 stream, each bit-identical to its stand-alone call; the backward pass accumulates BOTH integrators'
- * gradients into grad_sigma_t (Z,Y,X,1) and grad_rgb (Z,Y,X,3) (albedo gradient + emission gradient: one parameter).
- * Either emitter (constant, environment map) and either kind of majorant (global, supergrid: the volpathsimple half then
- * tracks through the supergrid on every path's own lane) - the reference's nerf scenes use an environment map and
- * majorant_resolution_factor 8 (python/scene_config.py:36,102-141).  Ray / seed conventions as for drt_render_*. */
+/* BASELINE config 5: the `nerf` march and volpathsimple scattering over ONE set of grids [sigma_t, r, g, b] in one call.
+ * The reference's scenes bind ONE asset as the medium's albedo and emission grid (python/scene_config.py:109-110), so the
+ * colour grid given to drt_set_medium as `albedo` is both.  Per ray, the pass computes NeRFIntegrator.sample (nerf.py:47-148;
+ * `cfg`) and VolpathSimpleIntegrator.sample (volpathsimple.py:38-290; the handle's drt_config) from the same camera ray, each
+ * on its own copy of the same PCG32 stream and bit-identical to its stand-alone call; the backward pass accumulates BOTH
+ * integrators' gradients into grad_sigma_t (Z,Y,X,1) and grad_rgb (Z,Y,X,3) (albedo gradient + emission gradient: one
+ * parameter).  Round 5: two dense passes over the rays instead of one kernel - the nerf march (adjoint of sensor rays:
+ * drt_nerf_tile.hip, lookups from an interleaved 16-byte-voxel apron-brick copy of sigma_t + colour, voxel gradients
+ * pre-reduced in LDS) and the volpathsimple half through the production tracers of drt_render_* (queued supergrid tracer /
+ * wave-cooperative tracer, path cache, deferred records) - any emitter, any kind of majorant.  Ray / seed conventions as
+ * for drt_render_*. */
 int drt_fused_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
                             uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_nerf_out, float *L_drt_out);
 int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
@@ -281,7 +281,8 @@ int drt_debug_eval(drt_handle h, int op, const float *in, uint64_t n, float *out
  * kernel for the adjoint too; bit 7 (128): gradient splats as atomics into the apron scratch (the path
  * used when the grid has more than 4096 tiles or the record streams exceed the memory budget) instead
  * of deferred records; bit 8 (256): two-chunk record streams (exercises the out-of-chunks fallback);
- * bits 9, 10 (512, 1024): reduction without LDS adds / without the flush (timing only); bit 11 (2048):
+ * bit 9 (512): the nerf adjoint of sensor rays through the record path (nerf_kernel + deferred splatting, as explicit ray batches go)
+ * instead of the LDS-window kernel drt_nerf_tile.hip; bit 10 (1024): reduction without the flush (timing only); bit 11 (2048):
  * overlap the tracer of ray sub-batch b with the reduction of sub-batch b - 1 on a side stream (also
  * DRT_PIPELINE in the environment; measured slower); bit 13
  * (8192): exact checksum of the flushed sums; bit 14 (16384): 8 MB record budget, i.e. many ray

@@ -26,11 +26,12 @@ def _h1(uivr, sg, integ, spp, seed):
     return img, grads
 
 
-@pytest.mark.parametrize("flags", [0, 128, 256])
+@pytest.mark.parametrize("flags", [0, 512, 512 | 128, 512 | 256])
 @pytest.mark.parametrize("props", [dict(), dict(queries_per_ray=64, activation="relu"),
                                    dict(queries_per_ray=17, jittering_enabled=False, hide_emitters=True)])
 def test_nerf_matches_oracle(uivr, oracle, gpu, props, flags):
-    """flags: 0 = deferred tile-binned splatting (production), 128 = atomics into the apron scratch,
+    """flags: 0 = production: the adjoint of sensor rays pre-reduces its splats in an LDS window (drt_nerf_tile.hip, round 5); 512 = the record
+    path that explicit ray batches take (nerf_kernel + deferred tile-binned splatting), with 128 = atomics into the apron scratch,
     256 = two-chunk record streams (out-of-chunks fallback)."""
     scene = uivr.cube_test_scene(32, 32, density_scale=1.5)
     if props.get("activation") == "relu":
@@ -110,3 +111,53 @@ def test_nerf_autograd_and_errors(uivr, gpu):
                                               bbox_max=sg.medium.bbox_max), emitter=sg.emitter, sensors=sg.sensors)
     with pytest.raises(TypeError):
         uivr.render_primal(no_em, integ, 0, 1, 1)
+
+
+@pytest.mark.parametrize("film,chunk,spp,props", [((33, 26), 33, 5, dict(queries_per_ray=40)), ((16, 40), 40, 19, dict(queries_per_ray=24, activation="relu")),
+                                                  ((24, 24), 48, 1, dict())])
+def test_nerf_tile_adjoint_equals_the_record_path(uivr, gpu, film, chunk, spp, props):
+    """drt_nerf_tile.hip against nerf_kernel + drt_deferred.hip (test hook 512) where the tile mapping is ragged: films that are no multiple of
+    the 8 x 8 tile, spp that is no multiple of a workgroup's 16 samples, a launch over a window of the film (ray_offset: most tiles hold
+    none of its rays) and the interleaved chunks of a sharded render (ShardSpec).  Same statements per ray: gradients up to summation order."""
+    rng = np.random.default_rng(11)
+    st = (rng.random((20, 18, 22, 1), dtype=np.float32) * 3.0).astype(np.float32)
+    st[rng.random(st.shape) < 0.5] = 0.0
+    if props.get("activation") == "relu":
+        st[3:6, 3:6, 3:6] = -0.4
+    em = (rng.random((20, 18, 22, 3), dtype=np.float32) * 0.9).astype(np.float32)
+    medium = uivr.GridMedium(sigma_t=st, albedo=em.copy(), emission=em, bbox_min=(-1, -0.9, -1.1), bbox_max=(1, 0.9, 1.1), scale=1.3)
+    sensor = uivr.PerspectiveSensor(origin=(2.5, 1.5, 3.0), target=(0, 0, 0), fov=40.0, width=film[0], height=film[1])
+    sg = uivr.scene_to(uivr.Scene(medium=medium, emitter=uivr.ConstantEmitter((0.3, 0.4, 0.5)), sensors=[sensor]), gpu)
+    n_pix, seed = film[0] * film[1], 99
+    out = {}
+    for name, flags in (("tile", 0), ("records", 512)):
+        integ = uivr.load_dict(dict(type="nerf", test_hooks=True, **props))
+        integ.native_handle(sg).set_debug_flags(flags)
+        cases = {}
+        # the whole film
+        img = uivr.render_primal(sg, integ, 0, spp, seed)
+        gi = ((2.0 / (n_pix * 3)) * (img - 0.4)).contiguous()
+        cases["film"] = uivr.render_backward(sg, integ, gi, 0, spp, seed)["_flat"].clone()
+        # the two shards of a sharded render, interleaved chunks of pixels
+        for rank in range(2):
+            sh = uivr.ShardSpec(rank, 2, chunk_pixels=chunk)
+            li = uivr.render_primal(sg, integ, 0, spp, seed, shard=sh)
+            cases[f"shard{rank}"] = uivr.render_backward(sg, integ, gi[sh.pixel_indices(n_pix, gpu)].contiguous(), 0, spp, seed, shard=sh)["_flat"].clone()
+            assert torch.equal(li, img[sh.pixel_indices(n_pix, gpu)])
+        # a window of rays in the middle of the film
+        first, n = (n_pix // 3) * spp + 2, (n_pix // 4) * spp
+        wb = uivr.RayBatch(n_rays=n, spp=spp, sensor=sg.sensors[0], ray_offset=first)
+        samp = uivr.IndependentSampler(seed, spp)
+        L, _, stt = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), wb)
+        dL = ((torch.arange(n * 3, device=gpu, dtype=torch.float32).reshape(n, 3) % 7) - 3.0) * 1e-3
+        grads = uivr.alloc_grads(sg, integ.param_keys)
+        integ.sample(uivr.ADMode.Backward, sg, samp, wb, δL=dL, state_in=stt, grads=grads)
+        cases["window"] = grads["_flat"].clone()
+        integ.native_handle(sg).set_debug_flags(0)
+        out[name] = cases
+    for k in out["tile"]:
+        a, b = out["tile"][k], out["records"][k]
+        assert float(b.abs().max()) > 0
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), k
+    total = out["tile"]["shard0"] + out["tile"]["shard1"]
+    assert float((total - out["tile"]["film"]).abs().max()) <= 2e-5 * float(total.abs().max())
