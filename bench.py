@@ -80,7 +80,7 @@ def committed_secondary(key, counters_adjoint):
            "kernels": {}}
     for k, v in util.items():
         counting = "<true, true" in k or "<false, true" in k                      # (the instantiation the counter step runs)
-        if ("trace_" in k or "fused_kernel" in k) and not counting and (v.get("avg_ms") or 0) > 0.05:
+        if ("trace_" in k or "nerf_tile_adjoint" in k or "nerf_kernel" in k) and not counting and (v.get("avg_ms") or 0) > 0.05:
             out["kernels"][k] = {"avg_ms": v["avg_ms"], "lanes_active": v["lanes_active"], "valu_busy": v["valu_busy"]}
     tr = next((v for k, v in util.items() if "tile_reduce_kernel" in k), None)
     if tr and (tr.get("ms_per_step") or tr.get("avg_ms")) and counters_adjoint:

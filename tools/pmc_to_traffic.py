@@ -41,10 +41,10 @@ for k in acc:
     detail[k] = {"read_bytes": rd, "write_bytes": wr, "total": rd + wr, "fetch_size_kib": mean(k, "FETCH_SIZE"),
                  "write_size_kib": mean(k, "WRITE_SIZE"), "atomics": mean(k, "TCC_EA0_ATOMIC_sum"),
                  "launches_seen": len(acc[k].get("TCC_EA0_RDREQ_sum", []))}
-adj = [k for k in detail if "trace_kernel<true, false" in k or "trace_coop_kernel<true, false" in k or "trace_super_kernel<true, false" in k or "trace_sq_kernel<true, false" in k or "fused_kernel<true, false" in k or
-       "bin_" in k or "tile_reduce" in k or "untile" in k]
+adj = [k for k in detail if "trace_kernel<true, false" in k or "trace_coop_kernel<true, false" in k or "trace_super_kernel<true, false" in k or "trace_sq_kernel<true, false" in k or "nerf_tile_" in k or
+       "bin_" in k or "tile_reduce" in k or "untile" in k]      # (nerf_tile_*: the nerf half of the fused pass - adjoint kernel + its bounds reduction)
 pri = [k for k in detail if "trace_wavefront_kernel<false, false" in k or "trace_coop_kernel<false, false" in k or "trace_super_kernel<false, false" in k or
-       "trace_sq_kernel<false, false" in k or "fused_kernel<false, false" in k]
+       "trace_sq_kernel<false, false" in k or "nerf_kernel<false, false" in k]
 sha = kernel_source_sha16()
 res = {}
 if os.path.exists(out):

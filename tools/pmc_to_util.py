@@ -46,7 +46,7 @@ for r in csv.DictReader(open(stats)):
     calls[short(r["Name"])] = int(r["Calls"])
 # launches of a primal tracer kernel (counting instantiation included) = steps of the profiled command
 steps = sum(c for k, c in calls.items() if any(t in k for t in ("trace_sq_kernel<false", "trace_coop_kernel<false", "trace_super_kernel<false",
-                                                                "trace_wavefront_kernel<false", "fused_kernel<false")))
+                                                                "trace_wavefront_kernel<false")))
 util = {}
 for k in acc:
     m = lambda c: (sum(acc[k][c]) / len(acc[k][c])) if acc[k].get(c) else 0.0
