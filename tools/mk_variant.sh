@@ -17,7 +17,8 @@ for o in $csrc/_obj/*.o; do
   [ $skip == 0 ] && objs+=($o)
 done
 for s in "${srcs[@]}"; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -DDRT_EXPERIMENT_BUILD=1 $defs -c $csrc/$s -o $out/$s.o
+  unit=""; [ "$s" == "drt_sq.hip" ] && unit="-O2"          # (as _build.py: UNIT_FLAGS)
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -DDRT_EXPERIMENT_BUILD=1 $unit $defs -c $csrc/$s -o $out/$s.o
   objs+=($out/$s.o)
 done
 hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o $out/libdrt_hip.so

@@ -70,6 +70,9 @@ struct drt_handle_s {
     void *d_sq_tail = nullptr;                // tail pool of the queued tracer's adjoint launches: 256-byte header {count, .., dummy cursors} + entries
     size_t sq_tail_bytes = 0;
     hipEvent_t ev_split = nullptr, ev_hist = nullptr;
+    hipStream_t nerf_stream = nullptr;  // the nerf half of the fused pass runs beside the volpathsimple half (drt_fused_render_*)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t *d_nerf_bounds = nullptr; // 16 bytes: max |dL|, |L_in|, |emission| of a nerf tile adjoint launch (drt_nerf_tile.hip)
     // path cache (drt_coop.hip): written by the primal launch of an H1 step, read by the adjoint launch of the
     // same job if nothing happened to the handle in between
     void *d_pcache = nullptr;          // [rays][kPathCacheCap][2] uint4 | [rays] hash words
@@ -697,17 +700,18 @@ int timed_reduce(drt_handle h, const drt::Params &P, const drt::DeferredPlan &D,
     return DRT_OK;
 }
 
-int timed_nerf(drt_handle h, int which, const drt::Params &P, bool adjoint)
+int timed_nerf(drt_handle h, int which, const drt::Params &P, bool adjoint, hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     hipEvent_t a = nullptr, b = nullptr;
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventCreate(&a));
         DRT_HIP_CHECK(h, hipEventCreate(&b));
-        DRT_HIP_CHECK(h, hipEventRecord(a, h->stream));
+        DRT_HIP_CHECK(h, hipEventRecord(a, st));
     }
-    DRT_HIP_CHECK(h, drt::launch_nerf(P, adjoint, h->counting, h->stream));
+    DRT_HIP_CHECK(h, drt::launch_nerf(P, adjoint, h->counting, st));
     if (h->timing) {
-        DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
+        DRT_HIP_CHECK(h, hipEventRecord(b, st));
         h->timed[which].emplace_back(a, b);
     }
     return DRT_OK;
@@ -798,6 +802,10 @@ int drt_destroy(drt_handle h)
         if (R.reduced) (void) hipEventDestroy(R.reduced);
     }
     if (h->side) (void) hipStreamDestroy(h->side);
+    if (h->nerf_stream) (void) hipStreamDestroy(h->nerf_stream);
+    if (h->ev_fork) (void) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void) hipEventDestroy(h->ev_join);
+    if (h->d_nerf_bounds) (void) hipFree(h->d_nerf_bounds);
     if (h->ev_split) (void) hipEventDestroy(h->ev_split);
     if (h->ev_hist) (void) hipEventDestroy(h->ev_hist);
     if (h->d_pcache) (void) hipFree(h->d_pcache);
@@ -1176,19 +1184,21 @@ static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, c
 // The nerf adjoint of a filled job.  Sensor rays: drt_nerf_tile.hip (a workgroup per pixel tile, the splats pre-reduced in an LDS window and
 // flushed with atomics into the caller's grids: no records, no sub-batches); explicit ray batches - the optimisation loop's random pixels -
 // and test hook 512: the record path (nerf_kernel + drt_deferred.hip).  g4: lookups from the four-channel copy (the fused pass).
-static int nerf_backward(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, bool g4)
+static int nerf_backward(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, bool g4, hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     if (drt::nerf_tile_supported(P) && !dbg(h->debug_flags, 512u)) {
         hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };   // (tracer slot and whole-pass slot: the pass is this launch)
         if (h->timing) {
             for (auto &e : ev) DRT_HIP_CHECK(h, hipEventCreate(&e));
-            DRT_HIP_CHECK(h, hipEventRecord(ev[0], h->stream));
-            DRT_HIP_CHECK(h, hipEventRecord(ev[2], h->stream));
+            DRT_HIP_CHECK(h, hipEventRecord(ev[0], st));
+            DRT_HIP_CHECK(h, hipEventRecord(ev[2], st));
         }
-        DRT_HIP_CHECK(h, drt::launch_nerf_tile_adjoint(P, g4, h->counting, (uint32_t *) h->d_queues, h->stream));
+        if (!h->d_nerf_bounds) DRT_HIP_CHECK(h, hipMalloc((void **) &h->d_nerf_bounds, 16));
+        DRT_HIP_CHECK(h, drt::launch_nerf_tile_adjoint(P, g4, h->counting, h->d_nerf_bounds, st));
         if (h->timing) {
-            DRT_HIP_CHECK(h, hipEventRecord(ev[1], h->stream));
-            DRT_HIP_CHECK(h, hipEventRecord(ev[3], h->stream));
+            DRT_HIP_CHECK(h, hipEventRecord(ev[1], st));
+            DRT_HIP_CHECK(h, hipEventRecord(ev[3], st));
             h->timed[1].emplace_back(ev[0], ev[1]);
             h->timed[3].emplace_back(ev[2], ev[3]);
         }
@@ -1200,7 +1210,7 @@ static int nerf_backward(drt_handle h, drt::Params &P, const drt_nerf_config *cf
 
 static int nerf_primal(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
                        const float *rays_d, uint64_t n_rays, uint64_t ray_offset, uint32_t spp, uint32_t seed,
-                       float *L_out, bool fused_half)
+                       float *L_out, bool fused_half, hipStream_t st = nullptr)
 {
     if (h && n_rays == 0) return DRT_OK;
     int rc = check_job(h, rays_o, rays_d, n_rays, ray_offset, spp, false);
@@ -1212,8 +1222,8 @@ static int nerf_primal(drt_handle h, const drt_nerf_config *cfg, const float *em
     rc = nerf_fill(h, P, cfg, emission, fused_half);
     if (rc) return rc;
     P.L_out = L_out;
-    h->pcache_sig.valid = false;
-    return timed_nerf(h, 0, P, false);
+    if (!fused_half) h->pcache_sig.valid = false;
+    return timed_nerf(h, 0, P, false, st);
 }
 
 int drt_nerf_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *emission, const float *rays_o,
@@ -1268,6 +1278,28 @@ static int ensure_grid4(drt_handle h, drt::Params &P)
 // sensor rays: drt_nerf_tile.hip, lookups from the four-channel copy, splats pre-reduced in LDS), and the volpathsimple half through
 // drt_render_primal / drt_render_backward - i.e. the queued supergrid tracer or the wave-cooperative tracer, path cache, record streams and
 // ONE tile_reduce.  Results: radiance of both halves bit-exact as before (the same statements per ray), gradients up to summation order.
+// the nerf half on its own stream beside the volpathsimple half: fork behind what the handle's stream holds so far (the caller's zeroed gradient
+// buffers, the four-channel copy), join before the call returns.  The two halves write disjoint radiance buffers and add to the gradient grids
+// with atomics only (the window flush of drt_nerf_tile.hip, tile_reduce's flush, direct splats): no order between them is needed.
+static int fused_fork(drt_handle h)
+{
+    if (!h->nerf_stream) {
+        DRT_HIP_CHECK(h, hipStreamCreateWithFlags(&h->nerf_stream, hipStreamNonBlocking));
+        DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    DRT_HIP_CHECK(h, hipEventRecord(h->ev_fork, h->stream));
+    DRT_HIP_CHECK(h, hipStreamWaitEvent(h->nerf_stream, h->ev_fork, 0));
+    return DRT_OK;
+}
+
+static int fused_join(drt_handle h)
+{
+    DRT_HIP_CHECK(h, hipEventRecord(h->ev_join, h->nerf_stream));
+    DRT_HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    return DRT_OK;
+}
+
 int drt_fused_render_primal(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
                             uint64_t ray_offset, uint32_t spp, uint32_t seed, float *L_nerf_out, float *L_drt_out)
 {
@@ -1276,9 +1308,19 @@ int drt_fused_render_primal(drt_handle h, const drt_nerf_config *cfg, const floa
     if (rc) return rc;
     if (!L_nerf_out || !L_drt_out) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_fused_render_primal: null output buffer");
     if (!cfg) return fail(h, DRT_ERR_INVALID_ARGUMENT, "fused: null nerf config");
-    rc = nerf_primal(h, cfg, h->base.albedo, rays_o, rays_d, n_rays, ray_offset, spp, seed, L_nerf_out, true);
-    if (rc) return rc;
-    return drt_render_primal(h, rays_o, rays_d, n_rays, ray_offset, spp, seed, L_drt_out);      // (last: its path cache serves the backward pass)
+    {
+        DeviceGuard g(h->device);
+        rc = fused_fork(h);
+        if (rc) return rc;
+    }
+    rc = nerf_primal(h, cfg, h->base.albedo, rays_o, rays_d, n_rays, ray_offset, spp, seed, L_nerf_out, true, h->nerf_stream);
+    int rc2 = rc ? rc : drt_render_primal(h, rays_o, rays_d, n_rays, ray_offset, spp, seed, L_drt_out);   // (its path cache serves the backward pass)
+    {
+        DeviceGuard g(h->device);
+        const int rj = fused_join(h);
+        if (!rc2) rc2 = rj;
+    }
+    return rc2;
 }
 
 int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const float *rays_o, const float *rays_d, uint64_t n_rays,
@@ -1290,6 +1332,8 @@ int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const fl
     if (rc) return rc;
     if (!dL_nerf || !L_nerf_in || !dL_drt || !L_drt_in || !grad_sigma_t || !grad_rgb)
         return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_fused_render_backward: null dL / L_in / gradient buffer");
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    size_t n_pass = 0;
     {
         DeviceGuard g(h->device);
         drt::Params P;
@@ -1299,10 +1343,33 @@ int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const fl
         P.dL = dL_nerf; P.L_in = L_nerf_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_rgb;
         const bool tile = drt::nerf_tile_supported(P) && !dbg(h->debug_flags, 512u);
         if (tile) { rc = ensure_grid4(h, P); if (rc) return rc; }   // (sigma_t and the colour of a query from ONE 256-byte block)
-        rc = nerf_backward(h, P, cfg, tile);
+        if (h->timing) {
+            DRT_HIP_CHECK(h, hipEventCreate(&t0));
+            DRT_HIP_CHECK(h, hipEventCreate(&t1));
+            DRT_HIP_CHECK(h, hipEventRecord(t0, h->stream));
+            n_pass = h->timed[3].size();
+        }
+        // the tile kernel (one workgroup of 16 waves and 139 KiB of LDS per CU) leaves room for the wave-cooperative tracer's workgroups beside it;
+        // the record path of explicit ray batches shares the handle's record streams with the volpathsimple half: one after the other
+        if (tile) {
+            rc = fused_fork(h);
+            if (rc) return rc;
+            rc = nerf_backward(h, P, cfg, true, h->nerf_stream);
+        } else rc = nerf_backward(h, P, cfg, false);
         if (rc) return rc;
+        // (launched first: its workgroups need almost a whole CU's LDS, which the other half's many small workgroups would not leave free)
     }
-    return drt_render_backward(h, rays_o, rays_d, n_rays, ray_offset, spp, seed, dL_drt, L_drt_in, grad_sigma_t, grad_rgb);
+    rc = drt_render_backward(h, rays_o, rays_d, n_rays, ray_offset, spp, seed, dL_drt, L_drt_in, grad_sigma_t, grad_rgb);
+    {
+        DeviceGuard g(h->device);
+        if (h->nerf_stream) { const int rj = fused_join(h); if (!rc) rc = rj; }
+        if (h->timing && t0) {                                   // the whole pass as ONE entry (the halves overlap)
+            DRT_HIP_CHECK(h, hipEventRecord(t1, h->stream));
+            while (h->timed[3].size() > n_pass) { (void) hipEventDestroy(h->timed[3].back().first); (void) hipEventDestroy(h->timed[3].back().second); h->timed[3].pop_back(); }
+            h->timed[3].emplace_back(t0, t1);
+        }
+    }
+    return rc;
 }
 
 int drt_batch_sample_rays_range(drt_handle h, const float *sensors, int32_t n_sensors, uint32_t batch_first,
