@@ -82,6 +82,33 @@ __global__ void __launch_bounds__(256) brick_grid4_kernel(const float *sigma_t, 
     dst[t] = make_float4(sigma_t[v], rgb[3 * v], rgb[3 * v + 1], rgb[3 * v + 2]);
 }
 
+// x * inv (|.| < 2^51) as a two's complement integer, rounded to nearest: the double 1.5 x 2^52 + n holds n in its low mantissa bits
+// (5 vector instructions where the float -> int64 cast takes 12: the kernel is bound by vector-instruction issue, profiles/r05_fused_pmc_util.txt)
+__device__ __forceinline__ unsigned long long fix64(float x, double inv)
+{
+    const double magic = 6755399441055744.0;
+    const double d = fma((double) x, inv, magic);
+    return (unsigned long long) __double_as_longlong(d) - (unsigned long long) __double_as_longlong(magic);
+}
+
+// eval4 (drt_device.h) for a footprint that is known already (unscaled indices): the splat below needs the same stencil
+__device__ __forceinline__ void eval4_at(const Params &P, const Stencil &s, float &sigma_t, float rgb[3])
+{
+    const uint32_t bx = __umul24((uint32_t) s.x0, 43691u) >> 17, ox = (uint32_t) s.x0 - 3u * bx;
+    const float4 *g = P.grid4 + ((size_t) ((uint32_t) s.z0 * (uint32_t) P.ry + (uint32_t) s.y0) * (uint32_t) P.g4_nbx + bx) * 16 + ox;
+    float4 d0 = g[0], d1 = g[1], d2 = g[4], d3 = g[5], d4 = g[8], d5 = g[9], d6 = g[12], d7 = g[13];
+    const bool border = s.x1 == s.x0 || s.y1 == s.y0 || s.z1 == s.z0;
+    if (__builtin_expect(__ballot(border) != 0ull, 0)) {
+        if (s.x1 == s.x0) { d1 = d0; d3 = d2; d5 = d4; d7 = d6; }
+        if (s.y1 == s.y0) { d2 = d0; d3 = d1; d6 = d4; d7 = d5; }
+        if (s.z1 == s.z0) { d4 = d0; d5 = d1; d6 = d2; d7 = d3; }
+    }
+    sigma_t = trilerp8(s, d0.x, d1.x, d2.x, d3.x, d4.x, d5.x, d6.x, d7.x) * P.scale;
+    rgb[0] = trilerp8(s, d0.y, d1.y, d2.y, d3.y, d4.y, d5.y, d6.y, d7.y);
+    rgb[1] = trilerp8(s, d0.z, d1.z, d2.z, d3.z, d4.z, d5.z, d6.z, d7.z);
+    rgb[2] = trilerp8(s, d0.w, d1.w, d2.w, d3.w, d4.w, d5.w, d6.w, d7.w);
+}
+
 // max |dL|, max |L_in| over the rays of the launch and max |emission| over the grid -> out[0..2] (float bits; zeroed by the caller):
 // what the fixed-point units of the window follow from
 __global__ void __launch_bounds__(256) nerf_tile_bounds_kernel(const float *dL, const float *L_in, size_t n_ray_floats, const float *em, size_t n_em,
@@ -163,7 +190,7 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
         }
     }
     // fixed-point units: 2^(e - 44) with 2^e >= the bound of a sigma_t splat / of a colour splat (|dL_k| x weight, weight <= 1)
-    float unit_s, inv_s, unit_c, inv_c;
+    float unit_s, unit_c; double inv_s, inv_c;
     {
         const float Dmax = __uint_as_float(T.bounds[0]), Lmax = __uint_as_float(T.bounds[1]), Emax = __uint_as_float(T.bounds[2]);
         const float ext = sqrtf((P.bmax[0] - P.bmin[0]) * (P.bmax[0] - P.bmin[0]) + (P.bmax[1] - P.bmin[1]) * (P.bmax[1] - P.bmin[1]) +
@@ -173,7 +200,7 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
         int es = 0, ec = 0;
         (void) frexpf(fmaxf(Bs, 1e-30f), &es); (void) frexpf(fmaxf(Dmax, 1e-30f), &ec);
         es = max(es - kFixBits, -100); ec = max(ec - kFixBits, -100);
-        unit_s = ldexpf(1.0f, es); inv_s = ldexpf(1.0f, -es); unit_c = ldexpf(1.0f, ec); inv_c = ldexpf(1.0f, -ec);
+        unit_s = ldexpf(1.0f, es); inv_s = ldexp(1.0, -es); unit_c = ldexpf(1.0f, ec); inv_c = ldexp(1.0, -ec);
     }
     uint32_t n_q = 0;
     int Wx = -(1 << 28), Wy = -(1 << 28), Wz = -(1 << 28);             // window origin (workgroup-uniform; none yet: the first splats all wait)
@@ -217,14 +244,14 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
                                     sz1 + sy0 + sx0, sz1 + sy0 + sx1, sz1 + sy1 + sx0, sz1 + sy1 + sx1 };
                 if (v0 != 0.0f) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) atomicAdd(win + sl[k], (unsigned long long) (long long) ((w[k] * v0) * inv_s));
+                    for (int k = 0; k < 8; ++k) atomicAdd(win + sl[k], fix64(w[k] * v0, inv_s));
                 }
                 if (colour) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         if (ge[c] != 0.0f) {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) atomicAdd(win + (c + 1) * kWinStore + sl[k], (unsigned long long) (long long) ((w[k] * ge[c]) * inv_c));
+                            for (int k = 0; k < 8; ++k) atomicAdd(win + (c + 1) * kWinStore + sl[k], fix64(w[k] * ge[c], inv_c));
                         }
                     }
                 }
@@ -236,8 +263,12 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             const float t_b = P.nerf_jitter ? step * ((float) (j + 1) + jit) : step * (float) (j + 1);
             const float dt = t_b - t_a;
             const V3 p = ray_at(o, d, t_b);
+            // the query's footprint (unscaled indices): the lookup's and, if the query splats, the splat's (no splat waits here: `st` is free)
+            axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, st.x0, st.x1, st.wx0, st.wx1);
+            axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, st.y0, st.y1, st.wy0, st.wy1);
+            axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, st.z0, st.z1, st.wz0, st.wz1);
             float raw, em[3];
-            if constexpr (G4) eval4(P, p, raw, em);
+            if constexpr (G4) eval4_at(P, st, raw, em);
             else { raw = eval_sigma_t(P, p, occ); eval_rgb(P, P.emission, p, em); }
             const float sigma = P.nerf_relu ? fmaxf(0.0f, raw) : raw;
             n_q++;
@@ -260,10 +291,6 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             ++j;
             colour = ge[0] != 0.0f || ge[1] != 0.0f || ge[2] != 0.0f;
             if (gs != 0.0f || colour) {                                         // (adding exact zeros changes nothing)
-                // the splat's footprint: unscaled indices (make_stencil premultiplies y / z by their strides)
-                axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, st.x0, st.x1, st.wx0, st.wx1);
-                axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, st.y0, st.y1, st.wy0, st.wy1);
-                axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, st.z0, st.z1, st.wz0, st.wz1);
                 v0 = gs * P.scale;
                 key = ent_t + t_b;                                              // distance from the camera
                 pend = true;
