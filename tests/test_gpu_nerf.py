@@ -161,3 +161,23 @@ def test_nerf_tile_adjoint_equals_the_record_path(uivr, gpu, film, chunk, spp, p
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), k
     total = out["tile"]["shard0"] + out["tile"]["shard1"]
     assert float((total - out["tile"]["film"]).abs().max()) <= 2e-5 * float(total.abs().max())
+
+
+def test_nerf_tile_adjoint_propagates_non_finite_inputs(uivr, gpu):
+    """The LDS window accumulates in fixed point, which cannot carry a NaN: a non-finite dL (a diverged optimisation) must not come out as a
+    finite, wrong gradient - the pass marks the gradient grids NaN, as the record path's float sums would be."""
+    scene = uivr.cube_test_scene(16, 16, density_scale=1.5)
+    sg = uivr.scene_to(scene, gpu)
+    integ = uivr.get_int_config("nerf").create(max_depth=64)
+    spp, seed = 4, 5
+    batch = uivr.RayBatch(n_rays=16 * 16 * spp, spp=spp, sensor=sg.sensors[0])
+    samp = uivr.IndependentSampler(seed, spp)
+    L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+    dL = torch.full_like(L, 1e-3)
+    grads = uivr.alloc_grads(sg, integ.param_keys)
+    integ.sample(uivr.ADMode.Backward, sg, samp.clone(), batch, δL=dL, state_in=st, grads=grads)
+    assert bool(torch.isfinite(grads["_flat"]).all()) and float(grads["_flat"].abs().max()) > 0
+    dL[37, 1] = float("nan")
+    grads = uivr.alloc_grads(sg, integ.param_keys)
+    integ.sample(uivr.ADMode.Backward, sg, samp.clone(), batch, δL=dL, state_in=st, grads=grads)
+    assert bool(torch.isnan(grads[uivr.SIGMA_T_KEY]).any()) and bool(torch.isnan(grads[uivr.EMISSION_KEY]).any())

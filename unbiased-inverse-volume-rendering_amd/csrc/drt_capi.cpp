@@ -1181,6 +1181,8 @@ static int nerf_fill(drt_handle h, drt::Params &P, const drt_nerf_config *cfg, c
     return DRT_OK;
 }
 
+static int ensure_grid4(drt_handle h, drt::Params &P, const float *rgb);
+
 // The nerf adjoint of a filled job.  Sensor rays: drt_nerf_tile.hip (a workgroup per pixel tile, the splats pre-reduced in an LDS window and
 // flushed with atomics into the caller's grids: no records, no sub-batches); explicit ray batches - the optimisation loop's random pixels -
 // and test hook 512: the record path (nerf_kernel + drt_deferred.hip).  g4: lookups from the four-channel copy (the fused pass).
@@ -1248,13 +1250,21 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
     rc = nerf_fill(h, P, cfg, emission);
     if (rc) return rc;
     P.dL = dL; P.L_in = L_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_emission;
-    return nerf_backward(h, P, cfg, false);
+    // (sensor rays: sigma_t and the emission of a query from ONE 256-byte block of a four-channel copy made for this call)
+    const bool tile = drt::nerf_tile_supported(P) && !dbg(h->debug_flags, 512u);
+    const bool g4 = tile && ensure_grid4(h, P, emission) == DRT_OK;   // (no memory / a grid beyond the copy's index range: the separate lookups)
+    if (tile && !g4) (void) hipGetLastError();
+    return nerf_backward(h, P, cfg, g4);
 }
 
 // ---- fused nerf + volpathsimple pass (BASELINE config 5; drt_fused.hip) ---------------------------------------------
 // the interleaved four-channel apron-brick copy [sigma_t, r, g, b] (eval4): (re)built when the parameter grids changed since the last copy
-static int ensure_grid4(drt_handle h, drt::Params &P)
+// `rgb`: the colour grid of the copy - the medium's albedo (the fused pass: the copy is kept until the parameters change) or the caller's emission
+// grid of a stand-alone nerf call (no version to go by: copied on every call, 0.46 ms at 256^3 against the 3 ms the four-channel lookups save)
+static int ensure_grid4(drt_handle h, drt::Params &P, const float *rgb)
 {
+    const bool own = rgb == nullptr || rgb == h->base.albedo;
+    if (!rgb) rgb = h->base.albedo;
     const drt::Params &B = h->base;
     const size_t nbx = ((size_t) B.rx + 2) / 3, quads = nbx * (size_t) B.ry * (size_t) B.rz * 16;
     if (quads > 0x7fffffffull) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the four-channel copy");
@@ -1263,9 +1273,9 @@ static int ensure_grid4(drt_handle h, drt::Params &P)
         DRT_HIP_CHECK(h, hipMalloc(&h->d_grid4, quads * sizeof(float4)));
         h->grid4_quads = quads; h->grid4_version = 0;
     }
-    if (h->grid4_version != h->medium_version) {           // the parameter grids (may) have changed since the copy was made
-        DRT_HIP_CHECK(h, drt::launch_brick_grid4(B.sigma_t, B.albedo, h->d_grid4, B.rx, B.ry, B.rz, (int) nbx, h->stream));
-        h->grid4_version = h->medium_version;
+    if (!own || h->grid4_version != h->medium_version) {   // the parameter grids (may) have changed since the copy was made
+        DRT_HIP_CHECK(h, drt::launch_brick_grid4(B.sigma_t, rgb, h->d_grid4, B.rx, B.ry, B.rz, (int) nbx, h->stream));
+        h->grid4_version = own ? h->medium_version : 0;
     }
     P.grid4 = h->d_grid4; P.g4_nbx = (int) nbx;
     return DRT_OK;
@@ -1342,7 +1352,8 @@ int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const fl
         if (rc) return rc;
         P.dL = dL_nerf; P.L_in = L_nerf_in; P.g_sigma = grad_sigma_t; P.g_albedo = grad_rgb;
         const bool tile = drt::nerf_tile_supported(P) && !dbg(h->debug_flags, 512u);
-        if (tile) { rc = ensure_grid4(h, P); if (rc) return rc; }   // (sigma_t and the colour of a query from ONE 256-byte block)
+        const bool g4 = tile && ensure_grid4(h, P, nullptr) == DRT_OK;   // (sigma_t and the colour of a query from ONE 256-byte block; else: separate lookups)
+        if (tile && !g4) (void) hipGetLastError();
         if (h->timing) {
             DRT_HIP_CHECK(h, hipEventCreate(&t0));
             DRT_HIP_CHECK(h, hipEventCreate(&t1));
@@ -1354,7 +1365,7 @@ int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const fl
         if (tile) {
             rc = fused_fork(h);
             if (rc) return rc;
-            rc = nerf_backward(h, P, cfg, true, h->nerf_stream);
+            rc = nerf_backward(h, P, cfg, g4, h->nerf_stream);
         } else rc = nerf_backward(h, P, cfg, false);
         if (rc) return rc;
         // (launched first: its workgroups need almost a whole CU's LDS, which the other half's many small workgroups would not leave free)

@@ -59,7 +59,7 @@ constexpr int kFixBits = 44;
 struct NerfTile {
     uint32_t tiles_x;              // tiles of 8 x 8 pixels per film row
     uint32_t groups;               // workgroups per tile: each marches DRT_NT_THREADS / 64 of the pixels' samples
-    const uint32_t *bounds;        // [0] max |dL|, [1] max |L_in| over the launch's rays, [2] max |emission| over the grid (float bits)
+    const uint32_t *bounds;        // [0] max |dL|, [1] max |L_in| over the launch's rays, [2] max |emission| over the grid (float bits), [3] a non-finite one was seen
     uint32_t g4;                   // lookups from the four-channel copy (Params::grid4) instead of sigma_b + emission
     uint32_t count;
 };
@@ -116,8 +116,14 @@ __global__ void __launch_bounds__(256) nerf_tile_bounds_kernel(const float *dL, 
 {
     float m[3] = { 0.0f, 0.0f, 0.0f };
     const size_t stride = (size_t) gridDim.x * blockDim.x, i0 = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t i = i0; i < n_ray_floats; i += stride) { m[0] = fmaxf(m[0], fabsf(dL[i])); m[1] = fmaxf(m[1], fabsf(L_in[i])); }
-    for (size_t i = i0; i < n_em; i += stride) m[2] = fmaxf(m[2], fabsf(em[i]));
+    bool bad = false;                                                   // a non-finite input: fixed point cannot carry it - out[3] makes the pass say so
+    for (size_t i = i0; i < n_ray_floats; i += stride) {
+        const float a = fabsf(dL[i]), b = fabsf(L_in[i]);
+        bad = bad || !(a < kInf) || !(b < kInf);
+        m[0] = fmaxf(m[0], a); m[1] = fmaxf(m[1], b);
+    }
+    for (size_t i = i0; i < n_em; i += stride) { const float a = fabsf(em[i]); bad = bad || !(a < kInf); m[2] = fmaxf(m[2], a); }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(out + 3, 1u);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -154,6 +160,8 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
         else i = rel;
         job = job && i >= P.ray_first && i < P.n_rays;
     }
+    // non-finite dL / L_in / emission values (as a diverged optimisation produces them) propagate as they do on the record path: NaN gradients
+    if (blockIdx.x == 0 && t == 0 && T.bounds[3]) { atomicAdd(P.g_sigma, __uint_as_float(0x7fc00000u)); atomicAdd(P.g_albedo, __uint_as_float(0x7fc00000u)); }
     if (__syncthreads_count(job) == 0) return;                       // (a launch over a window of the film: most tiles hold none of its rays)
 
     for (int w = t; w < 4 * kWinStore; w += NT) win[w] = 0ull;
