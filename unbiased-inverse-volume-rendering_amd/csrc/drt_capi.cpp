@@ -377,7 +377,17 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
             // the pool, 3.31 with it - such a launch IS its longest path, a second launch only adds its own start; at 4 GPUs, 2 M rays: 4.00 / 4.07 ms).
             // (test hooks: 268435456 no tail pool, 1073741824 launches from 4096 rays on have one)
             const uint64_t tail_min = dbg(h->debug_flags, 1073741824u) ? 4096u : (1u << 21);
-            const bool tail = DRT_SQ_TAIL && adjoint && h->early_plan && Q.rec_buf[0] && span >= tail_min && !dbg(h->debug_flags, 268435456u);
+            const bool big = adjoint && h->early_plan && Q.rec_buf[0] && span >= tail_min;
+            // Round 5, SOLO tails: where the majorants fit LDS the tail launch runs its records to their ends in registers, without queue hops
+            // (drt_sq.hip: SOLO) - a lone ray's bounce then costs its lookups and one wave's instructions, not eight hand-overs.  That pays
+            // without anything running beside it: the primal launch and the small adjoint launches (a rank's share at 8 GPUs) hand their last
+            // records to a tail launch over the whole chip.  (test hook 268435456: no tail pool of either kind)
+#ifndef DRT_SQ_TAIL_SOLO
+#define DRT_SQ_TAIL_SOLO 3          // bit 0: primal launches, bit 1: adjoint launches below the size of the overlapped tail
+#endif
+            const bool solo = drt::sq_tail_solo(Q) && span >= 8192u && !big &&
+                              (adjoint ? ((DRT_SQ_TAIL_SOLO & 2) != 0 && Q.rec_buf[0] != nullptr) : (DRT_SQ_TAIL_SOLO & 1) != 0);
+            const bool tail = DRT_SQ_TAIL && (big || solo) && !dbg(h->debug_flags, 268435456u);
             if (tail) {
                 const size_t cap = (size_t) h->n_cus * drt::sq_tail_push();
                 const size_t need_b = 256 + cap * drt::sq_tail_entry_quads() * sizeof(uint4);
@@ -392,32 +402,34 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
             }
             DRT_HIP_CHECK(h, drt::launch_trace_sq(Q, adjoint, h->counting, h->n_cus, h->stream));
             if (tail && Q.tail_pool) {
-                if (!h->side) {
-                    int lo = 0, hi = 0;
-                    DRT_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                    DRT_HIP_CHECK(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
-                }
-                if (!h->ev_split) {
-                    DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_split, hipEventDisableTiming));
-                    DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_hist, hipEventDisableTiming));
-                }
-                // the main launch's records are complete (the tail launch emits none): partition them on the side stream ...
-                DRT_HIP_CHECK(h, hipEventRecord(h->ev_split, h->stream));
-                DRT_HIP_CHECK(h, hipStreamWaitEvent(h->side, h->ev_split, 0));
                 hipEvent_t ta = nullptr, tb = nullptr;
-                if (h->timing) { DRT_HIP_CHECK(h, hipEventCreate(&ta)); DRT_HIP_CHECK(h, hipEventCreate(&tb)); DRT_HIP_CHECK(h, hipEventRecord(ta, h->side)); }
-                DRT_HIP_CHECK(h, drt::launch_deferred_reduce(Q, *h->early_plan, h->side, nullptr, false, 1));
-                if (h->timing) { DRT_HIP_CHECK(h, hipEventRecord(tb, h->side)); h->timed[2].emplace_back(ta, tb); }
-                DRT_HIP_CHECK(h, hipEventRecord(h->ev_hist, h->side));
+                if (big) {
+                    if (!h->side) {
+                        int lo = 0, hi = 0;
+                        DRT_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                        DRT_HIP_CHECK(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));
+                    }
+                    if (!h->ev_split) {
+                        DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_split, hipEventDisableTiming));
+                        DRT_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_hist, hipEventDisableTiming));
+                    }
+                    // the main launch's records are complete (the tail launch emits none): partition them on the side stream ...
+                    DRT_HIP_CHECK(h, hipEventRecord(h->ev_split, h->stream));
+                    DRT_HIP_CHECK(h, hipStreamWaitEvent(h->side, h->ev_split, 0));
+                    if (h->timing) { DRT_HIP_CHECK(h, hipEventCreate(&ta)); DRT_HIP_CHECK(h, hipEventCreate(&tb)); DRT_HIP_CHECK(h, hipEventRecord(ta, h->side)); }
+                    DRT_HIP_CHECK(h, drt::launch_deferred_reduce(Q, *h->early_plan, h->side, nullptr, false, 1));
+                    if (h->timing) { DRT_HIP_CHECK(h, hipEventRecord(tb, h->side)); h->timed[2].emplace_back(ta, tb); }
+                    DRT_HIP_CHECK(h, hipEventRecord(h->ev_hist, h->side));
+                }
                 // ... beside the tail launch: the pool's records to their ends, splats as direct atomics into the caller's grids (no chunk is
                 // handed out: the cursors it touches are dummies in the pool's header)
                 drt::Params T = Q;
-                T.tail_mode = 1;
+                T.tail_mode = big ? 1 : 2;                                 // (2: nothing runs beside it - over the whole chip)
                 T.rec_cursor = (uint32_t *) h->d_sq_tail + 8;
                 T.rec_cap_chunks[0] = T.rec_cap_chunks[1] = 0;
                 T.order = nullptr; T.unit_empty = nullptr;
                 DRT_HIP_CHECK(h, drt::launch_trace_sq(T, adjoint, h->counting, h->n_cus, h->stream));
-                h->early_done = true; h->early_partition = true;
+                if (big) { h->early_done = true; h->early_partition = true; }
             }
         }
 #ifdef DRT_TEST_HOOKS

@@ -38,6 +38,7 @@ hipError_t launch_trace_sq(const Params &P, bool adjoint, bool count, int n_cus,
 // tail pool of the queued tracer's adjoint launches (Params::tail_pool / tail_count / tail_cap / tail_mode): a drained workgroup writes its last
 // <= sq_tail_push() records to the pool and ends; launch_trace_sq with tail_mode = 1 finishes them (its splats as direct atomics)
 uint32_t sq_tail_push();
+bool sq_tail_solo(const Params &P);       // the tail launch finishes its records in registers, no queue hops (supergrids whose majorants fit LDS)
 size_t sq_tail_entry_quads();
 size_t super_order_bytes(uint32_t units);
 // flags[u] = 1: every ray of unit u (the `unit` = spp rays of one pixel, sensor rays only) crosses only empty supergrid cells (Params::unit_empty)

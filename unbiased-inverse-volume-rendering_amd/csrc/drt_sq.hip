@@ -257,7 +257,11 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     constexpr int NWV = DRT_SQ_THREADS / 64;
     constexpr int R4 = 7;                                                    // uint4 per ray record in LDS
     static_assert(ADJ || !QUAD, "the primal pass of the quadratic estimator is the ordinary one");
-    static_assert(ADJ || !TAILM, "only adjoint launches have a tail pool");
+    // SOLO: the tail launch runs a batch's rays to their ENDS in the registers of the lanes that loaded them - transitions, the next flight walked to
+    // its end right where it is set up, its collision, round again - without a queue hop in between: a launch's last paths are latency, and a lone
+    // ray's hop through the queues (store the record, another wave finds it, loads it) costs more than the work it carries.  (Not with majorants in
+    // L2, MG: those flights are not stepped by the lanes that set them up.)
+    constexpr bool SOLO = TAILM && !MG;
     constexpr int NB = QUAD ? 9 : 6;                                         // uint4 of part b of the global record (adjoint)
     constexpr int NC = ADJ ? 3 + NB : 3;                                     // uint4 per ray in global memory (Params::sq_cold)
     // LDS record: [0] {tn.x, tn.y, tn.z, cell} [1] {td.x, td.y, td.z, steps left (9 bits per axis) + direction signs}
@@ -290,7 +294,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     }
     if (threadIdx.x < SQ_KINDS) ctl[threadIdx.x] = threadIdx.x == SQ_REGEN ? ((unsigned long long) NRAY << 32) : 0ull;
     if (threadIdx.x < 8) misc[threadIdx.x] = (threadIdx.x == 3 && TAILM) ? 8u                // (tail mode: the ray queues count as drained)
-                                           : (threadIdx.x == 4 && ADJ && !TAILM && P.tail_pool) ? (uint32_t) DRT_SQ_TAIL_PUSH : 0u;
+                                           : (threadIdx.x == 4 && !TAILM && P.tail_pool) ? (uint32_t) DRT_SQ_TAIL_PUSH : 0u;
     if (threadIdx.x < 2) pool[threadIdx.x] = 0ull;
     for (int w = threadIdx.x; w < NWV * 8; w += blockDim.x) recst[w] = 0u;
     __syncthreads();
@@ -377,10 +381,10 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 id_k = (uint32_t) __builtin_amdgcn_readfirstlane((int) id_k);
                 const uint4 *src = P.tail_pool + ((size_t) blockIdx.x + (size_t) k * gridDim.x) * kSqTailQuads;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (lane < 11u + NB) v = src[lane];
+                if (lane < (ADJ ? 11u + NB : 11u)) v = src[lane];
                 if (lane < 7u) rec4[R4 * id_k + lane] = v;
                 else if (lane >= 8u && lane < 11u) cold_a[3 * id_k + (lane - 8u)] = v;
-                else if (lane >= 11u && lane < 11u + NB) cold_b[NB * id_k + (lane - 11u)] = v;
+                else if (ADJ && lane >= 11u && lane < 11u + NB) cold_b[NB * id_k + (lane - 11u)] = v;
                 const int kd = __builtin_amdgcn_readlane((int) v.x, 7);
                 __threadfence_block();
                 sq_fence();
@@ -409,7 +413,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         const uint32_t dead = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[0]);
         if (dead >= (uint32_t) NRAY) break;
         const bool drained = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((sq_vu32 *) misc)[3]) >= 8u;
-        if constexpr (ADJ && !TAILM) {
+        if constexpr (!TAILM) {
             // a drained workgroup's last paths are latency: nothing on this CU can hide them.  Their records go to the tail pool (behind the loop) and
             // the workgroup ends; the tail launch finishes them while the partition passes of the gradient reduction run on the CUs this frees.
             // (`live` counts the records in the queues or in a wave's registers; the two LDS reads are not one snapshot: it may be low by one batch)
@@ -605,7 +609,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     const uint4 q1 = R[1], q2 = R[2];
                     c_lm = __uint_as_float(R[0].x); c_tau = __uint_as_float(q2.x); c_t = __uint_as_float(q2.z); c_acc = __uint_as_float(q2.w);
                     w_tdx = __uint_as_float(q1.x); w_tdy = __uint_as_float(q1.y); w_tdz = __uint_as_float(q1.z); w_rem = q1.w;
-                } else {                                                        // transitions: the rest of the ray, from global memory
+                }
+                if (SOLO || kind != SQ_COLL) {                                  // transitions (SOLO: every batch): the rest of the ray, from global memory
+                    const V3 ro_walk = ro;                                      // (in / just out of a DRT walk the record's copy is the current one: the same value)
                     const uint4 *ca = cold_a + 3 * id;
                     const uint4 c0 = ca[0], c1 = ca[1], c2 = ca[2];
                     ro = v3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z)); si_t = __uint_as_float(c0.w);
@@ -634,15 +640,15 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                         if (gA) { S.state = os; S.inc = oi; } else { A.state = os; A.inc = oi; }
                       }
                     }
+                    if (drtw) ro = ro_walk;
                 }
             }
         }
 
         if (kind == SQ_COLL) SQ_STAMP(2); else SQ_STAMP(4);
-        if (kind == SQ_COLL) {
-            // ================= (Fe) the collision a flight ended in =========================================
-            SQ_PROF(2, 1); SQ_PROF(3, nb);
-            if (act) {
+        // ================= (Fe) the collision a flight ended in (collision batches; SOLO: right behind the flight's walk) ===================
+        auto collide = [&](bool on) {
+            if (on) {
                 const bool drt = ph == SP_DRT;
                 const bool useA = ADJ && !rec_mode && drt;
                 Pcg32 Rg; Rg.state = useA ? A.state : S.state; Rg.inc = useA ? A.inc : S.inc;
@@ -686,6 +692,10 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
                 if (useA) A.state = Rg.state; else S.state = Rg.state;
             }
+        };
+        if (kind == SQ_COLL) {
+            SQ_PROF(2, 1); SQ_PROF(3, nb);
+            collide(act);
         } else if (kind == SQ_REGEN) {
             // ================= (A) regeneration ===========================================================
             // Ray indices come from a wave-local pool refilled DRT_SQ_CHUNK at a time with ONE returning atomic on the
@@ -845,7 +855,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             }
         };
         for (;;) {
-            if (kind != SQ_COLL && __ballot(sq_is_trans<QUAD>(ph))) {
+            if ((SOLO || kind != SQ_COLL) && __ballot(sq_is_trans<QUAD>(ph))) {
                 uint4 pce1 = make_uint4(0u, 0u, 0u, 0u); bool pce1_ok = false;   // this iteration's NEE entry of the path cache, read at the loop head
                 SQ_BLK(8, sq_is_trans<QUAD>(ph)); SQ_BLK(0, ph == SP_DRT_END); SQ_BLK(1, ph == SP_RT_END || ph == SP_RTA_END);
                 // ---- DRT vertex selected: enter the detached recursive path (:553-575, :610-655) -----
@@ -1171,6 +1181,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                             uint32_t wrem = rem;
                             const int sx = sgx < 0 ? -1 : 1, sy = sgy < 0 ? -lin_y : lin_y, sz = sgz < 0 ? -lin_z : lin_z;
                             bool wfly = true;
+                            do {                                                    // (SOLO: to the flight's end)
 #pragma unroll
                             for (int k = 0; k < (MG ? 0 : DRT_SQ_INLINE_K); ++k) {
                                 const float tmin = fminf(fminf(wnx, wny), wnz);
@@ -1190,6 +1201,11 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                                 wcell += go ? (isx ? sx : isy ? sy : sz) : 0;
                                 wnx = (go && isx) ? tnn : wnx; wny = (go && isy) ? tnn : wny; wnz = (go && !isx && !isy) ? tnn : wnz;
                             }
+                            } while (SOLO && wfly);
+                            if constexpr (SOLO) {                                   // the finished flight stays in registers: its collision follows below
+                                c_lm = res_mc; c_tau = tau; c_t = wt_; c_acc = wacc;
+                                w_tdx = tdx; w_tdy = tdy; w_tdz = tdz; w_rem = wrem;
+                            }
                             R[0] = make_uint4(wfly ? __float_as_uint(wnx) : __float_as_uint(res_mc), __float_as_uint(wny), __float_as_uint(wnz), (uint32_t) wcell);
                             R[1] = make_uint4(__float_as_uint(tdx), __float_as_uint(tdy), __float_as_uint(tdz), wrem);
                             R[2] = make_uint4(__float_as_uint(tau), __float_as_uint(tmax), __float_as_uint(wt_), __float_as_uint(wacc));
@@ -1201,7 +1217,13 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
             }
             SQ_STAMP(6);
-            if (kind == SQ_COLL || __popcll(__ballot(sq_is_trans<QUAD>(ph))) < DRT_SQ_T_PASS) break;   // (what is left goes to the transition queue)
+            if constexpr (SOLO) {
+                if (__ballot(act && walk_done)) { collide(act && walk_done); walk_done = false; }
+                // round again while a ray has a transition to make or a flight to set up
+                if (!__ballot(act && (sq_is_trans<QUAD>(ph) || (ph < SP_HEAD && fl != SF_WAIT)))) break;
+            } else {
+                if (kind == SQ_COLL || __popcll(__ballot(sq_is_trans<QUAD>(ph))) < DRT_SQ_T_PASS) break;   // (what is left goes to the transition queue)
+            }
         }
 
         // ================= store the rays, hand them on ====================================================
@@ -1238,7 +1260,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             R[6] = make_uint4(drtw ? __float_as_uint(ro.x) : __float_as_uint(adjsum), drtw ? __float_as_uint(ro.y) : pc_steps,
                               drtw ? __float_as_uint(ro.z) : 0u, f);
 #endif
-            if (kind != SQ_COLL) {
+            if (SOLO || kind != SQ_COLL) {
                 uint4 *ca = cold_a + 3 * id;
                 ca[0] = make_uint4(__float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z), __float_as_uint(si_t));
                 ca[1] = make_uint4(__float_as_uint(beta[0]), __float_as_uint(beta[1]), __float_as_uint(beta[2]), __float_as_uint(nt0));
@@ -1265,9 +1287,9 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                     }
                 }
             }
-            if (go_trans && kind == SQ_COLL) { R[1] = make_uint4(__float_as_uint(w_tdx), __float_as_uint(w_tdy), __float_as_uint(w_tdz), w_rem); }
+            if (!SOLO && go_trans && kind == SQ_COLL) { R[1] = make_uint4(__float_as_uint(w_tdx), __float_as_uint(w_tdy), __float_as_uint(w_tdz), w_rem); }
         }
-        if (kind != SQ_COLL) __threadfence_block();                            // (the global part of the records)
+        if (SOLO || kind != SQ_COLL) __threadfence_block();                    // (the global part of the records)
         sq_fence();
         const int tk = sq_trans_kind<DRT_SQ_SPLIT == 2 || (DRT_SQ_SPLIT == 1 && ADJ)>(ph);
 #if DRT_SQ_PUSH_ALL
@@ -1282,7 +1304,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
         SQ_STAMP(7);
     }
 
-    if constexpr (ADJ) {
+    {
         if (!TAILM && P.tail_pool) {
             // hand-over: every wave is out of the loop with no record in its registers (a batch is stored and queued before the loop head is seen again):
             // what the queues hold goes to the pool - wave k the entries of queue kind k, three records per round (lane = 20 x record + quad)
@@ -1296,19 +1318,19 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 const uint32_t sub = lane / (uint32_t) kSqTailQuads, quad = lane - sub * (uint32_t) kSqTailQuads;
 #pragma unroll 1
                 for (uint32_t r = sub; r < nq; r += 3u) {
-                    if (sub < 3u && base + r < P.tail_cap && quad < 11u + NB) {
+                    if (sub < 3u && base + r < P.tail_cap && quad < (ADJ ? 11u + NB : 11u)) {
                         const uint32_t id_r = q_lds[wave * DRT_SQ_RING + ((head + r) & (DRT_SQ_RING - 1u))];
                         uint4 v;
                         if (quad < 7u) v = rec4[R4 * id_r + quad];
                         else if (quad == 7u) v = make_uint4((uint32_t) wave, 0u, 0u, 0u);
                         else if (quad < 11u) v = cold_a[3 * id_r + (quad - 8u)];
-                        else v = cold_b[NB * id_r + (quad - 11u)];
+                        else v = ADJ ? cold_b[NB * id_r + (quad - 11u)] : make_uint4(0u, 0u, 0u, 0u);
                         P.tail_pool[(size_t) (base + r) * kSqTailQuads + quad] = v;
                     }
                 }
             }
         }
-        close_records(P, rec);
+        if constexpr (ADJ) close_records(P, rec);
     }
 #if DRT_SQ_PROFILE == 6
     __syncthreads();
@@ -1370,6 +1392,13 @@ static uint32_t sq_rays_for(const Params &P, size_t *bytes, bool *global_majoran
     return 0;
 }
 
+// the tail launch runs its records to their ends without queue hops (SOLO) unless the majorants are read from L2 (MG)
+bool sq_tail_solo(const Params &P)
+{
+    bool mg = false;
+    return sq_rays_for(P, nullptr, &mg) != 0 && !mg;
+}
+
 uint32_t sq_tail_push() { return DRT_SQ_TAIL_PUSH + 64; }   // (the hand-over's count of live records may be low by one batch)
 size_t sq_tail_entry_quads() { return kSqTailQuads; }
 
@@ -1391,15 +1420,20 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
     P.sq_rays = nray;
     unsigned blocks = (unsigned) n_cus;                                         // one workgroup per CU
     const uint64_t need = (P.n_rays - P.ray_first + nray - 1) / nray;           // no more workgroups than groups of records
-    if (need < blocks) blocks = (unsigned) need;
-    if (adjoint && P.tail_mode) blocks = blocks < (unsigned) DRT_SQ_TAIL_BLOCKS ? blocks : (unsigned) DRT_SQ_TAIL_BLOCKS;   // the tail launch: the pool's (few thousand) records over a few workgroups
-    else if (adjoint && P.tail_pool && (uint64_t) P.tail_cap < (uint64_t) blocks * (DRT_SQ_TAIL_PUSH + 64)) P.tail_pool = nullptr;   // (capacity invariant of the hand-over)
+    if (need < blocks && !P.tail_mode) blocks = (unsigned) need;
+    // the tail launch: the pool's (few thousand) records over a few workgroups (tail_mode 1: the partition passes of the reduction run beside it) or the chip (2)
+    if (P.tail_mode == 1u) {
+        const unsigned fit = (unsigned) ((P.tail_cap + nray - 1) / nray);           // (every pool entry needs a record)
+        const unsigned want = fit > (unsigned) DRT_SQ_TAIL_BLOCKS ? fit : (unsigned) DRT_SQ_TAIL_BLOCKS;
+        blocks = blocks < want ? blocks : want;
+    }
+    else if (!P.tail_mode && P.tail_pool && (uint64_t) P.tail_cap < (uint64_t) blocks * (DRT_SQ_TAIL_PUSH + 64)) P.tail_pool = nullptr;   // (capacity invariant of the hand-over)
     dim3 block(DRT_SQ_THREADS), grid(blocks);
     const bool env = P.env_pix != nullptr;
     hipError_t e = hipSuccess;
     const bool quad = adjoint && P.use_drt && !P.use_drt_subsampling;           // quadratic DRT: the QUAD instantiations of the adjoint kernels
-    const bool tailm = adjoint && P.tail_mode != 0u;
-#define DRT_SQ_LAUNCH(A, C, E) do { if (A && tailm) DRT_SQ_LAUNCH_Q(A, C, E, A); else DRT_SQ_LAUNCH_Q(A, C, E, false); } while (0)
+    const bool tailm = P.tail_mode != 0u;
+#define DRT_SQ_LAUNCH(A, C, E) do { if (tailm) DRT_SQ_LAUNCH_Q(A, C, E, true); else DRT_SQ_LAUNCH_Q(A, C, E, false); } while (0)
 #define DRT_SQ_LAUNCH_Q(A, C, E, T) do { if (A && quad) { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, A, T); else DRT_SQ_LAUNCH_(A, C, E, false, A, T); } \
                                     else { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, false, T); else DRT_SQ_LAUNCH_(A, C, E, false, false, T); } } while (0)
 #define DRT_SQ_LAUNCH_(A, C, E, M, Q, T)                                                                             \
