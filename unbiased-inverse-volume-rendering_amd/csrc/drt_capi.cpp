@@ -422,11 +422,13 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
                     DRT_HIP_CHECK(h, hipEventRecord(h->ev_hist, h->side));
                 }
                 // ... beside the tail launch: the pool's records to their ends, splats as direct atomics into the caller's grids (no chunk is
-                // handed out: the cursors it touches are dummies in the pool's header)
+                // handed out: the cursors it touches are dummies in the pool's header - the partition of the main launch's records is under way)
                 drt::Params T = Q;
                 T.tail_mode = big ? 1 : 2;                                 // (2: nothing runs beside it - over the whole chip)
-                T.rec_cursor = (uint32_t *) h->d_sq_tail + 8;
-                T.rec_cap_chunks[0] = T.rec_cap_chunks[1] = 0;
+                if (big) {                                                 // (a SOLO tail of a small launch appends to the record streams: their reduction follows it)
+                    T.rec_cursor = (uint32_t *) h->d_sq_tail + 8;
+                    T.rec_cap_chunks[0] = T.rec_cap_chunks[1] = 0;
+                }
                 T.order = nullptr; T.unit_empty = nullptr;
                 DRT_HIP_CHECK(h, drt::launch_trace_sq(T, adjoint, h->counting, h->n_cus, h->stream));
                 if (big) { h->early_done = true; h->early_partition = true; }

@@ -6,21 +6,23 @@
 // (nerf_kernel<ADJ, ., DEFER>, drt_deferred.hip) that is 14.5 GB of 16-byte records per step, written, histogrammed, scattered and read
 // again: the reduction passes were 25 of the 46 ms of the fused adjoint pass (profiles/r04_fused_kernel_stats.csv).  But a march is
 // COHERENT where a scattering path is not: the rays of a small pixel tile walk through the grid side by side, so at march step j
-// all their queries lie within a few voxels of each other.  Here a workgroup owns a pixel tile, marches all its rays in lock-step and adds
+// all their queries lie within a few voxels of each other.  Here a workgroup owns an 8 x 8-pixel tile (lane = pixel, wave = sample) and adds
 // every splat into a 16^3-voxel WINDOW of four-channel accumulators in LDS (torus addressing: voxel (x, y, z) lives in slot (z & 15, y & 15,
-// x & 15) while the window covers it).  The accumulators are 64-bit FIXED-POINT integers (ds_add_u64): measured on this chip
-// (tools/ubench/lds_atomic_conflict_rate.hip) ds_add_f32 retires 0.2 T lane-adds/s whatever the addresses - a first version with float
-// accumulators spent 62 % of its wave-cycles waiting for the LDS, 72 ms per launch - where ds_add_u64 retires 1.4 - 3.2 T/s at 8 - 64 distinct
-// addresses per instruction.  The unit is a power of two 2^44 below a bound of the launch's largest possible splat (from max |dL|, max |L_in|,
-// max emission, the longest march step: nerf_tile_bounds_kernel), so a contribution converts exactly down to 2^-44 of that bound and 2^19
-// of them fit: sums inside a window are exact, whatever their order.  When a share of the tile's queries falls outside, the workgroup flushes the
-// window's non-zero accumulators to the caller's grids (one global atomic per voxel and channel - consecutive lanes flush consecutive x,
-// one 64-byte request per 16 voxels) and re-centres it ahead of the march; the few queries outside even then (tiles across the
-// silhouette of the box) go to the grids directly.  Global atomics per step of config 5: ~10^8 instead of 907 M x 8 corners; no records.
+// x & 15) while the window covers it).  Every ray runs on by itself until a splat falls outside the window; when every ray of the workgroup
+// waits (or is done) the window's non-zero accumulators are flushed to the caller's grids (one global atomic per voxel and channel -
+// consecutive lanes flush consecutive x, one 64-byte request per 16 voxels) and the window moves to the waiting splat closest to the camera:
+// that ray is inside by construction, so every phase makes progress and no splat ever bypasses the window (config 5: 11 phases per workgroup
+// for 128 queries; ~10^8 global atomic lanes per step instead of 907 M x 8 corners; no records).
+// The accumulators are 64-bit FIXED-POINT integers (ds_add_u64): measured on this chip (tools/ubench/lds_atomic_conflict_rate.hip) ds_add_f32
+// retires 0.2 T lane-adds/s whatever the addresses - a first version with float accumulators spent 62 % of its wave-cycles waiting for the LDS,
+// 72 ms per launch - where ds_add_u64 retires 1.4 - 3.2 T/s at 8 - 64 distinct addresses per instruction.  The unit is a power of two 2^44 below
+// a bound of the launch's largest possible splat (from max |dL|, max |L_in|, max emission, the longest march step: nerf_tile_bounds_kernel), so a
+// contribution converts exactly down to 2^-44 of that bound and 2^19 of them fit: sums inside a window are exact, whatever their order.
+// Non-finite inputs cannot travel through fixed point: the bounds kernel flags them and the pass marks the gradient grids NaN.
 //
 // Arithmetic per ray: the statements of nerf_kernel<ADJ> (drt_kernels.hip) in the same order - same lookups, same weights
 // (stencil_weights); gradients differ from the record path by summation order only.  Used for launches of sensor rays
-// (Params::sensor_flow) with spp <= the workgroup size; explicit ray batches keep the record path.
+// (Params::sensor_flow), any spp (a workgroup marches 16 samples of its 64 pixels); explicit ray batches keep the record path.
 #include <atomic>
 #include "drt_device.h"
 #include "drt_launch.h"
