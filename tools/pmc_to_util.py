@@ -45,8 +45,10 @@ for r in csv.DictReader(open(stats)):
     ms[short(r["Name"])] = float(r["AverageNs"]) / 1e6
     calls[short(r["Name"])] = int(r["Calls"])
 # launches of a primal tracer kernel (counting instantiation included) = steps of the profiled command
+# (the queued tracer's tail launches - last template argument true - are second launches of a step, not steps)
 steps = sum(c for k, c in calls.items() if any(t in k for t in ("trace_sq_kernel<false", "trace_coop_kernel<false", "trace_super_kernel<false",
-                                                                "trace_wavefront_kernel<false")))
+                                                                "trace_wavefront_kernel<false"))
+            and not ("trace_sq_kernel<" in k and k.rstrip().endswith(", true>")))
 util = {}
 for k in acc:
     m = lambda c: (sum(acc[k][c]) / len(acc[k][c])) if acc[k].get(c) else 0.0
