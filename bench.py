@@ -463,7 +463,8 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
                                      "lookup_rate_GBs": round(b_a / (avg_pass * 1e-3) / 1e9, 1) if avg_pass else None,
                                      "lookup_rate_frac": round(b_a / (avg_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_pass else None,
                                      "algorithmic_bytes": b_a,
-                                     "secondary": committed_secondary("fused-256-512x32", ca),
+                                     # (tile_reduce only sums the volpathsimple half's records since round 5: the nerf half's splats are pre-reduced in LDS by its own kernel)
+                                     "secondary": committed_secondary("fused-256-512x32", dict(ca, n_sc=ca["n_sc"] - n_q, n_sc_alb=ca["n_sc_alb"] - n_q)),
                                      # HBM-side bytes of the adjoint pass from the request-size counters (committed profile of
                                      # these kernel sources, or null) and the bandwidth they mean over the measured pass time
                                      "traffic": committed_traffic("fused-256-512x32")[0],
