@@ -124,6 +124,8 @@ def test_nerf_tile_adjoint_equals_the_record_path(uivr, gpu, film, chunk, spp, p
     st[rng.random(st.shape) < 0.5] = 0.0
     if props.get("activation") == "relu":
         st[3:6, 3:6, 3:6] = -0.4
+    elif spp == 1:
+        st[8:11, 8:11, 8:11] = -0.8          # identity activation with negative densities: a > 1, growing throughput (the fixed-point bound follows)
     em = (rng.random((20, 18, 22, 3), dtype=np.float32) * 0.9).astype(np.float32)
     medium = uivr.GridMedium(sigma_t=st, albedo=em.copy(), emission=em, bbox_min=(-1, -0.9, -1.1), bbox_max=(1, 0.9, 1.1), scale=1.3)
     sensor = uivr.PerspectiveSensor(origin=(2.5, 1.5, 3.0), target=(0, 0, 0), fov=40.0, width=film[0], height=film[1])

@@ -72,7 +72,7 @@ struct drt_handle_s {
     hipEvent_t ev_split = nullptr, ev_hist = nullptr;
     hipStream_t nerf_stream = nullptr;  // the nerf half of the fused pass runs beside the volpathsimple half (drt_fused_render_*)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    uint32_t *d_nerf_bounds = nullptr; // 16 bytes: max |dL|, |L_in|, |emission| of a nerf tile adjoint launch (drt_nerf_tile.hip)
+    uint32_t *d_nerf_bounds = nullptr; // 32 bytes: max |dL|, |L_in|, |emission|, non-finite flag, largest negative density of a nerf tile adjoint launch (drt_nerf_tile.hip)
     // path cache (drt_coop.hip): written by the primal launch of an H1 step, read by the adjoint launch of the
     // same job if nothing happened to the handle in between
     void *d_pcache = nullptr;          // [rays][kPathCacheCap][2] uint4 | [rays] hash words
@@ -1210,7 +1210,7 @@ static int nerf_backward(drt_handle h, drt::Params &P, const drt_nerf_config *cf
             DRT_HIP_CHECK(h, hipEventRecord(ev[0], st));
             DRT_HIP_CHECK(h, hipEventRecord(ev[2], st));
         }
-        if (!h->d_nerf_bounds) DRT_HIP_CHECK(h, hipMalloc((void **) &h->d_nerf_bounds, 16));
+        if (!h->d_nerf_bounds) DRT_HIP_CHECK(h, hipMalloc((void **) &h->d_nerf_bounds, 32));
         DRT_HIP_CHECK(h, drt::launch_nerf_tile_adjoint(P, g4, h->counting, h->d_nerf_bounds, st));
         if (h->timing) {
             DRT_HIP_CHECK(h, hipEventRecord(ev[1], st));

@@ -19,7 +19,7 @@ hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t st
 // drt_nerf_tile.hip: the nerf adjoint for sensor rays - a workgroup per pixel tile, its splats pre-reduced in an LDS window of 16^3 voxels, no records
 // (g4: lookups from Params::grid4 - the fused pass, emission = the medium's albedo grid - instead of sigma_b + Params::emission)
 bool nerf_tile_supported(const Params &P);
-// bounds: 16 bytes of device scratch (the fixed-point units of the LDS window follow from max |dL|, max |L_in|, max |emission|, reduced there first)
+// bounds: 32 bytes of device scratch (the fixed-point units of the LDS window follow from max |dL|, max |L_in|, max |emission|, reduced there first)
 hipError_t launch_nerf_tile_adjoint(const Params &P, bool g4, bool count, uint32_t *bounds, hipStream_t stream);
 hipError_t launch_trace_wavefront(const Params &P, bool adjoint, bool count, int n_cus, hipStream_t stream);
 // supergrid scenes (majorant_resolution_factor > 0): lane-level state machine stepping one supergrid cell at a time, the

@@ -61,7 +61,7 @@ constexpr int kFixBits = 44;
 struct NerfTile {
     uint32_t tiles_x;              // tiles of 8 x 8 pixels per film row
     uint32_t groups;               // workgroups per tile: each marches DRT_NT_THREADS / 64 of the pixels' samples
-    const uint32_t *bounds;        // [0] max |dL|, [1] max |L_in| over the launch's rays, [2] max |emission| over the grid (float bits), [3] a non-finite one was seen
+    const uint32_t *bounds;        // [0] max |dL|, [1] max |L_in| over the launch's rays, [2] max |emission| over the grid (float bits), [3] a non-finite one was seen, [4] the largest negative density's magnitude
     uint32_t g4;                   // lookups from the four-channel copy (Params::grid4) instead of sigma_b + emission
     uint32_t count;
 };
@@ -113,10 +113,11 @@ __device__ __forceinline__ void eval4_at(const Params &P, const Stencil &s, floa
 
 // max |dL|, max |L_in| over the rays of the launch and max |emission| over the grid -> out[0..2] (float bits; zeroed by the caller):
 // what the fixed-point units of the window follow from
+// out[4]: the largest NEGATIVE density of the grid, as a magnitude (identity activation: a = exp(-sigma dt) > 1 there, throughput and weights can grow)
 __global__ void __launch_bounds__(256) nerf_tile_bounds_kernel(const float *dL, const float *L_in, size_t n_ray_floats, const float *em, size_t n_em,
-                                                               uint32_t *out)
+                                                               const float *sig, size_t n_sig, uint32_t *out)
 {
-    float m[3] = { 0.0f, 0.0f, 0.0f };
+    float m[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
     const size_t stride = (size_t) gridDim.x * blockDim.x, i0 = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     bool bad = false;                                                   // a non-finite input: fixed point cannot carry it - out[3] makes the pass say so
     for (size_t i = i0; i < n_ray_floats; i += stride) {
@@ -125,12 +126,13 @@ __global__ void __launch_bounds__(256) nerf_tile_bounds_kernel(const float *dL, 
         m[0] = fmaxf(m[0], a); m[1] = fmaxf(m[1], b);
     }
     for (size_t i = i0; i < n_em; i += stride) { const float a = fabsf(em[i]); bad = bad || !(a < kInf); m[2] = fmaxf(m[2], a); }
+    for (size_t i = i0; i < n_sig; i += stride) { const float a = sig[i]; bad = bad || !(fabsf(a) < kInf); m[3] = fmaxf(m[3], -a); }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(out + 3, 1u);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m[k] = fmaxf(m[k], __shfl_down(m[k], off, 64));
-        if ((threadIdx.x & 63) == 0 && m[k] > 0.0f) atomicMax(out + k, __float_as_uint(m[k]));      // (non-negative floats order like their bits)
+        if ((threadIdx.x & 63) == 0 && m[k] > 0.0f) atomicMax(out + (k < 3 ? k : 4), __float_as_uint(m[k]));   // (non-negative floats order like their bits)
     }
 }
 
@@ -206,9 +208,13 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
         const float ext = sqrtf((P.bmax[0] - P.bmin[0]) * (P.bmax[0] - P.bmin[0]) + (P.bmax[1] - P.bmin[1]) * (P.bmax[1] - P.bmin[1]) +
                                 (P.bmax[2] - P.bmin[2]) * (P.bmax[2] - P.bmin[2]));
         // |gs| <= sum_k |dL_k| (|em_k| dt a T + |result_k| dt a / (a + 1e-10)) <= 3 Dmax (2 Emax + Lmax) dt, dt <= 2 ext / (N - 1)
-        const float Bs = fabsf(P.scale) * 3.0f * Dmax * (2.0f * Emax + Lmax) * (2.0f * ext / (float) (P.nerf_queries - 1)) * 1.001f;
+        // negative densities under the identity activation (a projected optimisation has none): a <= exp(|sigma| dt), throughput <= exp(|sigma| x chord) =: G;
+        // the bounds grow by G^2 (capped: beyond e^60 the grids hold nonsense anyway)
+        const float neg = P.nerf_relu ? 0.0f : __uint_as_float(T.bounds[4]);
+        const float G = expf(fminf(neg * fabsf(P.scale) * ext, 30.0f)), G2 = G * G;
+        const float Bs = fabsf(P.scale) * 3.0f * Dmax * (2.0f * Emax + Lmax) * (2.0f * ext / (float) (P.nerf_queries - 1)) * 1.001f * G2;
         int es = 0, ec = 0;
-        (void) frexpf(fmaxf(Bs, 1e-30f), &es); (void) frexpf(fmaxf(Dmax, 1e-30f), &ec);
+        (void) frexpf(fmaxf(Bs, 1e-30f), &es); (void) frexpf(fmaxf(Dmax * G2, 1e-30f), &ec);
         es = max(es - kFixBits, -100); ec = max(ec - kFixBits, -100);
         unit_s = ldexpf(1.0f, es); inv_s = ldexp(1.0, -es); unit_c = ldexpf(1.0f, ec); inv_c = ldexp(1.0, -ec);
     }
@@ -377,11 +383,11 @@ hipError_t launch_nerf_tile_adjoint(const Params &P, bool g4, bool count, uint32
     if (!nerf_tile_supported(P) || (g4 && !P.grid4) || !bounds || !P.emission) return hipErrorInvalidValue;
     NerfTile T;
     {
-        hipError_t e = hipMemsetAsync(bounds, 0, 4 * sizeof(uint32_t), stream);
+        hipError_t e = hipMemsetAsync(bounds, 0, 8 * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
         const size_t n_em = (size_t) P.rx * P.ry * P.rz * 3;
         hipLaunchKernelGGL(nerf_tile_bounds_kernel, dim3(2048), dim3(256), 0, stream, P.dL + 3 * P.ray_first, P.L_in + 3 * P.ray_first,
-                           (size_t) (P.n_rays - P.ray_first) * 3, P.emission, n_em, bounds);
+                           (size_t) (P.n_rays - P.ray_first) * 3, P.emission, n_em, P.sigma_t, n_em / 3, bounds);
         T.bounds = bounds;
     }
     T.tiles_x = ((uint32_t) P.width + 7u) / 8u;
