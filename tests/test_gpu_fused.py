@@ -1,6 +1,6 @@
 """BASELINE config 5: nerf emission-absorption (python/integrators/nerf.py:47-165, 128 queries) FUSED with DRT
 scattering (python/integrators/volpathsimple.py) in one pass over one interleaved four-channel [sigma_t, r, g, b] grid
-(csrc/drt_fused.hip; the reference's scenes bind ONE asset as albedo and emission, python/scene_config.py:109-110).
+(drt_fused_render_* in csrc/drt_capi.cpp - since round 5 two dense passes: the nerf march, adjoint in csrc/drt_nerf_tile.hip, beside the volpathsimple half in the production tracers; the reference's scenes bind ONE asset as albedo and emission, python/scene_config.py:109-110).
 
 Oracle: the two restated integrators run on the same rays / streams (oracle.binding.fused_render_*).
   * radiance of both halves BIT-EXACT per ray, event counters equal, gradients within 2e-4 max|oracle|;

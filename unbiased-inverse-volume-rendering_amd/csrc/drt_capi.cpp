@@ -373,8 +373,9 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
             // few records per CU, 0.45 ms of the headline's adjoint launch.  Drained workgroups write them to the pool and end; the partition
             // passes of the gradient reduction (histogram, offsets, scan, scatter: they do not touch the gradient grids) run on a side stream
             // BESIDE the tail launch, which finishes the pooled records with its splats as direct atomics; tile_reduce follows both.
-            // Launches of fewer than 2 M rays keep their last paths (a rank's share of the headline at 8 GPUs, 1 M rays: 3.19 ms per step without
-            // the pool, 3.31 with it - such a launch IS its longest path, a second launch only adds its own start; at 4 GPUs, 2 M rays: 4.00 / 4.07 ms).
+            // Below 2 M rays this overlapped kind does not pay (a rank's share of the headline at 8 GPUs, 1 M rays: 3.19 ms per step without the pool,
+            // 3.31 with it - such a launch IS its longest path, a second launch only adds its own start; at 4 GPUs, 2 M rays: 4.00 / 4.07 ms): those
+            // launches take the SOLO kind below.
             // (test hooks: 268435456 no tail pool, 1073741824 launches from 4096 rays on have one)
             const uint64_t tail_min = dbg(h->debug_flags, 1073741824u) ? 4096u : (1u << 21);
             const bool big = adjoint && h->early_plan && Q.rec_buf[0] && span >= tail_min;
@@ -1271,7 +1272,7 @@ int drt_nerf_render_backward(drt_handle h, const drt_nerf_config *cfg, const flo
     return nerf_backward(h, P, cfg, g4);
 }
 
-// ---- fused nerf + volpathsimple pass (BASELINE config 5; drt_fused.hip) ---------------------------------------------
+// ---- nerf + volpathsimple over one set of grids (BASELINE config 5): two dense passes on two streams, see drt_fused_render_* below ------------
 // the interleaved four-channel apron-brick copy [sigma_t, r, g, b] (eval4): (re)built when the parameter grids changed since the last copy
 // `rgb`: the colour grid of the copy - the medium's albedo (the fused pass: the copy is kept until the parameters change) or the caller's emission
 // grid of a stand-alone nerf call (no version to go by: copied on every call, 0.46 ms at 256^3 against the 3 ms the four-channel lookups save)

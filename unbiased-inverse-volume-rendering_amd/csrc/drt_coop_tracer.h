@@ -1,5 +1,5 @@
 // drt_coop_tracer.h -- wave-cooperative tracking loops for the one-ray-per-lane tracer (CoopTracer).
-// Included by drt_coop.hip (the volpathsimple kernels) and drt_fused.hip (nerf + volpathsimple in one pass).
+// Included by drt_coop.hip / drt_coop_super.hip (the volpathsimple kernels of global-majorant scenes and the supergrid fallback).
 //
 // Measured on the headline workload (wave-level vs lane-level iteration counts): 85 % of
 // the per-lane adjoint kernel's VALU instructions are the delta- and ratio-tracking step loops, executed with
