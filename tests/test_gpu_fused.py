@@ -210,3 +210,16 @@ def test_config5_fused_256_512x32_128_queries(uivr, oracle, gpu):
     h.enable_counters(False)
     _close(grads[uivr.SIGMA_T_KEY], gs, "fused window grad sigma_t")
     _close(grads[uivr.ALBEDO_KEY], grgb, "fused window grad colour")
+
+
+def test_nerf_tile_adjoint_and_fused_pass_repeat_at_size(gpu):
+    """tools/stress_nerf_tile.py: config 5 (nerf and nerf + DRT, 256^3, 512^2 x 32 spp) and two ragged shapes, the same seeds over and over - the LDS
+    window protocol of drt_nerf_tile.hip (rays waiting for the window, flushes, moves) and the two streams of the fused pass must not change a result:
+    radiance bitwise the same every time, gradients equal up to summation order and finite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_nerf_tile.py"), "--reps", "6"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "STRESS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
