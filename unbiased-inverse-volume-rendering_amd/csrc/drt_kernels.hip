@@ -556,6 +556,12 @@ __global__ void __launch_bounds__(256) nerf_kernel(const Params P)
                 float t_b = P.nerf_jitter ? step * ((float)(j + 1) + jit) : step * (float)(j + 1);
                 float dt = t_b - t_a;
                 V3 p = ray_at(o, d, t_b);                                    // query_medium :151-165
+                if constexpr (!ADJ) {
+                    // a query in empty space (every voxel its lookup can touch is exactly 0: the occupancy mask) changes nothing in the primal:
+                    // sigma = 0, a = exp(-0) = 1 (or the last query's 1), weight = 0 x throughput = 0, 1 + 1e-10 == 1 in fp32 - most queries of a sparse
+                    // volume end here, without the exponential and the bookkeeping of exact zeros
+                    if (occ && occ_empty(P, p, occ)) { n_q++; t_a = t_b; continue; }
+                }
                 float raw = eval_sigma_t(P, p, occ);
                 float sigma = P.nerf_relu ? fmaxf(0.0f, raw) : raw;
                 n_q++;
