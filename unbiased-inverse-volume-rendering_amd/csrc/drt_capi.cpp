@@ -1377,12 +1377,17 @@ int drt_fused_render_backward(drt_handle h, const drt_nerf_config *cfg, const fl
         }
         // the tile kernel (one workgroup of 16 waves and 139 KiB of LDS per CU) leaves room for the wave-cooperative tracer's workgroups beside it;
         // the record path of explicit ray batches shares the handle's record streams with the volpathsimple half: one after the other
+        bool forked = false;
         if (tile) {
             rc = fused_fork(h);
-            if (rc) return rc;
-            rc = nerf_backward(h, P, cfg, g4, h->nerf_stream);
+            forked = rc == DRT_OK;
+            if (!rc) rc = nerf_backward(h, P, cfg, g4, h->nerf_stream);
         } else rc = nerf_backward(h, P, cfg, false);
-        if (rc) return rc;
+        if (rc) {                                                    // (nothing of the other stream may outlive the call)
+            if (forked) (void) fused_join(h);
+            if (t0) { (void) hipEventDestroy(t0); (void) hipEventDestroy(t1); }
+            return rc;
+        }
         // (launched first: its workgroups need almost a whole CU's LDS, which the other half's many small workgroups would not leave free)
     }
     rc = drt_render_backward(h, rays_o, rays_d, n_rays, ray_offset, spp, seed, dL_drt, L_drt_in, grad_sigma_t, grad_rgb);
