@@ -74,6 +74,40 @@ def test_fused_matches_oracle_on_the_fixture(uivr, oracle, gpu, variant, nerf):
     h.enable_counters(False)
 
 
+@pytest.mark.parametrize("flags", [128, 16384 | 524288], ids=["atomic-path", "record-memory-runs-out"])
+def test_fused_backward_when_the_volpathsimple_half_leaves_the_deferred_path(uivr, oracle, gpu, flags):
+    """The nerf half's window flush adds to the gradient grids on its own stream WHILE the volpathsimple half runs.  When that half
+    takes the atomic gradient path (test hook 128; or record memory that runs out after the first ray sub-batch: 16384 | 524288) its
+    last kernel is untile_gradients_kernel, whose flush must then be atomic too - a plain `+=` would lose window flushes that land
+    between its load and its store.  Repeated: a lost update is a race, not a certainty."""
+    scene = uivr.cube_test_scene(48, 48, density_scale=2.0)
+    props, nerf_props = props_for("drt"), dict(queries_per_ray=64, activation="identity", jittering_enabled=True, hide_emitters=False)
+    spp, seed = 16, 99
+    osc = oracle.OracleScene(scene)
+    Lr, _ = oracle.fused_render_primal(osc, props, nerf_props, spp, seed)
+    n = Lr.shape[0]
+    dL = ((np.random.default_rng(3).random((n, 6), dtype=np.float32) - 0.5) * 1e-2).astype(np.float32)
+    gs, grgb, _ = oracle.fused_render_backward(osc, props, nerf_props, spp, seed, dL, Lr)
+    sg = uivr.scene_to(scene, gpu)
+    d = {"type": "nerf+volpathsimple", "test_hooks": True, "queries_per_ray": 64}
+    d.update(props)
+    integ = uivr.load_dict(d)
+    h = integ.native_handle(sg)
+    batch = uivr.RayBatch(n_rays=n, spp=spp, sensor=sg.sensors[0])
+    samp = uivr.IndependentSampler(seed, spp)
+    h.set_debug_flags(flags)
+    try:
+        for rep in range(4):
+            L, _, st = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+            np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+            grads = uivr.alloc_grads(sg, integ.param_keys)
+            integ.sample(uivr.ADMode.Backward, sg, samp.clone(), batch, δL=torch.from_numpy(dL).to(gpu), state_in=st, grads=grads)
+            _close(grads[uivr.SIGMA_T_KEY], gs, f"flags {flags} rep {rep} grad sigma_t")
+            _close(grads[uivr.ALBEDO_KEY], grgb, f"flags {flags} rep {rep} grad colour")
+    finally:
+        h.set_debug_flags(0)
+
+
 @pytest.mark.parametrize("env,factor", [(True, 0), (False, 3), (True, 3)])
 def test_fused_with_envmap_and_supergrid_matches_oracle(uivr, oracle, gpu, env, factor):
     """the reference's nerf scenes run an environment map AND majorant_resolution_factor 8

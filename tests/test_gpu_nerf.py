@@ -182,4 +182,11 @@ def test_nerf_tile_adjoint_propagates_non_finite_inputs(uivr, gpu):
     dL[37, 1] = float("nan")
     grads = uivr.alloc_grads(sg, integ.param_keys)
     integ.sample(uivr.ADMode.Backward, sg, samp.clone(), batch, δL=dL, state_in=st, grads=grads)
-    assert bool(torch.isnan(grads[uivr.SIGMA_T_KEY]).any()) and bool(torch.isnan(grads[uivr.EMISSION_KEY]).any())
+    # EVERY voxel: a caller (or a masked all-reduce) that looks at part of the grids must not find plausible finite numbers there
+    assert bool(torch.isnan(grads[uivr.SIGMA_T_KEY]).all()) and bool(torch.isnan(grads[uivr.EMISSION_KEY]).all())
+    # ... and a dL that is finite but overflows the bound the fixed-point units follow from
+    dL = torch.full_like(L, 1e-3)
+    dL[5, 0] = 3.0e38
+    grads = uivr.alloc_grads(sg, integ.param_keys)
+    integ.sample(uivr.ADMode.Backward, sg, samp.clone(), batch, δL=dL, state_in=st, grads=grads)
+    assert not bool(torch.isfinite(grads["_flat"]).any())

@@ -77,6 +77,7 @@ struct drt_handle_s {
     // same job if nothing happened to the handle in between
     void *d_pcache = nullptr;          // [rays][kPathCacheCap][2] uint4 | [rays] hash words
     size_t pcache_bytes = 0;
+    uint32_t pcache_cap = 0;           // bounce-loop iterations per ray of the cache as the last primal launch laid it out
     struct JobSig { uint64_t n_rays, ray_offset, chunk, stride; uint32_t spp, seed; const void *rays_o, *rays_d; uint64_t scene_version; bool valid; } pcache_sig{};
     bool order_valid = false;          // block_order of the last primal launch is usable
     bool perm_valid = false;           // ray_perm was written by the primal launch the path cache signature describes
@@ -193,6 +194,7 @@ void clear_timings(drt_handle h)
 constexpr uint32_t kPathCacheCap = DRT_PATH_CACHE_CAP;  // bounce-loop iterations cached per ray (headline: 2.4 on average)
 constexpr uint64_t kHeavyFirstMaxBlocks = 12288;       // launches up to this many 256-ray blocks run heavy blocks first
 constexpr uint64_t kPathCacheMaxRays = 1ull << 24;     // larger primal launches (reference renders) skip the cache
+constexpr size_t kPathCacheMaxBytes = 36ull << 30;     // the cache never takes more than this (2^24 rays x 64 iterations x 32 B = 34 GB)
 
 bool same_job(const drt_handle_s::JobSig &a, const drt_handle_s::JobSig &b)
 {
@@ -218,18 +220,34 @@ void bind_path_cache_write(drt_handle h, drt::Params &P)
     h->pcache_sig.valid = false;
     if (P.n_rays != h->order_rays) h->order_rays = 0;           // another launch shape re-carves the buffer: the stored order dies
     if (dbg(h->debug_flags, 1048576u) || P.n_rays > kPathCacheMaxRays) return;
-    const size_t entries = (size_t) P.n_rays * kPathCacheCap * 2 * sizeof(uint4), n_blocks = (size_t) ((P.n_rays + 255) / 256);
+    const size_t n_blocks = (size_t) ((P.n_rays + 255) / 256);
     const size_t perm_slots = ((size_t) P.n_rays + drt::kPermGroup - 1) / drt::kPermGroup * drt::kPermGroup;
-    const size_t need = entries + (size_t) P.n_rays * sizeof(uint32_t) + 2 * n_blocks * sizeof(uint32_t) + perm_slots * 3 + 16;
+    const size_t rest = (size_t) P.n_rays * sizeof(uint32_t) + 2 * n_blocks * sizeof(uint32_t) + perm_slots * 3 + 16;
+    auto entry_bytes = [&](uint32_t cap) { return (size_t) P.n_rays * cap * 2 * sizeof(uint4); };
+    // Depth of the cache: kPathCacheCap iterations per ray (2 KiB per ray: 17 GB at the headline's 8.4 M rays) where that fits what the buffer holds
+    // already or HALF of what the device has free now, at most kPathCacheMaxBytes - the record streams of the backward pass are sized from the free
+    // memory too (run_backward), and a handle on a smaller device, or one that shares its device with other ranks, must leave them room; otherwise
+    // halved until it fits (from 4 iterations down: no cache - deep main paths then walk again in the adjoint pass, results unchanged).
+    uint32_t cap = kPathCacheCap;
+    if (entry_bytes(cap) + rest > h->pcache_bytes) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); free_b = 0; }
+        size_t budget = h->pcache_bytes + free_b / 2;
+        if (budget > kPathCacheMaxBytes) budget = kPathCacheMaxBytes;
+        while (cap >= 4u && entry_bytes(cap) + rest > budget) cap /= 2u;
+        if (cap < 4u) return;
+    }
+    const size_t entries = entry_bytes(cap), need = entries + rest;
     if (need > h->pcache_bytes) {
         if (h->d_pcache) { if (hipStreamSynchronize(h->stream) != hipSuccess) return; (void) hipFree(h->d_pcache); h->d_pcache = nullptr; h->pcache_bytes = 0; }
         h->order_rays = 0;
         if (hipMalloc(&h->d_pcache, need) != hipSuccess) { (void) hipGetLastError(); h->d_pcache = nullptr; return; }
         h->pcache_bytes = need;
     }
+    h->pcache_cap = cap;
     P.path_cache = (uint4 *) h->d_pcache;
     P.ray_hash = (uint32_t *) ((char *) h->d_pcache + entries);
-    P.path_cache_cap = kPathCacheCap; P.path_cache_mode = 1;
+    P.path_cache_cap = cap; P.path_cache_mode = 1;
     P.block_cost = P.ray_hash + P.n_rays;
     if (hipMemsetAsync(P.block_cost, 0, n_blocks * sizeof(uint32_t), h->stream) != hipSuccess) { (void) hipGetLastError(); P.block_cost = nullptr; }
     if (!dbg(h->debug_flags, 4194304u)) P.ray_iters = (uint8_t *) (perm_base(P.ray_hash, P.n_rays) + perm_slots);   // written by the cooperative primal kernel only
@@ -242,10 +260,10 @@ void bind_path_cache_read(drt_handle h, drt::Params &P, uint64_t job_rays)
 {
     drt::Params J = P; J.n_rays = job_rays;
     if (!h->pcache_sig.valid || dbg(h->debug_flags, 1048576u) || !same_job(h->pcache_sig, job_sig(h, J))) return;
-    const size_t entries = (size_t) job_rays * kPathCacheCap * 2 * sizeof(uint4);
+    const size_t entries = (size_t) job_rays * h->pcache_cap * 2 * sizeof(uint4);   // (the depth the primal pass of this job wrote)
     P.path_cache = (uint4 *) h->d_pcache;
     P.ray_hash = (uint32_t *) ((char *) h->d_pcache + entries);
-    P.path_cache_cap = kPathCacheCap; P.path_cache_mode = 2;
+    P.path_cache_cap = h->pcache_cap; P.path_cache_mode = 2;
     const bool no_lpt = dbg(h->debug_flags, 16777216u);   // test hook: plain XCD block map
     // (measured: film 184^2 x 32 spp, the per-rank share at 8 GPUs: adjoint 2.22 -> 1.70 ms; 256^2: 3.11 -> 2.85 ms; at
     //  the full 512^2 the XCD-contiguous block map is worth more than the order: 9.48 vs 10.02 ms)

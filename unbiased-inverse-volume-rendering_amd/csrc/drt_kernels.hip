@@ -798,12 +798,15 @@ __device__ __forceinline__ void untile_march(const Params &P, int plane0, int bx
         if (out) {
             const size_t v = ((size_t) Z * P.ry + y) * P.rx + X;
             for (int j = 0; j < nvx; ++j) {
+                // (atomic adds: every voxel is flushed by ONE thread of this kernel, but the fused nerf + volpathsimple pass runs the nerf half's
+                //  window flush - atomics into the same grids - on another stream beside it, drt_capi.cpp: drt_fused_render_backward; only
+                //  the non-zero entries, i.e. the support of this job's gradient, pay for it)
                 if (NPL == 1) {
-                    if (acc[0][j] != 0.0f) P.g_sigma[v + j] += acc[0][j];
+                    if (acc[0][j] != 0.0f) atomicAdd(P.g_sigma + v + j, acc[0][j]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < NPL; ++k)
-                        if (acc[k][j] != 0.0f) P.g_albedo[3 * (v + j) + k] += acc[k][j];
+                        if (acc[k][j] != 0.0f) atomicAdd(P.g_albedo + 3 * (v + j) + k, acc[k][j]);
                 }
             }
         }

@@ -164,8 +164,33 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
         else i = rel;
         job = job && i >= P.ray_first && i < P.n_rays;
     }
-    // non-finite dL / L_in / emission values (as a diverged optimisation produces them) propagate as they do on the record path: NaN gradients
-    if (blockIdx.x == 0 && t == 0 && T.bounds[3]) { atomicAdd(P.g_sigma, __uint_as_float(0x7fc00000u)); atomicAdd(P.g_albedo, __uint_as_float(0x7fc00000u)); }
+    // fixed-point units: 2^(e - 44) with 2^e >= the bound of a sigma_t splat / of a colour splat (|dL_k| x weight, weight <= 1)
+    float unit_s, unit_c; double inv_s, inv_c;
+    {
+        const float Dmax = __uint_as_float(T.bounds[0]), Lmax = __uint_as_float(T.bounds[1]), Emax = __uint_as_float(T.bounds[2]);
+        const float ext = sqrtf((P.bmax[0] - P.bmin[0]) * (P.bmax[0] - P.bmin[0]) + (P.bmax[1] - P.bmin[1]) * (P.bmax[1] - P.bmin[1]) +
+                                (P.bmax[2] - P.bmin[2]) * (P.bmax[2] - P.bmin[2]));
+        // |gs| <= sum_k |dL_k| (|em_k| dt a T + |result_k| dt a / (a + 1e-10)) <= 3 Dmax (2 Emax + Lmax) dt, dt <= 2 ext / (N - 1)
+        // negative densities under the identity activation (a projected optimisation has none): a <= exp(|sigma| dt), throughput <= exp(|sigma| x chord) =: G;
+        // the bounds grow by G^2 (capped: beyond e^60 the grids hold nonsense anyway)
+        const float neg = P.nerf_relu ? 0.0f : __uint_as_float(T.bounds[4]);
+        const float G = expf(fminf(neg * fabsf(P.scale) * ext, 30.0f)), G2 = G * G;
+        const float Bs = fabsf(P.scale) * 3.0f * Dmax * (2.0f * Emax + Lmax) * (2.0f * ext / (float) (P.nerf_queries - 1)) * 1.001f * G2;
+        // Non-finite dL / L_in / emission / density values (as a diverged optimisation produces them), or bounds that overflow fp32: fixed point
+        // cannot carry them.  The march is skipped and BOTH gradient grids are filled with NaN - every voxel, so that a caller (or a masked
+        // all-reduce) that looks at any part of the grids sees that this gradient is void, as it would find NaN in the voxels the record path touches.
+        if (T.bounds[3] || !(Bs < kInf) || !(Dmax * G2 < kInf)) {
+            const float nan = __uint_as_float(0x7fc00000u);
+            const size_t nv = (size_t) P.rx * P.ry * P.rz, i0 = (size_t) blockIdx.x * NT + t, stride = (size_t) gridDim.x * NT;
+            for (size_t v = i0; v < nv; v += stride) P.g_sigma[v] = nan;
+            for (size_t v = i0; v < 3 * nv; v += stride) P.g_albedo[v] = nan;
+            return;
+        }
+        int es = 0, ec = 0;
+        (void) frexpf(fmaxf(Bs, 1e-30f), &es); (void) frexpf(fmaxf(Dmax * G2, 1e-30f), &ec);
+        es = max(es - kFixBits, -100); ec = max(ec - kFixBits, -100);
+        unit_s = ldexpf(1.0f, es); inv_s = ldexp(1.0, -es); unit_c = ldexpf(1.0f, ec); inv_c = ldexp(1.0, -ec);
+    }
     if (__syncthreads_count(job) == 0) return;                       // (a launch over a window of the film: most tiles hold none of its rays)
 
     for (int w = t; w < 4 * kWinStore; w += NT) win[w] = 0ull;
@@ -200,23 +225,6 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             step = P.nerf_jitter ? (si.t - 0.0f) / (float) N : (si.t - 0.0f) / (float) (N - 1);
             jit = S.next_1d();
         }
-    }
-    // fixed-point units: 2^(e - 44) with 2^e >= the bound of a sigma_t splat / of a colour splat (|dL_k| x weight, weight <= 1)
-    float unit_s, unit_c; double inv_s, inv_c;
-    {
-        const float Dmax = __uint_as_float(T.bounds[0]), Lmax = __uint_as_float(T.bounds[1]), Emax = __uint_as_float(T.bounds[2]);
-        const float ext = sqrtf((P.bmax[0] - P.bmin[0]) * (P.bmax[0] - P.bmin[0]) + (P.bmax[1] - P.bmin[1]) * (P.bmax[1] - P.bmin[1]) +
-                                (P.bmax[2] - P.bmin[2]) * (P.bmax[2] - P.bmin[2]));
-        // |gs| <= sum_k |dL_k| (|em_k| dt a T + |result_k| dt a / (a + 1e-10)) <= 3 Dmax (2 Emax + Lmax) dt, dt <= 2 ext / (N - 1)
-        // negative densities under the identity activation (a projected optimisation has none): a <= exp(|sigma| dt), throughput <= exp(|sigma| x chord) =: G;
-        // the bounds grow by G^2 (capped: beyond e^60 the grids hold nonsense anyway)
-        const float neg = P.nerf_relu ? 0.0f : __uint_as_float(T.bounds[4]);
-        const float G = expf(fminf(neg * fabsf(P.scale) * ext, 30.0f)), G2 = G * G;
-        const float Bs = fabsf(P.scale) * 3.0f * Dmax * (2.0f * Emax + Lmax) * (2.0f * ext / (float) (P.nerf_queries - 1)) * 1.001f * G2;
-        int es = 0, ec = 0;
-        (void) frexpf(fmaxf(Bs, 1e-30f), &es); (void) frexpf(fmaxf(Dmax * G2, 1e-30f), &ec);
-        es = max(es - kFixBits, -100); ec = max(ec - kFixBits, -100);
-        unit_s = ldexpf(1.0f, es); inv_s = ldexp(1.0, -es); unit_c = ldexpf(1.0f, ec); inv_c = ldexp(1.0, -ec);
     }
     uint32_t n_q = 0;
     int Wx = -(1 << 28), Wy = -(1 << 28), Wz = -(1 << 28);             // window origin (workgroup-uniform; none yet: the first splats all wait)

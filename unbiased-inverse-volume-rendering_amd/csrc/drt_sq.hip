@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     const unsigned long long pt_start = __builtin_amdgcn_s_memrealtime(); unsigned long long pt_drained = 0;
 #endif
 
+    for (;;) {   // (once, unless a hand-over to the tail pool finds more records than the workgroup's share: then the loop is resumed, see behind it)
     for (;;) {
         // ---- what is there to do? ---------------------------------------------------------------------------
         uint32_t qn = 0;
@@ -1309,6 +1310,20 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             // hand-over: every wave is out of the loop with no record in its registers (a batch is stored and queued before the loop head is seen again):
             // what the queues hold goes to the pool - wave k the entries of queue kind k, three records per round (lane = 20 x record + quad)
             __syncthreads();
+            // The decision inside the loop came from two LDS reads that are not one snapshot (records retired between them count twice): here the
+            // count is exact.  More than the workgroup's share of the pool (the host sizes it as workgroups x sq_tail_push()): nothing is handed
+            // over or dropped - the flag is taken back, the threshold set to 0 and the workgroup finishes its records itself.
+            if ((((sq_vu32 *) misc)[0] & 0x80000000u) != 0u) {
+                uint32_t queued = 0;
+#pragma unroll
+                for (int k = 0; k <= SQ_TB; ++k) { const unsigned long long c = ((sq_vu64 *) ctl)[k]; queued += (uint32_t) (c >> 32) - (uint32_t) c; }
+                if (queued > (uint32_t) (DRT_SQ_TAIL_PUSH + 64)) {
+                    __syncthreads();
+                    if (threadIdx.x == 0) { ((sq_vu32 *) misc)[4] = 0u; atomicAnd(misc, 0x7fffffffu); }
+                    __syncthreads();
+                    continue;
+                }
+            }
             if ((((sq_vu32 *) misc)[0] & 0x80000000u) != 0u && wave <= SQ_TB) {
                 const unsigned long long c = ((sq_vu64 *) ctl)[wave];
                 const uint32_t head = (uint32_t) c, nq = (uint32_t) (c >> 32) - head;
@@ -1331,6 +1346,8 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             }
         }
         if constexpr (ADJ) close_records(P, rec);
+    }
+    break;
     }
 #if DRT_SQ_PROFILE == 6
     __syncthreads();

@@ -229,7 +229,7 @@ def gradient_support(sigma_t: torch.Tensor, grads: Dict[str, torch.Tensor], spar
 
 class _ReduceState:
     """What one (process group, buffer) remembers between backward passes."""
-    __slots__ = ("in_set", "src", "pos", "count", "calls", "pending")
+    __slots__ = ("in_set", "src", "pos", "count", "calls", "pending", "dev_mode")
 
     def __init__(self):
         self.in_set = None          # uint8 [n_blocks]: the packing set grown from the gradients seen so far
@@ -238,6 +238,7 @@ class _ReduceState:
         self.count = 0
         self.calls = 0
         self.pending = None         # (pinned host float, event): blocks found outside a GradientSupport, not looked at yet
+        self.dev_mode = None        # which of src / pos the history set was laid out for (the packing kernels or the torch formulation)
 
 
 _STATE: Dict[tuple, _ReduceState] = {}
@@ -328,7 +329,8 @@ def _allreduce_flat_body(flat, group, compact, stats, support, strict, dist, n, 
         raise ValueError("allreduce_gradients: `support` was built for another buffer")
 
     # ---- the packing set ------------------------------------------------------------------------------------------------
-    dev_path = flat.is_cuda and flat.dtype == torch.float32 and flat.data_ptr() % 16 == 0          # the packing kernels
+    dev_path = (flat.is_cuda and flat.dtype == torch.float32 and flat.data_ptr() % 16 == 0        # the packing kernels ...
+                and B in (64, 128, 256))                                                         # ... are instantiated for these block sizes
     if support is not None:
         in_set, count, pos = support.mask, support.count, support.pos
         src = None
@@ -338,6 +340,11 @@ def _allreduce_flat_body(flat, group, compact, stats, support, strict, dist, n, 
             dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
             n_coll += 1
             _set_history(st, mask, dev_path)                       # (host wait: first call and resets only)
+        elif st.dev_mode != dev_path:
+            # the same (group, buffer size) came back with another alignment / dtype: the set stays, its index tables are rebuilt for
+            # the formulation that runs now (pos for the packing kernels, src for the torch one) - never a None table, never a
+            # nonzero() per call
+            _set_history(st, st.in_set, dev_path)
         in_set, count, src, pos = st.in_set, st.count, st.src, st.pos
     frac = count / n_blocks
     if compact != "always" and frac > COMPACT_MAX_ACTIVE:          # (known before anything is packed)
@@ -397,6 +404,7 @@ def _allreduce_flat_body(flat, group, compact, stats, support, strict, dist, n, 
 def _set_history(st: _ReduceState, mask: torch.Tensor, dev_path: bool) -> None:
     """The packing set grown from the sums seen so far (no `GradientSupport`): its size is needed on the host."""
     st.in_set = mask
+    st.dev_mode = dev_path
     if dev_path:
         st.pos, cnt = _positions(mask)
         st.src = None
