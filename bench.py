@@ -355,10 +355,17 @@ def other_configs(torch, u, synthetic, dev, integ_name="volpathsimple-drt", only
             oc = u.OptimizationConfig(name="r", spp=16, n_iter=n_iter, lr=3e-4, primal_spp_factor=64, batch_size=32768,
                                       lr_schedule=u.Schedule.Last25, upsample=[0.04, 0.16, 0.36, 0.64])
             stamps = []
+            # (the loop keeps no device -> host wait per iteration: the stamps that delimit a level wait for the device themselves)
+            sync_at = {1, n_iter} | {int(x) for x in oc.upsample_at}
+
+            def prog(i, l):
+                if (i + 1) in sync_at:
+                    torch.cuda.synchronize()
+                stamps.append(time.perf_counter())
+
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            _, params, _, hist = u.run_optimization(None, oc, scfg, integ_name, ref_images=ref,
-                                                    progress=lambda i, l: stamps.append(time.perf_counter()))
+            _, params, _, hist = u.run_optimization(None, oc, scfg, integ_name, ref_images=ref, progress=prog)
             torch.cuda.synchronize()
             total = time.perf_counter() - t0
             bounds = [0] + sorted(oc.upsample_at) + [n_iter]

@@ -4,8 +4,10 @@
 The reference stores no golden vectors for this path and cannot be imported here
 (Mitsuba 3 / Dr.Jit absent), so these fixtures are produced by the
 build's own oracle (oracle/drt_oracle.c) on the reference's fully specified 3^3 cube
-fixture (tests/test_integrators.py:19-116) and pin it against regressions; the GPU
-tests compare the HIP path against the same vectors.
+fixture (tests/test_integrators.py:19-116) and pin it against regressions:
+tests/test_oracle_kat.py (CPU) checks the oracle against the committed file, and
+tests/test_gpu_film_shapes.py::test_hip_path_equals_the_committed_golden_* compare the
+HIP path with the committed file directly (without calling the oracle).
 
     python tests/golden/make_golden.py
 """

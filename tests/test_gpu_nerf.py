@@ -115,10 +115,11 @@ def test_nerf_autograd_and_errors(uivr, gpu):
 
 @pytest.mark.parametrize("film,chunk,spp,props", [((33, 26), 33, 5, dict(queries_per_ray=40)), ((16, 40), 40, 19, dict(queries_per_ray=24, activation="relu")),
                                                   ((24, 24), 48, 1, dict())])
-def test_nerf_tile_adjoint_equals_the_record_path(uivr, gpu, film, chunk, spp, props):
-    """drt_nerf_tile.hip against nerf_kernel + drt_deferred.hip (test hook 512) where the tile mapping is ragged: films that are no multiple of
-    the 8 x 8 tile, spp that is no multiple of a workgroup's 16 samples, a launch over a window of the film (ray_offset: most tiles hold
-    none of its rays) and the interleaved chunks of a sharded render (ShardSpec).  Same statements per ray: gradients up to summation order."""
+def test_nerf_tile_adjoint_equals_the_record_path(uivr, oracle, gpu, film, chunk, spp, props):
+    """drt_nerf_tile.hip against the ORACLE (round 6: directly, not only through the record path) and against nerf_kernel + drt_deferred.hip
+    (test hook 512) where the tile mapping is ragged: films that are no multiple of the 8 x 8 tile and not square, spp that is no multiple of a
+    workgroup's 16 samples, a launch over a window of the film (ray_offset: most tiles hold none of its rays) and the interleaved chunks of a
+    sharded render (ShardSpec).  Same statements per ray: gradients up to summation order."""
     rng = np.random.default_rng(11)
     st = (rng.random((20, 18, 22, 1), dtype=np.float32) * 3.0).astype(np.float32)
     st[rng.random(st.shape) < 0.5] = 0.0
@@ -161,6 +162,34 @@ def test_nerf_tile_adjoint_equals_the_record_path(uivr, gpu, film, chunk, spp, p
         a, b = out["tile"][k], out["records"][k]
         assert float(b.abs().max()) > 0
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), k
+    # ... and each case against oracle.nerf_render (python/integrators/nerf.py:47-148 restated): radiance bit-exact, gradients within 2e-4 max
+    osc = oracle.OracleScene(uivr.Scene(medium=uivr.GridMedium(sigma_t=st, albedo=em.copy(), emission=em, bbox_min=(-1, -0.9, -1.1),
+                                                                bbox_max=(1, 0.9, 1.1), scale=1.3),
+                                        emitter=uivr.ConstantEmitter((0.3, 0.4, 0.5)), sensors=[sensor]))
+    Lr, _ = oracle.nerf_render(osc, em, props, spp, seed)
+    integ = uivr.load_dict(dict(type="nerf", **props))
+    L_hip, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(seed, spp), uivr.RayBatch(n_rays=n_pix * spp, spp=spp, sensor=sg.sensors[0]))
+    np.testing.assert_array_equal(L_hip.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+    gi_r = (2.0 / (n_pix * 3)) * (oracle.develop(Lr, spp) - 0.4)
+    dL_film = np.repeat(gi_r / spp, spp, axis=0).astype(np.float32)
+
+    def oracle_grads(first, n, dL_rays):
+        gs, ge, _ = oracle.nerf_render(osc, em, props, spp, seed, dL=dL_rays, L_in=Lr[first:first + n], n_rays=n, ray_offset=first)
+        return np.concatenate([gs.reshape(-1), ge.reshape(-1)])
+
+    ref = {"film": oracle_grads(0, n_pix * spp, dL_film)}
+    for rank in range(2):                                                # rank r of 2 takes the pixel chunks c with c % 2 == r
+        acc = np.zeros_like(ref["film"])
+        for c in range(rank, (n_pix + chunk - 1) // chunk, 2):
+            p0, p1 = c * chunk, min((c + 1) * chunk, n_pix)
+            acc += oracle_grads(p0 * spp, (p1 - p0) * spp, dL_film[p0 * spp:p1 * spp])
+        ref[f"shard{rank}"] = acc
+    first, n = (n_pix // 3) * spp + 2, (n_pix // 4) * spp
+    ref["window"] = oracle_grads(first, n, (((np.arange(n * 3, dtype=np.float32).reshape(n, 3) % 7) - 3.0) * 1e-3).astype(np.float32))
+    for k, r in ref.items():
+        a = out["tile"][k].double().cpu().numpy()
+        assert np.abs(r).max() > 0
+        assert np.abs(a - r).max() <= 2e-4 * np.abs(r).max() + 1e-12, ("tile kernel vs oracle", k)
     total = out["tile"]["shard0"] + out["tile"]["shard1"]
     assert float((total - out["tile"]["film"]).abs().max()) <= 2e-5 * float(total.abs().max())
 

@@ -1,0 +1,60 @@
+#!/bin/bash
+# ONE parametrised runner for a gpurun call (round 6; the per-call scratch scripts of round 5 are gone):
+#   gpurun --timeout N -- 'bash tools/gpu/run.sh TAG STEP [STEP ...]'        outputs -> gpurun_out/TAG/
+# STEPs (in the order given):
+#   tests[:EXPR]        pytest -m gpu (-k EXPR), tail of the log
+#   smoke               __graft_entry__.smoke()
+#   bench               headline line (no side configs, no CPU baseline)
+#   only:NAME           bench.py --only-config NAME
+#   sweep:V1,V2,..      tools/gpu/sweep2.sh over variant libraries (variants/V/libdrt_hip.so; "default" = the in-tree library)
+#   sweep3:V1,..        headline + config3_as_reproduce per variant
+#   share:V1,..         a rank's share at G = 1 / 4 / 8 per variant
+#   sqprof              block budget of the queued tracer: variants sqprof1..4 through tools/super_profile.py
+#   c3prof:R1,R2,..     kernel trace of config 3's level R (tools/config3_level_profile.py), untrained and trained
+#   stress              tools/stress_super.py --reps 20
+TAG=$1; shift
+cd /root/repo
+R=/root/repo/gpurun_out/$TAG
+mkdir -p $R
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [[ "$step" == *:* ]] && arg=${step#*:}
+  echo "=== $step"
+  case $name in
+    tests)
+      if [ -n "$arg" ]; then timeout 2700 python -m pytest tests -m gpu -x -q -k "$arg" > $R/pytest.txt 2>&1; else timeout 2700 python -m pytest tests -m gpu -x -q > $R/pytest.txt 2>&1; fi
+      tail -n 15 $R/pytest.txt ;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 4 ;;
+    bench) timeout 300 python bench.py --no-cpu-baseline --no-extra-configs > $R/bench_headline.json 2> $R/bench_err.txt
+           python -c "import json; d=json.load(open('$R/bench_headline.json')); print(d['value'], d['t_primal_ms'], d['t_adjoint_ms'], d['t_grad_reduce_ms'], d['roofline']['frac'])" ;;
+    only) timeout 1200 python bench.py --only-config $arg > $R/only_$arg.json 2>> $R/bench_err.txt
+          python -c "import json; d=json.load(open('$R/only_$arg.json')); print(json.dumps(d['other_configs'])[:1500])" ;;
+    sweep) bash tools/gpu/sweep2.sh ${arg//,/ } | tee -a $R/sweep.txt ;;
+    sweep3)
+      for v in ${arg//,/ }; do
+        L=""; [ "$v" != "default" ] && L="variants/$v"
+        a=$(LD_LIBRARY_PATH=$L timeout 100 python bench.py --no-cpu-baseline --no-extra-configs --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['t_primal_ms'], d['t_adjoint_ms'], d['t_grad_reduce_ms'])")
+        b=$(LD_LIBRARY_PATH=$L timeout 600 python bench.py --only-config config3_as_reproduce 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read())['other_configs']['config3_as_reproduce']; print(d.get('value'), [l['iterations_per_s'] for l in d.get('levels', [])], d.get('error'))")
+        echo "$v | headline8: $a | config3_as_reproduce: $b" | tee -a $R/sweep3.txt
+      done ;;
+    share) for v in ${arg//,/ }; do L=""; [ "$v" != "default" ] && L="variants/$v"; echo "$v | $(LD_LIBRARY_PATH=$L timeout 300 python tools/gpu/share.py 2>/dev/null)" | tee -a $R/share.txt; done ;;
+    sqprof)
+      for m in 1 2 3 4; do
+        mode=sq; [ $m != 1 ] && mode=sq$m
+        echo "--- DRT_SQ_PROFILE=$m" >> $R/sqprof.txt
+        LD_LIBRARY_PATH=variants/sqprof$m DRT_PROFILE_MODE=$mode timeout 300 python tools/super_profile.py >> $R/sqprof.txt 2>> $R/sqprof_err.txt
+      done
+      cat $R/sqprof.txt ;;
+    c3prof)
+      for res in ${arg//,/ }; do
+        for tr in "" "--trained"; do
+          sfx=$res; [ -n "$tr" ] && sfx=${res}_trained
+          (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/c3_$sfx -o lv -- python /root/repo/tools/config3_level_profile.py --res $res --iters 40 $tr > $R/c3_$sfx.json 2>> $R/c3_err.txt)
+          python tools/rocpd_stats.py $R/c3_$sfx/lv_results.db --csv $R/c3_${sfx}_kernel_stats.csv --top 12 > $R/c3_${sfx}_top.txt 2>&1
+          rm -rf $R/c3_$sfx
+          cat $R/c3_$sfx.json; head -n 12 $R/c3_${sfx}_top.txt | cut -c1-60,120-200
+        done
+      done ;;
+    stress) timeout 900 python tools/stress_super.py --reps 20 > $R/stress.txt 2>&1; tail -n 5 $R/stress.txt ;;
+    *) echo "unknown step $step" ;;
+  esac
+done

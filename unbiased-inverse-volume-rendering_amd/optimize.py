@@ -520,8 +520,11 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
         done = opt.step({k: leaves[k].grad for k in keys if k in leaves and leaves[k].requires_grad},    # :352
                         bounds=param_bounds(scene_config, keys))
         enforce_valid_params(scene_config, opt, skip=done or ())       # :353 (what the fused step did not clamp itself)
+        # (the loss stays on the device: the reference does not read it back at all - python/optimize.py:325-358 logs nothing per iteration -, and
+        #  a float() here would make the host wait for iteration i before it can enqueue iteration i + 1.  `history` is converted once, behind
+        #  the loop; a `progress` callback receives the 0-d device tensor and pays for the wait only if it looks at the value)
         total = allreduce_scalar(loss_value.detach()) if shard.partitioned else loss_value.detach()
-        history.append(float(total))
+        history.append(total)
         if shard.partitioned and opt_config.checkpoint_stride and it_i > 0 and it_i % opt_config.checkpoint_stride == 0:
             verify_pending()                                           # (no checkpoint of parameters that took an unsummed gradient)
         if writer and it_i > 0 and opt_config.checkpoint_stride and it_i % opt_config.checkpoint_stride == 0:
@@ -537,4 +540,5 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
         save_params(os.path.join(output_dir, 'params'), scene_config, params, 'final', scene.medium)
     if writer:
         render_previews(output_dir, opt_config, scene_config, scene, integrator, 'final')     # :362
+    history = [float(v) for v in torch.stack(history).tolist()] if history else []            # ONE device -> host copy for the whole run
     return scene, params, opt, history

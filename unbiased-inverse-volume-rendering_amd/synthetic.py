@@ -77,7 +77,12 @@ def constant_cube_scene(res: int = 64, sigma_t: float = 1.0, albedo: float = 0.8
     return Scene(medium=medium, emitter=ConstantEmitter((1.0, 0.8, 0.2)), sensors=[sensor])
 
 
-def smoke_scene(res: int = 128, film: int = 512, seed: int = 1234, device="cpu",
+def _film(film):
+    """(width, height) of a film given as one number (square) or a pair - the paper's scenes render 720 x 620 (scene_config.py:100-101)."""
+    return (int(film), int(film)) if isinstance(film, (int, float)) else (int(film[0]), int(film[1]))
+
+
+def smoke_scene(res: int = 128, film=512, seed: int = 1234, device="cpu",
                 optical_side: float = 16.0) -> Scene:
     """BASELINE config 2 stand-in for janga-smoke: sigma_t = s * max(0, fbm - 0.45) * plume,
     s chosen so that majorant * bbox side = `optical_side`; albedo 0.6
@@ -93,11 +98,28 @@ def smoke_scene(res: int = 128, film: int = 512, seed: int = 1234, device="cpu",
     st = d.unsqueeze(-1).contiguous()
     al = torch.full((res, res, res, 3), 0.6, dtype=torch.float32, device=device)
     medium = GridMedium(sigma_t=st, albedo=al, bbox_min=(-1.0, -1.0, -1.0), bbox_max=(1.0, 1.0, 1.0))
-    sensor = PerspectiveSensor(origin=(0.0, 0.6, 5.0), target=(0.0, 0.0, 0.0), fov=30.0, width=film, height=film)
+    fw, fh = _film(film)
+    sensor = PerspectiveSensor(origin=(0.0, 0.6, 5.0), target=(0.0, 0.0, 0.0), fov=30.0, width=fw, height=fh)
     return Scene(medium=medium, emitter=ConstantEmitter((1.0, 1.0, 1.0)), sensors=[sensor])
 
 
-def dust_devil_scene(res: int = 256, film: int = 512, seed: int = 4321, device="cpu",
+def smoke_scene_janga_shape(film=(720, 620), seed: int = 1234, device="cpu", optical_side: float = 16.0) -> Scene:
+    """A smoke plume on a grid of janga-smoke's REAL shape, 264 x 136 x 136 voxels (`volumes/janga-smoke-264-136-136.vol`,
+    scene_config.py:108; the asset itself is a separate download): the generator of `smoke_scene` at 264^3, the plume's axis laid along
+    the grid's long (x) axis and the other two axes cropped to 136 voxels around it; cubic voxels, i.e. a box of 3.88 x 2 x 2."""
+    cube = smoke_scene(res=264, film=film, seed=seed, device=device, optical_side=optical_side)
+    st = cube.medium.sigma_t[..., 0]                               # (Z, Y, X): the plume rises along Y
+    st = st.permute(0, 2, 1)                                       # -> its axis along the last (x) index
+    st = st[64:200, 64:200, :].contiguous().unsqueeze(-1)          # 136 x 136 x 264
+    al = torch.full(tuple(st.shape[:3]) + (3,), 0.6, dtype=torch.float32, device=device)
+    hx = 264.0 / 136.0
+    medium = GridMedium(sigma_t=st, albedo=al, bbox_min=(-hx, -1.0, -1.0), bbox_max=(hx, 1.0, 1.0))
+    fw, fh = _film(film)
+    sensor = PerspectiveSensor(origin=(1.5, 1.2, 7.5), target=(0.0, 0.0, 0.0), fov=30.0, width=fw, height=fh)
+    return Scene(medium=medium, emitter=ConstantEmitter((1.0, 1.0, 1.0)), sensors=[sensor])
+
+
+def dust_devil_scene(res: int = 256, film=512, seed: int = 4321, device="cpu",
                      optical_side: float = 20.0, n_sensors: int = 1) -> Scene:
     """BASELINE config 3 / headline stand-in for dust-devil: a swirling vortex column,
     sigma_t (res^3 x 1) + sand-like albedo (res^3 x 3); `n_sensors` on a ring
@@ -120,5 +142,6 @@ def dust_devil_scene(res: int = 256, film: int = 512, seed: int = 4321, device="
     sand = torch.tensor([0.8, 0.65, 0.45], dtype=torch.float32, device=device)
     al = (sand * (0.9 + 0.1 * _fbm(res, seed + 1, octaves=3, device=device)).unsqueeze(-1)).contiguous()
     medium = GridMedium(sigma_t=st, albedo=al, bbox_min=(-1.0, -1.0, -1.0), bbox_max=(1.0, 1.0, 1.0))
-    sensors = ring_sensors(n_sensors, radius=5.0, height=0.6, fov=30.0, width=film, film_height=film)
+    fw, fh = _film(film)
+    sensors = ring_sensors(n_sensors, radius=5.0, height=0.6, fov=30.0, width=fw, film_height=fh)
     return Scene(medium=medium, emitter=ConstantEmitter((1.0, 1.0, 1.0)), sensors=sensors)
