@@ -737,6 +737,35 @@ def main():
         h.release_scratch()
         other = other_configs(torch, u, synthetic, dev, integ_name=args.integrator, main_factor=args.majorant_factor)
 
+    # the side configurations' headline numbers in ONE compact dict inside fields the driver's record keeps (`roofline`, `config`): the
+    # full entries stay under `other_configs`
+    side = None
+    if other:
+        def num(path, key="value"):
+            d = other
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d.get(key) if isinstance(d, dict) else None
+
+        lv256 = None
+        for lv in (num(("config3_as_reproduce",), "levels") or []):
+            if lv.get("grid") == "256^3":
+                lv256 = lv.get("iterations_per_s")
+        side = {"unit": "Msamples/s unless the key says it/s or ms",
+                "config2_smoke128_512x16": num(("config2_smoke128_512x16",)),
+                "headline_global_majorant": num(("headline_global_majorant",)) or num(("headline_majorant_factor8",)),
+                "headline_envmap_factor8": num(("headline_envmap_factor8",)),
+                "config3_it_per_s_factor8": num(("config3_optimize_loop",)),
+                "config3_it_per_s_global_majorant": num(("config3_optimize_loop", "global_majorant")),
+                "config3_it_per_s_envmap_factor8": num(("config3_optimize_loop", "envmap_factor8")),
+                "config3_as_reproduce_it_per_s": num(("config3_as_reproduce",)),
+                "config3_as_reproduce_it_per_s_at_256": lv256,
+                "config4_512_rank_share": num(("config4_512_rank_share_1024x64",)),
+                "config5_nerf": num(("config5_nerf_256_512x32",)),
+                "config5_fused_nerf_drt": num(("config5_fused_nerf_drt_256_512x32",)),
+                "headline_rank_share_G8_ms_UNMEASURED_ON_MULTI_GPU": num(("headline_rank_share", "G8"), "ms_per_step")}
+        roofline["side"] = side
+
     if rank == 0:
         out = {
             "metric": "Msamples/s primal+adjoint DRT, 256^3 grid 512^2x32spp",
@@ -749,7 +778,7 @@ def main():
                                    f"({'the reference default, scene_config.py:36; the global majorant is reported under other_configs.headline_global_majorant' if args.majorant_factor == 8 else 'global majorant; the reference default 8 is reported under other_configs.headline_majorant_factor8'}), single sensor, "
                                    f"image tiles sharded over {world} GPU(s)",
                        "n_samples_per_step": n_total, "grid": [args.res] * 3, "film": [sensor.width, sensor.height],
-                       "spp": spp, "integrator": args.integrator},
+                       "spp": spp, "integrator": args.integrator, "side": side},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "t_primal_ms": round(avg_p, 3), "t_adjoint_ms": round(avg_a, 3),

@@ -96,6 +96,12 @@ int drt_set_ray_interleave(drt_handle h, uint64_t chunk_rays, uint64_t stride_ra
 int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, const int32_t res[3],
                    const float bbox_min[3], const float bbox_max[3], float scale,
                    int32_t majorant_resolution_factor);
+/* The COLOUR grids - `albedo`, and the `emission` grid of the drt_nerf_* / drt_fused_* calls - on their own lattice res = {X,Y,Z}
+ * (the same box): Mitsuba's GridVolume::eval interpolates every grid on its own resolution, and the reference's janga-smoke pairs a
+ * 264 x 136 x 136 density with 256 x 128 x 128 albedo / emission grids (python/scene_config.py:108-110).  The colour gradient buffers of
+ * the backward calls then have that shape.  NULL or {0,0,0}: sigma_t's lattice (what drt_set_medium leaves; call this after it).  Scenes
+ * whose lattices differ run the kernels of csrc/drt_own.hip: correct (parity: tests/test_gpu_lattice.py), not the tuned path. */
+int drt_set_colour_resolution(drt_handle h, const int32_t res[3]);
 /* params.update(opt) after an optimizer step (python/optimize.py:354) and
  * medium.set_majorant_resolution_factor (:195-199): refresh the majorant from
  * the (same) parameter buffers.  No host synchronisation. */

@@ -27,7 +27,7 @@ class Config(C.Structure):
 class Medium(C.Structure):
     _fields_ = [("sigma_t", C.POINTER(C.c_float)), ("albedo", C.POINTER(C.c_float)),
                 ("res", C.c_int32 * 3), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
-                ("scale", C.c_float), ("majorant_factor", C.c_int32)]
+                ("scale", C.c_float), ("majorant_factor", C.c_int32), ("res_colour", C.c_int32 * 3)]
 
 
 class Emitter(C.Structure):
@@ -176,12 +176,18 @@ class OracleScene:
     def __init__(self, scene, sensor_index: Optional[int] = 0):
         m = scene.medium
         self.sigma_t = _f32(m.sigma_t)
-        self.albedo = _f32(m.albedo) if m.albedo is not None else np.zeros(self.sigma_t.shape[:3] + (3,), np.float32)
+        # the colour grids (albedo; the nerf integrator's emission) may live on their own lattice (scene_config.py:108-110)
+        em = getattr(m, "emission", None)
+        cshape = tuple(m.albedo.shape[:3]) if m.albedo is not None else (tuple(em.shape[:3]) if em is not None else tuple(self.sigma_t.shape[:3]))
+        self.albedo = _f32(m.albedo) if m.albedo is not None else np.zeros(cshape + (3,), np.float32)
         z, y, x = self.sigma_t.shape[:3]
-        assert self.albedo.shape[:3] == (z, y, x) and self.albedo.shape[-1] == 3
+        assert self.albedo.shape[-1] == 3
+        own = cshape != (z, y, x)
+        self.colour_shape = cshape
         self.medium = Medium(_fp(self.sigma_t), _fp(self.albedo), (C.c_int32 * 3)(x, y, z),
                              (C.c_float * 3)(*m.bbox_min), (C.c_float * 3)(*m.bbox_max),
-                             float(m.scale), int(getattr(m, "majorant_resolution_factor", 0)))
+                             float(m.scale), int(getattr(m, "majorant_resolution_factor", 0)),
+                             (C.c_int32 * 3)(*(cshape[2], cshape[1], cshape[0]) if own else (0, 0, 0)))
         self.emitter, self._emitter_pixels = make_emitter(scene.emitter)
         self.sensor = None
         self.film = None
@@ -238,7 +244,7 @@ def render_backward(oscene: OracleScene, props: dict, spp: int, seed: int, dL, L
     assert dL.shape == (job.n_rays, 3) and L_in.shape == (job.n_rays, 3)
     z, y, x = oscene.grid_shape()
     gs = np.zeros((z, y, x, 1), dtype=np.float64)
-    ga = np.zeros((z, y, x, 3), dtype=np.float64)
+    ga = np.zeros(tuple(oscene.colour_shape) + (3,), dtype=np.float64)
     cnt = Counters()
     rc = lib().drto_render_backward(C.byref(job), _fp(dL), _fp(L_in), _dp(gs), _dp(ga), C.byref(cnt))
     if rc:
@@ -255,7 +261,7 @@ def h1_step(oscene: OracleScene, props: dict, spp: int, seed: int, **kw):
     image = np.zeros((n // spp, 3), dtype=np.float32)
     z, y, x = oscene.grid_shape()
     gs = np.zeros((z, y, x, 1), dtype=np.float64)
-    ga = np.zeros((z, y, x, 3), dtype=np.float64)
+    ga = np.zeros(tuple(oscene.colour_shape) + (3,), dtype=np.float64)
     loss = C.c_double(0.0)
     cnt = Counters()
     rc = lib().drto_h1_step(C.byref(job), _fp(L), _fp(image), C.byref(loss), _dp(gs), _dp(ga),
@@ -294,7 +300,8 @@ def nerf_render(oscene: OracleScene, emission, props: dict, spp: int, seed: int,
     dL, L_in = _f32(dL), _f32(L_in)
     z, y, x = oscene.grid_shape()
     gs = np.zeros((z, y, x, 1), dtype=np.float64)
-    ge = np.zeros((z, y, x, 3), dtype=np.float64)
+    ge = np.zeros(tuple(oscene.colour_shape) + (3,), dtype=np.float64)
+    assert tuple(em.shape[:3]) == tuple(oscene.colour_shape), "the emission grid must lie on the medium's colour lattice"
     rc = lib().drto_nerf_render(C.byref(job), C.byref(ncfg), _fp(em), 1, _fp(dL), _fp(L_in), None, _dp(gs), _dp(ge),
                                 C.byref(cnt))
     if rc:

@@ -393,6 +393,8 @@ typedef struct {
     drto_config cfg;
     const float *sigma_t, *albedo;
     int rx, ry, rz;
+    int crx, cry, crz;           /* the colour grids' own lattice (albedo, nerf emission); = rx, ry, rz unless drto_medium::res_colour says otherwise */
+    int own_colour;              /* ... it differs from sigma_t's */
     v3 bmin, bmax, inv_ext;
     float scale, majorant, inv_majorant;
     /* majorant supergrid (majorant_resolution_factor > 0): gx*gy*gz cells, [2*cell] = majorant,
@@ -469,11 +471,25 @@ static inline float eval_sigma_t(const scene_t *sc, v3 p)
     make_stencil(sc, p, &s);
     return trilerp(&s, sc->sigma_t, 1, 0) * sc->scale;
 }
+/* the same on the colour grids' lattice (GridVolume::eval interpolates every grid on its own resolution): identical to
+ * make_stencil when the lattices are equal */
+static inline void make_stencil_colour(const scene_t *sc, v3 p, stencil_t *s)
+{
+    int x0, x1, y0, y1, z0, z1;
+    axis_setup(p.x, sc->bmin.x, sc->inv_ext.x, sc->crx, &x0, &x1, &s->wx0, &s->wx1);
+    axis_setup(p.y, sc->bmin.y, sc->inv_ext.y, sc->cry, &y0, &y1, &s->wy0, &s->wy1);
+    axis_setup(p.z, sc->bmin.z, sc->inv_ext.z, sc->crz, &z0, &z1, &s->wz0, &s->wz1);
+    int sy = sc->crx, sz = sc->crx * sc->cry;
+    s->idx[0] = z0 * sz + y0 * sy + x0; s->idx[1] = z0 * sz + y0 * sy + x1;
+    s->idx[2] = z0 * sz + y1 * sy + x0; s->idx[3] = z0 * sz + y1 * sy + x1;
+    s->idx[4] = z1 * sz + y0 * sy + x0; s->idx[5] = z1 * sz + y0 * sy + x1;
+    s->idx[6] = z1 * sz + y1 * sy + x0; s->idx[7] = z1 * sz + y1 * sy + x1;
+}
 /* get_albedo */
 static inline void eval_albedo(const scene_t *sc, v3 p, float out[3])
 {
     stencil_t s;
-    make_stencil(sc, p, &s);
+    make_stencil_colour(sc, p, &s);
     for (int c = 0; c < 3; ++c) out[c] = trilerp(&s, sc->albedo, 3, c);
 }
 
@@ -492,12 +508,14 @@ static inline void shared_add(double *dst, double v)
 #endif
     *dst += v;
 }
+/* (colour grids on their own lattice: their voxels are cached under tag | 0x80000000 and only use v[1..3]) */
 static inline void gcache_evict(ctx_t *c, gcache_line *l)
 {
     if (l->tag == 0xffffffffu) return;
     if (l->v[0] != 0.0) shared_add(&c->g_sigma[l->tag], l->v[0]);
+    const size_t cv = l->tag & 0x7fffffffu;
     for (int ch = 0; ch < 3; ++ch)
-        if (l->v[1 + ch] != 0.0) shared_add(&c->g_albedo[(size_t) l->tag * 3 + ch], l->v[1 + ch]);
+        if (l->v[1 + ch] != 0.0) shared_add(&c->g_albedo[cv * 3 + ch], l->v[1 + ch]);
     l->v[0] = l->v[1] = l->v[2] = l->v[3] = 0.0;
 }
 static inline double *gcache_slot(ctx_t *c, uint32_t voxel)
@@ -528,10 +546,11 @@ static inline void splat_sigma_t(ctx_t *c, v3 p, float g)
 static inline void splat_albedo(ctx_t *c, v3 p, const float g[3])
 {
     stencil_t s; float w[8];
-    make_stencil(c->sc, p, &s);
+    make_stencil_colour(c->sc, p, &s);
     stencil_weights(&s, w);
+    const uint32_t tag_bit = c->sc->own_colour ? 0x80000000u : 0u;
     for (int k = 0; k < 8; ++k) {
-        double *slot = c->gcache ? gcache_slot(c, (uint32_t) s.idx[k]) : NULL;
+        double *slot = c->gcache ? gcache_slot(c, (uint32_t) s.idx[k] | tag_bit) : NULL;
         for (int ch = 0; ch < 3; ++ch) {
             double v = (double)(w[k] * g[ch]);
             if (slot) slot[1 + ch] += v;
@@ -1058,7 +1077,7 @@ static void nerf_sample(ctx_t *c, const nerf_t *nf, pcg32 *S, int adjoint, ray_t
             c->cnt.n_dt++;
             float sigma = nf->relu ? fmaxf(0.0f, raw) : raw;
             float em[3];
-            { stencil_t s; make_stencil(sc, p, &s); for (int k = 0; k < 3; ++k) em[k] = trilerp(&s, nf->emission, 3, k); }
+            { stencil_t s; make_stencil_colour(sc, p, &s); for (int k = 0; k < 3; ++k) em[k] = trilerp(&s, nf->emission, 3, k); }
             c->cnt.n_alb++;
             int last = !(j + 1 < N);
             float a = last ? 1.0f : drt_expf(-sigma * dt);    /* :104-106 */
@@ -1078,7 +1097,7 @@ static void nerf_sample(ctx_t *c, const nerf_t *nf, pcg32 *S, int adjoint, ray_t
                 splat_sigma_t(c, p, gs); c->cnt.n_sc++;
                 {
                     stencil_t s; float w[8];
-                    make_stencil(sc, p, &s); stencil_weights(&s, w);
+                    make_stencil_colour(sc, p, &s); stencil_weights(&s, w);
                     for (int q = 0; q < 8; ++q) for (int k = 0; k < 3; ++k) {
                         double v = (double)(w[q] * ge[k]);
 #ifdef _OPENMP
@@ -1159,6 +1178,10 @@ static int scene_init(scene_t *sc, const drto_job *job)
     sc->cfg = *job->cfg;
     sc->sigma_t = m->sigma_t; sc->albedo = m->albedo;
     sc->rx = m->res[0]; sc->ry = m->res[1]; sc->rz = m->res[2];
+    sc->crx = sc->rx; sc->cry = sc->ry; sc->crz = sc->rz;
+    if (m->res_colour[0] > 0 && m->res_colour[1] > 0 && m->res_colour[2] > 0) { sc->crx = m->res_colour[0]; sc->cry = m->res_colour[1]; sc->crz = m->res_colour[2]; }
+    else if (m->res_colour[0] | m->res_colour[1] | m->res_colour[2]) return -2;
+    sc->own_colour = sc->crx != sc->rx || sc->cry != sc->ry || sc->crz != sc->rz;
     sc->bmin = v3_make(m->bbox_min[0], m->bbox_min[1], m->bbox_min[2]);
     sc->bmax = v3_make(m->bbox_max[0], m->bbox_max[1], m->bbox_max[2]);
     sc->inv_ext = v3_make(1.0f / (sc->bmax.x - sc->bmin.x), 1.0f / (sc->bmax.y - sc->bmin.y),

@@ -55,6 +55,10 @@ typedef struct drto_medium {
     float bbox_max[3];
     float scale;            /* medium `scale` (density_scale) */
     int32_t majorant_factor; /* majorant_resolution_factor (scene_config.py:36); 0 = global majorant */
+    /* The colour grids - `albedo`, and the `emission` grid of drto_nerf_render - on their OWN lattice (X, Y, Z), as Mitsuba
+     * interpolates every GridVolume on its own resolution: the reference's janga-smoke pairs a 264 x 136 x 136 density with
+     * 256 x 128 x 128 albedo / emission grids (python/scene_config.py:108-110).  All zero: the lattice of sigma_t (`res`). */
+    int32_t res_colour[3];
 } drto_medium;
 
 /* The scene's single infinite emitter (volpathsimple.py:16).

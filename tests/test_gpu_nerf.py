@@ -218,4 +218,4 @@ def test_nerf_tile_adjoint_propagates_non_finite_inputs(uivr, gpu):
     dL[5, 0] = 3.0e38
     grads = uivr.alloc_grads(sg, integ.param_keys)
     integ.sample(uivr.ADMode.Backward, sg, samp.clone(), batch, δL=dL, state_in=st, grads=grads)
-    assert not bool(torch.isfinite(grads["_flat"]).any())
+    assert not bool(torch.isfinite(grads[uivr.SIGMA_T_KEY]).any()) and not bool(torch.isfinite(grads[uivr.EMISSION_KEY]).any())

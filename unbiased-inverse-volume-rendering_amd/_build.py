@@ -20,11 +20,11 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 _ROOT = os.path.dirname(_PKG)
 
-HIP_SOURCES = ["drt_kernels.hip", "drt_deferred.hip", "drt_coop.hip", "drt_coop_super.hip", "drt_order.hip", "drt_sq.hip", "drt_nerf_tile.hip", "drt_capi.cpp"]
+HIP_SOURCES = ["drt_kernels.hip", "drt_deferred.hip", "drt_coop.hip", "drt_coop_super.hip", "drt_order.hip", "drt_sq.hip", "drt_nerf_tile.hip", "drt_own.hip", "drt_capi.cpp"]
 # older generations of the tracer (round 1/2 state machine of whole flights, round 3 lane state machines with posted flights): no production call
 # reaches them ("which call reaches which kernel"); the flavour with test hooks keeps them in lock-step with the oracle
 HOOKS_ONLY_SOURCES = ["drt_wavefront.hip", "drt_super.hip"]
-HIP_HEADERS = ["drt_device.h", "drt_launch.h", "drt_coop_tracer.h", "drt_coop_kernel.h", os.path.join(_ROOT, "include", "drt_hip.h")]
+HIP_HEADERS = ["drt_device.h", "drt_launch.h", "drt_coop_tracer.h", "drt_coop_kernel.h", "drt_nerf_kernel.h", os.path.join(_ROOT, "include", "drt_hip.h")]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
              "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall"]
 

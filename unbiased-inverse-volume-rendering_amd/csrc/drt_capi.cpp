@@ -314,6 +314,19 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
     //   Every primal kernel writes the path cache the adjoint pass of the job reads.  Only the library flavour with test hooks also holds the older
     //   generations - the round-3 supergrid kernel (drt_super.hip; hook 4096), the round-2 state machine of whole flights (drt_wavefront.hip; hooks
     //   32 / 65536 / 134217728) and the plain per-lane Tracer (drt_kernels.hip; hooks 8 / 32768) - where the variant tests keep them in lock-step.
+    //   Colour grids on their own lattice (drt_set_colour_resolution): the kernels of drt_own.hip - CoopTracer with either kind of majorant, compiled
+    //   with the colour lookups and splats on that lattice; no tail pool, no queued tracer (correct first: the configurations it serves are rare).
+    if (P.colour_own) {
+        drt::Params Q = P;
+        Q.tail_pool = nullptr; Q.tail_count = nullptr; Q.tail_cap = 0; Q.tail_mode = 0;
+        if (P.mgrid) Q.ray_perm = nullptr;
+        DRT_HIP_CHECK(h, drt::launch_trace_own(Q, adjoint, h->counting, h->stream));
+        if (h->timing) {
+            DRT_HIP_CHECK(h, hipEventRecord(b, h->stream));
+            h->timed[which].emplace_back(a, b);
+        }
+        return DRT_OK;
+    }
     const bool quadratic = h->cfg.use_drt && !h->cfg.use_drt_subsampling;
     // (the records' global halves, ~44 MB, are allocated only by a launch that will run the queued kernel: not when a test hook or the atomic
     //  gradient path routes this launch to the older kernels)
@@ -742,7 +755,7 @@ int timed_nerf(drt_handle h, int which, const drt::Params &P, bool adjoint, hipS
         DRT_HIP_CHECK(h, hipEventCreate(&b));
         DRT_HIP_CHECK(h, hipEventRecord(a, st));
     }
-    DRT_HIP_CHECK(h, drt::launch_nerf(P, adjoint, h->counting, st));
+    DRT_HIP_CHECK(h, P.colour_own ? drt::launch_nerf_own(P, adjoint, h->counting, st) : drt::launch_nerf(P, adjoint, h->counting, st));
     if (h->timing) {
         DRT_HIP_CHECK(h, hipEventRecord(b, st));
         h->timed[which].emplace_back(a, b);
@@ -928,6 +941,7 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
     drt::Params &B = h->base;
     B.sigma_t = sigma_t; B.albedo = albedo;
     B.rx = res[0]; B.ry = res[1]; B.rz = res[2];
+    B.crx = res[0]; B.cry = res[1]; B.crz = res[2]; B.colour_own = 0;     // (until drt_set_colour_resolution says otherwise)
     for (int a = 0; a < 3; ++a) {
         B.bmin[a] = bbox_min[a]; B.bmax[a] = bbox_max[a];
         B.inv_ext[a] = 1.0f / (bbox_max[a] - bbox_min[a]);
@@ -996,6 +1010,26 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
     }
     h->have_medium = true; h->scene_version++;
     return drt_params_changed(h);
+}
+
+int drt_set_colour_resolution(drt_handle h, const int32_t res[3])
+{
+    if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->have_medium) return fail(h, DRT_ERR_NOT_CONFIGURED, "drt_set_colour_resolution: no medium set");
+    drt::Params &B = h->base;
+    if (!res || (res[0] == 0 && res[1] == 0 && res[2] == 0)) {        // back to sigma_t's lattice
+        B.crx = B.rx; B.cry = B.ry; B.crz = B.rz; B.colour_own = 0;
+        h->scene_version++;
+        return DRT_OK;
+    }
+    for (int a = 0; a < 3; ++a)
+        if (res[a] < 1) return fail(h, DRT_ERR_INVALID_ARGUMENT, "colour grid resolution must be >= 1");
+    if ((uint64_t) res[0] * res[1] * res[2] > 0x7fffffffull / 3)
+        return fail(h, DRT_ERR_UNSUPPORTED, "colour grid too large for 32-bit voxel indexing");
+    B.crx = res[0]; B.cry = res[1]; B.crz = res[2];
+    B.colour_own = (B.crx != B.rx || B.cry != B.ry || B.crz != B.rz) ? 1 : 0;
+    h->scene_version++;
+    return DRT_OK;
 }
 
 int drt_set_emitter_constant(drt_handle h, const float radiance[3])
@@ -1299,6 +1333,7 @@ static int ensure_grid4(drt_handle h, drt::Params &P, const float *rgb)
     const bool own = rgb == nullptr || rgb == h->base.albedo;
     if (!rgb) rgb = h->base.albedo;
     const drt::Params &B = h->base;
+    if (B.colour_own) return fail(h, DRT_ERR_UNSUPPORTED, "the four-channel copy needs the colour grid on sigma_t's lattice");
     const size_t nbx = ((size_t) B.rx + 2) / 3, quads = nbx * (size_t) B.ry * (size_t) B.rz * 16;
     if (quads > 0x7fffffffull) return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for the four-channel copy");
     if (quads != h->grid4_quads) {

@@ -322,8 +322,15 @@ struct Params {
     // sq_rays: ray records per workgroup (set by launch_trace_sq: what fits LDS next to the majorants)
     void *sq_cold;
     uint32_t sq_rays;
+    uint32_t sq_chunk;              // queue positions a workgroup reserves per refill of its ray pool (set by launch_trace_sq)
     unsigned long long *counters;   // 9 x u64 or nullptr
     uint32_t debug_flags;           // ablation switches for profiling (drt_set_debug_flags); 0 in production
+    // The colour grids - `albedo`, the nerf integrator's `emission` - on their OWN lattice (drt_set_colour_resolution): Mitsuba interpolates every
+    // GridVolume on its own resolution, and the reference's janga-smoke pairs a 264 x 136 x 136 density with 256 x 128 x 128 albedo / emission grids
+    // (python/scene_config.py:108-110).  colour_own = 0: the lattice of sigma_t (crx = rx, ...), every kernel as before.  colour_own = 1: the job
+    // runs the kernels of drt_own.hip - the only translation unit compiled with DRT_COLOUR_OWN, in which eval_rgb and the colour splats read
+    // crx / cry / crz; in every other unit these fields are never read.  (At the end of the block: no other field moves.)
+    int crx, cry, crz, colour_own;
 };
 
 // ---------------------------------------------------------------------------
@@ -759,9 +766,26 @@ __device__ __forceinline__ void eval4(const Params &P, V3 p, float &sigma_t, flo
     rgb[2] = trilerp8(s, d0.w, d1.w, d2.w, d3.w, d4.w, d5.w, d6.w, d7.w);
 }
 
+// the stencil of a lookup into a COLOUR grid: on sigma_t's lattice everywhere but in drt_own.hip (DRT_COLOUR_OWN), where it is the grids' own
+__device__ __forceinline__ Stencil make_stencil_colour(const Params &P, V3 p)
+{
+#ifdef DRT_COLOUR_OWN
+    Stencil s;
+    axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.crx, s.x0, s.x1, s.wx0, s.wx1);
+    axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.cry, s.y0, s.y1, s.wy0, s.wy1);
+    axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.crz, s.z0, s.z1, s.wz0, s.wz1);
+    s.y0 *= P.crx; s.y1 *= P.crx;
+    int sz = P.crx * P.cry;
+    s.z0 *= sz; s.z1 *= sz;
+    return s;
+#else
+    return make_stencil(P, p);
+#endif
+}
+
 __device__ __forceinline__ void eval_rgb(const Params &P, const float *g, V3 p, float out[3])
 {
-    Stencil s = make_stencil(P, p);
+    Stencil s = make_stencil_colour(P, p);
     int a = s.z0 + s.y0, b = s.z0 + s.y1, c = s.z1 + s.y0, d = s.z1 + s.y1;
     int i0 = 3 * (a + s.x0), i1 = 3 * (a + s.x1), i2 = 3 * (b + s.x0), i3 = 3 * (b + s.x1);
     int i4 = 3 * (c + s.x0), i5 = 3 * (c + s.x1), i6 = 3 * (d + s.x0), i7 = 3 * (d + s.x1);
@@ -1025,10 +1049,36 @@ __device__ __forceinline__ void splat_sigma_t(const Params &P, V3 p, float g, ui
     coop_scatter<1>(P.gt, 0, idx, val, rec);
 }
 
+#ifdef DRT_COLOUR_OWN
+// drt_own.hip: the colour grids have their own lattice, which the tile partition, the LDS tiles and the apron scratch (all laid out on
+// sigma_t's) do not know - the 8 x 3 corner products go straight to the caller's colour gradient grid (fp32 atomics).  Slow and correct: this
+// unit serves the configurations whose grids differ in resolution, not the benchmark.
+__device__ __forceinline__ void splat_colour_own(const Params &P, V3 p, const float g[3])
+{
+    if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) return;
+    if (dbg(P.debug_flags, 1u)) return;
+    const Stencil st = make_stencil_colour(P, p);
+    float w[8];
+    stencil_weights(st, w);
+    const int idx[8] = { st.z0 + st.y0 + st.x0, st.z0 + st.y0 + st.x1, st.z0 + st.y1 + st.x0, st.z0 + st.y1 + st.x1,
+                         st.z1 + st.y0 + st.x0, st.z1 + st.y0 + st.x1, st.z1 + st.y1 + st.x0, st.z1 + st.y1 + st.x1 };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float *dst = P.g_albedo + 3 * (size_t) idx[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) if (g[c] != 0.0f) atomicAdd(dst + c, w[k] * g[c]);
+    }
+}
+#endif
+
 template <bool DEFER = false>
 __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float g[3], uint32_t *rec)
 {
     static_assert(!DEFER, "deferred colour splats travel with their sigma_t splat: splat_scatter");
+#ifdef DRT_COLOUR_OWN
+    splat_colour_own(P, p, g);
+    return;
+#endif
     if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) return;   // e.g. nerf queries in empty space (weight 0)
     float w[8]; int idx[8];
     make_grad_indices(P, p, idx, w);
@@ -1055,6 +1105,11 @@ __device__ __forceinline__ void splat_albedo(const Params &P, V3 p, const float 
 template <bool DEFER = false>
 __device__ __forceinline__ void splat_scatter(const Params &P, V3 p, float gs, const float ga[3], uint32_t *rec)
 {
+#ifdef DRT_COLOUR_OWN
+    splat_sigma_t<DEFER>(P, p, gs, rec);         // (its record / its scratch line: sigma_t's lattice, as everywhere)
+    splat_colour_own(P, p, ga);
+    return;
+#endif
     if constexpr (DEFER) {
         if (dbg(P.debug_flags, 1u)) return;
         const bool colour = ga[0] != 0.0f || ga[1] != 0.0f || ga[2] != 0.0f;

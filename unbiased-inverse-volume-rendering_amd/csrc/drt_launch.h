@@ -16,6 +16,9 @@ hipError_t launch_occupancy(const float *sigma_t, int rx, int ry, int rz, int sh
 hipError_t launch_brick_sigma(const float *src, float *dst, int rx, int ry, int rz, int nbx, int nby,
                               hipStream_t stream);
 hipError_t launch_nerf(const Params &P, bool adjoint, bool count, hipStream_t stream);
+// drt_own.hip: the same kernels with the colour grids on their own lattice (Params::colour_own)
+hipError_t launch_nerf_own(const Params &P, bool adjoint, bool count, hipStream_t stream);
+hipError_t launch_trace_own(const Params &P, bool adjoint, bool count, hipStream_t stream);
 // drt_nerf_tile.hip: the nerf adjoint for sensor rays - a workgroup per pixel tile, its splats pre-reduced in an LDS window of 16^3 voxels, no records
 // (g4: lookups from Params::grid4 - the fused pass, emission = the medium's albedo grid - instead of sigma_b + Params::emission)
 bool nerf_tile_supported(const Params &P);

@@ -378,10 +378,11 @@ hipError_t launch_brick_grid4(const float *sigma_t, const float *rgb, float4 *ds
     return hipGetLastError();
 }
 
-// sensor rays of whole samples-per-pixel groups, at most one workgroup of rays per pixel, a grid the flush can index
+// sensor rays of whole samples-per-pixel groups, at most one workgroup of rays per pixel, a grid the flush can index, every grid on sigma_t's lattice
+// (the window's four planes share one footprint; own colour lattice: drt_own.hip's nerf kernel)
 bool nerf_tile_supported(const Params &P)
 {
-    return P.sensor_flow && P.spp >= 1 && P.width >= 1 && P.height >= 1 && P.g_sigma && P.g_albedo &&
+    return !P.colour_own && P.sensor_flow && P.spp >= 1 && P.width >= 1 && P.height >= 1 && P.g_sigma && P.g_albedo &&
            (uint64_t) P.width * (uint64_t) P.height * P.spp < (1ull << 32) && (!P.chunk || P.stride >= P.chunk);
 }
 

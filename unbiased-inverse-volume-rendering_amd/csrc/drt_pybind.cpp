@@ -81,6 +81,7 @@ public:
         }
         check(rc, "drt_set_medium");
     }
+    void set_colour_resolution(std::array<int32_t, 3> res) { check(drt_set_colour_resolution(h_, res.data()), "drt_set_colour_resolution"); }
     void params_changed()
     {
         int rc;
@@ -304,6 +305,7 @@ PYBIND11_MODULE(DRT_PYBIND_NAME, m)
         .def("release_scratch", &Integrator::release_scratch)
         .def("set_ray_interleave", &Integrator::set_ray_interleave)
         .def("set_medium", &Integrator::set_medium)
+        .def("set_colour_resolution", &Integrator::set_colour_resolution)
         .def("params_changed", &Integrator::params_changed)
         .def("set_emitter_constant", &Integrator::set_emitter_constant)
         .def("set_emitter_envmap", &Integrator::set_emitter_envmap)

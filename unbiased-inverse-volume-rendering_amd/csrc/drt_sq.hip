@@ -88,13 +88,28 @@
 #define DRT_SQ_EARLY_OUT 1         // flights that cannot collide (target optical depth > largest majorant x segment length) are not walked
 #endif
 #ifndef DRT_SQ_CHUNK
-#define DRT_SQ_CHUNK 256           // queue positions a wave reserves per refill of its ray pool
+#define DRT_SQ_CHUNK 256           // queue positions a workgroup reserves per refill of its ray pool (launches with a ray order)
+#endif
+#ifndef DRT_SQ_CHUNK_MAX
+#define DRT_SQ_CHUNK_MAX 4096      // ... launches in index order: span / (32 x workgroups), between DRT_SQ_CHUNK and this.  Round 6: the refill is ONE
+                                   // returning atomic on one of eight queue heads, and returning atomics on one address serialise in L2 (~10 M/s):
+                                   // the optimisation loop's 33.5 M-ray primal launch - 131 000 refills of 256, 16 000 per head - took 1.66 ms whatever
+                                   // its rays did (thin medium, every ray over at once: profiles/r06_config3_levels.txt); with 4096 positions per
+                                   // refill the heads see 1 000 each.  Launches with a ray order keep 256: their units are sorted thick-first, and
+                                   // larger reservations concentrate the expensive rays on few workgroups (measured in round 3: 512 / 1024: -2 % / -30 %)
 #endif
 #ifndef DRT_SQ_RUN
 #define DRT_SQ_RUN 16384           // consecutive rays per XCD-owned run
 #endif
 #ifndef DRT_SQ_INLINE_K
 #define DRT_SQ_INLINE_K 4          // cells a flight is stepped by the lanes that set it up, before it is posted for the walkers
+#endif
+#ifndef DRT_SQ_REGEN_FINISH
+#define DRT_SQ_REGEN_FINISH 2      // primal kernels: 1 = rays that are over before they begin (box misses, a first flight that cannot collide) are finished in the
+                                   // regeneration block; 2 = ... and when most of a batch's records are free again they take the next rays in the same block (rounds)
+#endif
+#ifndef DRT_SQ_REGEN_AGAIN
+#define DRT_SQ_REGEN_AGAIN 48      // DRT_SQ_REGEN_FINISH 2: free records of the batch that make another round worth it (a thin medium: nearly every ray is over at once)
 #endif
 #ifndef DRT_SQ_TAIL_PUSH
 #define DRT_SQ_TAIL_PUSH 64        // adjoint launches with a tail pool (Params::tail_pool): a workgroup whose ray queues are drained and that holds at most
@@ -321,6 +336,11 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     // whatever cells it crosses: it is not walked (flight set-up below; the bound is drt_super.hip's).
     const float mmax = __uint_as_float(__builtin_amdgcn_readfirstlane((int) misc[1]));
     const uint32_t *occ = nullptr;   // (tentative collisions lie in non-empty supergrid cells: the voxel bitmask would rarely say "empty")
+    // (DRT_SQ_REGEN_FINISH) "thin": a flight across the whole box has a fair chance (> e^-3) of an optical-depth target beyond that bound - only then
+    // is it worth looking at a ray's first target in the regeneration block
+    const float box_diag = sqrtf((P.bmax[0] - P.bmin[0]) * (P.bmax[0] - P.bmin[0]) + (P.bmax[1] - P.bmin[1]) * (P.bmax[1] - P.bmin[1]) +
+                                 (P.bmax[2] - P.bmin[2]) * (P.bmax[2] - P.bmin[2]));
+    const bool thin = !ADJ && mmax * box_diag < 3.0f;
 
     const uint32_t lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -364,7 +384,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
     const uint64_t n_runs = (span + DRT_SQ_RUN - 1) / DRT_SQ_RUN;
     // queue x serves the runs x, x + 8, ...; a workgroup starts on the queue of the XCD it runs on (L2 locality) and moves on
     // to the next ones when that one is drained: every ray is traced whatever the placement of the workgroups.  The
-    // positions a workgroup has reserved (DRT_SQ_CHUNK at a time) are handed out from LDS under a lock: any wave starts rays.
+    // positions a workgroup has reserved (Params::sq_chunk at a time) are handed out from LDS under a lock: any wave starts rays.
     int polls = 0;
     if constexpr (TAILM) {
         // tail mode (Params::tail_mode): this launch finishes the records the main launch's drained workgroups wrote to the pool - workgroup b takes
@@ -699,105 +719,253 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
             collide(act);
         } else if (kind == SQ_REGEN) {
             // ================= (A) regeneration ===========================================================
-            // Ray indices come from a wave-local pool refilled DRT_SQ_CHUNK at a time with ONE returning atomic on the
+            // Ray indices come from a wave-local pool refilled Params::sq_chunk at a time with ONE returning atomic on the
             // XCD's queue head.
-            SQ_PROF(6, 1); SQ_PROF(7, nb);
-            const uint64_t wmask = __ballot(act);
-            uint64_t first = 0; uint32_t got = 0, qx = 0, qs_ = 0;
-            if (lane == 0) {
-                while (atomicCAS(misc + 2, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
-                uint64_t pn = ((sq_vu64 *) pool)[0], pe = ((sq_vu64 *) pool)[1];
-                uint32_t qs = ((sq_vu32 *) misc)[3];
-                while (pn >= pe && qs < 8u) {                                // refill from the ray queues
-                    const uint32_t x = (xcc + qs) & 7u;
-                    const uint64_t len = (n_runs > x ? (n_runs - x + 7) / 8 : 0) * DRT_SQ_RUN;
-                    const unsigned long long base = atomicAdd(P.queues + x, (unsigned long long) DRT_SQ_CHUNK);
-                    if (base < len) { pn = base; pe = base + DRT_SQ_CHUNK < len ? base + DRT_SQ_CHUNK : len; }
-                    else ++qs;                                               // this queue is drained: next one
-                }
-                qx = (xcc + qs) & 7u; qs_ = qs;
-                const uint64_t want = (uint64_t) __popcll(wmask);
-                got = (uint32_t) (pe - pn < want ? pe - pn : want);
-                if (qs >= 8u) got = 0;
-                first = pn; pn += got;
-                ((sq_vu64 *) pool)[0] = pn; ((sq_vu64 *) pool)[1] = pe; ((sq_vu32 *) misc)[3] = qs;
-                sq_fence();
-                ((sq_vu32 *) misc)[2] = 0u;                                  // unlock
-            }
-            first = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (first >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) first);
-            got = (uint32_t) __builtin_amdgcn_readfirstlane((int) got); qx = (uint32_t) __builtin_amdgcn_readfirstlane((int) qx);
-            qs_ = (uint32_t) __builtin_amdgcn_readfirstlane((int) qs_);
-            if (qs_ >= 8u && !got) {                       // all eight queues are empty: these records are done
-                if (lane == 0) atomicAdd(misc, nb);
-                continue;
-            }
-            const uint32_t myr = (uint32_t) __popcll(wmask & ((1ull << lane) - 1ull));
-            const bool take = act && myr < got;
-            const uint64_t q = first + myr;
-            if (act) ph = SP_IDLE;                                           // (no ray for this record: it stays free and draws again)
-            if (take) {
-                uint64_t i = ((q / DRT_SQ_RUN) * 8 + qx) * DRT_SQ_RUN + (q % DRT_SQ_RUN);
-                if (P.order) {                                              // position -> unit of the order -> ray
-                    const uint32_t g = (uint32_t) i, u = P.order_unit == 1u ? g : g / P.order_unit;
-                    i = i < span ? (uint64_t) P.order[u] * P.order_unit + (g - u * P.order_unit) : P.n_rays;
-                }
-                if (P.unit_empty && i + P.ray_first < P.n_rays) unit_empty = P.unit_empty[(uint32_t) i / P.empty_unit] != 0;
-                i += P.ray_first;
-                if (i < P.n_rays) {
-                    // ---- sample() prologue (:51-108) + reach_medium (:292-319) ----
-                    li = (uint32_t) i;
-#if DRT_SQ_PROFILE == 6
-                    t_start = (uint32_t) __builtin_amdgcn_s_memrealtime() | 1u;
-#endif
-                    const uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
-                    const uint32_t gi = (uint32_t) g64;
-                    S.seed(P.seed, gi);
-                    if (P.sensor_flow) {
-                        float ux = S.next_1d(), uy = S.next_1d();
-                        sensor_ray(P, gi / P.spp, ux, uy, ro, rd);
-                    } else {
-                        ro = v3(P.rays_o[3 * i], P.rays_o[3 * i + 1], P.rays_o[3 * i + 2]);
-                        rd = v3(P.rays_d[3 * i], P.rays_d[3 * i + 1], P.rays_d[3 * i + 2]);
+            // (the adjoint kernels - and every kernel with DRT_SQ_REGEN_FINISH 0 - keep the block as it was: a source change in here moved the adjoint
+            //  kernel's register allocation and cost it 0.19 ms at the headline, profiles/r06_sq_instruction_budget.txt)
+            if constexpr (ADJ || DRT_SQ_REGEN_FINISH == 0) {
+                SQ_PROF(6, 1); SQ_PROF(7, nb);
+                const uint64_t wmask = __ballot(act);
+                uint64_t first = 0; uint32_t got = 0, qx = 0, qs_ = 0;
+                if (lane == 0) {
+                    while (atomicCAS(misc + 2, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+                    uint64_t pn = ((sq_vu64 *) pool)[0], pe = ((sq_vu64 *) pool)[1];
+                    uint32_t qs = ((sq_vu32 *) misc)[3];
+                    while (pn >= pe && qs < 8u) {                                // refill from the ray queues
+                        const uint32_t x = (xcc + qs) & 7u;
+                        const uint64_t len = (n_runs > x ? (n_runs - x + 7) / 8 : 0) * DRT_SQ_RUN;
+                        const unsigned long long base = atomicAdd(P.queues + x, (unsigned long long) P.sq_chunk);
+                        if (base < len) { pn = base; pe = base + P.sq_chunk < len ? base + P.sq_chunk : len; }
+                        else ++qs;                                               // this queue is drained: next one
                     }
-                    SQ_COUNT(C_RAYS);
-                    pc_on = false; pc_it = 0;
-                    if (P.path_cache_mode) {
-                        // one word per ray ties the cache entries to THIS ray: explicit rays are hashed (the buffers
-                        // may have been refilled between the two passes), sensor rays follow from the job signature
-                        uint32_t hsh = 0x9e3779b9u ^ gi;
-                        if (!P.sensor_flow) {
-                            const uint32_t w[6] = { __float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z),
-                                                    __float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z) };
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) hsh = (hsh ^ w[k]) * 0x01000193u + (hsh >> 15);
+                    qx = (xcc + qs) & 7u; qs_ = qs;
+                    const uint64_t want = (uint64_t) __popcll(wmask);
+                    got = (uint32_t) (pe - pn < want ? pe - pn : want);
+                    if (qs >= 8u) got = 0;
+                    first = pn; pn += got;
+                    ((sq_vu64 *) pool)[0] = pn; ((sq_vu64 *) pool)[1] = pe; ((sq_vu32 *) misc)[3] = qs;
+                    sq_fence();
+                    ((sq_vu32 *) misc)[2] = 0u;                                  // unlock
+                }
+                first = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (first >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) first);
+                got = (uint32_t) __builtin_amdgcn_readfirstlane((int) got); qx = (uint32_t) __builtin_amdgcn_readfirstlane((int) qx);
+                qs_ = (uint32_t) __builtin_amdgcn_readfirstlane((int) qs_);
+                if (qs_ >= 8u && !got) {                       // all eight queues are empty: these records are done
+                    if (lane == 0) atomicAdd(misc, nb);
+                    continue;
+                }
+                const uint32_t myr = (uint32_t) __popcll(wmask & ((1ull << lane) - 1ull));
+                const bool take = act && myr < got;
+                const uint64_t q = first + myr;
+                if (act) ph = SP_IDLE;                                           // (no ray for this record: it stays free and draws again)
+                if (take) {
+                    uint64_t i = ((q / DRT_SQ_RUN) * 8 + qx) * DRT_SQ_RUN + (q % DRT_SQ_RUN);
+                    if (P.order) {                                              // position -> unit of the order -> ray
+                        const uint32_t g = (uint32_t) i, u = P.order_unit == 1u ? g : g / P.order_unit;
+                        i = i < span ? (uint64_t) P.order[u] * P.order_unit + (g - u * P.order_unit) : P.n_rays;
+                    }
+                    if (P.unit_empty && i + P.ray_first < P.n_rays) unit_empty = P.unit_empty[(uint32_t) i / P.empty_unit] != 0;
+                    i += P.ray_first;
+                    if (i < P.n_rays) {
+                        // ---- sample() prologue (:51-108) + reach_medium (:292-319) ----
+                        li = (uint32_t) i;
+    #if DRT_SQ_PROFILE == 6
+                        t_start = (uint32_t) __builtin_amdgcn_s_memrealtime() | 1u;
+    #endif
+                        const uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
+                        const uint32_t gi = (uint32_t) g64;
+                        S.seed(P.seed, gi);
+                        if (P.sensor_flow) {
+                            float ux = S.next_1d(), uy = S.next_1d();
+                            sensor_ray(P, gi / P.spp, ux, uy, ro, rd);
+                        } else {
+                            ro = v3(P.rays_o[3 * i], P.rays_o[3 * i + 1], P.rays_o[3 * i + 2]);
+                            rd = v3(P.rays_d[3 * i], P.rays_d[3 * i + 1], P.rays_d[3 * i + 2]);
                         }
-                        if (!ADJ && P.path_cache_mode == 1) { P.ray_hash[i] = hsh; pc_on = true; }
-                        if (ADJ && P.path_cache_mode == 2) pc_on = P.ray_hash[i] == hsh;
+                        SQ_COUNT(C_RAYS);
+                        pc_on = false; pc_it = 0;
+                        if (P.path_cache_mode) {
+                            // one word per ray ties the cache entries to THIS ray: explicit rays are hashed (the buffers
+                            // may have been refilled between the two passes), sensor rays follow from the job signature
+                            uint32_t hsh = 0x9e3779b9u ^ gi;
+                            if (!P.sensor_flow) {
+                                const uint32_t w[6] = { __float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z),
+                                                        __float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z) };
+    #pragma unroll
+                                for (int k = 0; k < 6; ++k) hsh = (hsh ^ w[k]) * 0x01000193u + (hsh >> 15);
+                            }
+                            if (!ADJ && P.path_cache_mode == 1) { P.ray_hash[i] = hsh; pc_on = true; }
+                            if (ADJ && P.path_cache_mode == 2) pc_on = P.ray_hash[i] == hsh;
+                        }
+                        beta[0] = beta[1] = beta[2] = 1.0f;
+                        result[0] = result[1] = result[2] = 0.0f;
+                        if constexpr (ADJ) {
+                            dL[0] = P.dL[3 * i]; dL[1] = P.dL[3 * i + 1]; dL[2] = P.dL[3 * i + 2];
+                            result[0] = P.L_in[3 * i]; result[1] = P.L_in[3 * i + 1]; result[2] = P.L_in[3 * i + 2];
+                        }
+                        depth = 0; escaped = false; has_scattered = false; scat_once = false;
+                        rec_mode = false; rec_first = false;
+                        (void) S.next_1d();                                     // :71
+                        bool active = true;
+                        Hit si = box_hit(P, ro, rd);
+                        if (!si.valid) { escaped = true; active = false; }
+                        else {
+                            ro = offset_p(si, rd);
+                            Hit sn = box_hit(P, ro, rd);
+                            if (!sn.valid) active = false; else si_t = sn.t;
+                        }
+                        r_depth = -1;
+                        r_wsum[0] = r_wsum[1] = r_wsum[2] = 0.0f;
+                        r_cw[0] = r_cw[1] = r_cw[2] = 0.0f;
+                        if (active) (void) S.next_1d();                         // :99
+                        if constexpr (ADJ) A.seed(P.alt_seed, gi);              // :100-107
+                        ph = active ? SP_HEAD : SP_END;
                     }
-                    beta[0] = beta[1] = beta[2] = 1.0f;
-                    result[0] = result[1] = result[2] = 0.0f;
-                    if constexpr (ADJ) {
-                        dL[0] = P.dL[3 * i]; dL[1] = P.dL[3 * i + 1]; dL[2] = P.dL[3 * i + 2];
-                        result[0] = P.L_in[3 * i]; result[1] = P.L_in[3 * i + 1]; result[2] = P.L_in[3 * i + 2];
-                    }
-                    depth = 0; escaped = false; has_scattered = false; scat_once = false;
-                    rec_mode = false; rec_first = false;
-                    (void) S.next_1d();                                     // :71
-                    bool active = true;
-                    Hit si = box_hit(P, ro, rd);
-                    if (!si.valid) { escaped = true; active = false; }
-                    else {
-                        ro = offset_p(si, rd);
-                        Hit sn = box_hit(P, ro, rd);
-                        if (!sn.valid) active = false; else si_t = sn.t;
-                    }
-                    r_depth = -1;
-                    r_wsum[0] = r_wsum[1] = r_wsum[2] = 0.0f;
-                    r_cw[0] = r_cw[1] = r_cw[2] = 0.0f;
-                    if (active) (void) S.next_1d();                         // :99
-                    if constexpr (ADJ) A.seed(P.alt_seed, gi);              // :100-107
-                    ph = active ? SP_HEAD : SP_END;
                 }
+            } else {
+                SQ_PROF(6, 1); SQ_PROF(7, nb);
+                if (act) ph = SP_IDLE;                                           // (no ray for this record: it stays free and draws again)
+                bool retired = false;
+                // (primal kernels, DRT_SQ_REGEN_FINISH >= 2: ROUNDS - the records whose ray was over at once take another ray right here)
+                for (int round = 0;; ++round) {
+                const bool need = act && ph == SP_IDLE;
+                const uint64_t wmask = __ballot(need);
+                uint64_t first = 0; uint32_t got = 0, qx = 0, qs_ = 0;
+                if (lane == 0) {
+                    while (atomicCAS(misc + 2, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+                    uint64_t pn = ((sq_vu64 *) pool)[0], pe = ((sq_vu64 *) pool)[1];
+                    uint32_t qs = ((sq_vu32 *) misc)[3];
+                    while (pn >= pe && qs < 8u) {                                // refill from the ray queues
+                        const uint32_t x = (xcc + qs) & 7u;
+                        const uint64_t len = (n_runs > x ? (n_runs - x + 7) / 8 : 0) * DRT_SQ_RUN;
+                        const unsigned long long base = atomicAdd(P.queues + x, (unsigned long long) P.sq_chunk);
+                        if (base < len) { pn = base; pe = base + P.sq_chunk < len ? base + P.sq_chunk : len; }
+                        else ++qs;                                               // this queue is drained: next one
+                    }
+                    qx = (xcc + qs) & 7u; qs_ = qs;
+                    const uint64_t want = (uint64_t) __popcll(wmask);
+                    got = (uint32_t) (pe - pn < want ? pe - pn : want);
+                    if (qs >= 8u) got = 0;
+                    first = pn; pn += got;
+                    ((sq_vu64 *) pool)[0] = pn; ((sq_vu64 *) pool)[1] = pe; ((sq_vu32 *) misc)[3] = qs;
+                    sq_fence();
+                    ((sq_vu32 *) misc)[2] = 0u;                                  // unlock
+                }
+                first = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (first >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) first);
+                got = (uint32_t) __builtin_amdgcn_readfirstlane((int) got); qx = (uint32_t) __builtin_amdgcn_readfirstlane((int) qx);
+                qs_ = (uint32_t) __builtin_amdgcn_readfirstlane((int) qs_);
+                if (qs_ >= 8u && !got) {                       // all eight queues are empty: these records are done
+                    if (round == 0) { if (lane == 0) atomicAdd(misc, nb); retired = true; }
+                    break;                                     // (a later round: the records that hold a ray go on, the others are retired by a later batch)
+                }
+                const uint32_t myr = (uint32_t) __popcll(wmask & ((1ull << lane) - 1ull));
+                const bool take = need && myr < got;
+                const uint64_t q = first + myr;
+                if (take) {
+                    uint64_t i = ((q / DRT_SQ_RUN) * 8 + qx) * DRT_SQ_RUN + (q % DRT_SQ_RUN);
+                    if (P.order) {                                              // position -> unit of the order -> ray
+                        const uint32_t g = (uint32_t) i, u = P.order_unit == 1u ? g : g / P.order_unit;
+                        i = i < span ? (uint64_t) P.order[u] * P.order_unit + (g - u * P.order_unit) : P.n_rays;
+                    }
+                    unit_empty = false;
+                    if (P.unit_empty && i + P.ray_first < P.n_rays) unit_empty = P.unit_empty[(uint32_t) i / P.empty_unit] != 0;
+                    i += P.ray_first;
+                    if (i < P.n_rays) {
+                        // ---- sample() prologue (:51-108) + reach_medium (:292-319) ----
+                        li = (uint32_t) i;
+    #if DRT_SQ_PROFILE == 6
+                        t_start = (uint32_t) __builtin_amdgcn_s_memrealtime() | 1u;
+    #endif
+                        const uint64_t g64 = P.chunk ? P.ray_offset + (i / P.chunk) * P.stride + (i % P.chunk) : P.ray_offset + i;
+                        const uint32_t gi = (uint32_t) g64;
+                        S.seed(P.seed, gi);
+                        if (P.sensor_flow) {
+                            float ux = S.next_1d(), uy = S.next_1d();
+                            sensor_ray(P, gi / P.spp, ux, uy, ro, rd);
+                        } else {
+                            ro = v3(P.rays_o[3 * i], P.rays_o[3 * i + 1], P.rays_o[3 * i + 2]);
+                            rd = v3(P.rays_d[3 * i], P.rays_d[3 * i + 1], P.rays_d[3 * i + 2]);
+                        }
+                        SQ_COUNT(C_RAYS);
+                        pc_on = false; pc_it = 0;
+                        if (P.path_cache_mode) {
+                            // one word per ray ties the cache entries to THIS ray: explicit rays are hashed (the buffers
+                            // may have been refilled between the two passes), sensor rays follow from the job signature
+                            uint32_t hsh = 0x9e3779b9u ^ gi;
+                            if (!P.sensor_flow) {
+                                const uint32_t w[6] = { __float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z),
+                                                        __float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z) };
+    #pragma unroll
+                                for (int k = 0; k < 6; ++k) hsh = (hsh ^ w[k]) * 0x01000193u + (hsh >> 15);
+                            }
+                            if (!ADJ && P.path_cache_mode == 1) { P.ray_hash[i] = hsh; pc_on = true; }
+                            if (ADJ && P.path_cache_mode == 2) pc_on = P.ray_hash[i] == hsh;
+                        }
+                        beta[0] = beta[1] = beta[2] = 1.0f;
+                        result[0] = result[1] = result[2] = 0.0f;
+                        if constexpr (ADJ) {
+                            dL[0] = P.dL[3 * i]; dL[1] = P.dL[3 * i + 1]; dL[2] = P.dL[3 * i + 2];
+                            result[0] = P.L_in[3 * i]; result[1] = P.L_in[3 * i + 1]; result[2] = P.L_in[3 * i + 2];
+                        }
+                        depth = 0; escaped = false; has_scattered = false; scat_once = false;
+                        rec_mode = false; rec_first = false;
+                        (void) S.next_1d();                                     // :71
+                        bool active = true;
+                        si_t = kInf;
+                        Hit si = box_hit(P, ro, rd);
+                        if (!si.valid) { escaped = true; active = false; }
+                        else {
+                            ro = offset_p(si, rd);
+                            Hit sn = box_hit(P, ro, rd);
+                            if (!sn.valid) active = false; else si_t = sn.t;
+                        }
+                        r_depth = -1;
+                        r_wsum[0] = r_wsum[1] = r_wsum[2] = 0.0f;
+                        r_cw[0] = r_cw[1] = r_cw[2] = 0.0f;
+                        if (active) (void) S.next_1d();                         // :99
+                        if constexpr (ADJ) A.seed(P.alt_seed, gi);              // :100-107
+                        ph = active ? SP_HEAD : SP_END;
+                        {
+                            // Rays that are over before they begin - they miss the medium's box, or their FIRST flight cannot collide (the pixel crosses
+                            // only empty supergrid cells: unit_empty; or its target optical depth exceeds largest majorant x segment length: the flight
+                            // set-up's early-out, which decides MOST rays of an optimisation that starts from a thin medium, scene_config.py:166-169) - are
+                            // finished right here.  The blocks below would take such a ray through the loop head (one roulette draw; no roulette at depth
+                            // 0 <= rr_depth), the flight set-up (one draw -> tau; the flight leaves the segment), the escape and the end of the path: two
+                            // rounds of the pass loop for two draws, the path-cache entry "escaped", the emitter's radiance.  The same statements, the
+                            // same draws, the same values - here.
+                            bool over = !active;
+                            if (active && DRT_SQ_EARLY_OUT && P.rr_depth >= 0 && (unit_empty || thin)) {
+                                Pcg32 T = S;
+                                (void) T.next_1d();                                 // :120 u_rr
+                                const float tau0 = -drt_logf(1.0f - T.next_1d());   // the first flight's target optical depth
+                                if (unit_empty || tau0 > (mmax * si_t) * 1.001f) {
+                                    S = T; over = true; escaped = true;             // :244-245
+                                    if (pc_on && 0 < (int) P.path_cache_cap)
+                                        P.path_cache[(size_t) li * P.path_cache_cap * 2] = make_uint4(__float_as_uint(kInf), (uint32_t) S.state, (uint32_t) (S.state >> 32), 0u);
+                                }
+                            }
+                            if (over) {
+                                if (escaped && !P.hide_emitters) {                  // (depth 0: volpathsimple.py:263-285; mis_weight(1, 0) = 1)
+                                    float Le[3];
+                                    (void) emitter_eval_pdf<ENV>(P, rd, Le);
+    #pragma unroll
+                                    for (int k = 0; k < 3; ++k) result[k] += (beta[k] * 1.0f) * Le[k];
+                                }
+                                const size_t o3 = 3 * (size_t) li;
+                                P.L_out[o3] = result[0]; P.L_out[o3 + 1] = result[1]; P.L_out[o3 + 2] = result[2];
+                                if (P.ray_iters) P.ray_iters[li] = (uint8_t) 0;
+                                ph = SP_IDLE;
+                            }
+                        }
+                    }
+                }
+                // (rounds only in a THIN medium, where nearly every ray is over at once - an optimisation's first iterations: 431 -> 537 iterations/s at
+                //  config 3's 16^3 level; in a thick one - the headline - they cost the primal launch 0.1 ms: profiles/r06_sq_instruction_budget.txt)
+                if (DRT_SQ_REGEN_FINISH < 2 || !thin) break;
+                // another round while at least DRT_SQ_REGEN_AGAIN of the batch's records are free again and the pool may hold more rays
+                if (got < (uint32_t) __popcll(wmask) || __popcll(__ballot(act && ph == SP_IDLE)) < DRT_SQ_REGEN_AGAIN) break;
+                }
+                if (retired) continue;
             }
         } else {
             SQ_PROF(4, 1); SQ_PROF(5, nb);
@@ -1438,6 +1606,11 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
     unsigned blocks = (unsigned) n_cus;                                         // one workgroup per CU
     const uint64_t need = (P.n_rays - P.ray_first + nray - 1) / nray;           // no more workgroups than groups of records
     if (need < blocks && !P.tail_mode) blocks = (unsigned) need;
+    P.sq_chunk = DRT_SQ_CHUNK;
+    if (!P.order && !P.tail_mode) {                                             // index order: fewer, larger refills (see DRT_SQ_CHUNK_MAX)
+        const uint64_t c = (P.n_rays - P.ray_first) / (32ull * blocks);
+        P.sq_chunk = (uint32_t) (c < DRT_SQ_CHUNK ? DRT_SQ_CHUNK : c > DRT_SQ_CHUNK_MAX ? DRT_SQ_CHUNK_MAX : c) & ~63u;
+    }
     // the tail launch: the pool's (few thousand) records over a few workgroups (tail_mode 1: the partition passes of the reduction run beside it) or the chip (2)
     if (P.tail_mode == 1u) {
         const unsigned fit = (unsigned) ((P.tail_cap + nray - 1) / nray);           // (every pool entry needs a record)

@@ -138,6 +138,10 @@ class _DeviceIntegrator:
     def native_handle(self, scene: Scene):
         return self._bind(scene)[0]
 
+    def _colour_grid(self, scene: Scene):
+        """The colour grid whose lattice the handle is told about (drt_set_colour_resolution): the albedo here, the emission for `nerf`."""
+        return scene.medium.albedo
+
     def _bind(self, scene: Scene):
         m = scene.medium
         st, al = m.sigma_t, m.albedo
@@ -151,7 +155,13 @@ class _DeviceIntegrator:
         if st.dim() != 4 or st.shape[-1] != 1:
             raise ValueError(f"sigma_t must have shape (Z,Y,X,1), got {tuple(st.shape)}")
         if isinstance(al, torch.Tensor):
-            _check(al, tuple(st.shape[:3]) + (3,), dev, "albedo")
+            _check(al, None, dev, "albedo")
+            if al.dim() != 4 or al.shape[-1] != 3:
+                raise ValueError(f"albedo must have shape (Z,Y,X,3), got {tuple(al.shape)}")
+        # the colour grid this integrator reads (albedo; nerf: emission) may live on its OWN lattice, as every Mitsuba GridVolume does
+        # (janga-smoke: 264 x 136 x 136 density, 256 x 128 x 128 albedo / emission, scene_config.py:108-110): drt_set_colour_resolution
+        cg = self._colour_grid(scene)
+        cshape = tuple(cg.shape[:3]) if isinstance(cg, torch.Tensor) else tuple(st.shape[:3])
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         h = self._handles.get(idx)
         if h is None:
@@ -164,7 +174,7 @@ class _DeviceIntegrator:
         # so an equal address means the same storage (whose views share one version counter) - a freshly
         # allocated grid can never alias a cached key through the caching allocator.
         al_key = (al.data_ptr(), al._version) if isinstance(al, torch.Tensor) else (0, 0)
-        key = (st.data_ptr(), st._version) + al_key + (tuple(st.shape),
+        key = (st.data_ptr(), st._version) + al_key + (tuple(st.shape), cshape,
                tuple(m.bbox_min), tuple(m.bbox_max), float(m.scale), int(m.majorant_resolution_factor))
         self._bind_emitter(h, idx, scene.emitter, dev)
         bound = self._bound.get(idx)
@@ -174,6 +184,8 @@ class _DeviceIntegrator:
                          [int(x), int(y), int(z)],
                          [float(v) for v in m.bbox_min], [float(v) for v in m.bbox_max],
                          float(m.scale), int(m.majorant_resolution_factor))
+            if cshape != tuple(st.shape[:3]):
+                h.set_colour_resolution([int(cshape[2]), int(cshape[1]), int(cshape[0])])
             self._bound[idx] = (key, st, al)
         return h, dev
 
@@ -314,6 +326,9 @@ class NeRFIntegrator(_DeviceIntegrator):
     param_keys = (SIGMA_T_KEY, EMISSION_KEY)
     needs_albedo = False
 
+    def _colour_grid(self, scene: Scene):
+        return scene.medium.emission
+
     def __init__(self, props: Optional[dict] = None):
         props = dict(props or {})
         self.hide_emitters = bool(props.get("hide_emitters", False))
@@ -360,7 +375,9 @@ class NeRFIntegrator(_DeviceIntegrator):
         em = scene.medium.emission
         if not isinstance(em, torch.Tensor):
             raise TypeError("the nerf integrator needs medium.emission as a torch device tensor")
-        _check(em, tuple(scene.medium.sigma_t.shape[:3]) + (3,), dev, "emission")
+        _check(em, None, dev, "emission")
+        if em.dim() != 4 or em.shape[-1] != 3:
+            raise ValueError(f"emission must have shape (Z,Y,X,3), got {tuple(em.shape)}")
         self._set_rays(h, ray)
         n, ro, rd = self._ray_ptrs(ray, dev)
         if mode == ADMode.Primal:

@@ -354,14 +354,6 @@ def _scene_with(scene: Scene, params: Dict[str, torch.Tensor], factor: int) -> S
     return Scene(medium=medium, emitter=scene.emitter, sensors=scene.sensors)
 
 
-def _resample_like(grid: torch.Tensor, res3) -> torch.Tensor:
-    """A non-optimised grid next to optimised ones at another resolution (multi-resolution schedules): the
-    integrator needs all grids on one lattice, so the fixed grid is resampled (trilinear, as `upsample_grid`)."""
-    if tuple(grid.shape[:3]) == tuple(res3):
-        return grid
-    return upsample_grid(grid, tuple(res3) + (grid.shape[-1],))
-
-
 def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, scene_config: SceneConfig,
                      int_config, ref_images: Optional[torch.Tensor] = None, progress: Optional[Callable] = None,
                      shard=None):
@@ -456,16 +448,16 @@ def run_optimization(output_dir: Optional[str], opt_config: OptimizationConfig, 
             raise ValueError(f'The integrator reads "{k}" but it is neither optimised nor present in the scene')
 
     def current_grids():
-        """The grids the integrator reads: optimised ones from `params`, the others from the scene, all on
-        the lattice of the current sigma_t."""
-        st = params[SIGMA_T_KEY] if SIGMA_T_KEY in params else None
-        res3 = tuple(st.shape[:3]) if st is not None else tuple(next(iter(params.values())).shape[:3])
+        """The grids the integrator reads: optimised ones from `params`, the others from the scene AS THEY ARE - a fixed grid next to
+        optimised ones at another resolution (multi-resolution schedules upsample only what is optimised, optimize.py:228-252 of the
+        reference) stays on its own lattice, as Mitsuba keeps it; colour grids that differ from sigma_t's lattice run the own-lattice
+        kernels (drt_set_colour_resolution).  Albedo and emission must agree with each other where an integrator reads both."""
         out = {}
         for k in (SIGMA_T_KEY, ALBEDO_KEY, EMISSION_KEY):
             if k in params:
                 out[k] = params[k]
             elif full[k] is not None:
-                out[k] = _resample_like(full[k], res3)
+                out[k] = full[k]
         return out
 
     grids = current_grids()

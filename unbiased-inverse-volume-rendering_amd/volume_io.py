@@ -57,12 +57,11 @@ def medium_from_vol(medium_filename: str, albedo_filename=None, emission_filenam
     warm start (`janga-smoke-from-nerf`: `<output>/<run>/nerf/params/final-medium1_sigma_t.vol`, :123-141).
 
     The bounding box is the one stored in the sigma_t file.  Without an albedo file the albedo is the constant
-    `albedo_value`.  The kernels read all grids on ONE lattice, sigma_t's: an albedo / emission file of a different
-    resolution (the reference pairs a 264x136x136 density with a 256x128x128 albedo, :108-109) is resampled to it
-    trilinearly (cell-centred, edge-replicated) - Mitsuba interpolates every grid on its own lattice, so that case is
-    an approximation, stated here."""
+    `albedo_value` on sigma_t's lattice.  An albedo / emission file keeps ITS OWN resolution (the reference pairs a
+    264x136x136 density with 256x128x128 albedo / emission grids, :108-110; Mitsuba interpolates every grid on its own
+    lattice): the integrators then run the own-lattice kernels (drt_set_colour_resolution, csrc/drt_own.hip).  Albedo and
+    emission files must share one lattice."""
     import torch
-    import torch.nn.functional as F
     from .scene import GridMedium
     sig, bmin, bmax = read_vol(medium_filename)
     if sig.shape[3] != 1:
@@ -78,15 +77,17 @@ def medium_from_vol(medium_filename: str, albedo_filename=None, emission_filenam
         t = torch.from_numpy(g)
         if t.shape[3] == 1:
             t = t.expand(-1, -1, -1, 3)
-        if tuple(t.shape[:3]) != tuple(res3):
-            t = F.interpolate(t.permute(3, 0, 1, 2).unsqueeze(0), size=tuple(res3), mode="trilinear",
-                              align_corners=False)[0].permute(1, 2, 3, 0)
         return t.contiguous()
 
     albedo = load(albedo_filename, "albedo")
     if albedo is None:
         albedo = torch.full(tuple(res3) + (3,), float(albedo_value), dtype=torch.float32)
     emission = load(emission_filename, "emission")
+    if emission is not None and albedo_filename is not None and tuple(emission.shape[:3]) != tuple(albedo.shape[:3]):
+        raise ValueError(f"{albedo_filename} and {emission_filename}: albedo and emission grids must share one lattice, "
+                         f"found {tuple(albedo.shape[:3])} and {tuple(emission.shape[:3])}")
+    if emission is not None and albedo_filename is None:                  # (a constant albedo follows the emission's lattice)
+        albedo = torch.full(tuple(emission.shape[:3]) + (3,), float(albedo_value), dtype=torch.float32)
     to = (lambda t: t.to(device)) if device is not None else (lambda t: t)
     return GridMedium(sigma_t=to(torch.from_numpy(sig.copy())), albedo=to(albedo), bbox_min=bmin, bbox_max=bmax, scale=scale,
                       majorant_resolution_factor=majorant_resolution_factor,
