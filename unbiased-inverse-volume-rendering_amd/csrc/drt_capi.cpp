@@ -25,6 +25,12 @@ struct drt_handle_s {
     drt::Params base{};            // scene part of the kernel parameter block
     bool have_medium = false, have_emitter = false, have_sensor = false;
     float *d_majorant = nullptr;   // [2]
+    // the global majorant as the HOST last saw it: drt_params_changed copies it to pinned memory behind the reduction and records an event; launches
+    // look at it when the event has completed (never waiting) - a hint for kernel choice only (a thin medium: Params::sq_rounds), stale by design
+    float *h_majorant = nullptr;   // pinned, [1]
+    hipEvent_t ev_majorant = nullptr;
+    bool majorant_pending = false;
+    float majorant_seen = -1.0f;   // < 0: never seen
     uint32_t *d_scratch = nullptr; // [1]
     unsigned long long *d_counters = nullptr;   // [C_COUNT]
     float *d_gt = nullptr;         // gradient scratch, 4 planes (always zero between launches)
@@ -394,6 +400,14 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
             }
         }
         Q.ray_perm = nullptr; Q.block_order = nullptr;
+        // thin medium (as far as the host has seen its majorant - drt_params_changed - without waiting for anything)?  Primal launches in index order then
+        // run the ROUNDS kernels (drt_sq.hip): an optimisation's first iterations, where nearly every ray is over before it begins
+        if (h->majorant_pending && hipEventQuery(h->ev_majorant) == hipSuccess) { h->majorant_seen = *h->h_majorant; h->majorant_pending = false; }
+        else if (h->majorant_pending) (void) hipGetLastError();                        // (hipErrorNotReady is not an error)
+        {
+            const float dx = P.bmax[0] - P.bmin[0], dy = P.bmax[1] - P.bmin[1], dz = P.bmax[2] - P.bmin[2];
+            Q.sq_rounds = (!adjoint && h->majorant_seen >= 0.0f && h->majorant_seen * std::sqrt(dx * dx + dy * dy + dz * dz) < 3.0f) ? 1u : 0u;
+        }
         DRT_HIP_CHECK(h, hipMemsetAsync(h->d_queues, 0, 8 * sizeof(unsigned long long), h->stream));
         if (queued) {
             Q.sq_cold = h->d_sq_cold;
@@ -828,6 +842,8 @@ int drt_destroy(drt_handle h)
     if (!h) return DRT_OK;
     DeviceGuard g(h->device);
     if (h->d_majorant) (void) hipFree(h->d_majorant);
+    if (h->h_majorant) (void) hipHostFree(h->h_majorant);
+    if (h->ev_majorant) (void) hipEventDestroy(h->ev_majorant);
     if (h->d_scratch) (void) hipFree(h->d_scratch);
     if (h->d_counters) (void) hipFree(h->d_counters);
     if (h->d_gt) (void) hipFree(h->d_gt);
@@ -916,6 +932,14 @@ int drt_params_changed(drt_handle h)
                                                    h->d_scratch, h->d_majorant, (uint32_t *) h->base.mocc_dil));
     else
         DRT_HIP_CHECK(h, drt::launch_majorant(h->base.sigma_t, n, h->base.scale, h->d_scratch, h->d_majorant, h->stream));
+    // (best effort: without the pinned word or the event the hint simply stays unknown)
+    if (!h->h_majorant && hipHostMalloc((void **) &h->h_majorant, sizeof(float), hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); h->h_majorant = nullptr; }
+    if (h->h_majorant && !h->ev_majorant && hipEventCreateWithFlags(&h->ev_majorant, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); h->ev_majorant = nullptr; }
+    if (h->h_majorant && h->ev_majorant && !h->majorant_pending) {        // (one copy in flight at a time: the word is read only behind its event)
+        if (hipMemcpyAsync(h->h_majorant, h->d_majorant, sizeof(float), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+            hipEventRecord(h->ev_majorant, h->stream) == hipSuccess) h->majorant_pending = true;
+        else (void) hipGetLastError();
+    }
     DRT_HIP_CHECK(h, drt::launch_occupancy(h->base.sigma_t, h->base.rx, h->base.ry, h->base.rz, h->base.occ_shift, h->base.occ_x,
                                            h->base.occ_y, h->occ_z, h->d_occ, h->base.occ_words, h->stream));
     DRT_HIP_CHECK(h, drt::launch_brick_sigma(h->base.sigma_t, h->d_sigma_b, h->base.rx, h->base.ry, h->base.rz,

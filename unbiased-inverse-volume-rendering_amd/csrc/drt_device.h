@@ -331,6 +331,7 @@ struct Params {
     // runs the kernels of drt_own.hip - the only translation unit compiled with DRT_COLOUR_OWN, in which eval_rgb and the colour splats read
     // crx / cry / crz; in every other unit these fields are never read.  (At the end of the block: no other field moves.)
     int crx, cry, crz, colour_own;
+    uint32_t sq_rounds;             // queued tracer, primal launches in index order: the medium is thin as far as the host knows (drt_capi.cpp: majorant read-back) - the ROUNDS kernels
 };
 
 // ---------------------------------------------------------------------------

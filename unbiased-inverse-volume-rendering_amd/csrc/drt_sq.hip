@@ -266,7 +266,10 @@ __device__ __forceinline__ void sq_push_all(unsigned long long *ctl, uint16_t *q
 // advanced by the detour's draws - and resumes with the second half of the block (SP_QSCAT2).
 // TAILM (adjoint kernels): the tail launch (Params::tail_mode) - it starts from the records of the tail pool instead of the ray queues.  An instantiation of
 // its own: with the pool's prologue compiled into the main kernels those came out 3 KB larger and 8 % slower (instruction cache; profiles/r05_sq_experiments.txt)
-template <bool ADJ, bool COUNT, bool ENV, bool MG, bool QUAD = false, bool TAILM = false>
+// ROUNDS (primal kernels of launches in index order over a THIN medium, Params::sq_rounds): the regeneration block hands the records whose ray was over
+// at once their next ray in the same block.  An instantiation of its own: compiled into the others the loop cost the headline's primal launch 0.15 ms
+// without running once (profiles/r06_sq_instruction_budget.txt)
+template <bool ADJ, bool COUNT, bool ENV, bool MG, bool QUAD = false, bool TAILM = false, bool ROUNDS = false>
 __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P)
 {
     constexpr int NWV = DRT_SQ_THREADS / 64;
@@ -961,7 +964,7 @@ __global__ void __launch_bounds__(DRT_SQ_THREADS) trace_sq_kernel(const Params P
                 }
                 // (rounds only in a THIN medium, where nearly every ray is over at once - an optimisation's first iterations: 431 -> 537 iterations/s at
                 //  config 3's 16^3 level; in a thick one - the headline - they cost the primal launch 0.1 ms: profiles/r06_sq_instruction_budget.txt)
-                if (DRT_SQ_REGEN_FINISH < 2 || !thin) break;
+                if (DRT_SQ_REGEN_FINISH < 2 || !ROUNDS || !thin) break;
                 // another round while at least DRT_SQ_REGEN_AGAIN of the batch's records are free again and the pool may hold more rays
                 if (got < (uint32_t) __popcll(wmask) || __popcll(__ballot(act && ph == SP_IDLE)) < DRT_SQ_REGEN_AGAIN) break;
                 }
@@ -1623,12 +1626,15 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
     hipError_t e = hipSuccess;
     const bool quad = adjoint && P.use_drt && !P.use_drt_subsampling;           // quadratic DRT: the QUAD instantiations of the adjoint kernels
     const bool tailm = P.tail_mode != 0u;
+    const bool rounds = DRT_SQ_REGEN_FINISH >= 2 && P.sq_rounds != 0u && !P.order;
 #define DRT_SQ_LAUNCH(A, C, E) do { if (tailm) DRT_SQ_LAUNCH_Q(A, C, E, true); else DRT_SQ_LAUNCH_Q(A, C, E, false); } while (0)
 #define DRT_SQ_LAUNCH_Q(A, C, E, T) do { if (A && quad) { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, A, T); else DRT_SQ_LAUNCH_(A, C, E, false, A, T); } \
                                     else { if (mg) DRT_SQ_LAUNCH_(A, C, E, true, false, T); else DRT_SQ_LAUNCH_(A, C, E, false, false, T); } } while (0)
-#define DRT_SQ_LAUNCH_(A, C, E, M, Q, T)                                                                             \
+#define DRT_SQ_LAUNCH_(A, C, E, M, Q, T) do { if (!(A) && !(C) && !(T) && rounds) DRT_SQ_LAUNCH_R(A, C, E, M, Q, T, (!(A) && !(C) && !(Q) && !(T))); \
+                                              else DRT_SQ_LAUNCH_R(A, C, E, M, Q, T, false); } while (0)
+#define DRT_SQ_LAUNCH_R(A, C, E, M, Q, T, R)                                                                         \
     do {                                                                                                          \
-        auto kern = trace_sq_kernel<A, C, E, M, Q, T>;                                                            \
+        auto kern = trace_sq_kernel<A, C, E, M, Q, T, R>;                                                         \
         static std::atomic<size_t> lds_set[64];                                                                        \
         int dev_ = 0;                                                                                             \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 63;                               \
@@ -1653,6 +1659,7 @@ hipError_t launch_trace_sq(const Params &Pin, bool adjoint, bool count, int n_cu
 #undef DRT_SQ_LAUNCH
 #undef DRT_SQ_LAUNCH_Q
 #undef DRT_SQ_LAUNCH_
+#undef DRT_SQ_LAUNCH_R
     return hipGetLastError();
 }
 
