@@ -258,6 +258,10 @@ int drt_adam_step_clamped(void *hip_stream, float *p, const float *g, float *m, 
 int drt_enable_counters(drt_handle h, int enable);
 int drt_reset_counters(drt_handle h);
 int drt_get_counters(drt_handle h, drt_counters *out);   /* synchronises the stream */
+/* The nerf adjoint of sensor rays (csrc/drt_nerf_tile.hip) is bound by the LDS atomic rate, not by HBM: with counting enabled, its last launch's
+ * LDS lane-adds (8 per non-zero plane of a query's splat, after the zero skips) - the numerator of that kernel's roofline in bench.py.
+ * Synchronises the handle's streams.  0 when no such launch ran with counting enabled. */
+int drt_nerf_tile_stats(drt_handle h, uint64_t *lds_lane_adds);
 
 /* Kernel timing for the roofline leg of bench.py: while enabled, every tracing
  * launch is bracketed by a HIP event pair recorded on the handle's stream.

@@ -56,3 +56,13 @@ def test_rccl_backend_runs_the_gradient_collectives_on_one_rank(gpu):
     r = _torchrun([os.path.join(ROOT, "tests", "workers", "nccl_smoke_worker.py")], world=1, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
     assert "NCCL_SMOKE_OK" in r.stdout
+
+
+def test_config4_gradient_exchange_at_its_size_on_rccl_one_rank(gpu):
+    """Config 4's 2 GiB gradient buffer (512^3 x 4 floats) through gradient_support, the pack / unpack kernels and ONE RCCL collective in a
+    world of one rank: the buffer comes back bit for bit, one collective, and the step's timings are printed."""
+    r = _torchrun([os.path.join(ROOT, "tests", "workers", "nccl_config4_worker.py")], world=1, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-6000:]
+    assert "CONFIG4_ALLREDUCE_OK" in r.stdout
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["flat_MiB"] == 2048.0 and out["collectives"] == 1 and out["mode"] in ("compact", "dense")

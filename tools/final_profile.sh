@@ -21,6 +21,7 @@ done
 [ -f /root/repo/variants/alb0/libdrt_hip.so ] && (LD_LIBRARY_PATH=/root/repo/variants/alb0 timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic_alb0 -- $B --steps 3 --warmup 1 --majorant-factor 8 > /dev/null 2>> $R/err.txt)
 (timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic_env8 -- python /root/repo/bench.py --only-config headline_envmap_factor8 > /dev/null 2>> $R/err.txt)
 (timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic_fused -- python /root/repo/bench.py --only-config config5_fused_nerf_drt_256_512x32 > /dev/null 2>> $R/err.txt)
+(timeout 900 rocprofv3 -i /root/repo/tools/pmc_traffic.txt --kernel-trace --output-format csv -d $R/pmc_traffic_c4 -- python /root/repo/bench.py --only-config config4_512_rank_share_1024x64 > /dev/null 2>> $R/err.txt)
 (timeout 900 rocprofv3 -i /root/repo/tools/pmc_util.txt --kernel-trace --output-format csv -d $R/pmc_util_fused -- python /root/repo/bench.py --only-config config5_fused_nerf_drt_256_512x32 > /dev/null 2>> $R/err.txt)
 (timeout 600 rocprofv3 --kernel-trace --stats -d $R/prof_fused -o hl -- python /root/repo/bench.py --only-config config5_fused_nerf_drt_256_512x32 > /dev/null 2>> $R/err.txt)
 cd /root/repo
@@ -35,12 +36,13 @@ python tools/pmc_to_traffic.py $R/pmc_traffic8 dust-devil-256-512x32-factor8 $R/
 python tools/pmc_to_traffic.py $R/pmc_traffic0 dust-devil-256-512x32 $R/roofline_traffic.json > $R/pmc_traffic_factor0.txt
 python tools/pmc_to_traffic.py $R/pmc_traffic_env8 dust-devil-256-512x32-factor8-envmap2048 $R/roofline_traffic.json > $R/pmc_traffic_envmap8.txt
 python tools/pmc_to_traffic.py $R/pmc_traffic_fused fused-256-512x32 $R/roofline_traffic.json > $R/pmc_traffic_fused.txt
+python tools/pmc_to_traffic.py $R/pmc_traffic_c4 config4-512-1024x64-rank0of8-factor8 $R/roofline_traffic.json > $R/pmc_traffic_config4.txt
 python tools/pmc_to_util.py $R/pmc_util.txt $R/kernel_stats.csv dust-devil-256-512x32-factor8 $R/roofline_traffic.json > $R/util.txt
 python tools/pmc_to_util.py $R/factor0_pmc_util.txt $R/kernel_stats_factor0.csv dust-devil-256-512x32 $R/roofline_traffic.json > $R/util_factor0.txt
 python tools/pmc_to_util.py $R/fused_pmc_util.txt $R/kernel_stats_fused.csv fused-256-512x32 $R/roofline_traffic.json > $R/util_fused.txt
 [ -d $R/pmc_traffic_alb0 ] && python tools/pmc_to_traffic.py $R/pmc_traffic_alb0 dust-devil-256-512x32-factor8 $R/traffic_alb0.json > /dev/null
 rm -rf $R/pmc_traffic_alb0
-rm -rf $R/pmc_util0 $R/pmc_util8 $R/pmc_traffic0 $R/pmc_traffic8 $R/pmc_traffic_fused $R/pmc_traffic_env8 $R/pmc_util_fused $R/prof0 $R/prof8 $R/prof_fused
+rm -rf $R/pmc_traffic_c4 $R/pmc_util0 $R/pmc_util8 $R/pmc_traffic0 $R/pmc_traffic8 $R/pmc_traffic_fused $R/pmc_traffic_env8 $R/pmc_util_fused $R/prof0 $R/prof8 $R/prof_fused
 cp $R/roofline_traffic.json profiles/roofline_traffic.json      # the bench lines below quote it (same kernel sources: hash checked)
 (timeout 1500 python bench.py > $R/bench.json 2>> $R/err.txt)
 (timeout 600 python bench.py --majorant-factor 0 --no-extra-configs --no-cpu-baseline > $R/bench_factor0.json 2>> $R/err.txt)

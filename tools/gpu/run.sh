@@ -14,6 +14,7 @@
 #   c3prof:R1,R2[@V]    kernel trace of config 3's level R (tools/config3_level_profile.py), untrained and trained, library of variant V
 #   traffic:V1,V2       counter traffic of the headline's kernels per variant
 #   c3lvl:V1,V2,..      config 3's levels 16^3 / 256^3, untrained / trained, per variant, WITHOUT a profiler: it/s and the host's ms per iteration
+#   config4ar           config 4's 2 GiB gradient exchange on one rank of RCCL: support / pack / collective / unpack timings
 #   stress              tools/stress_super.py --reps 20
 TAG=$1; shift
 cd /root/repo
@@ -81,6 +82,7 @@ PY
           echo "$v | $(LD_LIBRARY_PATH=$L timeout 300 python tools/config3_level_profile.py --res $res --iters 60 $tr 2>/dev/null)" | tee -a $R/c3lvl.txt
         done; done
       done ;;
+    config4ar) HSA_ENABLE_IPC_MODE_LEGACY=0 MASTER_ADDR=127.0.0.1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 tests/workers/nccl_config4_worker.py 2> $R/config4ar_err.txt | tee $R/config4ar.txt ;;
     stress) timeout 900 python tools/stress_super.py --reps 20 > $R/stress.txt 2>&1; tail -n 5 $R/stress.txt ;;
     *) echo "unknown step $step" ;;
   esac

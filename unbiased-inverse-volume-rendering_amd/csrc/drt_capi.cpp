@@ -1602,6 +1602,20 @@ int drt_set_debug_flags(drt_handle h, uint32_t flags)
     return DRT_OK;
 }
 
+int drt_nerf_tile_stats(drt_handle h, uint64_t *lds_lane_adds)
+{
+    if (!h || !lds_lane_adds) return fail(h, DRT_ERR_INVALID_ARGUMENT, "drt_nerf_tile_stats: null argument");
+    *lds_lane_adds = 0;
+    if (!h->d_nerf_bounds) return DRT_OK;                          // (no tile launch yet)
+    DeviceGuard g(h->device);
+    DRT_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->nerf_stream) DRT_HIP_CHECK(h, hipStreamSynchronize(h->nerf_stream));
+    unsigned long long v = 0;
+    DRT_HIP_CHECK(h, hipMemcpy(&v, h->d_nerf_bounds + 6, sizeof v, hipMemcpyDeviceToHost));
+    *lds_lane_adds = (uint64_t) v;
+    return DRT_OK;
+}
+
 int drt_enable_counters(drt_handle h, int enable)
 {
     if (!h) return fail(nullptr, DRT_ERR_INVALID_ARGUMENT, "null handle");

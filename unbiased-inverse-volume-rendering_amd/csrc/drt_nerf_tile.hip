@@ -61,7 +61,7 @@ constexpr int kFixBits = 44;
 struct NerfTile {
     uint32_t tiles_x;              // tiles of 8 x 8 pixels per film row
     uint32_t groups;               // workgroups per tile: each marches DRT_NT_THREADS / 64 of the pixels' samples
-    const uint32_t *bounds;        // [0] max |dL|, [1] max |L_in| over the launch's rays, [2] max |emission| over the grid (float bits), [3] a non-finite one was seen, [4] the largest negative density's magnitude
+    uint32_t *bounds;              // [0] max |dL|, [1] max |L_in| over the launch's rays, [2] max |emission| over the grid (float bits), [3] a non-finite one was seen, [4] the largest negative density's magnitude
     uint32_t g4;                   // lookups from the four-channel copy (Params::grid4) instead of sigma_b + emission
     uint32_t count;
 };
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             jit = S.next_1d();
         }
     }
-    uint32_t n_q = 0;
+    uint32_t n_q = 0, n_adds = 0;                                      // (n_adds: LDS lane-adds of this ray, counting launches only: bounds[6..7])
     int Wx = -(1 << 28), Wy = -(1 << 28), Wz = -(1 << 28);             // window origin (workgroup-uniform; none yet: the first splats all wait)
     const int N = P.nerf_queries;
     int j = 0;
@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
                 if (v0 != 0.0f) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) atomicAdd(win + sl[k], fix64(w[k] * v0, inv_s));
+                    if (T.count) n_adds += 8u;
                 }
                 if (colour) {
 #pragma unroll
@@ -276,6 +277,7 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
                         if (ge[c] != 0.0f) {
 #pragma unroll
                             for (int k = 0; k < 8; ++k) atomicAdd(win + (c + 1) * kWinStore + sl[k], fix64(w[k] * ge[c], inv_c));
+                            if (T.count) n_adds += 8u;
                         }
                     }
                 }
@@ -365,6 +367,11 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0 && v) atomicAdd(P.counters + s, (unsigned long long) v);
         }
+        // the kernel's own ceiling is the LDS atomic rate: lane-adds of this launch (after the zero skips) -> bounds[6..7] (drt_nerf_tile_stats)
+        uint32_t a = n_adds;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0 && a) atomicAdd((unsigned long long *) (T.bounds + 6), (unsigned long long) a);
     }
 }
 

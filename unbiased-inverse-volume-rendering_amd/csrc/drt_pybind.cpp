@@ -81,6 +81,7 @@ public:
         }
         check(rc, "drt_set_medium");
     }
+    uint64_t nerf_tile_lds_adds() { uint64_t v = 0; check(drt_nerf_tile_stats(h_, &v), "drt_nerf_tile_stats"); return v; }
     void set_colour_resolution(std::array<int32_t, 3> res) { check(drt_set_colour_resolution(h_, res.data()), "drt_set_colour_resolution"); }
     void params_changed()
     {
@@ -306,6 +307,7 @@ PYBIND11_MODULE(DRT_PYBIND_NAME, m)
         .def("set_ray_interleave", &Integrator::set_ray_interleave)
         .def("set_medium", &Integrator::set_medium)
         .def("set_colour_resolution", &Integrator::set_colour_resolution)
+        .def("nerf_tile_lds_adds", &Integrator::nerf_tile_lds_adds)
         .def("params_changed", &Integrator::params_changed)
         .def("set_emitter_constant", &Integrator::set_emitter_constant)
         .def("set_emitter_envmap", &Integrator::set_emitter_envmap)
