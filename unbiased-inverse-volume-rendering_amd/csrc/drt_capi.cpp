@@ -433,7 +433,11 @@ int timed_launch(drt_handle h, int which, const drt::Params &P, bool adjoint)
 #endif
             const bool solo = drt::sq_tail_solo(Q) && span >= 8192u && !big &&
                               (adjoint ? ((DRT_SQ_TAIL_SOLO & 2) != 0 && Q.rec_buf[0] != nullptr) : (DRT_SQ_TAIL_SOLO & 1) != 0);
-            const bool tail = DRT_SQ_TAIL && (big || solo) && !dbg(h->debug_flags, 268435456u);
+#ifndef DRT_SQ_TAIL_THIN
+#define DRT_SQ_TAIL_THIN 0          // 0: primal launches over a thin medium (the ROUNDS kernels) make no tail launch - their few real paths are short, a second
+                                    // launch over the whole chip costs more than they do (config3_as_reproduce 302-305 -> 308-310 iterations/s); 1: they do
+#endif
+            const bool tail = DRT_SQ_TAIL && (big || solo) && !dbg(h->debug_flags, 268435456u) && (DRT_SQ_TAIL_THIN || !Q.sq_rounds);
             if (tail) {
                 const size_t cap = (size_t) h->n_cus * drt::sq_tail_push();
                 const size_t need_b = 256 + cap * drt::sq_tail_entry_quads() * sizeof(uint4);
