@@ -762,8 +762,10 @@ def main():
         # atomics than about the algorithm.  The better of the two is the stated baseline; both are reported.
         # (2^16 lines of 40 B per thread, and 2^20 - 40 MB per thread, 10 GB on a 256-thread host: a splat's voxel stays cached for the whole
         #  pixel neighbourhood that hits it)
+        # ... and -1: TILE-BINNED accumulation, the CPU counterpart of the device's deferred splatting (oracle/drt_oracle.c: gbucket_t) - every thread
+        # appends records to its own bucket of the splat's z layer, the layers are then reduced without atomics in an even and an odd sweep
         dt_cached, cache_log2 = None, None
-        for lg in (16, 20):
+        for lg in (16, 20, -1):
             tc = time.perf_counter()
             ob.h1_step(osc, integ.props(), cpu_spp, seed_c, grad_cache_log2=lg)
             d = time.perf_counter() - tc
@@ -778,8 +780,9 @@ def main():
             "kind": "port",
             "sample": f"same workload, full {sensor.width}x{sensor.height} image at {cpu_spp} spp "
                       f"({n_pixels * cpu_spp} samples, {dt:.1f} s); oracle/drt_oracle.c with OpenMP over rays, gradients "
-                      + (f"through a per-thread write-combining cache of 2^{cache_log2} voxels " if dt_cached <= dt_atomic else "as atomic adds into the shared grids ") +
-                      f"(the better of the two, both reported) "
+                      + (("tile-binned: per-thread record buckets by z layer, reduced without atomics " if cache_log2 == -1 else
+                          f"through a per-thread write-combining cache of 2^{cache_log2} voxels ") if dt_cached <= dt_atomic else "as atomic adds into the shared grids ") +
+                      f"(the best of the accumulation modes, the others reported beside it) "
                       f"(the reference's llvm_ad_rgb needs Mitsuba 3 / Dr.Jit, absent here)",
             "value_shared_atomics": round(n_pixels * cpu_spp / dt_atomic / 1e6, 4),
             "value_thread_local_cache": round(n_pixels * cpu_spp / dt_cached / 1e6, 4),

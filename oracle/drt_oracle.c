@@ -411,6 +411,25 @@ typedef struct {
  * shared grid - without it 256 threads mostly wait for each other's cache lines (`omp atomic` on doubles). */
 typedef struct { uint32_t tag; double v[4]; } gcache_line;   /* [0] sigma_t, [1..3] albedo rgb of voxel `tag` */
 
+/* Tile-binned gradient accumulation for the timed CPU-baseline leg (job->grad_cache_log2 == -1), the CPU counterpart of the device's deferred
+ * splatting: a thread appends its splats as records {p, value(s)} to ITS bucket of the base corner's z layer (sigma_t records by sigma_t's
+ * lattice, colour records by the colour lattice); behind the ray loop the layers are reduced in two sweeps - even layers, then odd ones: a
+ * record of layer z adds to layers z and z + 1, so layers of one parity never touch the same voxels - each layer by one thread with plain adds.
+ * No atomics, no shared cache lines in the hot loop; the fp64 sums differ from the other modes by their order only. */
+typedef struct { float p[3]; float v[3]; } grec_t;           /* sigma_t record: v[0]; colour record: v[0..2] */
+typedef struct gbucket { grec_t *r; uint32_t n, cap; } gbucket_t;
+static inline void gbucket_push(gbucket_t *b, v3 p, float v0, float v1, float v2)
+{
+    if (b->n == b->cap) {
+        uint32_t cap = b->cap ? b->cap * 2u : 256u;
+        grec_t *r = (grec_t *) realloc(b->r, (size_t) cap * sizeof(grec_t));
+        if (!r) return;                                      /* (out of memory: the record is lost - a timing leg, checked nowhere) */
+        b->r = r; b->cap = cap;
+    }
+    grec_t *q = &b->r[b->n++];
+    q->p[0] = p.x; q->p[1] = p.y; q->p[2] = p.z; q->v[0] = v0; q->v[1] = v1; q->v[2] = v2;
+}
+
 typedef struct {
     const scene_t *sc;
     double *g_sigma, *g_albedo;   /* NULL in primal */
@@ -419,6 +438,7 @@ typedef struct {
     uint32_t ray_index;
     gcache_line *gcache;          /* NULL: every splat goes to the shared grids with atomics */
     uint32_t gcache_mask;
+    struct gbucket *gbin;         /* job->grad_cache_log2 == -1 (timed CPU-baseline leg): this thread's splat records by z layer, see run_job */
 } ctx_t;
 
 /* E3: GridVolume::eval, trilinear, clamp, cell-centred (q = p*res - 0.5) */
@@ -534,6 +554,12 @@ static void gcache_flush(ctx_t *c)
 static inline void splat_sigma_t(ctx_t *c, v3 p, float g)
 {
     stencil_t s; float w[8];
+    if (c->gbin) {                                           /* binned mode: the record, by its base corner's z layer */
+        int z0, z1; float w0, w1;
+        axis_setup(p.z, c->sc->bmin.z, c->sc->inv_ext.z, c->sc->rz, &z0, &z1, &w0, &w1);
+        gbucket_push(&c->gbin[z0], p, g, 0.0f, 0.0f);
+        return;
+    }
     make_stencil(c->sc, p, &s);
     stencil_weights(&s, w);
     float gs = g * c->sc->scale;
@@ -546,6 +572,12 @@ static inline void splat_sigma_t(ctx_t *c, v3 p, float g)
 static inline void splat_albedo(ctx_t *c, v3 p, const float g[3])
 {
     stencil_t s; float w[8];
+    if (c->gbin) {
+        int z0, z1; float w0, w1;
+        axis_setup(p.z, c->sc->bmin.z, c->sc->inv_ext.z, c->sc->crz, &z0, &z1, &w0, &w1);
+        gbucket_push(&c->gbin[c->sc->rz + z0], p, g[0], g[1], g[2]);   /* (colour layers behind sigma_t's) */
+        return;
+    }
     make_stencil_colour(c->sc, p, &s);
     stencil_weights(&s, w);
     const uint32_t tag_bit = c->sc->own_colour ? 0x80000000u : 0u;
@@ -1298,11 +1330,24 @@ static int run_job(const drto_job *job, int adjoint, const float *dL, const floa
     drto_counters total; memset(&total, 0, sizeof total);
 #ifdef _OPENMP
     int nt = job->n_threads > 0 ? job->n_threads : omp_get_max_threads();
+#else
+    int nt = 1;
+#endif
+    /* binned mode (see gbucket_t): [thread][sigma_t layers | colour layers] buckets */
+    const int binned = adjoint && job->grad_cache_log2 == -1;
+    const int n_layers = sc.rz + sc.crz;
+    gbucket_t *bins = binned ? (gbucket_t *) calloc((size_t) nt * n_layers, sizeof(gbucket_t)) : NULL;
+#ifdef _OPENMP
 #pragma omp parallel num_threads(nt)
 #endif
     {
         ctx_t c; memset(&c, 0, sizeof c);
         c.sc = &sc; c.g_sigma = g_sigma; c.g_albedo = g_albedo; c.alt_seed = alt_seed;
+#ifdef _OPENMP
+        if (bins) c.gbin = bins + (size_t) omp_get_thread_num() * n_layers;
+#else
+        if (bins) c.gbin = bins;
+#endif
         if (adjoint && job->grad_cache_log2 > 0 && job->grad_cache_log2 <= 24) {
             const uint32_t lines = 1u << job->grad_cache_log2;
             c.gcache = (gcache_line *) malloc((size_t) lines * sizeof(gcache_line));
@@ -1328,10 +1373,45 @@ static int run_job(const drto_job *job, int adjoint, const float *dL, const floa
         }
         gcache_flush(&c);
         free(c.gcache);
+        if (bins) {
+            /* every thread's records are in: reduce the layers, even ones first (the implicit barriers of the two loops separate the sweeps) */
+            for (int parity = 0; parity < 2; ++parity) {
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+                for (int l = parity; l < n_layers + (n_layers & 1); l += 2) {
+                    /* (sigma_t layers and colour layers interleave in one index range: layer l of sigma_t and layer l' of the colour grid
+                     *  write different grids) */
+                    if (l >= n_layers) continue;
+                    const int colour = l >= sc.rz;
+                    for (int t = 0; t < nt; ++t) {
+                        const gbucket_t *b = &bins[(size_t) t * n_layers + l];
+                        for (uint32_t i = 0; i < b->n; ++i) {
+                            const grec_t *q = &b->r[i];
+                            stencil_t s; float w[8];
+                            const v3 p = v3_make(q->p[0], q->p[1], q->p[2]);
+                            if (!colour) {
+                                make_stencil(&sc, p, &s); stencil_weights(&s, w);
+                                const float gs = q->v[0] * sc.scale;
+                                for (int k = 0; k < 8; ++k) g_sigma[s.idx[k]] += (double) (w[k] * gs);
+                            } else {
+                                make_stencil_colour(&sc, p, &s); stencil_weights(&s, w);
+                                for (int k = 0; k < 8; ++k)
+                                    for (int ch = 0; ch < 3; ++ch) g_albedo[(size_t) s.idx[k] * 3 + ch] += (double) (w[k] * q->v[ch]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
 #ifdef _OPENMP
 #pragma omp critical
 #endif
         cnt_add(&total, &c.cnt);
+    }
+    if (bins) {
+        for (size_t i = 0; i < (size_t) nt * n_layers; ++i) free(bins[i].r);
+        free(bins);
     }
     if (cnt) cnt_add(cnt, &total);
     scene_free(&sc);

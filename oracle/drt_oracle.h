@@ -122,7 +122,9 @@ typedef struct drto_job {
     uint32_t seed;
     int32_t  n_threads;     /* OpenMP threads (0 = default) */
     int32_t  grad_cache_log2; /* > 0: per-thread write-combining cache of 2^n voxels in front of the shared gradient
-                               * grids (timed CPU-baseline leg; changes the fp64 summation order only); 0: atomics */
+                               * grids; -1: tile-binned accumulation (per-thread record buckets by z layer, reduced without
+                               * atomics) - both for the timed CPU-baseline leg, both change the fp64 summation order only;
+                               * 0: atomic adds into the shared grids */
 } drto_job;
 
 /* sample(Primal): L_out[n][3].  volpathsimple.py:38-290 */

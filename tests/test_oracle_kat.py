@@ -289,3 +289,16 @@ def test_supergrid_majorants_bound_and_ratio_tracking_stays_unbiased(oracle, uiv
         tau = sum(L.drto_eval_sigma_t(C.byref(osc.medium), (C.c_float * 3)(*(o + np.float32(t) * d))) for t in ts) * tmax / 6000
         est = L.drto_ratio_tracking_mean(C.byref(osc.medium), (C.c_float * 3)(*o), (C.c_float * 3)(*d), tmax, 7, 200000)
         assert est == pytest.approx(np.exp(-tau), rel=8e-3), (factor, o, tau)
+
+
+def test_gradient_accumulation_modes_of_the_timed_cpu_leg_agree(oracle, uivr):
+    """bench.py's cpu_baseline leg runs the oracle with a per-thread write-combining cache (grad_cache_log2 > 0) or tile-binned record
+    buckets (-1) in front of the shared fp64 gradient grids: the same per-ray contributions in another summation order."""
+    scene = uivr.cube_test_scene(24, 20, density_scale=2.0)
+    props = props_for("drt")
+    ref = oracle.h1_step(oracle.OracleScene(scene), props, 16, 3)
+    for mode in (12, -1):
+        r = oracle.h1_step(oracle.OracleScene(scene), props, 16, 3, grad_cache_log2=mode)
+        assert r["counters"] == ref["counters"] and r["loss"] == ref["loss"]
+        for k in ("grad_sigma_t", "grad_albedo"):
+            assert np.abs(r[k] - ref[k]).max() <= 1e-12 * np.abs(ref[k]).max(), (mode, k)
