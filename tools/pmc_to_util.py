@@ -40,6 +40,14 @@ for f in ([] if os.path.isfile(root) else glob.glob(root + "/**/*counter_collect
             per[(short(r["Kernel_Name"]), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (k, d, c), v in per.items():
         acc[k][c].append(v)
+def is_sq_tail(k):
+    """trace_sq_kernel<ADJ, COUNT, ENV, MG, QUAD, TAILM[, ROUNDS]>: the tail launch of a step (TAILM) is a second launch, not a step."""
+    if "trace_sq_kernel<" not in k:
+        return False
+    args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+    return len(args) > 5 and args[5] == "true"
+
+
 ms, calls = {}, {}
 for r in csv.DictReader(open(stats)):
     ms[short(r["Name"])] = float(r["AverageNs"]) / 1e6
@@ -48,7 +56,7 @@ for r in csv.DictReader(open(stats)):
 # (the queued tracer's tail launches - last template argument true - are second launches of a step, not steps)
 steps = sum(c for k, c in calls.items() if any(t in k for t in ("trace_sq_kernel<false", "trace_coop_kernel<false", "trace_super_kernel<false",
                                                                 "trace_wavefront_kernel<false"))
-            and not ("trace_sq_kernel<" in k and k.rstrip().endswith(", true>")))
+            and not is_sq_tail(k))
 util = {}
 for k in acc:
     m = lambda c: (sum(acc[k][c]) / len(acc[k][c])) if acc[k].get(c) else 0.0
