@@ -291,6 +291,18 @@ def nerf_render(oscene: OracleScene, emission, props: dict, spp: int, seed: int,
     ncfg = make_nerf_config(props)
     em = _f32(emission)
     cnt = Counters()
+    # the colour lattice of THIS call is the emission grid's (the medium's albedo, which the march does not read, may have another one)
+    z, y, x = oscene.grid_shape()
+    ez, ey, ex = em.shape[:3]
+    saved = tuple(oscene.medium.res_colour)
+    oscene.medium.res_colour = (C.c_int32 * 3)(*((ex, ey, ez) if (ez, ey, ex) != (z, y, x) else (0, 0, 0)))
+    try:
+        return _nerf_render(oscene, job, ncfg, em, cnt, dL, L_in)
+    finally:
+        oscene.medium.res_colour = (C.c_int32 * 3)(*saved)
+
+
+def _nerf_render(oscene, job, ncfg, em, cnt, dL, L_in):
     if dL is None:
         L = np.zeros((job.n_rays, 3), dtype=np.float32)
         rc = lib().drto_nerf_render(C.byref(job), C.byref(ncfg), _fp(em), 0, None, None, _fp(L), None, None, C.byref(cnt))
@@ -300,8 +312,7 @@ def nerf_render(oscene: OracleScene, emission, props: dict, spp: int, seed: int,
     dL, L_in = _f32(dL), _f32(L_in)
     z, y, x = oscene.grid_shape()
     gs = np.zeros((z, y, x, 1), dtype=np.float64)
-    ge = np.zeros(tuple(oscene.colour_shape) + (3,), dtype=np.float64)
-    assert tuple(em.shape[:3]) == tuple(oscene.colour_shape), "the emission grid must lie on the medium's colour lattice"
+    ge = np.zeros(tuple(em.shape[:3]) + (3,), dtype=np.float64)
     rc = lib().drto_nerf_render(C.byref(job), C.byref(ncfg), _fp(em), 1, _fp(dL), _fp(L_in), None, _dp(gs), _dp(ge),
                                 C.byref(cnt))
     if rc:
