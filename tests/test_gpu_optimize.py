@@ -44,6 +44,35 @@ def test_run_optimization_reduces_loss(uivr, gpu, batched, tmp_path):
     assert opt.state[uivr.SIGMA_T_KEY][0] == 20          # Adam state restarted at the upsampling step
 
 
+def test_multiresolution_run_keeps_the_fixed_albedo_on_its_own_lattice(uivr, gpu):
+    """Only sigma_t is optimised, on an 8^3 grid that is upsampled once; the scene's 16^3 albedo is NOT a parameter: the reference upsamples what
+    it optimises and leaves the other grids alone (python/optimize.py:228-252) - Mitsuba interpolates each grid on its own lattice.  Round 6: so does
+    this build (drt_set_colour_resolution / drt_own.hip for the first half of the run, the production kernels after the upsampling step)."""
+    scene = _target_scene(uivr, gpu)
+    sc = uivr.SceneConfig(name="smoke16", scene=scene, param_keys=[uivr.SIGMA_T_KEY], sensors=list(range(4)),
+                          start_from_value={uivr.SIGMA_T_KEY: 0.4}, max_depth=16, ref_spp=1024, max_density=20.0)
+    oc = uivr.OptimizationConfig("own", spp=4, n_iter=30, lr=5e-2, primal_spp_factor=4, batch_size=1024, upsample=[0.5])
+    seen = []
+    final_scene, params, _, hist = uivr.run_optimization(None, oc, sc, "volpathsimple-drt",
+                                                         progress=lambda i, l: seen.append(i))
+    assert len(hist) == 30 and np.isfinite(hist).all() and seen == list(range(30))
+    assert tuple(params[uivr.SIGMA_T_KEY].shape) == (16, 16, 16, 1) and list(params) == [uivr.SIGMA_T_KEY]
+    assert final_scene.medium.albedo is scene.medium.albedo                  # the scene's grid as it is: never resampled
+    assert np.mean(hist[-6:]) < np.mean(hist[:6])
+    # one step on the coarse grid against the oracle: sigma_t 8^3, albedo 16^3
+    from oracle import binding as ob
+    from conftest import props_for
+    m = scene.medium
+    coarse = uivr.Scene(medium=uivr.GridMedium(sigma_t=torch.full((8, 8, 8, 1), 0.4, device=gpu), albedo=m.albedo, bbox_min=m.bbox_min,
+                                               bbox_max=m.bbox_max, scale=m.scale), emitter=scene.emitter, sensors=scene.sensors)
+    integ = uivr.get_int_config("volpathsimple-drt").create(max_depth=16)
+    img = uivr.render_primal(coarse, integ, 0, 8, 77)
+    cpu = uivr.Scene(medium=uivr.GridMedium(sigma_t=np.full((8, 8, 8, 1), 0.4, np.float32), albedo=m.albedo.cpu().numpy(), bbox_min=m.bbox_min,
+                                            bbox_max=m.bbox_max, scale=m.scale), emitter=scene.emitter, sensors=scene.sensors)
+    Lr, _ = ob.render_primal(ob.OracleScene(cpu), props_for("drt", max_depth=16), 8, 77)
+    np.testing.assert_allclose(img.cpu().numpy(), ob.develop(Lr, 8), rtol=0, atol=1e-6)
+
+
 def test_reference_cache_previews_and_checkpoints(uivr, gpu, tmp_path):
     """N3 around the loop (python/optimize.py:24-131, 255-272, 318-324, 355-362): reference renderings cached on
     disk (only the missing ones are rendered; multi-pass mean with seeds 1234 + pass), previews at the start, at
