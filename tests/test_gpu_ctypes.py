@@ -86,3 +86,64 @@ def test_raw_ctypes_primal_and_backward_match_oracle(uivr, oracle, gpu, factor):
             assert float((got.double() - r).abs().max()) <= tol, what
     finally:
         lib.drt_destroy(h)
+
+
+def test_raw_ctypes_colour_grid_on_its_own_lattice(uivr, oracle, gpu):
+    """drt_set_colour_resolution through the bare C ABI, as INTEGRATION.md section 3 binds it: a 33 x 17 x 17 density with a 32 x 16 x 16 albedo
+    (the reference's janga-smoke ratio, python/scene_config.py:108-110) - primal bit-exact, the albedo gradient on the albedo's lattice - and
+    back to one lattice on the same handle."""
+    from uivr_amd._native import library_path
+    from test_gpu_lattice import _scene
+    lib = C.CDLL(library_path())
+    lib.drt_last_error.restype = C.c_char_p
+
+    def ok(h, rc):
+        assert rc == 0, lib.drt_last_error(h)
+
+    props = props_for("drt")
+    cfg = _Cfg(0, 1, 1, 1, 1, int(props["max_depth"]), int(props["rr_depth"]))
+    h = C.c_void_p()
+    ok(None, lib.drt_create(C.byref(cfg), gpu.index or 0, C.byref(h)))
+    try:
+        assert lib.drt_set_colour_resolution(h, (C.c_int32 * 3)(32, 16, 16)) != 0          # no medium yet: refused, with a message
+        assert b"no medium" in lib.drt_last_error(h)
+        for colour in ((16, 16, 32), (17, 17, 33)):
+            scene = _scene(uivr, factor=4, colour=colour)
+            spp, seed = 4, 424
+            osc = oracle.OracleScene(scene)
+            Lr, _ = oracle.render_primal(osc, props, spp, seed)
+            n = Lr.shape[0]
+            dL = ((np.random.default_rng(6).random((n, 3), dtype=np.float32) - 0.5) * 1e-2).astype(np.float32)
+            gs_ref, ga_ref, _ = oracle.render_backward(osc, props, spp, seed, dL, Lr)
+            m = scene.medium
+            sig = torch.from_numpy(np.ascontiguousarray(m.sigma_t, dtype=np.float32)).to(gpu)
+            alb = torch.from_numpy(np.ascontiguousarray(m.albedo, dtype=np.float32)).to(gpu)
+            z, y, x = sig.shape[:3]
+            ok(h, lib.drt_set_medium(h, C.c_void_p(sig.data_ptr()), C.c_void_p(alb.data_ptr()), (C.c_int32 * 3)(x, y, z),
+                                     _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(float(m.scale)), C.c_int32(4)))
+            if tuple(alb.shape[:3]) != (z, y, x):
+                az, ay, ax = alb.shape[:3]
+                ok(h, lib.drt_set_colour_resolution(h, (C.c_int32 * 3)(ax, ay, az)))
+                assert lib.drt_set_colour_resolution(h, (C.c_int32 * 3)(ax, 0, az)) != 0     # a zero extent next to non-zero ones
+                ok(h, lib.drt_set_colour_resolution(h, (C.c_int32 * 3)(ax, ay, az)))
+            ok(h, lib.drt_set_emitter_constant(h, _f3(scene.emitter.radiance)))
+            s = scene.sensors[0]
+            f = s.frame()
+            ok(h, lib.drt_set_sensor_perspective(h, _f3(f["origin"]), _f3(f["left"]), _f3(f["up"]), _f3(f["dir"]),
+                                                 C.c_float(float(f["tan_x"])), C.c_float(float(f["tan_y"])), C.c_int32(s.width), C.c_int32(s.height)))
+            L = torch.empty((n, 3), dtype=torch.float32, device=gpu)
+            ok(h, lib.drt_render_primal(h, None, None, C.c_uint64(n), C.c_uint64(0), C.c_uint32(spp), C.c_uint32(seed), C.c_void_p(L.data_ptr())))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+            gsig, galb = torch.zeros_like(sig), torch.zeros_like(alb)
+            dLd = torch.from_numpy(dL).to(gpu)
+            ok(h, lib.drt_render_backward(h, None, None, C.c_uint64(n), C.c_uint64(0), C.c_uint32(spp), C.c_uint32(seed),
+                                          C.c_void_p(dLd.data_ptr()), C.c_void_p(L.data_ptr()), C.c_void_p(gsig.data_ptr()),
+                                          C.c_void_p(galb.data_ptr())))
+            ok(h, lib.drt_synchronize(h))
+            for got, ref, what in ((gsig, gs_ref, "sigma_t"), (galb, ga_ref, "albedo")):
+                r = torch.from_numpy(ref).to(gpu)
+                assert tuple(got.shape) == tuple(r.shape)
+                assert float((got.double() - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-9, (colour, what)
+    finally:
+        lib.drt_destroy(h)
