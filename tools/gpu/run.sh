@@ -16,6 +16,7 @@
 #   c3lvl:V1,V2,..      config 3's levels 16^3 / 256^3, untrained / trained, per variant, WITHOUT a profiler: it/s and the host's ms per iteration
 #   config4ar           config 4's 2 GiB gradient exchange on one rank of RCCL: support / pack / collective / unpack timings
 #   stress              tools/stress_super.py --reps 20
+#   fuzz:LO:HI          tests/test_gpu_fuzz.py over the seeds LO .. HI-1 (random scenes against the oracle; no -x: every failing seed is listed)
 TAG=$1; shift
 cd /root/repo
 R=/root/repo/gpurun_out/$TAG
@@ -83,6 +84,7 @@ PY
         done; done
       done ;;
     config4ar) HSA_ENABLE_IPC_MODE_LEGACY=0 MASTER_ADDR=127.0.0.1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 tests/workers/nccl_config4_worker.py 2> $R/config4ar_err.txt | tee $R/config4ar.txt ;;
+    fuzz) DRT_FUZZ_SEEDS=$arg timeout 2700 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -n 6 > $R/fuzz.txt 2>&1; grep -E "^FAILED|^ERROR|passed|failed" $R/fuzz.txt | cut -c1-400 | tail -n 40 ;;
     stress) timeout 900 python tools/stress_super.py --reps 20 > $R/stress.txt 2>&1; tail -n 5 $R/stress.txt ;;
     *) echo "unknown step $step" ;;
   esac
