@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
     __shared__ int wctl[16];                                          // [0..2] min, [3..5] max of the waiting splats' corners, [6..8] direction signs, [9..14] footprint of the ray the window moves to
     __shared__ unsigned long long wkey[1];                           // the waiting splat closest to the camera: {distance bits, thread}
     __shared__ uint32_t occ_lds[kOccWords];
+    __shared__ uint32_t wgain[2];                                     // negative densities: the workgroup's M1, W (float bits)
     const uint32_t t = threadIdx.x, lane = t & 63u;
 
     // ---- thread -> ray: lane = pixel of the 8 x 8 tile, wave = sample (a wave's 64 lanes splat around 64 DIFFERENT pixel centres: lanes that add
@@ -164,32 +165,29 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
         else i = rel;
         job = job && i >= P.ray_first && i < P.n_rays;
     }
-    // fixed-point units: 2^(e - 44) with 2^e >= the bound of a sigma_t splat / of a colour splat (|dL_k| x weight, weight <= 1)
+    // fixed-point units: 2^(e - 44) with 2^e >= the bound of a sigma_t splat / of a colour splat (|dL_k| x weight), per WORKGROUP (the window's sums are
+    // flushed as floats: every workgroup may count in its own unit)
+    //   |ge_k| = |dL_k| |1 - a| T                                        <= Dmax M1,              M1 = max over the queries of max(a, 1) x T
+    //   |gs|  <= sum_k |dL_k| (|em_k| dt a T + |result_k| dt a / (a + 1e-10)) <= 3 Dmax dt (Emax M1 + Lmax + Emax W),  W = sum over the queries of |1 - a| T
+    //   (|result_k| <= |L_in| + sum |weight| |em_k|), dt <= 2 ext / (N - 1)
+    // Without negative densities a <= 1 and T <= 1: M1 <= 1, W <= 1.  NEGATIVE densities under the identity activation (a projected optimisation has
+    // none) make a = exp(-sigma dt) > 1 and let throughput and weights grow: the workgroup then marches its rays once for M1 and W (below) before it
+    // marches them for the gradients.  (Until round 6 the bound was the launch's worst case exp(2 |sigma|max x diagonal): with a strongly negative
+    // region anywhere in the grid the unit came out so coarse that ordinary gradients lost their digits - tests/test_gpu_fuzz.py found it.)
     float unit_s, unit_c; double inv_s, inv_c;
-    {
-        const float Dmax = __uint_as_float(T.bounds[0]), Lmax = __uint_as_float(T.bounds[1]), Emax = __uint_as_float(T.bounds[2]);
-        const float ext = sqrtf((P.bmax[0] - P.bmin[0]) * (P.bmax[0] - P.bmin[0]) + (P.bmax[1] - P.bmin[1]) * (P.bmax[1] - P.bmin[1]) +
-                                (P.bmax[2] - P.bmin[2]) * (P.bmax[2] - P.bmin[2]));
-        // |gs| <= sum_k |dL_k| (|em_k| dt a T + |result_k| dt a / (a + 1e-10)) <= 3 Dmax (2 Emax + Lmax) dt, dt <= 2 ext / (N - 1)
-        // negative densities under the identity activation (a projected optimisation has none): a <= exp(|sigma| dt), throughput <= exp(|sigma| x chord) =: G;
-        // the bounds grow by G^2 (capped: beyond e^60 the grids hold nonsense anyway)
-        const float neg = P.nerf_relu ? 0.0f : __uint_as_float(T.bounds[4]);
-        const float G = expf(fminf(neg * fabsf(P.scale) * ext, 30.0f)), G2 = G * G;
-        const float Bs = fabsf(P.scale) * 3.0f * Dmax * (2.0f * Emax + Lmax) * (2.0f * ext / (float) (P.nerf_queries - 1)) * 1.001f * G2;
-        // Non-finite dL / L_in / emission / density values (as a diverged optimisation produces them), or bounds that overflow fp32: fixed point
-        // cannot carry them.  The march is skipped and BOTH gradient grids are filled with NaN - every voxel, so that a caller (or a masked
-        // all-reduce) that looks at any part of the grids sees that this gradient is void, as it would find NaN in the voxels the record path touches.
-        if (T.bounds[3] || !(Bs < kInf) || !(Dmax * G2 < kInf)) {
-            const float nan = __uint_as_float(0x7fc00000u);
-            const size_t nv = (size_t) P.rx * P.ry * P.rz, i0 = (size_t) blockIdx.x * NT + t, stride = (size_t) gridDim.x * NT;
-            for (size_t v = i0; v < nv; v += stride) P.g_sigma[v] = nan;
-            for (size_t v = i0; v < 3 * nv; v += stride) P.g_albedo[v] = nan;
-            return;
-        }
-        int es = 0, ec = 0;
-        (void) frexpf(fmaxf(Bs, 1e-30f), &es); (void) frexpf(fmaxf(Dmax * G2, 1e-30f), &ec);
-        es = max(es - kFixBits, -100); ec = max(ec - kFixBits, -100);
-        unit_s = ldexpf(1.0f, es); inv_s = ldexp(1.0, -es); unit_c = ldexpf(1.0f, ec); inv_c = ldexp(1.0, -ec);
+    const float Dmax = __uint_as_float(T.bounds[0]), Lmax = __uint_as_float(T.bounds[1]), Emax = __uint_as_float(T.bounds[2]);
+    const float neg = P.nerf_relu ? 0.0f : __uint_as_float(T.bounds[4]);
+    const float dt_max = 2.0f * sqrtf((P.bmax[0] - P.bmin[0]) * (P.bmax[0] - P.bmin[0]) + (P.bmax[1] - P.bmin[1]) * (P.bmax[1] - P.bmin[1]) +
+                                      (P.bmax[2] - P.bmin[2]) * (P.bmax[2] - P.bmin[2])) / (float) (P.nerf_queries - 1);
+    // Non-finite dL / L_in / emission / density values (as a diverged optimisation produces them), or bounds that overflow fp32: fixed point
+    // cannot carry them.  The march is skipped and BOTH gradient grids are filled with NaN - every voxel, so that a caller (or a masked
+    // all-reduce) that looks at any part of the grids sees that this gradient is void, as it would find NaN in the voxels the record path touches.
+    if (T.bounds[3] || !(fabsf(P.scale) * 3.0f * Dmax * (2.0f * Emax + Lmax) * dt_max * 1.001f < kInf) || !(Dmax < kInf)) {
+        const float nan = __uint_as_float(0x7fc00000u);
+        const size_t nv = (size_t) P.rx * P.ry * P.rz, i0 = (size_t) blockIdx.x * NT + t, stride = (size_t) gridDim.x * NT;
+        for (size_t v = i0; v < nv; v += stride) P.g_sigma[v] = nan;
+        for (size_t v = i0; v < 3 * nv; v += stride) P.g_albedo[v] = nan;
+        return;
     }
     if (__syncthreads_count(job) == 0) return;                       // (a launch over a window of the film: most tiles hold none of its rays)
 
@@ -225,6 +223,56 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             step = P.nerf_jitter ? (si.t - 0.0f) / (float) N : (si.t - 0.0f) / (float) (N - 1);
             jit = S.next_1d();
         }
+    }
+    // ---- negative densities: this workgroup's M1 and W (the march of the loop below, sigma_t only) ----------------------------------------------
+    {
+        float M1 = 1.0f, Wm = 1.0f;
+        if (neg > 0.0f) {                                               // (workgroup-uniform)
+            if (t < 2) wgain[t] = 0u;
+            __syncthreads();
+            float m1 = 0.0f, W = 0.0f;
+            if (active) {
+                const int N = P.nerf_queries;
+                float thr = 1.0f, ta = 0.0f;
+                for (int q = 0; q < N; ++q) {
+                    const float t_b = P.nerf_jitter ? step * ((float) (q + 1) + jit) : step * (float) (q + 1);
+                    const float dt = t_b - ta;
+                    const V3 p = ray_at(o, d, t_b);
+                    float raw;
+                    if constexpr (G4) {
+                        Stencil s4; float em4[3];
+                        axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, s4.x0, s4.x1, s4.wx0, s4.wx1);
+                        axis_setup(p.y, P.bmin[1], P.inv_ext[1], P.ry, s4.y0, s4.y1, s4.wy0, s4.wy1);
+                        axis_setup(p.z, P.bmin[2], P.inv_ext[2], P.rz, s4.z0, s4.z1, s4.wz0, s4.wz1);
+                        eval4_at(P, s4, raw, em4);
+                    } else raw = eval_sigma_t(P, p, occ);
+                    const bool last = !(q + 1 < N);
+                    const float a = last ? 1.0f : drt_expf(-raw * dt);
+                    m1 = fmaxf(m1, fmaxf(a, 1.0f) * thr);
+                    W += fabsf(1.0f - a) * thr;
+                    ta = t_b;
+                    if (!last) thr *= a + 1e-10f;
+                }
+                if (!(thr < kInf) || !(W < kInf) || !(m1 < kInf)) m1 = kInf;   // (an overflow, or inf x 0 behind it: this workgroup's gradients are void)
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { m1 = fmaxf(m1, __shfl_xor(m1, off, 64)); W = fmaxf(W, __shfl_xor(W, off, 64)); }
+            if (lane == 0) { atomicMax(wgain, __float_as_uint(m1)); atomicMax(wgain + 1, __float_as_uint(W)); }   // (non-negative floats order like their bits)
+            __syncthreads();
+            M1 = fmaxf(1.0f, __uint_as_float(wgain[0])) * 1.001f; Wm = fmaxf(1.0f, __uint_as_float(wgain[1])) * 1.001f;
+        }
+        const float Bs = fabsf(P.scale) * 3.0f * Dmax * (Emax * M1 + Emax * Wm + Lmax) * dt_max * 1.001f, Bc = Dmax * M1;
+        if (!(Bs < kInf) || !(Bc < kInf)) {                             // this workgroup's rays overflow fp32: its share of the gradient is void - and so is the whole
+            const float nan = __uint_as_float(0x7fc00000u);
+            const size_t nv = (size_t) P.rx * P.ry * P.rz;
+            for (size_t v = t; v < nv; v += NT) P.g_sigma[v] = nan;
+            for (size_t v = t; v < 3 * nv; v += NT) P.g_albedo[v] = nan;
+            return;
+        }
+        int es = 0, ec = 0;
+        (void) frexpf(fmaxf(Bs, 1e-30f), &es); (void) frexpf(fmaxf(Bc, 1e-30f), &ec);
+        es = max(es - kFixBits, -100); ec = max(ec - kFixBits, -100);
+        unit_s = ldexpf(1.0f, es); inv_s = ldexp(1.0, -es); unit_c = ldexpf(1.0f, ec); inv_c = ldexp(1.0, -ec);
     }
     uint32_t n_q = 0, n_adds = 0;                                      // (n_adds: LDS lane-adds of this ray, counting launches only: bounds[6..7])
     int Wx = -(1 << 28), Wy = -(1 << 28), Wz = -(1 << 28);             // window origin (workgroup-uniform; none yet: the first splats all wait)
