@@ -28,6 +28,39 @@ def _close(g_hip, g_ref, what):
     assert np.abs(g - g_ref).max() <= tol, f"{what}: {np.abs(g - g_ref).max():.3e} > {tol:.3e}"
 
 
+def _random_map(rng):
+    """A lat-long map of a random size (2 x 2 ... 48 x 96, not a power of two as a rule): noise of a random contrast, now and then a sun, black rows
+    (zero-probability regions of the importance sampler), or one colour throughout."""
+    if rng.random() < 0.25:
+        return _blob_map()
+    h, w = int(rng.integers(2, 49)), int(rng.integers(2, 97))
+    pix = (rng.random((h, w, 3)) ** float(rng.choice([1.0, 3.0, 8.0])) * 2.0 + 0.01).astype(np.float32)
+    k = rng.random()
+    if k < 0.3:
+        y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+        pix[y:y + 2, x:x + 3] += np.float32(50.0)                                    # a sun
+    elif k < 0.5:
+        pix[int(rng.integers(0, h)):, :] = 0.0                                      # black from some row down
+    elif k < 0.6:
+        pix[:] = np.asarray(rng.random(3) + 0.1, dtype=np.float32)                  # one colour
+    return pix
+
+
+def _random_rotation(rng):
+    if rng.random() < 0.4:
+        return ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)) if rng.random() < 0.3 else _rot_y(rng)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return tuple(tuple(float(v) for v in row) for row in q)
+
+
+def _rot_y(rng):
+    a = np.deg2rad(float(rng.random() * 360.0))
+    c, s = float(np.cos(a)), float(np.sin(a))
+    return ((c, 0.0, s), (0.0, 1.0, 0.0), (-s, 0.0, c))
+
+
 def _draw(uivr, seed, medium_size=False):
     rng = np.random.default_rng((20_000 if medium_size else 10_000) + seed)
     shape = tuple(int(v) for v in (rng.integers(20, 97, size=3) if medium_size else rng.integers(2, 29, size=3)))       # (z, y, x)
@@ -66,7 +99,7 @@ def _draw(uivr, seed, medium_size=False):
     sensor = uivr.PerspectiveSensor(origin=tuple(origin), target=tuple(target), fov=float(rng.random() * 60.0 + 15.0), width=w, height=h)
     env = rng.random() < 0.4
     if env:
-        em = uivr.EnvmapEmitter(pixels=_blob_map(), scale=float(rng.random() + 0.2), to_world=uivr.EnvmapEmitter.rotation_y(float(rng.random() * 360.0)))
+        em = uivr.EnvmapEmitter(pixels=_random_map(rng), scale=float(rng.random() + 0.2), to_world=_random_rotation(rng))
     else:
         em = uivr.ConstantEmitter(tuple(float(v) for v in rng.random(3) * 1.5 + 0.05))
     variant = list(VARIANTS)[int(rng.integers(0, len(VARIANTS)))]
