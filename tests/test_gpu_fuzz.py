@@ -324,3 +324,49 @@ def test_random_shards_add_up_to_the_whole(uivr, oracle, gpu, seed):
     assert torch.equal(acc_img, img), tag
     tol = GRAD_RTOL * grads["_flat"].abs().max().item() + 1e-12
     assert (acc - grads["_flat"]).abs().max().item() <= tol, tag
+
+
+@pytest.mark.parametrize("seed", SEEDS[:max(1, len(SEEDS) // 4)])
+def test_random_batched_render_matches_the_oracle(uivr, oracle, gpu, seed):
+    """N1 over the draws (python/batched.py:397-467, optimize.py:325-358): 1 ... 7 sensors of a random film shape around the box, a batch of 1 ... 700
+    random (sensor, pixel) entries, spp / spp_grad 1 ... 6, a random loss - image and both gradients against the oracle run over the oracle's own
+    restatement of the batch sampling."""
+    import torch
+    from uivr_amd import synthetic
+    c = _draw(uivr, seed + 1700)
+    rng = c["rng"]
+    m = c["scene"].medium
+    n_s = int(rng.integers(1, 8))
+    w, h = int(rng.integers(1, 33)), int(rng.integers(1, 33))
+    centre = tuple(float(v) for v in c["centre"])
+    sensors = synthetic.ring_sensors(n_s, radius=float(np.linalg.norm(c["ext"]) * (0.8 + rng.random() * 1.5)), height=float(rng.normal() * 0.5),
+                                     target=centre, fov=float(rng.random() * 50.0 + 15.0), width=w, film_height=h)
+    scene = uivr.Scene(medium=m, emitter=c["scene"].emitter, sensors=sensors)
+    props = dict(c["props"])
+    B, spp, spp_grad = int(rng.integers(1, 701)), int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    rs, rs_grad = c["seed"], c["seed"] ^ 0x5bd1e995
+    loss_name = str(rng.choice(["l1", "l2", "huber"]))
+    tag = f"seed {seed}: {c['variant']} factor {c['factor']} grid {c['shape']} colour {c['cshape']} sensors {n_s} x {(w, h)} batch {B} spp {spp}/{spp_grad} {loss_name}"
+    sg = uivr.scene_to(scene, gpu)
+    integ = uivr.load_dict(dict(type="volpathsimple", **props))
+    params = {k: v.clone().requires_grad_(True) for k, v in sg.params().items() if k in integ.param_keys}
+    image, _, _, sidx, pix = uivr.render_batch(B, sg, params=params, integrator=integ, seed=rs, seed_grad=rs_grad, spp=spp, spp_grad=spp_grad)
+    ref = torch.from_numpy(rng.random((n_s, h, w, 3), dtype=np.float32)).to(gpu)
+    ref_values = uivr.gather_ref_values(ref, sidx, pix)
+    getattr(uivr.losses, loss_name)(image, ref_values).backward()
+
+    osc = oracle.OracleScene(scene, sensor_index=None)
+    ro, rd, si_r, px_r = oracle.batch_sample_rays(scene.sensors, B, spp, uivr.sample_tea_32(rs, 5)[0], uivr.sample_tea_32(rs, 22)[0])
+    np.testing.assert_array_equal(sidx.cpu().numpy().astype(np.uint32), si_r, err_msg=tag)
+    np.testing.assert_array_equal(pix.cpu().numpy().astype(np.uint32), px_r, err_msg=tag)
+    L, _ = oracle.render_primal(osc, props, spp, rs, rays_o=ro, rays_d=rd)
+    # (the per-ray radiance is bit-exact - the other tests - ; the film's mean over spp samples is a sum in another order: one ulp of fp32)
+    np.testing.assert_allclose(image.detach().cpu().numpy(), oracle.develop(L, spp), rtol=1e-6, atol=1e-6, err_msg=tag)
+    ro2, rd2, _, _ = oracle.batch_sample_rays(scene.sensors, B, spp_grad, uivr.sample_tea_32(rs, 5)[0], uivr.sample_tea_32(rs, 39)[0])
+    L2, _ = oracle.render_primal(osc, props, spp_grad, rs_grad, rays_o=ro2, rays_d=rd2)
+    img_d = image.detach().clone().requires_grad_(True)                              # the loss's own gradient, by autograd on the detached image
+    getattr(uivr.losses, loss_name)(img_d, ref_values).backward()
+    dL = np.repeat(img_d.grad.cpu().numpy() / spp_grad, spp_grad, axis=0).astype(np.float32)
+    gs, ga, _ = oracle.render_backward(osc, props, spp_grad, rs_grad, dL, L2, rays_o=ro2, rays_d=rd2)
+    _close(params[uivr.SIGMA_T_KEY].grad, gs, tag + " grad sigma_t")
+    _close(params[uivr.ALBEDO_KEY].grad, ga, tag + " grad albedo")
