@@ -370,3 +370,134 @@ def test_random_batched_render_matches_the_oracle(uivr, oracle, gpu, seed):
     gs, ga, _ = oracle.render_backward(osc, props, spp_grad, rs_grad, dL, L2, rays_o=ro2, rays_d=rd2)
     _close(params[uivr.SIGMA_T_KEY].grad, gs, tag + " grad sigma_t")
     _close(params[uivr.ALBEDO_KEY].grad, ga, tag + " grad albedo")
+
+
+@pytest.mark.parametrize("seed", SEEDS[:max(1, len(SEEDS) // 4)])
+def test_random_sequence_on_one_handle_matches_the_oracle(uivr, oracle, gpu, seed):
+    """ONE integrator (one native handle: its scratch buffers, ray orders, path cache, bound grids and emitter tables live across calls) taken through
+    eight random steps - another scene (grid / colour lattice / box / film / emitter of other shapes), the bound sigma_t or albedo changed IN PLACE,
+    only the emitter replaced, only spp and seed changed, the adjoint asked for twice - each step's result against the oracle's."""
+    _check_sequence(uivr, oracle, gpu, seed)
+
+
+@pytest.mark.parametrize("seed", [16, 33, 97, 148])
+def test_one_handle_rebound_to_a_grid_with_as_many_tiles_in_another_arrangement(uivr, oracle, gpu, seed):
+    """What the sequences found (round 6; 15 of the first 400): the record slot of the deferred gradient reduction was re-planned when the NUMBER of its
+    32 x 16 x 16-voxel tiles changed, not when their arrangement did - 7 x 25 x 25 voxels are 1 x 2 x 1 tiles, 25 x 3 x 5 voxels 1 x 1 x 2 - so a handle
+    rebound to such a grid sorted its splat records by the old arrangement and lost part of the gradient (radiance unaffected).  csrc/drt_capi.cpp:
+    ensure_deferred."""
+    _check_sequence(uivr, oracle, gpu, seed)
+
+
+def _check_sequence(uivr, oracle, gpu, seed):
+    import torch
+    rng = np.random.default_rng(77_000 + seed)
+    c = _draw(uivr, seed + 2600, medium_size=seed % 5 == 4)
+    props = c["props"]
+    integ = uivr.load_dict(dict(type="volpathsimple", **props))
+    scene = c["scene"]
+    sg = uivr.scene_to(scene, gpu)
+    for step in range(8):
+        k = int(rng.integers(0, 6)) if step else 0
+        if k == 1:                                                                   # another scene altogether (the estimator stays: it is the handle's)
+            c2 = _draw(uivr, int(rng.integers(0, 10_000)) + 5000, medium_size=rng.random() < 0.2)
+            scene = c2["scene"]
+            sg = uivr.scene_to(scene, gpu)
+        elif k == 2:                                                                 # sigma_t changed in place (an optimiser step)
+            f = np.float32(rng.random() * 1.5 + 0.25)
+            scene.medium.sigma_t = (np.asarray(scene.medium.sigma_t) * f).astype(np.float32)
+            sg.medium.sigma_t.mul_(float(f))
+        elif k == 3:                                                                 # albedo changed in place
+            al = np.asarray(scene.medium.albedo)
+            al2 = np.clip(al * np.float32(0.9) + np.float32(0.03), 0.0, 1.0).astype(np.float32)
+            scene.medium.albedo = al2
+            sg.medium.albedo.copy_(torch.from_numpy(al2))
+        elif k == 4:                                                                 # the emitter alone
+            em = uivr.EnvmapEmitter(pixels=_random_map(rng), scale=float(rng.random() + 0.2), to_world=_random_rotation(rng)) if rng.random() < 0.5 \
+                else uivr.ConstantEmitter(tuple(float(v) for v in rng.random(3) + 0.1))
+            scene = uivr.Scene(medium=scene.medium, emitter=em, sensors=scene.sensors)
+            sg = uivr.Scene(medium=sg.medium, emitter=uivr.scene_to(uivr.Scene(medium=scene.medium, emitter=em, sensors=[]), gpu).emitter, sensors=sg.sensors)
+        spp, rs = int(rng.choice([1, 2, 3, 4, 8])), int(rng.integers(1, 2**31 - 1))
+        s = scene.sensors[0]
+        n_pix = s.width * s.height
+        tag = f"seed {seed} step {step} kind {k}: grid {tuple(np.asarray(scene.medium.sigma_t).shape[:3])} film {(s.width, s.height)} spp {spp}"
+        osc = oracle.OracleScene(scene)
+        ref = oracle.h1_step(osc, props, spp, rs)
+        batch = uivr.RayBatch(n_rays=n_pix * spp, spp=spp, sensor=sg.sensors[0])
+        L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(rs, spp), batch)
+        np.testing.assert_array_equal(_bits(L.cpu().numpy()), _bits(ref["L"]), err_msg=tag)
+        img = uivr.render_primal(sg, integ, 0, spp, rs)
+        for rep in range(2 if k == 5 else 1):
+            grads = uivr.render_backward(sg, integ, ((2.0 / (n_pix * 3)) * (img - 0.5)).contiguous(), 0, spp, rs)
+            _close(grads[uivr.SIGMA_T_KEY], ref["grad_sigma_t"], tag + f" grad sigma_t (call {rep})")
+            _close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], tag + f" grad albedo (call {rep})")
+
+
+@pytest.mark.parametrize("which", ["nerf", "fused"])
+@pytest.mark.parametrize("seed", SEEDS[:max(1, len(SEEDS) // 8)])
+def test_random_nerf_or_fused_sequence_on_one_handle_matches_the_oracle(uivr, oracle, gpu, seed, which):
+    """The sequences of test_random_sequence_on_one_handle ... for the nerf integrator and config 5's fused pass: their handles keep a four-channel copy of
+    the grids, the LDS-window kernel's bounds, a second stream."""
+    import torch
+    rng = np.random.default_rng(88_000 + seed)
+    c = _draw(uivr, seed + 3600, medium_size=seed % 5 == 4)
+    props = dict(c["props"])
+    props.pop("hide_emitters", None)
+    nerf_props = _nerf_props(rng) if which == "nerf" else dict(queries_per_ray=int(rng.choice([2, 5, 16, 40])), activation="identity",
+                                                               jittering_enabled=True, hide_emitters=False)
+    if which == "nerf":
+        integ = uivr.load_dict(dict(type="nerf", **nerf_props))
+    else:
+        d = {"type": "nerf+volpathsimple", "queries_per_ray": nerf_props["queries_per_ray"]}
+        d.update(props)
+        integ = uivr.load_dict(d)
+
+    def with_emission(scene):
+        m = scene.medium
+        cs = tuple(np.asarray(m.albedo).shape[:3])
+        em = (rng.random(cs + (3,), dtype=np.float32) * 1.5).astype(np.float32) if which == "nerf" else np.array(m.albedo, dtype=np.float32).copy()
+        return uivr.Scene(medium=uivr.GridMedium(sigma_t=m.sigma_t, albedo=m.albedo, emission=em, bbox_min=m.bbox_min, bbox_max=m.bbox_max, scale=m.scale,
+                                                 majorant_resolution_factor=m.majorant_resolution_factor), emitter=scene.emitter, sensors=scene.sensors)
+
+    scene = with_emission(c["scene"])
+    sg = uivr.scene_to(scene, gpu)
+    colour_key = uivr.EMISSION_KEY if which == "nerf" else uivr.ALBEDO_KEY
+    for step in range(6):
+        k = int(rng.integers(0, 5)) if step else 0
+        if k == 1:
+            c2 = _draw(uivr, int(rng.integers(0, 10_000)) + 7000, medium_size=rng.random() < 0.2)
+            scene = with_emission(c2["scene"])
+            sg = uivr.scene_to(scene, gpu)
+        elif k == 2:
+            f = np.float32(rng.random() * 1.5 + 0.25)
+            scene.medium.sigma_t = (np.asarray(scene.medium.sigma_t) * f).astype(np.float32)
+            sg.medium.sigma_t.mul_(float(f))
+        elif k == 3:                                                                 # the colour grid in place (the fused pass reads ONE colour grid: albedo = emission)
+            a2 = np.clip(np.asarray(scene.medium.emission) * np.float32(0.9) + np.float32(0.03), 0.0, 1.0).astype(np.float32)
+            scene.medium.emission = a2
+            sg.medium.emission.copy_(torch.from_numpy(a2))
+            if which == "fused":
+                scene.medium.albedo = a2.copy()
+                sg.medium.albedo.copy_(torch.from_numpy(a2))
+        spp, rs = int(rng.choice([1, 2, 3, 4])), int(rng.integers(1, 2**31 - 1))
+        s = scene.sensors[0]
+        n = s.width * s.height * spp
+        tag = f"seed {seed} {which} step {step} kind {k}: grid {tuple(np.asarray(scene.medium.sigma_t).shape[:3])} colour {tuple(np.asarray(scene.medium.emission).shape[:3])} " \
+              f"film {(s.width, s.height)} spp {spp}"
+        osc = oracle.OracleScene(scene)
+        n_ch = 3 if which == "nerf" else 6
+        dL = ((rng.random((n, n_ch), dtype=np.float32) - 0.5) * 1e-2).astype(np.float32)
+        if which == "nerf":
+            Lr, _ = oracle.nerf_render(osc, scene.medium.emission, nerf_props, spp, rs)
+            gs, gc, _ = oracle.nerf_render(osc, scene.medium.emission, nerf_props, spp, rs, dL=dL, L_in=Lr)
+        else:
+            Lr, _ = oracle.fused_render_primal(osc, props, nerf_props, spp, rs)
+            gs, gc, _ = oracle.fused_render_backward(osc, props, nerf_props, spp, rs, dL, Lr)
+        batch = uivr.RayBatch(n_rays=n, spp=spp, sensor=sg.sensors[0])
+        samp = uivr.IndependentSampler(rs, spp)
+        L, _, st_ = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+        np.testing.assert_array_equal(_bits(L.cpu().numpy()), _bits(Lr), err_msg=tag)
+        grads = uivr.alloc_grads(sg, integ.param_keys)
+        integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=st_, grads=grads)
+        _close(grads[uivr.SIGMA_T_KEY], gs, tag + " grad sigma_t")
+        _close(grads[colour_key], gc, tag + " grad colour")

@@ -637,6 +637,10 @@ int ensure_deferred(drt_handle h, drt_handle_s::RecSlot &R, drt::Params &P, uint
         R.clear_bytes = clear; R.rays = n_rays; R.bins = n_bins; R.tiny = tiny;
         R.per_ray[0] = per_ray_sigma; R.per_ray[1] = per_ray_colour;
     }
+    // the tile grid of THIS medium: a slot sized for another grid with the same NUMBER of tiles keeps its buffers, not that grid's tile arrangement
+    // (7 x 25 x 25 voxels: 1 x 2 x 1 tiles, then 25 x 3 x 5: 1 x 1 x 2 - the records went to the wrong tiles and part of the gradient was lost;
+    //  found by tests/test_gpu_fuzz.py::test_random_sequence_on_one_handle_matches_the_oracle, round 6)
+    D.ntx = ntx; D.nty = nty; D.ntz = ntz;
     DRT_HIP_CHECK(h, hipMemsetAsync(R.mem, 0, R.clear_bytes, h->stream));
     for (int s = 0; s < 2; ++s) { P.rec_buf[s] = D.in[s]; P.rec_chunk_count[s] = D.chunk_count[s]; P.rec_cap_chunks[s] = D.cap_chunks[s]; }
     P.rec_cursor = D.cursor;
