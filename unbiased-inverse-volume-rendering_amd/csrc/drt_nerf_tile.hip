@@ -6,7 +6,7 @@
 // (nerf_kernel<ADJ, ., DEFER>, drt_deferred.hip) that is 14.5 GB of 16-byte records per step, written, histogrammed, scattered and read
 // again: the reduction passes were 25 of the 46 ms of the fused adjoint pass (profiles/r04_fused_kernel_stats.csv).  But a march is
 // COHERENT where a scattering path is not: the rays of a small pixel tile walk through the grid side by side, so at march step j
-// all their queries lie within a few voxels of each other.  Here a workgroup owns an 8 x 8-pixel tile (lane = pixel, wave = sample) and adds
+// all their queries lie within a few voxels of each other.  Here a workgroup owns an 8 x 8-pixel tile (a wave = 16 of its pixels x 4 samples) and adds
 // every splat into a 16^3-voxel WINDOW of four-channel accumulators in LDS (torus addressing: voxel (x, y, z) lives in slot (z & 15, y & 15,
 // x & 15) while the window covers it).  Every ray runs on by itself until a splat falls outside the window; when every ray of the workgroup
 // waits (or is done) the window's non-zero accumulators are flushed to the caller's grids (one global atomic per voxel and channel -
@@ -27,6 +27,9 @@
 #include "drt_device.h"
 #include "drt_launch.h"
 
+#ifndef DRT_NT_SPW
+#define DRT_NT_SPW 4               // samples per wave (lane -> ray map of the adjoint kernel): 4, or 1 = a wave is one sample of the tile's 64 pixels (round 5)
+#endif
 #ifndef DRT_NT_THREADS
 #define DRT_NT_THREADS 1024        // threads per workgroup: the 64 pixels of a tile x (DRT_NT_THREADS / 64) samples
 #endif
@@ -152,8 +155,20 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
     //      index runs, every add instruction had ~10 lanes per address and the march took 18 us per step) --------------------------------------
     const uint32_t tile = blockIdx.x / T.groups, sg = blockIdx.x - tile * T.groups;
     const uint32_t bx = tile % T.tiles_x, by = tile / T.tiles_x;
+#if DRT_NT_SPW == 4
+    // Round 6: a wave = the 16 pixels of one stride-2 sub-lattice of the tile x 4 samples.  The kernel is bound by the LDS atomic unit's serialisation of
+    // lanes that add to the SAME address in one instruction (12 + 2 x (lanes per address - 1) clocks per ds_add_u64, tools/ubench/lds_atomic_conflict_rate.hip):
+    // with the 64 pixels of one sample side by side (~0.6 voxel apart) 4 - 8 lanes shared every corner; now a wave's pixels lie 1.2 voxels apart and its
+    // four samples of a pixel a jittered fraction of the march step apart in depth.  Counters (profiles/r06_nerf_tile_experiments.txt): SQ_LDS_ADDR_CONFLICT
+    // 1.83 G -> 0.48 G, SQ_WAIT_INST_LDS 4.49 G -> 1.27 G of 32.7 G wave-cycles; launch 15.6 -> 14.3 ms.  (2 / 8 / 16 samples per wave: 15.3 / 15.8 / 17.6 ms -
+    // beyond four the lanes' texel loads scatter and a pixel's samples meet again in depth.)
+    const uint32_t wv = t >> 6, pix = lane & 15u, q = wv & 3u;
+    const uint32_t smp = sg * (NT / 64) + 4u * (wv >> 2) + (lane >> 4);
+    const uint32_t px = bx * 8u + 2u * (pix & 3u) + (q & 1u), py = by * 8u + 2u * (pix >> 2) + (q >> 1);
+#else
     const uint32_t smp = sg * (NT / 64) + (t >> 6);
     const uint32_t px = bx * 8u + (lane & 7u), py = by * 8u + (lane >> 3);
+#endif
     bool job = smp < P.spp && px < (uint32_t) P.width && py < (uint32_t) P.height;
     uint64_t i = 0; uint32_t gi = 0;
     if (job) {
