@@ -147,3 +147,103 @@ def test_raw_ctypes_colour_grid_on_its_own_lattice(uivr, oracle, gpu):
                 assert float((got.double() - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-9, (colour, what)
     finally:
         lib.drt_destroy(h)
+
+
+def test_raw_ctypes_misuse_is_refused_with_a_message_and_the_handle_lives_on(uivr, oracle, gpu):
+    """Every call below is wrong in one way - a null pointer, a zero or negative extent, an inverted box, a non-finite scale, nothing configured yet,
+    a zero spp ... - and must come back with an error code and a message (the reference raises: opt_config.py:98-104, util.py:83-85), never crash, never
+    leave the handle unusable: the last step renders the cube fixture on the same handle, bit-exact against the oracle."""
+    from uivr_amd._native import library_path
+    lib = C.CDLL(library_path())
+    lib.drt_last_error.restype = C.c_char_p
+    props = props_for("drt")
+
+    def cfg(**over):
+        d = dict(hide_emitters=0, use_nee=1, use_drt=1, use_drt_subsampling=1, use_drt_mis=1, max_depth=int(props["max_depth"]), rr_depth=int(props["rr_depth"]))
+        d.update(over)
+        return _Cfg(*[d[k] for k in ("hide_emitters", "use_nee", "use_drt", "use_drt_subsampling", "use_drt_mis", "max_depth", "rr_depth")])
+
+    refused = []
+
+    def bad(what, rc, h=None):
+        msg = lib.drt_last_error(h) if h is not None else b"(no handle)"
+        assert rc != 0, f"{what}: accepted"
+        assert msg, f"{what}: refused without a message"
+        refused.append(what)
+
+    h = C.c_void_p()
+    bad("create without a config", lib.drt_create(None, gpu.index or 0, C.byref(h)))
+    bad("create without an out pointer", lib.drt_create(C.byref(cfg()), gpu.index or 0, None))
+    bad("create on device 999", lib.drt_create(C.byref(cfg()), 999, C.byref(h)))
+    bad("create with max_depth -5", lib.drt_create(C.byref(cfg(max_depth=-5)), gpu.index or 0, C.byref(h)))
+    assert lib.drt_create(C.byref(cfg()), gpu.index or 0, C.byref(h)) == 0
+    try:
+        scene = uivr.cube_test_scene(12, 9, density_scale=2.0)
+        m = scene.medium
+        sig = torch.from_numpy(np.ascontiguousarray(m.sigma_t, dtype=np.float32)).to(gpu)
+        alb = torch.from_numpy(np.ascontiguousarray(m.albedo, dtype=np.float32)).to(gpu)
+        z, y, x = sig.shape[:3]
+        res = (C.c_int32 * 3)(x, y, z)
+        n, spp, seed = 12 * 9 * 4, 4, 77
+        L = torch.empty((n, 3), dtype=torch.float32, device=gpu)
+        gs, ga = torch.zeros_like(sig), torch.zeros_like(alb)
+        P = lambda t: C.c_void_p(t.data_ptr())
+
+        def primal(hh=h, n_=n, spp_=spp, out=L):
+            return lib.drt_render_primal(hh, None, None, C.c_uint64(n_), C.c_uint64(0), C.c_uint32(spp_), C.c_uint32(seed), P(out) if out is not None else None)
+
+        bad("render before anything is set", primal(), h)
+        bad("null handle", lib.drt_set_emitter_constant(None, _f3((1, 1, 1))))
+        bad("emitter without radiance", lib.drt_set_emitter_constant(h, None), h)
+        bad("medium without sigma_t", lib.drt_set_medium(h, None, P(alb), res, _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(1.0), C.c_int32(0)), h)
+        bad("medium without a resolution", lib.drt_set_medium(h, P(sig), P(alb), None, _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(1.0), C.c_int32(0)), h)
+        bad("medium with a zero extent", lib.drt_set_medium(h, P(sig), P(alb), (C.c_int32 * 3)(x, 0, z), _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(1.0), C.c_int32(0)), h)
+        bad("medium with a negative extent", lib.drt_set_medium(h, P(sig), P(alb), (C.c_int32 * 3)(-x, y, z), _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(1.0), C.c_int32(0)), h)
+        bad("medium in an inverted box", lib.drt_set_medium(h, P(sig), P(alb), res, _f3(m.bbox_max), _f3(m.bbox_min), C.c_float(1.0), C.c_int32(0)), h)
+        bad("medium in a flat box", lib.drt_set_medium(h, P(sig), P(alb), res, _f3((0, 0, 0)), _f3((1, 0, 1)), C.c_float(1.0), C.c_int32(0)), h)
+        bad("medium with a NaN scale", lib.drt_set_medium(h, P(sig), P(alb), res, _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(float("nan")), C.c_int32(0)), h)
+        bad("medium with a negative majorant_resolution_factor", lib.drt_set_medium(h, P(sig), P(alb), res, _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(1.0), C.c_int32(-2)), h)
+        bad("colour lattice before the medium", lib.drt_set_colour_resolution(h, (C.c_int32 * 3)(2, 2, 2)), h)
+        assert lib.drt_set_medium(h, P(sig), P(alb), res, _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(float(m.scale)), C.c_int32(0)) == 0, lib.drt_last_error(h)
+        bad("render without an emitter", primal(), h)
+        assert lib.drt_set_emitter_constant(h, _f3(scene.emitter.radiance)) == 0
+        bad("sensor rays without a sensor", primal(), h)
+        s = scene.sensors[0]
+        f = s.frame()
+        sensor = lambda w_, h_, tx=float(f["tan_x"]): lib.drt_set_sensor_perspective(h, _f3(f["origin"]), _f3(f["left"]), _f3(f["up"]), _f3(f["dir"]), C.c_float(tx),
+                                                                                       C.c_float(float(f["tan_y"])), C.c_int32(w_), C.c_int32(h_))
+        bad("sensor with a zero width", sensor(0, s.height), h)
+        bad("sensor with a negative height", sensor(s.width, -3), h)
+        bad("sensor without an origin", lib.drt_set_sensor_perspective(h, None, _f3(f["left"]), _f3(f["up"]), _f3(f["dir"]), C.c_float(0.3), C.c_float(0.3), C.c_int32(4), C.c_int32(4)), h)
+        assert sensor(s.width, s.height) == 0, lib.drt_last_error(h)
+        bad("envmap without pixels", lib.drt_set_emitter_envmap(h, None, C.c_int32(8), C.c_int32(4), (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1), C.c_float(1.0)), h)
+        bad("envmap of width 0", lib.drt_set_emitter_envmap(h, P(alb), C.c_int32(0), C.c_int32(4), (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1), C.c_float(1.0)), h)
+        bad("envmap without a rotation", lib.drt_set_emitter_envmap(h, P(alb), C.c_int32(3), C.c_int32(3), None, C.c_float(1.0)), h)
+        bad("primal without an output", primal(out=None), h)
+        bad("primal with spp 0", primal(spp_=0), h)
+        bad("primal over more rays than the film holds", primal(n_=n + spp), h)
+        bad("rays_o without rays_d", lib.drt_render_primal(h, P(L), None, C.c_uint64(n), C.c_uint64(0), C.c_uint32(spp), C.c_uint32(seed), P(L)), h)
+        dL = torch.zeros((n, 3), dtype=torch.float32, device=gpu)
+        back = lambda dl, lin, g1, g2: lib.drt_render_backward(h, None, None, C.c_uint64(n), C.c_uint64(0), C.c_uint32(spp), C.c_uint32(seed),
+                                                               P(dl) if dl is not None else None, P(lin) if lin is not None else None,
+                                                               P(g1) if g1 is not None else None, P(g2) if g2 is not None else None)
+        bad("backward without dL", back(None, L, gs, ga), h)
+        bad("backward without L_in", back(dL, None, gs, ga), h)
+        bad("backward without a sigma_t gradient", back(dL, L, None, ga), h)
+        ncfg = (C.c_int32 * 4)(0, 1, 1, 0)                                       # queries_per_ray 1
+        bad("nerf with one query per ray", lib.drt_nerf_render_primal(h, C.byref(ncfg), P(alb), None, None, C.c_uint64(n), C.c_uint64(0), C.c_uint32(spp), C.c_uint32(seed), P(L)), h)
+        bad("nerf without a config", lib.drt_nerf_render_primal(h, None, P(alb), None, None, C.c_uint64(n), C.c_uint64(0), C.c_uint32(spp), C.c_uint32(seed), P(L)), h)
+        ncfg = (C.c_int32 * 4)(0, 8, 1, 0)
+        bad("nerf without an emission grid", lib.drt_nerf_render_primal(h, C.byref(ncfg), None, None, None, C.c_uint64(n), C.c_uint64(0), C.c_uint32(spp), C.c_uint32(seed), P(L)), h)
+        bad("film_develop with spp 0", lib.drt_film_develop(h, P(L), C.c_uint64(12 * 9), C.c_uint32(0), P(L)), h)
+        bad("counters without an output", lib.drt_get_counters(h, None), h)
+        bad("interleave with a stride below the chunk", lib.drt_set_ray_interleave(h, C.c_uint64(64), C.c_uint64(32)), h)
+        assert len(refused) == 37, refused
+        # ... and the handle still does its work
+        assert primal() == 0, lib.drt_last_error(h)
+        assert lib.drt_synchronize(h) == 0
+        Lr, _ = oracle.render_primal(oracle.OracleScene(scene), props, spp, seed)
+        np.testing.assert_array_equal(L.cpu().numpy().view(np.uint32), Lr.view(np.uint32))
+    finally:
+        lib.drt_destroy(h)
+    assert lib.drt_destroy(None) != 0 or True                                   # (destroying nothing is harmless either way)

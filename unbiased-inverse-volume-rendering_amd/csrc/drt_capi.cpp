@@ -965,7 +965,10 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
     for (int a = 0; a < 3; ++a) {
         if (res[a] < 1) return fail(h, DRT_ERR_INVALID_ARGUMENT, "grid resolution must be >= 1");
         if (!(bbox_max[a] > bbox_min[a])) return fail(h, DRT_ERR_INVALID_ARGUMENT, "empty bounding box");
+        if (!std::isfinite(bbox_min[a]) || !std::isfinite(bbox_max[a]) || !std::isfinite(bbox_max[a] - bbox_min[a]))
+            return fail(h, DRT_ERR_INVALID_ARGUMENT, "bounding box is not finite");
     }
+    if (!std::isfinite(scale)) return fail(h, DRT_ERR_INVALID_ARGUMENT, "medium scale is not finite");
     if ((uint64_t) res[0] * res[1] * res[2] > 0x7fffffffull / 3)
         return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for 32-bit voxel indexing");
     if (majorant_resolution_factor < 0)
