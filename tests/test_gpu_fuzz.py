@@ -501,3 +501,56 @@ def test_random_nerf_or_fused_sequence_on_one_handle_matches_the_oracle(uivr, or
         integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=st_, grads=grads)
         _close(grads[uivr.SIGMA_T_KEY], gs, tag + " grad sigma_t")
         _close(grads[colour_key], gc, tag + " grad colour")
+
+
+@pytest.mark.parametrize("which", ["volpathsimple", "nerf", "fused"])
+@pytest.mark.parametrize("seed", SEEDS[:max(1, len(SEEDS) // 8)])
+def test_random_windows_of_the_wavefront_add_up_to_the_whole(uivr, oracle, gpu, seed, which):
+    """Launches over WINDOWS of the global wavefront (RayBatch.ray_offset: rays [offset, offset + n) of width x height x spp, cut anywhere - inside a
+    pixel's samples, inside a pixel tile of the LDS-window kernel): every window's radiance is the whole launch's slice bit for bit, the windows' gradients
+    add up to the whole launch's."""
+    import torch
+    c = _draw(uivr, seed + 4400, medium_size=seed % 3 == 2)
+    rng = c["rng"]
+    props = dict(c["props"])
+    m = c["scene"].medium
+    if which == "volpathsimple":
+        integ = uivr.load_dict(dict(type="volpathsimple", **props))
+        scene = c["scene"]
+    else:
+        props.pop("hide_emitters", None)
+        nerf_props = _nerf_props(rng) if which == "nerf" else dict(queries_per_ray=int(rng.choice([2, 5, 16, 40])), activation="identity", jittering_enabled=True)
+        em = (rng.random(tuple(c["cshape"]) + (3,), dtype=np.float32) * 1.5).astype(np.float32) if which == "nerf" else np.array(m.albedo, dtype=np.float32).copy()
+        scene = uivr.Scene(medium=uivr.GridMedium(sigma_t=m.sigma_t, albedo=m.albedo, emission=em, bbox_min=m.bbox_min, bbox_max=m.bbox_max, scale=m.scale,
+                                                  majorant_resolution_factor=m.majorant_resolution_factor), emitter=c["scene"].emitter, sensors=c["scene"].sensors)
+        if which == "nerf":
+            integ = uivr.load_dict(dict(type="nerf", **nerf_props))
+        else:
+            d = {"type": "nerf+volpathsimple", "queries_per_ray": nerf_props["queries_per_ray"]}
+            d.update(props)
+            integ = uivr.load_dict(d)
+    sg = uivr.scene_to(scene, gpu)
+    s = scene.sensors[0]
+    spp, rs = c["spp"], c["seed"]
+    n = s.width * s.height * spp
+    n_ch = 6 if which == "fused" else 3
+    tag = f"seed {seed} {which}: grid {c['shape']} colour {c['cshape']} film {(s.width, s.height)} spp {spp}"
+    dL = torch.from_numpy(((rng.random((n, n_ch), dtype=np.float32) - 0.5) * 1e-2).astype(np.float32)).to(gpu)
+
+    def run(first, count):
+        batch = uivr.RayBatch(n_rays=count, spp=spp, sensor=sg.sensors[0], ray_offset=first)
+        samp = uivr.IndependentSampler(rs, spp)
+        L, _, st_ = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+        grads = uivr.alloc_grads(sg, integ.param_keys)
+        integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=dL[first:first + count].contiguous(), state_in=st_, grads=grads)
+        return L, grads["_flat"].clone()
+
+    L_all, g_all = run(0, n)
+    cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, size=int(rng.integers(1, 5)))]))
+    acc = torch.zeros_like(g_all)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        L, g = run(a, b - a)
+        assert torch.equal(L, L_all[a:b]), tag + f" window [{a}, {b})"
+        acc += g
+    tol = GRAD_RTOL * float(g_all.abs().max()) + 1e-12
+    assert float((acc - g_all).abs().max()) <= tol, tag + f" cuts {cuts}"
