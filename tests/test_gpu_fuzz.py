@@ -200,7 +200,16 @@ def test_nerf_with_strongly_negative_densities(uivr, oracle, gpu, seed):
     _check_nerf(uivr, oracle, gpu, seed)
 
 
-def _check_nerf(uivr, oracle, gpu, seed):
+@pytest.mark.parametrize("seed", SEEDS[:max(1, len(SEEDS) // 8)])
+def test_random_nerf_scene_on_the_record_path_matches_the_oracle(uivr, oracle, gpu, seed):
+    """The nerf draws with the adjoint of sensor rays sent through the record path (test hook 512: nerf_kernel + deferred splatting, as explicit ray batches
+    and own-lattice scenes go in production) and its fall-backs: atomics (128), two-chunk streams (256), many sub-batches (16384), memory running out."""
+    rng = np.random.default_rng(55_000 + seed)
+    flags = 512 | int(rng.choice([0, 0, 128, 256, 16384, 16384 | 524288, 262144]))
+    _check_nerf(uivr, oracle, gpu, seed + 300, flags=flags)
+
+
+def _check_nerf(uivr, oracle, gpu, seed, flags=None):
     import torch
     c = _draw(uivr, seed, medium_size=seed % 4 == 3)
     rng = c["rng"]
@@ -222,20 +231,27 @@ def _check_nerf(uivr, oracle, gpu, seed):
     dL = ((rng.random((n_pix * spp, 3), dtype=np.float32) - 0.5) * 1e-2).astype(np.float32)
     gs, ge, ca = oracle.nerf_render(osc, em, props, spp, rs, dL=dL, L_in=Lr)
     sg = uivr.scene_to(scene, gpu)
-    integ = uivr.load_dict(dict(type="nerf", **props))
+    integ = uivr.load_dict(dict(type="nerf", **props, **({"test_hooks": True} if flags is not None else {})))
     h = integ.native_handle(sg)
+    if flags is not None:
+        h.set_debug_flags(flags)
+        tag += f" flags {flags}"
     batch = uivr.RayBatch(n_rays=n_pix * spp, spp=spp, sensor=sg.sensors[0])
     samp = uivr.IndependentSampler(rs, spp)
-    h.enable_counters(True)
-    h.reset_counters()
-    L, _, st_ = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
-    np.testing.assert_array_equal(_bits(L.cpu().numpy()), _bits(Lr), err_msg=tag)
-    assert {k: int(v) for k, v in h.get_counters().items()} == cr, tag
-    h.reset_counters()
-    grads = uivr.alloc_grads(sg, integ.param_keys)
-    integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=st_, grads=grads)
-    assert {k: int(v) for k, v in h.get_counters().items()} == ca, tag
-    h.enable_counters(False)
+    try:
+        h.enable_counters(True)
+        h.reset_counters()
+        L, _, st_ = integ.sample(uivr.ADMode.Primal, sg, samp.clone(), batch)
+        np.testing.assert_array_equal(_bits(L.cpu().numpy()), _bits(Lr), err_msg=tag)
+        assert {k: int(v) for k, v in h.get_counters().items()} == cr, tag
+        h.reset_counters()
+        grads = uivr.alloc_grads(sg, integ.param_keys)
+        integ.sample(uivr.ADMode.Backward, sg, samp, batch, δL=torch.from_numpy(dL).to(gpu), state_in=st_, grads=grads)
+        assert {k: int(v) for k, v in h.get_counters().items()} == ca, tag
+    finally:
+        h.enable_counters(False)
+        if flags is not None:
+            h.set_debug_flags(0)
     _close(grads[uivr.SIGMA_T_KEY], gs, tag + " grad sigma_t")
     _close(grads[uivr.EMISSION_KEY], ge, tag + " grad emission")
 
@@ -554,3 +570,47 @@ def test_random_windows_of_the_wavefront_add_up_to_the_whole(uivr, oracle, gpu, 
         acc += g
     tol = GRAD_RTOL * float(g_all.abs().max()) + 1e-12
     assert float((acc - g_all).abs().max()) <= tol, tag + f" cuts {cuts}"
+
+
+# schedules and fall-backs that production takes only at size or under memory pressure, selectable through the library flavour with test hooks
+# (include/drt_hip.h, drt_set_debug_flags): none of them may change a result
+_HOOKS = [16, 128, 256, 2048, 16384, 16384 | 524288, 262144, 1048576, 2097152, 33554432, 67108864, 268435456, 536870912, 1073741824,
+          1073741824 | 268435456, 2147483648, 8, 32, 32768, 65536, 134217728]
+
+
+@pytest.mark.parametrize("seed", SEEDS[:max(1, len(SEEDS) // 4)])
+def test_random_scene_under_random_schedules_matches_the_oracle(uivr, oracle, gpu, seed):
+    """The draws under one to three of the schedule / fall-back switches of the test-hooks flavour: splats as atomics, two-chunk record streams, many ray
+    sub-batches, record memory 'running out', no path cache, generic kernels, no hand-offs, index order, small launches scheduled like large ones
+    (ray order, tail pool, tail launch beside the partition), every flight walked, the older tracers.  Radiance bit-exact, counters equal, gradients close."""
+    rng = np.random.default_rng(99_000 + seed)
+    c = _draw(uivr, seed + 6100, medium_size=seed % 2 == 1)
+    flags = 0
+    for _ in range(int(rng.integers(1, 4))):
+        flags |= int(_HOOKS[int(rng.integers(0, len(_HOOKS)))])
+    scene, props, spp, rs = c["scene"], c["props"], c["spp"], c["seed"]
+    tag = f"seed {seed} flags {flags}: {c['variant']} factor {c['factor']} grid {c['shape']} colour {c['cshape']} film {c['film']} spp {spp} env {c['env']}"
+    s = scene.sensors[0]
+    n_pix = s.width * s.height
+    osc = oracle.OracleScene(scene)
+    ref = oracle.h1_step(osc, props, spp, rs)
+    _, c_p = oracle.render_primal(osc, props, spp, rs)
+    sg = uivr.scene_to(scene, gpu)
+    integ = uivr.load_dict(dict(type="volpathsimple", test_hooks=True, **props))
+    h = integ.native_handle(sg)
+    h.set_debug_flags(flags)
+    try:
+        h.enable_counters(True)
+        h.reset_counters()
+        batch = uivr.RayBatch(n_rays=n_pix * spp, spp=spp, sensor=sg.sensors[0])
+        L, _, _ = integ.sample(uivr.ADMode.Primal, sg, uivr.IndependentSampler(rs, spp), batch)
+        np.testing.assert_array_equal(_bits(L.cpu().numpy()), _bits(ref["L"]), err_msg=tag)
+        img = uivr.render_primal(sg, integ, 0, spp, rs)
+        grads = uivr.render_backward(sg, integ, ((2.0 / (n_pix * 3)) * (img - 0.5)).contiguous(), 0, spp, rs)
+        cnt = {k: int(v) for k, v in h.get_counters().items()}
+    finally:
+        h.enable_counters(False)
+        h.set_debug_flags(0)
+    assert cnt == {k: ref["counters"][k] + 2 * c_p[k] for k in ref["counters"]}, tag
+    _close(grads[uivr.SIGMA_T_KEY], ref["grad_sigma_t"], tag + " grad sigma_t")
+    _close(grads[uivr.ALBEDO_KEY], ref["grad_albedo"], tag + " grad albedo")
