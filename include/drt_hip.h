@@ -91,7 +91,7 @@ int drt_set_ray_interleave(drt_handle h, uint64_t chunk_rays, uint64_t stride_ra
 /* The single medium of the scene: util.get_single_medium (python/util.py:75-86) +
  * the `heterogeneous` medium / `gridvolume` parameters of the fixture
  * (tests/test_integrators.py:79-111).  sigma_t: (Z,Y,X,1); albedo: (Z,Y,X,3);
- * res = {X,Y,Z}.  Pointers are borrowed until the next drt_set_medium.
+ * res = {X,Y,Z}; scale finite and >= 0, the box finite and not empty.  Pointers are borrowed until the next drt_set_medium.
  * Also (re)computes the majorant on device. */
 int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, const int32_t res[3],
                    const float bbox_min[3], const float bbox_max[3], float scale,

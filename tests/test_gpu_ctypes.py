@@ -202,6 +202,7 @@ def test_raw_ctypes_misuse_is_refused_with_a_message_and_the_handle_lives_on(uiv
         bad("medium in an inverted box", lib.drt_set_medium(h, P(sig), P(alb), res, _f3(m.bbox_max), _f3(m.bbox_min), C.c_float(1.0), C.c_int32(0)), h)
         bad("medium in a flat box", lib.drt_set_medium(h, P(sig), P(alb), res, _f3((0, 0, 0)), _f3((1, 0, 1)), C.c_float(1.0), C.c_int32(0)), h)
         bad("medium with a NaN scale", lib.drt_set_medium(h, P(sig), P(alb), res, _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(float("nan")), C.c_int32(0)), h)
+        bad("medium with a negative scale", lib.drt_set_medium(h, P(sig), P(alb), res, _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(-1.0), C.c_int32(0)), h)
         bad("medium with a negative majorant_resolution_factor", lib.drt_set_medium(h, P(sig), P(alb), res, _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(1.0), C.c_int32(-2)), h)
         bad("colour lattice before the medium", lib.drt_set_colour_resolution(h, (C.c_int32 * 3)(2, 2, 2)), h)
         assert lib.drt_set_medium(h, P(sig), P(alb), res, _f3(m.bbox_min), _f3(m.bbox_max), C.c_float(float(m.scale)), C.c_int32(0)) == 0, lib.drt_last_error(h)
@@ -238,7 +239,7 @@ def test_raw_ctypes_misuse_is_refused_with_a_message_and_the_handle_lives_on(uiv
         bad("film_develop with spp 0", lib.drt_film_develop(h, P(L), C.c_uint64(12 * 9), C.c_uint32(0), P(L)), h)
         bad("counters without an output", lib.drt_get_counters(h, None), h)
         bad("interleave with a stride below the chunk", lib.drt_set_ray_interleave(h, C.c_uint64(64), C.c_uint64(32)), h)
-        assert len(refused) == 37, refused
+        assert len(refused) == 38, refused
         # ... and the handle still does its work
         assert primal() == 0, lib.drt_last_error(h)
         assert lib.drt_synchronize(h) == 0

@@ -969,6 +969,8 @@ int drt_set_medium(drt_handle h, const float *sigma_t, const float *albedo, cons
             return fail(h, DRT_ERR_INVALID_ARGUMENT, "bounding box is not finite");
     }
     if (!std::isfinite(scale)) return fail(h, DRT_ERR_INVALID_ARGUMENT, "medium scale is not finite");
+    if (scale < 0.0f)                 // (densities of the other sign under the identity activation belong into the grid, where the kernels' bounds look for them)
+        return fail(h, DRT_ERR_INVALID_ARGUMENT, "medium scale must be >= 0");
     if ((uint64_t) res[0] * res[1] * res[2] > 0x7fffffffull / 3)
         return fail(h, DRT_ERR_UNSUPPORTED, "grid too large for 32-bit voxel indexing");
     if (majorant_resolution_factor < 0)

@@ -274,7 +274,9 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             for (int off = 32; off > 0; off >>= 1) { m1 = fmaxf(m1, __shfl_xor(m1, off, 64)); W = fmaxf(W, __shfl_xor(W, off, 64)); }
             if (lane == 0) { atomicMax(wgain, __float_as_uint(m1)); atomicMax(wgain + 1, __float_as_uint(W)); }   // (non-negative floats order like their bits)
             __syncthreads();
-            M1 = fmaxf(1.0f, __uint_as_float(wgain[0])) * 1.001f; Wm = fmaxf(1.0f, __uint_as_float(wgain[1])) * 1.001f;
+            // (workgroup-uniform: kept in scalar registers, like the bounds they multiply)
+            M1 = fmaxf(1.0f, __uint_as_float(__builtin_amdgcn_readfirstlane(wgain[0]))) * 1.001f;
+            Wm = fmaxf(1.0f, __uint_as_float(__builtin_amdgcn_readfirstlane(wgain[1]))) * 1.001f;
         }
         const float Bs = fabsf(P.scale) * 3.0f * Dmax * (Emax * M1 + Emax * Wm + Lmax) * dt_max * 1.001f, Bc = Dmax * M1;
         if (!(Bs < kInf) || !(Bc < kInf)) {                             // this workgroup's rays overflow fp32: its share of the gradient is void - and so is the whole
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
         es = max(es - kFixBits, -100); ec = max(ec - kFixBits, -100);
         unit_s = ldexpf(1.0f, es); inv_s = ldexp(1.0, -es); unit_c = ldexpf(1.0f, ec); inv_c = ldexp(1.0, -ec);
     }
-    uint32_t n_q = 0, n_adds = 0;                                      // (n_adds: LDS lane-adds of this ray, counting launches only: bounds[6..7])
+    uint32_t n_adds = 0;                                               // (LDS lane-adds of this ray, counting launches only: bounds[6..7])
     int Wx = -(1 << 28), Wy = -(1 << 28), Wz = -(1 << 28);             // window origin (workgroup-uniform; none yet: the first splats all wait)
     const int N = P.nerf_queries;
     int j = 0;
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
     bool pend = false, colour = false;
     Stencil st;
     st.x0 = st.x1 = st.y0 = st.y1 = st.z0 = st.z1 = 0; st.wx0 = st.wx1 = st.wy0 = st.wy1 = st.wz0 = st.wz1 = 0.0f;
-    float v0 = 0.0f, ge[3] = { 0.0f, 0.0f, 0.0f }, key = 0.0f;
+    float v0 = 0.0f, ge[3] = { 0.0f, 0.0f, 0.0f };
     auto flush = [&]() {                                                // slot -> the voxel it holds under the current origin
         for (int l = t; l < kWinSlots; l += NT) {
             const int sx = l & 15, sy = (l >> 4) & 15, sz = l >> 8, s = sz * kSZ + sy * kSY + sx;
@@ -350,7 +352,6 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             if (!(active && j < N)) break;
             // query j
             const float t_b = P.nerf_jitter ? step * ((float) (j + 1) + jit) : step * (float) (j + 1);
-            const float dt = t_b - t_a;
             const V3 p = ray_at(o, d, t_b);
             // the query's footprint (unscaled indices): the lookup's and, if the query splats, the splat's (no splat waits here: `st` is free)
             axis_setup(p.x, P.bmin[0], P.inv_ext[0], P.rx, st.x0, st.x1, st.wx0, st.wx1);
@@ -359,8 +360,8 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             float raw, em[3];
             if constexpr (G4) eval4_at(P, st, raw, em);
             else { raw = eval_sigma_t(P, p, occ); eval_rgb(P, P.emission, p, em); }
+            const float dt = t_b - t_a;
             const float sigma = P.nerf_relu ? fmaxf(0.0f, raw) : raw;
-            n_q++;
             const bool last = !(j + 1 < N);
             const float a = last ? 1.0f : drt_expf(-sigma * dt);
             const float weight = (1.0f - a) * throughput;
@@ -381,7 +382,6 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
             colour = ge[0] != 0.0f || ge[1] != 0.0f || ge[2] != 0.0f;
             if (gs != 0.0f || colour) {                                         // (adding exact zeros changes nothing)
                 v0 = gs * P.scale;
-                key = ent_t + t_b;                                              // distance from the camera
                 pend = true;
             }
         }
@@ -389,7 +389,8 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
         if (t < 8) wctl[t] = t < 3 ? 1 << 28 : t < 6 ? -(1 << 28) : 0;
         if (t == 0) { wkey[0] = ~0ull; NT_STAT(0, 1); }
         __syncthreads();                                                        // (... and the phase's LDS adds are done)
-        unsigned long long mine = pend ? (((unsigned long long) __float_as_uint(key) << 32) | t) : ~0ull;   // (distances are positive: ordered like their bits)
+        // (a waiting splat's distance from the camera: ent_t + the t_b of its query, which is t_a by now; distances are positive: ordered like their bits)
+        unsigned long long mine = pend ? (((unsigned long long) __float_as_uint(ent_t + t_a) << 32) | t) : ~0ull;
         unsigned long long best = mine;
         int mn[3] = { pend ? st.x0 : 1 << 28, pend ? st.y0 : 1 << 28, pend ? st.z0 : 1 << 28 };
         int mx[3] = { pend ? st.x1 : -(1 << 28), pend ? st.y1 : -(1 << 28), pend ? st.z1 : -(1 << 28) };
@@ -415,13 +416,15 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
         }
         __syncthreads();
         // per axis: the box's corner on the side the rays come from, moved as far as that ray's footprint allows
-        Wx = wctl[6] >= 0 ? max(wctl[0], wctl[10] - (kWin - 1)) : min(wctl[3] - (kWin - 1), wctl[9]);
-        Wy = wctl[7] >= 0 ? max(wctl[1], wctl[12] - (kWin - 1)) : min(wctl[4] - (kWin - 1), wctl[11]);
-        Wz = wctl[8] >= 0 ? max(wctl[2], wctl[14] - (kWin - 1)) : min(wctl[5] - (kWin - 1), wctl[13]);
+        // (workgroup-uniform: scalar registers - 6 vector registers fewer, with the leaner bookkeeping of round 6 119 instead of 127)
+        Wx = __builtin_amdgcn_readfirstlane(wctl[6] >= 0 ? max(wctl[0], wctl[10] - (kWin - 1)) : min(wctl[3] - (kWin - 1), wctl[9]));
+        Wy = __builtin_amdgcn_readfirstlane(wctl[7] >= 0 ? max(wctl[1], wctl[12] - (kWin - 1)) : min(wctl[4] - (kWin - 1), wctl[11]));
+        Wz = __builtin_amdgcn_readfirstlane(wctl[8] >= 0 ? max(wctl[2], wctl[14] - (kWin - 1)) : min(wctl[5] - (kWin - 1), wctl[13]));
         __syncthreads();                                                        // (wctl / wkey are reset by the next phase's end)
     }
     if (T.count && P.counters) {
         // (as nerf_kernel counts: one sigma_t + one colour lookup, one sigma_t + one colour splat per query)
+        const uint32_t n_q = (uint32_t) j;                                        // (one lookup and one splat per query of the march)
         uint32_t vals[C_COUNT] = { job && !P.nerf_fused_half ? 1u : 0u, n_q, 0, 0, n_q, 0, 0, n_q, n_q };
 #pragma unroll
         for (int s = 0; s < C_COUNT; ++s) {
