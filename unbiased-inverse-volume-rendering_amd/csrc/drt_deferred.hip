@@ -33,6 +33,13 @@
 #include "drt_device.h"
 #include "drt_launch.h"
 
+#ifndef DRT_PART_NT
+#define DRT_PART_NT 5              // non-temporal accesses of the passes that stream the records: bit 0 the histogram's and the scatter's loads of the emitted records,
+                                   // bit 2 tile_reduce's loads of stream 0's sorted records (read once; stream 1's are read by four planes and stay cached),
+                                   // bit 1 the scatter's stores.  Measured, alternating runs on one box (headline Msamples/s / reductions ms; default = 0):
+                                   // 0: 939-943 / 1.99   1: 948-962 / 1.82-1.95   4: 947 / 1.94   5: 955-960 / 1.76-1.88   2: 883 / 2.54   3: 886 / 2.52
+                                   // - the loads leave the L2 to the scatter's open output lines; non-temporal STORES lose their write combining
+#endif
 #ifndef DRT_PART_UNROLL
 #define DRT_PART_UNROLL 4
 #endif
@@ -40,6 +47,10 @@
 namespace drt {
 
 namespace {
+
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4 *p) { const nt_f4 v = __builtin_nontemporal_load((const nt_f4 *) p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void nt_store4(float4 v, float4 *p) { nt_f4 w = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(w, (nt_f4 *) p); }
 
 constexpr int kLdsTile = (kTileX + 1) * (kTileY + 1) * (kTileZ + 1);
 
@@ -108,8 +119,8 @@ __device__ __forceinline__ void bin_histogram_stream(const Params &P, const Defe
             ok[k] = c >= lo && c < used && rec < D.chunk_count[S][c];
             if (ok[k]) {
                 const float4 *src = D.in[S] + ((size_t) c * kRecChunk + rec) * kQuads;
-                r[k] = src[0];
-                if constexpr (S == 1) q[k] = src[1];
+                r[k] = DRT_PART_NT & 1 ? nt_load4(src) : src[0];
+                if constexpr (S == 1) q[k] = DRT_PART_NT & 1 ? nt_load4(src + 1) : src[1];
             }
         }
 #pragma unroll
@@ -225,8 +236,8 @@ __device__ __forceinline__ void bin_scatter_stream(const Params &P, const Deferr
             ok[k] = c < used && rec < D.chunk_count[S][c];
             if (ok[k]) {
                 const float4 *src = D.in[S] + ((size_t) c * kRecChunk + rec) * kQuads;
-                r[k] = src[0];
-                if constexpr (S == 1) q[k] = src[1];
+                r[k] = DRT_PART_NT & 1 ? nt_load4(src) : src[0];
+                if constexpr (S == 1) q[k] = DRT_PART_NT & 1 ? nt_load4(src + 1) : src[1];
             }
         }
         uint32_t slot[kPartUnroll];
@@ -235,8 +246,8 @@ __device__ __forceinline__ void bin_scatter_stream(const Params &P, const Deferr
 #pragma unroll
         for (int k = 0; k < kPartUnroll; ++k) if (ok[k]) {
             float4 *o = dst + (size_t) slot[k] * kQuads;
-            o[0] = r[k];
-            if constexpr (S == 1) o[1] = q[k];
+            if (DRT_PART_NT & 2) { nt_store4(r[k], o); if constexpr (S == 1) nt_store4(q[k], o + 1); }
+            else { o[0] = r[k]; if constexpr (S == 1) o[1] = q[k]; }
         }
     }
 }
@@ -388,7 +399,7 @@ __global__ void __launch_bounds__(DRT_REDUCE_THREADS) tile_reduce_kernel(const P
                     ok[k] = r0 + k < n_rows && i < last;
                     if (ok[k]) {
                         const float4 *rp = src + (size_t) i * quads;
-                        rr[k] = rp[0];
+                        rr[k] = (DRT_PART_NT & 4) && s == 0 ? nt_load4(rp) : rp[0];
                         vv[k] = rr[k].w;
                         if (s == 1 && ch > 0) { const float4 c4 = rp[1]; vv[k] = ch == 1 ? c4.x : (ch == 2 ? c4.y : c4.z); }
                     }
@@ -403,7 +414,7 @@ __global__ void __launch_bounds__(DRT_REDUCE_THREADS) tile_reduce_kernel(const P
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (i0 + k * blockDim.x < last) {
                 const float4 *rp = src + (size_t) (i0 + k * blockDim.x) * quads;
-                rr[k] = rp[0];
+                rr[k] = (DRT_PART_NT & 4) && s == 0 ? nt_load4(rp) : rp[0];
                 vv[k] = rr[k].w;
                 if (s == 1 && ch > 0) { const float4 c4 = rp[1]; vv[k] = ch == 1 ? c4.x : (ch == 2 ? c4.y : c4.z); }
             }

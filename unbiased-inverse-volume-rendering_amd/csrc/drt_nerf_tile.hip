@@ -150,18 +150,17 @@ __global__ void __launch_bounds__(DRT_NT_THREADS) nerf_tile_adjoint_kernel(const
     __shared__ uint32_t wgain[2];                                     // negative densities: the workgroup's M1, W (float bits)
     const uint32_t t = threadIdx.x, lane = t & 63u;
 
-    // ---- thread -> ray: lane = pixel of the 8 x 8 tile, wave = sample (a wave's 64 lanes splat around 64 DIFFERENT pixel centres: lanes that add
-    //      to the same LDS address in one instruction are served one after the other - with a pixel's 32 samples side by side in a wave, as the ray
-    //      index runs, every add instruction had ~10 lanes per address and the march took 18 us per step) --------------------------------------
+    // ---- thread -> ray.  The kernel is bound by the LDS atomic unit, which serves the lanes of ONE add instruction that share an address one after the other
+    //      (12 + 2 x (lanes per address - 1) clocks per ds_add_u64, tools/ubench/lds_atomic_conflict_rate.hip), so the map decides how many do:
+    //        rays in index order (a pixel's 32 samples side by side in a wave; first version)      ~10 lanes per address, 18 us per march step
+    //        round 5: lane = pixel of the 8 x 8 tile, wave = sample (64 pixel centres ~0.6 voxel apart)      4 - 8 lanes per address, launch 15.6 ms
+    //        round 6: a wave = the 16 pixels of one stride-2 sub-lattice of the tile x 4 samples - pixels 1.2 voxels apart, a pixel's four samples a
+    //                 jittered fraction of the march step apart in depth: SQ_LDS_ADDR_CONFLICT 1.83 -> 0.48 G, SQ_WAIT_INST_LDS 4.49 -> 1.27 G of 32.7 G
+    //                 wave-cycles, launch 14.3 ms (2 / 8 / 16 samples per wave: 15.3 / 15.8 / 17.6 ms - beyond four the lanes' texel loads scatter and a
+    //                 pixel's samples meet again in depth; profiles/r06_nerf_tile_experiments.txt) -------------------------------------------------------
     const uint32_t tile = blockIdx.x / T.groups, sg = blockIdx.x - tile * T.groups;
     const uint32_t bx = tile % T.tiles_x, by = tile / T.tiles_x;
 #if DRT_NT_SPW == 4
-    // Round 6: a wave = the 16 pixels of one stride-2 sub-lattice of the tile x 4 samples.  The kernel is bound by the LDS atomic unit's serialisation of
-    // lanes that add to the SAME address in one instruction (12 + 2 x (lanes per address - 1) clocks per ds_add_u64, tools/ubench/lds_atomic_conflict_rate.hip):
-    // with the 64 pixels of one sample side by side (~0.6 voxel apart) 4 - 8 lanes shared every corner; now a wave's pixels lie 1.2 voxels apart and its
-    // four samples of a pixel a jittered fraction of the march step apart in depth.  Counters (profiles/r06_nerf_tile_experiments.txt): SQ_LDS_ADDR_CONFLICT
-    // 1.83 G -> 0.48 G, SQ_WAIT_INST_LDS 4.49 G -> 1.27 G of 32.7 G wave-cycles; launch 15.6 -> 14.3 ms.  (2 / 8 / 16 samples per wave: 15.3 / 15.8 / 17.6 ms -
-    // beyond four the lanes' texel loads scatter and a pixel's samples meet again in depth.)
     const uint32_t wv = t >> 6, pix = lane & 15u, q = wv & 3u;
     const uint32_t smp = sg * (NT / 64) + 4u * (wv >> 2) + (lane >> 4);
     const uint32_t px = bx * 8u + 2u * (pix & 3u) + (q & 1u), py = by * 8u + 2u * (pix >> 2) + (q >> 1);
